@@ -1,0 +1,76 @@
+// Shared device helpers for the fsnet_amd HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define FS_WAVE 64
+
+// status codes returned by every C-ABI entry point
+#define FS_OK 0
+#define FS_EINVAL 1
+#define FS_ELAUNCH 2
+
+static inline int fs_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? FS_OK : FS_ELAUNCH;
+}
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+  static constexpr int EG = 4;  // elements per 16-byte group
+  __device__ static inline float to_f(float v) { return v; }
+  __device__ static inline float from_f(float v) { return v; }
+};
+template <> struct ElemTraits<bf16> {
+  static constexpr int EG = 8;
+  __device__ static inline float to_f(bf16 v) { return (float)v; }
+  __device__ static inline bf16 from_f(float v) { return (bf16)v; }
+};
+
+__device__ static inline float bf16_bits_to_f(uint32_t b16) { return __uint_as_float(b16 << 16); }
+// round-to-nearest-even fp32 -> bf16 bits (NaN not expected on this path)
+__device__ static inline uint32_t f_to_bf16_bits(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ static inline uint32_t pack_bf16x2(float lo, float hi) {
+  return f_to_bf16_bits(lo) | (f_to_bf16_bits(hi) << 16);
+}
+
+// load / store `n<=4` consecutive channel values as float, for either element type
+template <typename T> __device__ inline void load4(const T* p, float v[4]);
+template <> __device__ inline void load4<float>(const float* p, float v[4]) {
+  float4 t = *reinterpret_cast<const float4*>(p);
+  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ inline void load4<bf16>(const bf16* p, float v[4]) {
+  uint2 t = *reinterpret_cast<const uint2*>(p);
+  v[0] = bf16_bits_to_f(t.x & 0xffffu); v[1] = bf16_bits_to_f(t.x >> 16);
+  v[2] = bf16_bits_to_f(t.y & 0xffffu); v[3] = bf16_bits_to_f(t.y >> 16);
+}
+template <typename T> __device__ inline void store4(T* p, const float v[4]);
+template <> __device__ inline void store4<float>(float* p, const float v[4]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ inline void store4<bf16>(bf16* p, const float v[4]) {
+  uint2 t; t.x = pack_bf16x2(v[0], v[1]); t.y = pack_bf16x2(v[2], v[3]);
+  *reinterpret_cast<uint2*>(p) = t;
+}
+
+__device__ static inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ static inline double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

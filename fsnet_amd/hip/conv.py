@@ -1,0 +1,149 @@
+"""Host-side plan for one convolution layer on the HIP library: packed MFMA weight operands,
+K-walk tables and the three launches (forward, dgrad, wgrad).  Activations are NHWC torch
+tensors (any n/h/w strides, channel axis contiguous) used purely as device memory."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .lib import lib, check, stream_ptr, FsConvArgs, FsWgradArgs, FS_DTYPE_BF16, FS_DTYPE_F32
+
+
+def dtype_code(dtype):
+    if dtype == torch.bfloat16:
+        return FS_DTYPE_BF16
+    if dtype == torch.float32:
+        return FS_DTYPE_F32
+    raise ValueError("unsupported compute dtype %s (bf16 or fp32)" % dtype)
+
+
+def roundup(a, b):
+    return (a + b - 1) // b * b
+
+
+def make_ktab(R, S, cs_p, eg, ngroups):
+    """One int per 16-byte K group: c | r<<16 | s<<24, -1 past the last tap."""
+    tab = np.full(ngroups, -1, dtype=np.int32)
+    real = R * S * cs_p // eg
+    k0 = np.arange(min(real, ngroups), dtype=np.int64) * eg
+    tap = k0 // cs_p
+    c = k0 % cs_p
+    r = tap // S
+    s = tap % S
+    tab[: len(k0)] = (c | (r << 16) | (s << 24)).astype(np.int32)
+    return tab
+
+
+def _nhwc_strides(t):
+    assert t.dim() == 4 and t.stride(3) == 1, "activation must be NHWC with contiguous channels"
+    return t.stride(0), t.stride(1), t.stride(2)
+
+
+class ConvOp:
+    def __init__(self, Ci, Co, R, S, stride, pad, dtype, device, need_dgrad=True):
+        assert stride in (1, 2)
+        self.Ci, self.Co, self.R, self.S, self.stride, self.pad = Ci, Co, R, S, stride, pad
+        self.dtype = dtype
+        self.code = dtype_code(dtype)
+        self.device = device
+        self.EG = 8 if dtype == torch.bfloat16 else 4
+        eg = self.EG
+        self.Ci_p = roundup(Ci, eg)      # channels of the input activation buffer
+        self.Co_p = roundup(Co, 16)      # channels of the output activation buffer
+        chunk = 4 * eg
+        # forward operand
+        self.nch_f = (R * S * self.Ci_p + chunk - 1) // chunk
+        self.kf_p = self.nch_f * chunk
+        self.ktab_f = torch.from_numpy(make_ktab(R, S, self.Ci_p, eg, self.nch_f * 4)).to(device)
+        self.w_f = torch.zeros(self.Co_p, self.kf_p, dtype=dtype, device=device)
+        # dgrad operand: rows = ci, K = (r, s, co)
+        self.need_dgrad = need_dgrad
+        if need_dgrad:
+            self.rows_d = roundup(self.Ci_p, 16)
+            self.nch_d = (R * S * self.Co_p + chunk - 1) // chunk
+            self.kd_p = self.nch_d * chunk
+            self.ktab_d = torch.from_numpy(make_ktab(R, S, self.Co_p, eg, self.nch_d * 4)).to(device)
+            self.w_d = torch.zeros(self.rows_d, self.kd_p, dtype=dtype, device=device)
+        # wgrad columns (r, s, ci): same grouping as the forward K walk without chunk padding
+        self.ncolgroups = R * S * self.Ci_p // eg
+        self.ktab_w = torch.from_numpy(make_ktab(R, S, self.Ci_p, eg, self.ncolgroups)).to(device)
+
+    # ------------------------------------------------------------------
+    def pack(self, weight):
+        """weight: fp32 OIHW master parameter on device."""
+        assert weight.dtype == torch.float32 and weight.is_contiguous()
+        st = stream_ptr()
+        check(lib.fs_pack_weights(weight.data_ptr(), self.w_f.data_ptr(), self.Co, self.Ci, self.R, self.S,
+                                  self.Co_p, self.Ci_p, self.kf_p, 0, self.code, st), "pack_weights")
+        if self.need_dgrad:
+            check(lib.fs_pack_weights(weight.data_ptr(), self.w_d.data_ptr(), self.Co, self.Ci, self.R, self.S,
+                                      self.rows_d, self.Co_p, self.kd_p, 1, self.code, st), "pack_weights_t")
+
+    def out_hw(self, H, W):
+        Ho = (H + 2 * self.pad - self.R) // self.stride + 1
+        Wo = (W + 2 * self.pad - self.S) // self.stride + 1
+        return Ho, Wo
+
+    # ------------------------------------------------------------------
+    def forward(self, x, out=None, bias=None, addend=None, stats=None, relu=False, out_f32=False):
+        N, H, W, Cs = x.shape
+        assert Cs == self.Ci_p and x.dtype == self.dtype, (x.shape, self.Ci_p, x.dtype)
+        Ho, Wo = self.out_hw(H, W)
+        if out is None:
+            out = torch.empty(N, Ho, Wo, self.Co_p, dtype=torch.float32 if out_f32 else self.dtype,
+                              device=x.device)
+        a = FsConvArgs()
+        a.src, a.wgt, a.dst = x.data_ptr(), self.w_f.data_ptr(), out.data_ptr()
+        a.bias = bias.data_ptr() if bias is not None else None
+        a.addend = addend.data_ptr() if addend is not None else None
+        a.stats = stats.data_ptr() if stats is not None else None
+        a.ktab = self.ktab_f.data_ptr()
+        a.sN, a.sH, a.sW = _nhwc_strides(x)
+        a.dN, a.dH, a.dW = _nhwc_strides(out)
+        if addend is not None:
+            a.aN, a.aH, a.aW = _nhwc_strides(addend)
+        a.Hs, a.Ws, a.Hd, a.Wd = H, W, Ho, Wo
+        a.M = N * Ho * Wo
+        a.Co, a.Co_p, a.nchunks = out.shape[3], self.Co_p, self.nch_f
+        a.hb_mul, a.hb_add, a.sgn, a.dshift = self.stride, -self.pad, 1, 0
+        a.relu, a.out_f32 = int(relu), int(out_f32)
+        check(lib.fs_conv_igemm(C.byref(a), self.code, stream_ptr()), "conv_fwd")
+        return out
+
+    def dgrad(self, dy, H, W, out=None, addend=None):
+        """dy: [N,Ho,Wo,Co_p] -> dx [N,H,W,Ci_p] (out may be a strided view; addend is summed in)."""
+        N, Ho, Wo, Cd = dy.shape
+        assert Cd == self.Co_p and dy.dtype == self.dtype and self.need_dgrad
+        if out is None:
+            out = torch.empty(N, H, W, self.Ci_p, dtype=self.dtype, device=dy.device)
+        a = FsConvArgs()
+        a.src, a.wgt, a.dst = dy.data_ptr(), self.w_d.data_ptr(), out.data_ptr()
+        a.bias, a.stats = None, None
+        a.addend = addend.data_ptr() if addend is not None else None
+        a.ktab = self.ktab_d.data_ptr()
+        a.sN, a.sH, a.sW = _nhwc_strides(dy)
+        a.dN, a.dH, a.dW = _nhwc_strides(out)
+        if addend is not None:
+            a.aN, a.aH, a.aW = _nhwc_strides(addend)
+        a.Hs, a.Ws, a.Hd, a.Wd = Ho, Wo, H, W
+        a.M = N * H * W
+        a.Co, a.Co_p, a.nchunks = out.shape[3], self.rows_d, self.nch_d
+        a.hb_mul, a.hb_add, a.sgn, a.dshift = 1, self.pad, -1, (1 if self.stride == 2 else 0)
+        a.relu, a.out_f32 = 0, 0
+        check(lib.fs_conv_igemm(C.byref(a), self.code, stream_ptr()), "conv_dgrad")
+        return out
+
+    def wgrad(self, dy, x, dw):
+        """accumulates into dw (fp32 OIHW [Co,Ci,R,S]); dy must be dense [N,Ho,Wo,Co_p]."""
+        N, Ho, Wo, Cd = dy.shape
+        assert dy.is_contiguous() and Cd == self.Co_p and x.shape[3] == self.Ci_p
+        assert dw.dtype == torch.float32 and dw.is_contiguous()
+        a = FsWgradArgs()
+        a.dy, a.x, a.dw, a.ktab = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), self.ktab_w.data_ptr()
+        a.sN, a.sH, a.sW = _nhwc_strides(x)
+        a.Hs, a.Ws, a.Hd, a.Wd = x.shape[1], x.shape[2], Ho, Wo
+        a.M, a.Cd = N * Ho * Wo, Cd
+        a.Co, a.Ci, a.R, a.S = self.Co, self.Ci, self.R, self.S
+        a.stride, a.pad, a.ncolgroups, a.pix_per_split = self.stride, self.pad, self.ncolgroups, 0
+        check(lib.fs_conv_wgrad(C.byref(a), self.code, stream_ptr()), "conv_wgrad")
+        return dw

@@ -1,0 +1,78 @@
+"""Loader for libfsnet_hip.so.  There is no fallback: if the library is missing the product
+path raises (build it with `python -m fsnet_amd.csrc.build` / __graft_entry__.build())."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libfsnet_hip.so")
+
+FS_DTYPE_F32 = 0
+FS_DTYPE_BF16 = 1
+
+
+class FsError(RuntimeError):
+    pass
+
+
+class FsConvArgs(C.Structure):
+    _fields_ = [
+        ("src", C.c_void_p), ("wgt", C.c_void_p), ("dst", C.c_void_p), ("bias", C.c_void_p),
+        ("addend", C.c_void_p), ("stats", C.c_void_p), ("ktab", C.c_void_p),
+        ("sN", C.c_int64), ("sH", C.c_int64), ("sW", C.c_int64),
+        ("dN", C.c_int64), ("dH", C.c_int64), ("dW", C.c_int64),
+        ("aN", C.c_int64), ("aH", C.c_int64), ("aW", C.c_int64),
+        ("Hs", C.c_int32), ("Ws", C.c_int32), ("Hd", C.c_int32), ("Wd", C.c_int32),
+        ("M", C.c_int32), ("Co", C.c_int32), ("Co_p", C.c_int32), ("nchunks", C.c_int32),
+        ("hb_mul", C.c_int32), ("hb_add", C.c_int32), ("sgn", C.c_int32), ("dshift", C.c_int32),
+        ("relu", C.c_int32), ("out_f32", C.c_int32),
+    ]
+
+
+class FsWgradArgs(C.Structure):
+    _fields_ = [
+        ("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("ktab", C.c_void_p),
+        ("sN", C.c_int64), ("sH", C.c_int64), ("sW", C.c_int64),
+        ("Hs", C.c_int32), ("Ws", C.c_int32), ("Hd", C.c_int32), ("Wd", C.c_int32),
+        ("M", C.c_int32), ("Cd", C.c_int32),
+        ("Co", C.c_int32), ("Ci", C.c_int32), ("R", C.c_int32), ("S", C.c_int32),
+        ("stride", C.c_int32), ("pad", C.c_int32), ("ncolgroups", C.c_int32),
+        ("pix_per_split", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def load_library(path=None):
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or os.environ.get("FSNET_HIP_LIB", LIB_PATH)
+    if not os.path.exists(path):
+        raise FsError(
+            "libfsnet_hip.so not found at %s — the HIP kernel library is required (no CPU fallback). "
+            "Build it with `python fsnet_amd/csrc/build.py` or __graft_entry__.build()." % path)
+    _lib = C.CDLL(path)
+    from . import signatures
+    signatures.declare(_lib)
+    return _lib
+
+
+class _LazyLib:
+    def __getattr__(self, name):
+        return getattr(load_library(), name)
+
+
+lib = _LazyLib()
+
+
+def check(status, what=""):
+    if status != 0:
+        raise FsError("libfsnet_hip call %s failed with status %d" % (what, status))
+
+
+def stream_ptr():
+    """Raw hipStream_t of torch's current stream (kernels are launched on it so that torch's
+    stream ordering, events and graph capture all apply)."""
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,114 @@
+"""GPU parity of the implicit-GEMM conv kernels (forward, dgrad, wgrad) against the CPU oracle
+for this op, torch's fp32 conv2d + autograd (the ATen op the reference calls)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # Ci, Co, k, stride, pad, N, H, W
+    (3, 64, 7, 2, 3, 2, 32, 64),      # depth stem
+    (6, 64, 7, 2, 3, 2, 32, 64),      # pose stem
+    (64, 64, 3, 1, 1, 2, 16, 32),     # layer1
+    (64, 128, 3, 2, 1, 2, 16, 32),    # stage entry
+    (64, 128, 1, 2, 0, 2, 16, 32),    # downsample
+    (128, 128, 3, 1, 1, 3, 12, 20),   # ragged M
+    (256, 512, 3, 2, 1, 2, 12, 40),
+    (512, 512, 3, 1, 1, 12, 6, 20),   # layer4 at bench batch
+    (96, 32, 3, 1, 1, 2, 24, 40),     # decoder skip concat
+    (32, 16, 3, 1, 1, 2, 24, 40),
+    (16, 16, 3, 1, 1, 2, 48, 64),
+    (512, 256, 1, 1, 0, 2, 6, 20),    # pose squeeze
+    (256, 12, 1, 1, 0, 2, 6, 20),     # pose out (Co padded to 16)
+    (64, 64, 3, 1, 1, 12, 48, 160),   # big M -> 128x64 tiles
+    (128, 128, 3, 1, 1, 12, 48, 160), # big M -> 128x128 tiles
+]
+
+
+def to_nhwc(x, cp, dtype):
+    n, c, h, w = x.shape
+    out = torch.zeros(n, h, w, cp, dtype=dtype, device=x.device)
+    out[..., :c] = x.permute(0, 2, 3, 1).to(dtype)
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd_bwd(dev, case, dtype):
+    from fsnet_amd.hip.conv import ConvOp
+    Ci, Co, k, stride, pad, N, H, W = case
+    g = torch.Generator().manual_seed(1234 + Ci * 7 + Co)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
+    b = torch.randn(Co, generator=g)
+    if dtype == torch.bfloat16:  # compare like with like: oracle sees the bf16-rounded operands
+        x = x.bfloat16().float()
+        w = w.bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, b, stride=stride, padding=pad)
+    gy = torch.randn(y_ref.shape, generator=g)
+    if dtype == torch.bfloat16:
+        gy = gy.bfloat16().float()
+    y_ref.backward(gy)
+
+    op = ConvOp(Ci, Co, k, k, stride, pad, dtype, dev, need_dgrad=True)
+    op.pack(w.to(dev).contiguous())
+    xd = to_nhwc(x.to(dev), op.Ci_p, dtype)
+    bias = torch.zeros(op.Co_p, device=dev)
+    bias[:Co] = b.to(dev)
+    stats = torch.zeros(2, op.Co_p, dtype=torch.float64, device=dev)
+    y = op.forward(xd, bias=bias, stats=stats, out_f32=True)
+    torch.cuda.synchronize()
+    y_nchw = y[..., :Co].permute(0, 3, 1, 2).float().cpu()
+    tol = 2e-5 if dtype == torch.float32 else 2e-3
+    scale = y_ref.abs().max().item()
+    assert (y_nchw - y_ref.detach()).abs().max().item() <= tol * scale
+    if Co % 16 != 0:
+        assert y[..., Co:].abs().max().item() == 0
+    # fused batch statistics
+    s1 = y_ref.detach().double().sum(dim=(0, 2, 3))
+    s2 = (y_ref.detach().double() ** 2).sum(dim=(0, 2, 3))
+    assert torch.allclose(stats[0, :Co].cpu(), s1, rtol=1e-3, atol=1e-3 * s2.max().sqrt().item())
+    assert torch.allclose(stats[1, :Co].cpu(), s2, rtol=2e-3)
+
+    # dgrad
+    gyd = to_nhwc(gy.to(dev), op.Co_p, dtype)
+    dx = op.dgrad(gyd, H, W)
+    torch.cuda.synchronize()
+    dx_nchw = dx[..., :Ci].permute(0, 3, 1, 2).float().cpu()
+    gscale = xr.grad.abs().max().item()
+    tol_g = 2e-5 if dtype == torch.float32 else 1e-2
+    assert (dx_nchw - xr.grad).abs().max().item() <= tol_g * gscale
+
+    # wgrad
+    dw = torch.zeros(Co, Ci, k, k, device=dev)
+    op.wgrad(gyd, xd, dw)
+    torch.cuda.synchronize()
+    wscale = wr.grad.abs().max().item()
+    tol_w = 5e-5 if dtype == torch.float32 else 2e-3
+    assert (dw.cpu() - wr.grad).abs().max().item() <= tol_w * wscale
+
+
+def test_conv_addend_relu_strided(dev):
+    """epilogue addend + relu, strided (padded-buffer interior) source and destination."""
+    from fsnet_amd.hip.conv import ConvOp
+    dtype = torch.float32
+    N, Ci, Co, H, W = 2, 32, 32, 10, 12
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / 17
+    add = torch.randn(N, Co, H, W, generator=g)
+    ref = F.relu(F.conv2d(x, w, None, padding=1) + add)
+    op = ConvOp(Ci, Co, 3, 3, 1, 1, dtype, dev)
+    op.pack(w.to(dev))
+    xp = torch.zeros(N, H + 2, W + 2, Ci, device=dev)
+    xp[:, 1:-1, 1:-1] = x.to(dev).permute(0, 2, 3, 1)
+    outp = torch.full((N, H + 2, W + 2, Co), -5.0, device=dev)
+    addd = add.to(dev).permute(0, 2, 3, 1).contiguous()
+    op.forward(xp[:, 1:-1, 1:-1], out=outp[:, 1:-1, 1:-1], addend=addd, relu=True)
+    torch.cuda.synchronize()
+    got = outp[:, 1:-1, 1:-1].permute(0, 3, 1, 2).cpu()
+    assert (got - ref).abs().max().item() < 1e-4
+    assert (outp[:, 0] == -5).all() and (outp[:, :, 0] == -5).all()
