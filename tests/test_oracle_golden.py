@@ -1,0 +1,112 @@
+"""Pins oracle/fsnet_oracle.py (the CPU restatement) to golden vectors produced by the REAL
+reference (tools/gen_golden.py, run in the build container).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fsnet_oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def maxdev(a, b):
+    return float((torch.as_tensor(a).double() - torch.as_tensor(b).double()).abs().max())
+
+
+def test_ops_golden():
+    g = np.load(os.path.join(GOLD, "ops.npz"))
+    depth, P2 = T(g["geo_depth"]), T(g["geo_P2"])
+    aa, tr = T(g["geo_aa"]), T(g["geo_tr"])
+    assert maxdev(O.transformation_from_parameters(aa, tr, False), g["geo_T"]) < 1e-6
+    assert maxdev(O.transformation_from_parameters(aa, tr, True), g["geo_Tinv"]) < 1e-6
+    K, invK = O.intrinsics(P2)
+    B, _, H, W = depth.shape
+    pix = O.project(O.backproject(depth, invK), K, T(g["geo_T"]), H, W)
+    assert maxdev(pix, g["geo_pix"]) < 1e-5
+    x, y = T(g["ssim_x"]), T(g["ssim_y"])
+    assert maxdev(O.ssim(x, y), g["ssim_out"]) < 1e-6
+    assert maxdev(O.reprojection_loss(x, y), g["reproj_out"]) < 1e-6
+    assert maxdev(O.smooth_loss(T(g["smooth_disp"]), x), g["smooth_out"]) < 1e-7
+    assert maxdev(O.depth_bins(0.5, 100.0, 16), g["head_bins"]) < 1e-5
+    d = O.gather_activation(T(g["head_logits"]), T(g["head_bins"]))
+    assert maxdev(d, g["head_depth"]) < 1e-4
+    assert maxdev(O.depth_to_disp(d, 0.5, 100.0), g["head_disp"]) < 1e-6
+
+
+def _chain_inputs(g):
+    data = {("original_image", 0): T(g["img_0"]), ("original_image", 1): T(g["img_p"]),
+            ("original_image", -1): T(g["img_m"]), "P2": T(g["P2"]), "patched_mask": T(g["patched_mask"])}
+    return data
+
+
+def test_loss_chain_golden():
+    g = np.load(os.path.join(GOLD, "loss_chain.npz"))
+    data = _chain_inputs(g)
+    outputs, leaves = {}, {}
+    for s in range(4):
+        d = T(g["depth_%d" % s]).clone().requires_grad_(True)
+        leaves[s] = d
+        outputs[("depth", s, s)] = d
+        outputs[("disp", s)] = O.depth_to_disp(d, 0.5, 100.0)
+    pose = {}
+    for f, tag in ((1, "p"), (-1, "m")):
+        aa = T(g["aa_" + tag]).clone().requires_grad_(True)
+        tr = T(g["tr_" + tag]).clone().requires_grad_(True)
+        pose[tag] = (aa, tr)
+        outputs[("cam_T_cam", f)] = O.transformation_from_parameters(aa, tr, invert=(f < 0))
+    total, ld = O.photometric_loss(outputs, data)
+    assert total.dtype == torch.float64  # patched_mask promotes the loss to float64
+    total.backward()
+    # the reference adds randn*1e-5 tie-break noise: bounded effect on the loss
+    assert abs(float(total.detach()) - float(g["total_loss"])) < 2e-7
+    for s in range(4):
+        assert abs(float(ld["loss/%d" % s]) - float(g["ld_loss_%d" % s])) < 5e-7
+        assert abs(float(ld["smooth_loss/%d" % s]) - float(g["ld_smooth_loss_%d" % s])) < 1e-10
+        ref = T(g["gdepth_%d" % s])
+        # argmin flips under the tie-break noise touch isolated pixels only: compare in L2
+        rel = float((leaves[s].grad - ref).norm() / ref.norm())
+        assert rel < 2e-3, (s, rel)
+    for tag in ("p", "m"):
+        for got, key in ((pose[tag][0].grad, "gaa_" + tag), (pose[tag][1].grad, "gtr_" + tag)):
+            ref = T(g[key])
+            assert maxdev(got, ref) < 2e-3 * float(ref.abs().max()) + 1e-9
+        assert maxdev(outputs[("original_image", 1 if tag == "p" else -1, 0)][:, :, ::4, ::4], g["warp0_" + tag]) < 1e-5
+        assert (outputs[("overlapped_mask", 1 if tag == "p" else -1, 0)].numpy() == g["ovmask0_" + tag]).mean() > 0.9999
+
+
+@pytest.mark.parametrize("tag,with_pose", [("depthpose", True), ("wpose", False)])
+def test_model_golden(tag, with_pose):
+    g = np.load(os.path.join(GOLD, "model_%s.npz" % tag))
+    B, H, W = int(g["B"]), int(g["H"]), int(g["W"])
+    sd0 = O.init_state(seed=int(g["init_seed"]), with_pose=with_pose)
+    # forward tensors at the initial state
+    data = O.synthetic_batch(B, H, W, seed=100)
+    sd = {k: v.clone() for k, v in sd0.items()}
+    feats = O.resnet_forward(sd, "depth_backbone.", data[("image", 0)])
+    outs = O.depth_decoder_forward(sd, "head.depth_decoder.", feats, 0.5, 100.0)
+    assert maxdev(feats[4], g["feat4"]) < 1e-4
+    for s in range(4):
+        ref = T(g["disp_%d" % s])
+        assert maxdev(outs[("disp", s)], ref) <= 1e-5 * float(ref.abs().max())
+    if with_pose:
+        pf = O.resnet_forward(sd, "pose_backbone.", torch.cat([data[("image", 0)], data[("image", 1)]], 1))
+        aa, tr = O.pose_decoder_forward(sd, "head.pose_decoder.", pf[-1])
+        assert maxdev(aa, g["axisangle_p"]) < 1e-7 and maxdev(tr, g["translation_p"]) < 1e-7
+    # three optimisation steps (clip 35, Adam 1e-4) in lock-step with the reference hook
+    trn = O.OracleTrainer(sd0, with_pose=with_pose)
+    for it in range(3):
+        total, ld, _, raw, norm = trn.step(O.synthetic_batch(B, H, W, seed=100 + it))
+        # tolerances = the reference's own run-to-run spread under its tie-break randn
+        assert abs(float(total) - float(g["loss_%d" % it])) < 5e-5 * abs(float(g["loss_%d" % it]))
+        assert abs(float(norm) - float(g["totalnorm_%d" % it])) < 2e-2 * float(g["totalnorm_%d" % it])
+        if it == 0:
+            gn = torch.stack([raw[k].norm() for k in trn.names])
+            ref = T(g["gradnorm_0"])
+            big = ref > 1e-4 * ref.max()
+            assert float(((gn - ref).abs() / ref)[big].max()) < 2e-2

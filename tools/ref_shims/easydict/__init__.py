@@ -1,0 +1,25 @@
+"""Dev-only stand-in for the `easydict` package (absent in this image) so that the reference can be
+imported by tools/gen_golden.py.  Never shipped to / imported on the GPU box."""
+
+
+class EasyDict(dict):
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        d = dict(d or {})
+        d.update(kw)
+        for k, v in d.items():
+            self[k] = v
+
+    def __setitem__(self, k, v):
+        if isinstance(v, dict) and not isinstance(v, EasyDict):
+            v = EasyDict(v)
+        super().__setitem__(k, v)
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
