@@ -1,0 +1,284 @@
+// Train-mode BatchNorm (+ residual add, + ReLU) forward and backward, HBM-bound elementwise /
+// reduction kernels.  Replaces nn.BatchNorm2d (train mode) + F.relu + residual add at
+//   vision_base/networks/models/backbone/resnet.py:33-50,70-89,201-203 (bn, relu, out += residual)
+//   vision_base/networks/blocks/blocks.py:44-52 (ConvBnReLU)
+// and their autograd backward.  Batch statistics arrive as per-channel f64 (sum, sumsq) produced by
+// the conv epilogue (conv_igemm.hip) — under data parallelism the host all-reduces that small
+// buffer between the conv and this kernel (SyncBatchNorm semantics, scripts/train.py:101).
+#include "common.h"
+#include "fsnet_hip_internal.h"
+#include <algorithm>
+
+namespace {
+
+constexpr int MAXC = 2048;
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+__device__ inline void bn_channel_coeffs(const double* stats, int C, int c, double count, float eps, float gamma,
+                                         float beta, float& mean, float& invstd, float& var_b, float& scale,
+                                         float& shift) {
+  double m = stats[c] / count;
+  double v = stats[C + c] / count - m * m;
+  if (v < 0) v = 0;
+  mean = (float)m;
+  var_b = (float)v;
+  invstd = (float)(1.0 / sqrt(v + (double)eps));
+  scale = gamma * invstd;
+  shift = beta - mean * scale;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const FsBnApplyArgs p) {
+  __shared__ float s_scale[MAXC], s_shift[MAXC];
+  __shared__ float s_scale2[MAXC], s_shift2[MAXC];
+  const int C = p.C;
+  const bool has2 = p.stats2 != nullptr;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float mean, invstd, varb, sc, sh;
+    bn_channel_coeffs(p.stats, C, c, p.count, p.eps, p.gamma[c], p.beta[c], mean, invstd, varb, sc, sh);
+    s_scale[c] = sc; s_shift[c] = sh;
+    if (blockIdx.x == 0) {
+      p.save_mean[c] = mean; p.save_invstd[c] = invstd;
+      if (p.running_mean) {
+        double unb = p.count > 1.0 ? (double)varb * p.count / (p.count - 1.0) : (double)varb;
+        p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * mean;
+        p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unb;
+      }
+    }
+    if (has2) {
+      bn_channel_coeffs(p.stats2, C, c, p.count, p.eps, p.gamma2[c], p.beta2[c], mean, invstd, varb, sc, sh);
+      s_scale2[c] = sc; s_shift2[c] = sh;
+      if (blockIdx.x == 0) {
+        p.save_mean2[c] = mean; p.save_invstd2[c] = invstd;
+        if (p.running_mean2) {
+          double unb = p.count > 1.0 ? (double)varb * p.count / (p.count - 1.0) : (double)varb;
+          p.running_mean2[c] = (1.f - p.momentum) * p.running_mean2[c] + p.momentum * mean;
+          p.running_var2[c] = (1.f - p.momentum) * p.running_var2[c] + p.momentum * (float)unb;
+        }
+      }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (p.num_batches_tracked) *p.num_batches_tracked += 1;
+    if (p.num_batches_tracked2) *p.num_batches_tracked2 += 1;
+  }
+  __syncthreads();
+
+  const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ res = reinterpret_cast<const T*>(p.res);
+  T* __restrict__ y = reinterpret_cast<T*>(p.y);
+  const int CG = C / 4;
+  const long total = (long)p.M * CG;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int cg = (int)(i % CG); long m = i / CG;
+    int c = cg * 4;
+    float v[4];
+    load4<T>(x + m * C + c, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = v[j] * s_scale[c + j] + s_shift[c + j];
+    if (res) {
+      float r[4];
+      load4<T>(res + m * C + c, r);
+      if (has2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = r[j] * s_scale2[c + j] + s_shift2[c + j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += r[j];
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    int w = (int)(m % p.W); long q = m / p.W; int h = (int)(q % p.H); long n = q / p.H;
+    if (!p.pad_out) {
+      store4<T>(y + n * p.yN + (long)h * p.yH + (long)w * p.yW + c, v);
+    } else {
+      // output buffer is [N, H+2, W+2, C] with a replicated border (consumer uses replicate padding)
+      // (H, W >= 2: decoder maps are never a single row/column)
+      int hs[2] = {h + 1, 0}, ws[2] = {w + 1, 0};
+      int nh = 1, nw = 1;
+      if (h == 0) { hs[1] = 0; nh = 2; } else if (h == p.H - 1) { hs[1] = p.H + 1; nh = 2; }
+      if (w == 0) { ws[1] = 0; nw = 2; } else if (w == p.W - 1) { ws[1] = p.W + 1; nw = 2; }
+      for (int a = 0; a < nh; ++a)
+        for (int b = 0; b < nw; ++b)
+          store4<T>(y + n * p.yN + (long)hs[a] * p.yH + (long)ws[b] * p.yW + c, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------
+// gradient w.r.t. the block output at interior pixel (n,h,w), channels c..c+3.  `fold`: dout is a
+// replicate-padded buffer [N,H+2,W+2,C]; the border copies fold back onto the edge pixel.
+template <typename T>
+__device__ inline void load_dout(const FsBnBwdArgs& p, const T* dout, long n, int h, int w, int c, float g[4]) {
+  if (!p.fold) {
+    load4<T>(dout + n * p.gN + (long)h * p.gH + (long)w * p.gW + c, g);
+    return;
+  }
+  g[0] = g[1] = g[2] = g[3] = 0.f;
+  int hs[2] = {h + 1, 0}, ws[2] = {w + 1, 0};
+  int nh = 1, nw = 1;
+  if (h == 0) { hs[1] = 0; nh = 2; } else if (h == p.H - 1) { hs[1] = p.H + 1; nh = 2; }
+  if (w == 0) { ws[1] = 0; nw = 2; } else if (w == p.W - 1) { ws[1] = p.W + 1; nw = 2; }
+  for (int a = 0; a < nh; ++a)
+    for (int b = 0; b < nw; ++b) {
+      float t[4];
+      load4<T>(dout + n * p.gN + (long)hs[a] * p.gH + (long)ws[b] * p.gW + c, t);
+      g[0] += t[0]; g[1] += t[1]; g[2] += t[2]; g[3] += t[3];
+    }
+}
+
+// pass 1: per-channel sum(g), sum(g * xhat) with g = dout * (y > 0)
+template <typename T, int CGB>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const FsBnBwdArgs p) {
+  constexpr int PL = 256 / CGB;
+  __shared__ float red[2][4][256];
+  const int C = p.C, CG = C / 4;
+  const int cgl = threadIdx.x % CGB, pl = threadIdx.x / CGB;
+  const int cg = blockIdx.y * CGB + cgl;
+  const bool act = cg < CG;
+  const int c = cg * 4;
+  const T* __restrict__ dout = reinterpret_cast<const T*>(p.dout);
+  const T* __restrict__ yv = reinterpret_cast<const T*>(p.y);
+  const T* __restrict__ xv = reinterpret_cast<const T*>(p.x);
+  float mean[4], istd[4];
+  if (act) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { mean[j] = p.save_mean[c + j]; istd[j] = p.save_invstd[c + j]; }
+  }
+  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if (act) {
+    for (long m = (long)blockIdx.x * PL + pl; m < p.M; m += (long)gridDim.x * PL) {
+      int w = (int)(m % p.W); long q = m / p.W; int h = (int)(q % p.H); long n = q / p.H;
+      float g[4], xr[4];
+      load_dout<T>(p, dout, n, h, w, c, g);
+      if (p.relu) {
+        float yy[4];
+        load4<T>(yv + n * p.yN + (long)h * p.yH + (long)w * p.yW + c, yy);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = yy[j] > 0.f ? g[j] : 0.f;
+      }
+      load4<T>(xv + m * C + c, xr);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s1[j] += g[j]; s2[j] += g[j] * (xr[j] - mean[j]) * istd[j]; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[0][j][threadIdx.x] = s1[j]; red[1][j][threadIdx.x] = s2[j]; }
+  __syncthreads();
+  if (pl == 0 && act) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = 0.f, b = 0.f;
+      for (int k = 0; k < PL; ++k) { a += red[0][j][k * CGB + cgl]; b += red[1][j][k * CGB + cgl]; }
+      atomicAdd(p.sums + c + j, (double)a);
+      atomicAdd(p.sums + C + c + j, (double)b);
+    }
+  }
+}
+
+// pass 2: dx = gamma*invstd * (g - sum_g/count - xhat * sum_gx/count); optional g output; param grads
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const FsBnBwdArgs p) {
+  __shared__ float s_a[MAXC], s_b[MAXC], s_k[MAXC], s_mean[MAXC], s_istd[MAXC];
+  const int C = p.C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double sg = p.sums[c], sgx = p.sums[C + c];
+    float istd = p.save_invstd[c];
+    s_mean[c] = p.save_mean[c]; s_istd[c] = istd;
+    s_k[c] = p.gamma[c] * istd;
+    s_a[c] = (float)(sg / p.count);
+    s_b[c] = (float)(sgx / p.count);
+    if (blockIdx.x == 0) {
+      // dgamma / dbeta of the local shard (the data-parallel all-reduce of gradients averages them later)
+      if (p.dgamma) p.dgamma[c] += (float)(p.sums_local ? p.sums_local[C + c] : sgx);
+      if (p.dbeta) p.dbeta[c] += (float)(p.sums_local ? p.sums_local[c] : sg);
+    }
+  }
+  __syncthreads();
+  const T* __restrict__ dout = reinterpret_cast<const T*>(p.dout);
+  const T* __restrict__ yv = reinterpret_cast<const T*>(p.y);
+  const T* __restrict__ xv = reinterpret_cast<const T*>(p.x);
+  T* __restrict__ dx = reinterpret_cast<T*>(p.dx);
+  T* __restrict__ gout = reinterpret_cast<T*>(p.g_out);
+  const int CG = C / 4;
+  const long total = (long)p.M * CG;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int cg = (int)(i % CG); long m = i / CG;
+    int c = cg * 4;
+    int w = (int)(m % p.W); long q = m / p.W; int h = (int)(q % p.H); long n = q / p.H;
+    float g[4], xr[4], o[4];
+    load_dout<T>(p, dout, n, h, w, c, g);
+    if (p.relu) {
+      float yy[4];
+      load4<T>(yv + n * p.yN + (long)h * p.yH + (long)w * p.yW + c, yy);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = yy[j] > 0.f ? g[j] : 0.f;
+    }
+    load4<T>(xv + m * C + c, xr);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float xh = (xr[j] - s_mean[c + j]) * s_istd[c + j];
+      o[j] = s_k[c + j] * (g[j] - s_a[c + j] - xh * s_b[c + j]);
+    }
+    store4<T>(dx + m * C + c, o);
+    if (gout) store4<T>(gout + m * C + c, g);
+  }
+}
+
+int grid_for(long items) {
+  long b = (items + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int fs_bn_apply(const FsBnApplyArgs* a, int dtype, void* stream) {
+  if (!a || !a->x || !a->y || !a->stats || !a->gamma || !a->beta || !a->save_mean || !a->save_invstd) return FS_EINVAL;
+  if (a->C % 4 != 0 || a->C > MAXC || a->M <= 0) return FS_EINVAL;
+  if (a->stats2 && (!a->res || !a->gamma2 || !a->beta2 || !a->save_mean2 || !a->save_invstd2)) return FS_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int grid = grid_for((long)a->M * (a->C / 4));
+  if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(grid), dim3(256), 0, st, *a);
+  else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, st, *a);
+  else return FS_EINVAL;
+  return fs_launch_status();
+}
+
+extern "C" int fs_bn_bwd_reduce(const FsBnBwdArgs* a, int dtype, void* stream) {
+  if (!a || !a->dout || !a->x || !a->sums || !a->save_mean || !a->save_invstd) return FS_EINVAL;
+  if (a->C % 4 != 0 || a->C > MAXC || a->M <= 0 || (a->relu && !a->y)) return FS_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int CG = a->C / 4;
+  // channel groups per block: 64 (4 pixel lanes) for wide layers, 16 (16 pixel lanes) for narrow ones
+  if (CG >= 64) {
+    dim3 grid((unsigned)std::min<long>(((long)a->M + 3) / 4, 1024), (CG + 63) / 64);
+    if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, 64>), grid, dim3(256), 0, st, *a);
+    else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 64>), grid, dim3(256), 0, st, *a);
+    else return FS_EINVAL;
+  } else {
+    dim3 grid((unsigned)std::min<long>(((long)a->M + 15) / 16, 2048), (CG + 15) / 16);
+    if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, 16>), grid, dim3(256), 0, st, *a);
+    else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 16>), grid, dim3(256), 0, st, *a);
+    else return FS_EINVAL;
+  }
+  return fs_launch_status();
+}
+
+extern "C" int fs_bn_bwd_apply(const FsBnBwdArgs* a, int dtype, void* stream) {
+  if (!a || !a->dout || !a->x || !a->sums || !a->dx || !a->gamma || !a->save_mean || !a->save_invstd) return FS_EINVAL;
+  if (a->C % 4 != 0 || a->C > MAXC || a->M <= 0 || (a->relu && !a->y)) return FS_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int grid = grid_for((long)a->M * (a->C / 4));
+  if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(grid), dim3(256), 0, st, *a);
+  else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, *a);
+  else return FS_EINVAL;
+  return fs_launch_status();
+}

@@ -1,0 +1,508 @@
+// Photometric loss chain, forward + backward, as HBM-bound gather / stencil kernels.
+// Replaces (reference, all eager ATen):
+//   MonoDepth2Decoder._generate_images_pred          monodepth2_decoder.py:61-116
+//     F.interpolate(bilinear, align_corners=True)     :68-69
+//     K / pinv(K) on host                             :82-85
+//     BackprojectDepth / Project3D                    monodepth_utils.py:101-165
+//     F.grid_sample(bilinear, border) / (nearest)     monodepth2_decoder.py:98-101,110-116
+//   compute_reprojection_loss (SSIM + L1)             monodepth2_decoder.py:118-128, monodepth_utils.py:184-215
+//   compute_total_reprojection_loss (min / masks)     monodepth2_decoder.py:205-292
+// All four scales run in ONE launch per stage (every stage works at full resolution; only the
+// low-res depth map differs).  Images stay planar NCHW fp32 exactly as the data layer hands them over.
+#include "common.h"
+#include "fsnet_hip_internal.h"
+#include <algorithm>
+
+namespace {
+
+constexpr float C1 = 0.01f * 0.01f;
+constexpr float C2 = 0.03f * 0.03f;
+constexpr int GEO_STRIDE = 48;  // per batch element: invK[9] K[9] P[2][12]
+
+__device__ __forceinline__ int refl(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// ---------------------------------------------------------------------------------------------
+// setup: K, K^-1 (f64 adjugate == pinv for a regular K), P_f = (K T_f)[:3]; zero the accumulators
+// ---------------------------------------------------------------------------------------------
+__global__ void photo_setup_kernel(const float* __restrict__ P2, const float* __restrict__ T0,
+                                   const float* __restrict__ T1, float* __restrict__ geo, int B) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double k[3][3];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) k[i][j] = (double)P2[b * 12 + i * 4 + j];
+  double c00 = k[1][1] * k[2][2] - k[1][2] * k[2][1];
+  double c01 = k[1][2] * k[2][0] - k[1][0] * k[2][2];
+  double c02 = k[1][0] * k[2][1] - k[1][1] * k[2][0];
+  double det = k[0][0] * c00 + k[0][1] * c01 + k[0][2] * c02;
+  double inv[3][3];
+  inv[0][0] = c00 / det; inv[1][0] = c01 / det; inv[2][0] = c02 / det;
+  inv[0][1] = (k[0][2] * k[2][1] - k[0][1] * k[2][2]) / det;
+  inv[1][1] = (k[0][0] * k[2][2] - k[0][2] * k[2][0]) / det;
+  inv[2][1] = (k[0][1] * k[2][0] - k[0][0] * k[2][1]) / det;
+  inv[0][2] = (k[0][1] * k[1][2] - k[0][2] * k[1][1]) / det;
+  inv[1][2] = (k[0][2] * k[1][0] - k[0][0] * k[1][2]) / det;
+  inv[2][2] = (k[0][0] * k[1][1] - k[0][1] * k[1][0]) / det;
+  float* g = geo + (long)b * GEO_STRIDE;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { g[i * 3 + j] = (float)inv[i][j]; g[9 + i * 3 + j] = (float)k[i][j]; }
+  for (int f = 0; f < 2; ++f) {
+    const float* T = (f == 0 ? T0 : T1) + (long)b * 16;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 4; ++j) {
+        float a = 0.f;
+        for (int m = 0; m < 3; ++m) a += g[9 + i * 3 + m] * T[m * 4 + j];
+        g[18 + f * 12 + i * 4 + j] = a;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// shared per-pixel geometry: depth upsample -> backproject -> project -> sample coordinates
+// ---------------------------------------------------------------------------------------------
+struct Geo {
+  float D;             // upsampled depth
+  int y0, x0, y1, x1;  // low-res taps
+  float ly, lx;        // low-res lambdas
+  float r[3];          // K^-1 [x y 1]
+  float X, Y, Zp;      // projected point, Zp = Z + eps
+  float ixu, iyu;      // unnormalised (unclamped) sample coordinates
+};
+
+__device__ __forceinline__ void upsample_taps(int y, int x, int H, int W, int h, int w, Geo& g) {
+  // ATen upsample_bilinear2d, align_corners=True: scale = (in-1)/(out-1)
+  float sh = (H > 1) ? (float)(h - 1) / (float)(H - 1) : 0.f;
+  float sw = (W > 1) ? (float)(w - 1) / (float)(W - 1) : 0.f;
+  float fy = sh * (float)y, fx = sw * (float)x;
+  g.y0 = (int)fy; g.x0 = (int)fx;
+  g.y1 = g.y0 + (g.y0 < h - 1 ? 1 : 0); g.x1 = g.x0 + (g.x0 < w - 1 ? 1 : 0);
+  g.ly = fy - (float)g.y0; g.lx = fx - (float)g.x0;
+}
+
+__device__ __forceinline__ void project_pixel(const float* __restrict__ depth, int b, int y, int x, int H, int W,
+                                              int h, int w, const float* __restrict__ ge, int f, Geo& g) {
+  upsample_taps(y, x, H, W, h, w, g);
+  const float* d = depth + (long)b * h * w;
+  float d00 = d[g.y0 * w + g.x0], d01 = d[g.y0 * w + g.x1], d10 = d[g.y1 * w + g.x0], d11 = d[g.y1 * w + g.x1];
+  g.D = (1.f - g.ly) * ((1.f - g.lx) * d00 + g.lx * d01) + g.ly * ((1.f - g.lx) * d10 + g.lx * d11);
+  float px = (float)x, py = (float)y;
+  g.r[0] = ge[0] * px + ge[1] * py + ge[2];
+  g.r[1] = ge[3] * px + ge[4] * py + ge[5];
+  g.r[2] = ge[6] * px + ge[7] * py + ge[8];
+  const float* P = ge + 18 + f * 12;
+  float cx = g.D * g.r[0], cy = g.D * g.r[1], cz = g.D * g.r[2];
+  g.X = P[0] * cx + P[1] * cy + P[2] * cz + P[3];
+  g.Y = P[4] * cx + P[5] * cy + P[6] * cz + P[7];
+  g.Zp = (P[8] * cx + P[9] * cy + P[10] * cz + P[11]) + 1e-7f;
+  float u = g.X / g.Zp, v = g.Y / g.Zp;
+  // Project3D normalisation followed by grid_sample's align_corners=True un-normalisation
+  float un = (u / (float)(W - 1) - 0.5f) * 2.f, vn = (v / (float)(H - 1) - 0.5f) * 2.f;
+  g.ixu = (un + 1.f) * 0.5f * (float)(W - 1);
+  g.iyu = (vn + 1.f) * 0.5f * (float)(H - 1);
+}
+
+struct Taps {
+  int x0, x1, y0, y1;
+  float wx, wy;   // weight of the x1 / y1 side
+  float mx, my;   // gradient multiplier of the border clamp (0 when clipped)
+};
+__device__ __forceinline__ void bilinear_taps(float ixu, float iyu, int H, int W, Taps& t) {
+  float ix = ixu, iy = iyu;
+  t.mx = 1.f; t.my = 1.f;
+  if (!(ix > 0.f)) { ix = 0.f; t.mx = 0.f; } else if (ix >= (float)(W - 1)) { ix = (float)(W - 1); t.mx = 0.f; }
+  if (!(iy > 0.f)) { iy = 0.f; t.my = 0.f; } else if (iy >= (float)(H - 1)) { iy = (float)(H - 1); t.my = 0.f; }
+  float fx = floorf(ix), fy = floorf(iy);
+  t.x0 = (int)fx; t.y0 = (int)fy;
+  t.wx = ix - fx; t.wy = iy - fy;
+  t.x1 = min(t.x0 + 1, W - 1); t.y1 = min(t.y0 + 1, H - 1);  // weight is 0 whenever the +1 tap is out of range
+}
+
+// ---------------------------------------------------------------------------------------------
+// identity reprojection losses (scale independent) + patched-mask sum
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float reproj_at(const float* __restrict__ xp, const float* __restrict__ tp, int y, int x,
+                                           int H, int W) {
+  // xp, tp: planar [3][H][W] of one batch element; returns 0.85*mean_c SSIM + 0.15*mean_c |t - x|
+  int ys[3] = {refl(y - 1, H), y, refl(y + 1, H)}, xs[3] = {refl(x - 1, W), x, refl(x + 1, W)};
+  float ssim_sum = 0.f, l1 = 0.f;
+  const long HW = (long)H * W;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        float xv = xp[c * HW + (long)ys[a] * W + xs[b]], tv = tp[c * HW + (long)ys[a] * W + xs[b]];
+        sx += xv; sy += tv; sxx += xv * xv; syy += tv * tv; sxy += xv * tv;
+      }
+    const float k = 1.f / 9.f;
+    float mux = sx * k, muy = sy * k;
+    float sgx = sxx * k - mux * mux, sgy = syy * k - muy * muy, sgxy = sxy * k - mux * muy;
+    float n = (2.f * mux * muy + C1) * (2.f * sgxy + C2);
+    float d = (mux * mux + muy * muy + C1) * (sgx + sgy + C2);
+    ssim_sum += fminf(fmaxf((1.f - n / d) * 0.5f, 0.f), 1.f);
+    l1 += fabsf(tp[c * HW + (long)y * W + x] - xp[c * HW + (long)y * W + x]);
+  }
+  return 0.85f * (ssim_sum / 3.f) + 0.15f * (l1 / 3.f);
+}
+
+__global__ __launch_bounds__(256) void photo_ident_kernel(const FsPhotoArgs p) {
+  const int b = blockIdx.y;
+  const long HW = (long)p.H * p.W;
+  double msum = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
+    int y = (int)(i / p.W), x = (int)(i % p.W);
+    const float* t = p.img0 + (long)b * 3 * HW;
+    for (int f = 0; f < 2; ++f) {
+      const float* s = p.img_src[f] + (long)b * 3 * HW;
+      p.ident[((long)b * 2 + f) * HW + i] = reproj_at(s, t, y, x, p.H, p.W);
+    }
+    msum += p.patched_mask ? p.patched_mask[(long)b * HW + i] : 1.0;
+  }
+  msum = wave_sum_d(msum);
+  if ((threadIdx.x & 63) == 0) atomicAdd(p.mask_sum, msum);
+}
+
+// ---------------------------------------------------------------------------------------------
+// warp: pred[s][f][b] = grid_sample(src_f, project(depth_s)), overlap mask
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void photo_warp_kernel(const FsPhotoArgs p) {
+  const int b = blockIdx.y, s = blockIdx.z >> 1, f = blockIdx.z & 1;
+  const long HW = (long)p.H * p.W;
+  const float* ge = p.geo + (long)b * GEO_STRIDE;
+  const float* src = p.img_src[f] + (long)b * 3 * HW;
+  float* pred = p.pred + (((long)s * 2 + f) * p.B + b) * 3 * HW;
+  uint8_t* ov = p.ov + (((long)s * 2 + f) * p.B + b) * HW;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
+    int y = (int)(i / p.W), x = (int)(i % p.W);
+    Geo g;
+    project_pixel(p.depth[s], b, y, x, p.H, p.W, p.dh[s], p.dw[s], ge, f, g);
+    Taps t;
+    bilinear_taps(g.ixu, g.iyu, p.H, p.W, t);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* sc = src + c * HW;
+      float v00 = sc[(long)t.y0 * p.W + t.x0], v01 = sc[(long)t.y0 * p.W + t.x1];
+      float v10 = sc[(long)t.y1 * p.W + t.x0], v11 = sc[(long)t.y1 * p.W + t.x1];
+      pred[c * HW + i] = (1.f - t.wy) * ((1.f - t.wx) * v00 + t.wx * v01) + t.wy * ((1.f - t.wx) * v10 + t.wx * v11);
+    }
+    // nearest sample of patched_mask with zeros padding (round half to even, like ATen's nearbyint)
+    float xn = nearbyintf(g.ixu), yn = nearbyintf(g.iyu);
+    bool inb = xn >= 0.f && xn <= (float)(p.W - 1) && yn >= 0.f && yn <= (float)(p.H - 1);
+    float mv = 0.f;
+    if (inb) mv = p.patched_mask ? (float)p.patched_mask[(long)b * HW + (long)yn * p.W + (long)xn] : 1.f;
+    ov[i] = (mv == 1.f) ? 1 : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// loss forward: per-pixel min over {identity_+, identity_-, reproj_+, reproj_-}, masked sum
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t hash_u32(uint32_t a) {
+  a ^= a >> 16; a *= 0x7feb352dU; a ^= a >> 15; a *= 0x846ca68bU; a ^= a >> 16;
+  return a;
+}
+__device__ __forceinline__ float tie_noise(int seed, uint32_t key) {
+  // stand-in for the reference's torch.randn(...)*1e-5 tie-break noise (monodepth2_decoder.py:258-259)
+  if (seed < 0) return 0.f;
+  uint32_t h1 = hash_u32(key * 2u + 0x9e3779b9u * (uint32_t)(seed + 1));
+  uint32_t h2 = hash_u32(h1 ^ 0x85ebca6bu);
+  float u1 = ((float)(h1 >> 8) + 1.f) * (1.f / 16777217.f), u2 = (float)(h2 >> 8) * (1.f / 16777216.f);
+  return 1e-5f * sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2);
+}
+
+__global__ __launch_bounds__(256) void photo_loss_fwd_kernel(const FsPhotoArgs p) {
+  const int b = blockIdx.y, s = blockIdx.z;
+  const long HW = (long)p.H * p.W;
+  const float* t = p.img0 + (long)b * 3 * HW;
+  double acc = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
+    int y = (int)(i / p.W), x = (int)(i % p.W);
+    float best = 0.f; int bi = 0;
+    for (int f = 0; f < 2; ++f) {
+      uint32_t key = (uint32_t)((((long)s * 2 + f) * p.B + b) * HW + i);
+      float v = p.ident[((long)b * 2 + f) * HW + i] + tie_noise(p.noise_seed, key);
+      if (f == 0 || v < best) { best = v; bi = f; }
+    }
+    for (int f = 0; f < 2; ++f) {
+      long o = (((long)s * 2 + f) * p.B + b);
+      float v = 100.f;
+      if (p.ov[o * HW + i]) v = reproj_at(p.pred + o * 3 * HW, t, y, x, p.H, p.W);
+      if (v < best) { best = v; bi = 2 + f; }
+    }
+    p.sel[((long)s * p.B + b) * HW + i] = (uint8_t)bi;
+    double pm = p.patched_mask ? p.patched_mask[(long)b * HW + i] : 1.0;
+    acc += (double)best * pm;
+  }
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) atomicAdd(p.loss_sums + s, acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// loss backward, LDS tiled: tile 32x8 pixels q; coefficients of p in tile(+)1 from pred/target in tile(+)2
+// ---------------------------------------------------------------------------------------------
+constexpr int TW = 32, TH = 8;
+constexpr int R2W = TW + 4, R2H = TH + 4;   // pred / target region
+constexpr int R1W = TW + 2, R1H = TH + 2;   // coefficient region
+
+__device__ __forceinline__ int refl_mult(int pc, int qc, int n) {
+  // how many taps delta in {-1,0,1} of window centre pc land (after reflection) on pixel qc
+  int m = 0;
+#pragma unroll
+  for (int d = -1; d <= 1; ++d) m += (refl(pc + d, n) == qc) ? 1 : 0;
+  return m;
+}
+
+__global__ __launch_bounds__(256) void photo_loss_bwd_kernel(const FsPhotoArgs p) {
+  __shared__ float s_t[3][R2H][R2W];
+  __shared__ float s_x[3][R2H][R2W];
+  __shared__ float s_coef[9][R1H][R1W];   // [c*3 + {A,B,C}]
+  __shared__ float s_red[12][4];
+  const int s = blockIdx.z / p.B, b = blockIdx.z % p.B;
+  const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+  const int H = p.H, W = p.W;
+  const long HW = (long)H * W;
+  const int tid = threadIdx.x;
+  const float* timg = p.img0 + (long)b * 3 * HW;
+  const uint8_t* sel = p.sel + ((long)s * p.B + b) * HW;
+  const float* ge = p.geo + (long)b * GEO_STRIDE;
+  const double gout = p.gout ? *p.gout : 1.0;
+  const float gscale = (float)(gout / ((double)p.S * (*p.mask_sum + 1e-6)));
+
+  for (int i = tid; i < 3 * R2H * R2W; i += 256) {
+    int c = i / (R2H * R2W), rem = i % (R2H * R2W), ry = rem / R2W, rx = rem % R2W;
+    int y = ty0 - 2 + ry, x = tx0 - 2 + rx;
+    float v = 0.f;
+    if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) v = timg[c * HW + (long)y * W + x];
+    s_t[c][ry][rx] = v;
+  }
+
+  const int qx = tx0 + (tid % TW), qy = ty0 + (tid / TW);
+  const bool qin = qx < W && qy < H;
+  float dD_total = 0.f;
+  Geo gq; gq.y0 = gq.x0 = gq.y1 = gq.x1 = 0; gq.ly = gq.lx = 0.f;
+
+  for (int f = 0; f < 2; ++f) {
+    const long o = ((long)s * 2 + f) * p.B + b;
+    const float* pred = p.pred + o * 3 * HW;
+    __syncthreads();  // previous iteration done with s_x / s_coef
+    for (int i = tid; i < 3 * R2H * R2W; i += 256) {
+      int c = i / (R2H * R2W), rem = i % (R2H * R2W), ry = rem / R2W, rx = rem % R2W;
+      int y = ty0 - 2 + ry, x = tx0 - 2 + rx;
+      float v = 0.f;
+      if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) v = pred[c * HW + (long)y * W + x];
+      s_x[c][ry][rx] = v;
+    }
+    __syncthreads();
+    // ---- coefficients at p in tile(+)1 ----
+    for (int i = tid; i < R1H * R1W; i += 256) {
+      int ry = i / R1W, rx = i % R1W;
+      int y = ty0 - 1 + ry, x = tx0 - 1 + rx;
+      float wgt = 0.f;
+      bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+      if (in && sel[(long)y * W + x] == 2 + f) {
+        float pm = p.patched_mask ? (float)p.patched_mask[(long)b * HW + (long)y * W + x] : 1.f;
+        wgt = pm * gscale * (0.85f / 3.f);
+      }
+      if (wgt == 0.f) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s_coef[k][ry][rx] = 0.f;
+        continue;
+      }
+      int ys[3] = {refl(y - 1, H) - (ty0 - 2), y - (ty0 - 2), refl(y + 1, H) - (ty0 - 2)};
+      int xs[3] = {refl(x - 1, W) - (tx0 - 2), x - (tx0 - 2), refl(x + 1, W) - (tx0 - 2)};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 3; ++bb) {
+            float xv = s_x[c][ys[a]][xs[bb]], tv = s_t[c][ys[a]][xs[bb]];
+            sx += xv; sy += tv; sxx += xv * xv; syy += tv * tv; sxy += xv * tv;
+          }
+        const float k9 = 1.f / 9.f;
+        float mux = sx * k9, muy = sy * k9;
+        float sgx = sxx * k9 - mux * mux, sgy = syy * k9 - muy * muy, sgxy = sxy * k9 - mux * muy;
+        float n1 = 2.f * mux * muy + C1, n2 = 2.f * sgxy + C2;
+        float d1 = mux * mux + muy * muy + C1, d2 = sgx + sgy + C2;
+        float n = n1 * n2, d = d1 * d2;
+        float sv = (1.f - n / d) * 0.5f;
+        float A = 0.f, Bc = 0.f, Cc = 0.f;
+        if (sv >= 0.f && sv <= 1.f) {
+          // d n / d x(q) = a1 + a2 (t(q) - muy),  d d / d x(q) = b1 + b2 (x(q) - mux)   (each tap weight 1/9)
+          float a1 = 2.f * muy * n2 * k9, a2 = 2.f * n1 * k9;
+          float b1 = 2.f * mux * d2 * k9, b2 = 2.f * d1 * k9;
+          float h = -0.5f / (d * d);
+          A = h * ((a1 - a2 * muy) * d - n * (b1 - b2 * mux));
+          Bc = -h * n * b2;
+          Cc = h * a2 * d;
+        }
+        s_coef[c * 3 + 0][ry][rx] = wgt * A;
+        s_coef[c * 3 + 1][ry][rx] = wgt * Bc;
+        s_coef[c * 3 + 2][ry][rx] = wgt * Cc;
+      }
+    }
+    __syncthreads();
+    // ---- gather d loss / d pred(q), chain through the sampler and the projection ----
+    float dP[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) dP[k] = 0.f;
+    if (qin) {
+      const int ly = tid / TW + 2, lx = tid % TW + 2;  // q inside the R2 arrays
+      float dpred[3] = {0.f, 0.f, 0.f};
+      for (int py = qy - 1; py <= qy + 1; ++py) {
+        if ((unsigned)py >= (unsigned)H) continue;
+        int my = refl_mult(py, qy, H);
+        if (!my) continue;
+        for (int px = qx - 1; px <= qx + 1; ++px) {
+          if ((unsigned)px >= (unsigned)W) continue;
+          int mx = refl_mult(px, qx, W);
+          if (!mx) continue;
+          float mult = (float)(my * mx);
+          int ry = py - (ty0 - 1), rx = px - (tx0 - 1);
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            dpred[c] += mult * (s_coef[c * 3][ry][rx] + s_coef[c * 3 + 1][ry][rx] * s_x[c][ly][lx] +
+                                s_coef[c * 3 + 2][ry][rx] * s_t[c][ly][lx]);
+        }
+      }
+      if (sel[(long)qy * W + qx] == 2 + f) {
+        float pm = p.patched_mask ? (float)p.patched_mask[(long)b * HW + (long)qy * W + qx] : 1.f;
+        float wl1 = pm * gscale * (0.15f / 3.f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float df = s_x[c][ly][lx] - s_t[c][ly][lx];
+          dpred[c] += wl1 * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
+        }
+      }
+      if (dpred[0] != 0.f || dpred[1] != 0.f || dpred[2] != 0.f) {
+        project_pixel(p.depth[s], b, qy, qx, H, W, p.dh[s], p.dw[s], ge, f, gq);
+        Taps t;
+        bilinear_taps(gq.ixu, gq.iyu, H, W, t);
+        const float* src = p.img_src[f] + (long)b * 3 * HW;
+        float gix = 0.f, giy = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float* sc = src + c * HW;
+          float v00 = sc[(long)t.y0 * W + t.x0], v01 = sc[(long)t.y0 * W + t.x1];
+          float v10 = sc[(long)t.y1 * W + t.x0], v11 = sc[(long)t.y1 * W + t.x1];
+          gix += dpred[c] * ((v01 - v00) * (1.f - t.wy) + (v11 - v10) * t.wy);
+          giy += dpred[c] * ((v10 - v00) * (1.f - t.wx) + (v11 - v01) * t.wx);
+        }
+        float du = gix * t.mx, dv = giy * t.my;   // (W-1)/2 of the sampler cancels 2/(W-1) of Project3D
+        float iz = 1.f / gq.Zp;
+        float dX = du * iz, dY = dv * iz;
+        float dZ = -(du * gq.X + dv * gq.Y) * iz * iz;
+        const float* P = ge + 18 + f * 12;
+        float pr0 = P[0] * gq.r[0] + P[1] * gq.r[1] + P[2] * gq.r[2];
+        float pr1 = P[4] * gq.r[0] + P[5] * gq.r[1] + P[6] * gq.r[2];
+        float pr2 = P[8] * gq.r[0] + P[9] * gq.r[1] + P[10] * gq.r[2];
+        dD_total += dX * pr0 + dY * pr1 + dZ * pr2;
+        float cam[3] = {gq.D * gq.r[0], gq.D * gq.r[1], gq.D * gq.r[2]};
+        float dxyz[3] = {dX, dY, dZ};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) dP[i * 4 + j] = dxyz[i] * cam[j];
+          dP[i * 4 + 3] = dxyz[i];
+        }
+      }
+    }
+    // block-reduce the 12 projection-matrix partials -> one atomic each
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      float v = wave_sum(dP[k]);
+      if ((tid & 63) == 0) s_red[k][tid >> 6] = v;
+    }
+    __syncthreads();
+    if (tid < 12) {
+      float v = s_red[tid][0] + s_red[tid][1] + s_red[tid][2] + s_red[tid][3];
+      if (v != 0.f) atomicAdd(p.dP + ((long)b * 2 + f) * 12 + tid, v);
+    }
+  }
+  // ---- transpose of the bilinear depth upsample ----
+  if (qin && dD_total != 0.f) {
+    Geo g;
+    upsample_taps(qy, qx, H, W, p.dh[s], p.dw[s], g);
+    float* dd = p.d_depth[s] + (long)b * p.dh[s] * p.dw[s];
+    const int w = p.dw[s];
+    float w00 = (1.f - g.ly) * (1.f - g.lx), w01 = (1.f - g.ly) * g.lx, w10 = g.ly * (1.f - g.lx), w11 = g.ly * g.lx;
+    if (w00 != 0.f) atomicAdd(dd + g.y0 * w + g.x0, w00 * dD_total);
+    if (w01 != 0.f) atomicAdd(dd + g.y0 * w + g.x1, w01 * dD_total);
+    if (w10 != 0.f) atomicAdd(dd + g.y1 * w + g.x0, w10 * dD_total);
+    if (w11 != 0.f) atomicAdd(dd + g.y1 * w + g.x1, w11 * dD_total);
+  }
+}
+
+// dT[f][b] (4x4, row 3 = 0) = K^T-contracted dP:  P = K3 * T[:3]  =>  dT[k][j] = sum_i K3[i][k] dP[i][j]
+__global__ void photo_pose_grad_kernel(const float* __restrict__ geo, const float* __restrict__ dP,
+                                       float* __restrict__ dT0, float* __restrict__ dT1, int B) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * 2) return;
+  int b = i >> 1, f = i & 1;
+  const float* K = geo + (long)b * GEO_STRIDE + 9;
+  const float* g = dP + ((long)b * 2 + f) * 12;
+  float* o = (f == 0 ? dT0 : dT1) + (long)b * 16;
+  for (int k = 0; k < 3; ++k)
+    for (int j = 0; j < 4; ++j) o[k * 4 + j] = K[0 * 3 + k] * g[0 * 4 + j] + K[1 * 3 + k] * g[1 * 4 + j] + K[2 * 3 + k] * g[2 * 4 + j];
+  for (int j = 0; j < 4; ++j) o[12 + j] = 0.f;
+}
+
+bool valid(const FsPhotoArgs* a) {
+  if (!a || !a->img0 || !a->img_src[0] || !a->img_src[1] || !a->geo) return false;
+  if (a->S < 1 || a->S > 4 || a->B < 1 || a->H < 2 || a->W < 2) return false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int fs_photo_setup(const float* P2, const float* T0, const float* T1, float* geo, int B, void* stream) {
+  if (!P2 || !T0 || !T1 || !geo) return FS_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(photo_setup_kernel, dim3((B + 63) / 64), dim3(64), 0, st, P2, T0, T1, geo, B);
+  return fs_launch_status();
+}
+
+extern "C" int fs_photo_identity(const FsPhotoArgs* a, void* stream) {
+  if (!valid(a) || !a->ident || !a->mask_sum) return FS_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  long HW = (long)a->H * a->W;
+  dim3 grid((unsigned)std::min<long>((HW + 255) / 256, 2048), a->B);
+  hipLaunchKernelGGL(photo_ident_kernel, grid, dim3(256), 0, st, *a);
+  return fs_launch_status();
+}
+
+extern "C" int fs_photo_warp(const FsPhotoArgs* a, void* stream) {
+  if (!valid(a) || !a->pred || !a->ov) return FS_EINVAL;
+  for (int s = 0; s < a->S; ++s) if (!a->depth[s]) return FS_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  long HW = (long)a->H * a->W;
+  dim3 grid((unsigned)std::min<long>((HW + 255) / 256, 2048), a->B, a->S * 2);
+  hipLaunchKernelGGL(photo_warp_kernel, grid, dim3(256), 0, st, *a);
+  return fs_launch_status();
+}
+
+extern "C" int fs_photo_loss_fwd(const FsPhotoArgs* a, void* stream) {
+  if (!valid(a) || !a->pred || !a->ov || !a->ident || !a->sel || !a->loss_sums) return FS_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  long HW = (long)a->H * a->W;
+  dim3 grid((unsigned)std::min<long>((HW + 255) / 256, 2048), a->B, a->S);
+  hipLaunchKernelGGL(photo_loss_fwd_kernel, grid, dim3(256), 0, st, *a);
+  return fs_launch_status();
+}
+
+extern "C" int fs_photo_loss_bwd(const FsPhotoArgs* a, void* stream) {
+  if (!valid(a) || !a->pred || !a->sel || !a->dP || !a->mask_sum) return FS_EINVAL;
+  for (int s = 0; s < a->S; ++s) if (!a->depth[s] || !a->d_depth[s]) return FS_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((a->W + TW - 1) / TW, (a->H + TH - 1) / TH, a->S * a->B);
+  hipLaunchKernelGGL(photo_loss_bwd_kernel, grid, dim3(256), 0, st, *a);
+  return fs_launch_status();
+}
+
+extern "C" int fs_photo_pose_grad(const float* geo, const float* dP, float* dT0, float* dT1, int B, void* stream) {
+  if (!geo || !dP || !dT0 || !dT1) return FS_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(photo_pose_grad_kernel, dim3((2 * B + 63) / 64), dim3(64), 0, st, geo, dP, dT0, dT1, B);
+  return fs_launch_status();
+}

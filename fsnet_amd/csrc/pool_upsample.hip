@@ -1,0 +1,256 @@
+// MaxPool 3x3/s2 (+argmax), nearest-x2 upsample + skip concat + replicate pad, and a per-channel
+// column sum (bias gradients).  All HBM-bound, NHWC, 4 channels (8/16 bytes) per lane.
+// Replaces:
+//   nn.MaxPool2d(3, 2, 1)                       resnet.py:122,206
+//   F.interpolate(nearest, x2) + torch.cat       depth_encoder.py:126-133
+//   the implicit replicate padding of upconv(i,1) depth_encoder.py:59 (materialised once here)
+//   conv bias gradients (sum over N,H,W of dY)
+#include "common.h"
+#include "fsnet_hip_internal.h"
+#include <algorithm>
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                          uint8_t* __restrict__ idx, int N, int H, int W, int C,
+                                                          int Ho, int Wo) {
+  const int CG = C / 4;
+  const long total = (long)N * Ho * Wo * CG;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int cg = (int)(i % CG); long m = i / CG;
+    int wo = (int)(m % Wo); long q = m / Wo; int ho = (int)(q % Ho); long n = q / Ho;
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bi[4] = {0, 0, 0, 0};
+    bool first = true;
+    for (int r = 0; r < 3; ++r) {
+      int h = ho * 2 - 1 + r;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int s = 0; s < 3; ++s) {
+        int w = wo * 2 - 1 + s;
+        if ((unsigned)w >= (unsigned)W) continue;
+        float v[4];
+        load4<T>(x + ((n * H + h) * W + w) * C + cg * 4, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (first || v[j] > best[j]) { best[j] = v[j]; bi[j] = r * 3 + s; }  // first max wins (ATen)
+        first = false;
+      }
+    }
+    store4<T>(y + m * C + cg * 4, best);
+    uint32_t packed = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+    *reinterpret_cast<uint32_t*>(idx + m * C + cg * 4) = packed;
+  }
+}
+
+// gather form: dx(h,w) = sum over the <=4 windows containing (h,w) whose argmax is (h,w), + addend
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                          const T* __restrict__ addend, T* __restrict__ dx, int N,
+                                                          int H, int W, int C, int Ho, int Wo) {
+  const int CG = C / 4;
+  const long total = (long)N * H * W * CG;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int cg = (int)(i % CG); long m = i / CG;
+    int w = (int)(m % W); long q = m / W; int h = (int)(q % H); long n = q / H;
+    float acc[4] = {0, 0, 0, 0};
+    if (addend) load4<T>(addend + m * C + cg * 4, acc);
+    for (int ho = (h - 1 + 1) / 2; ho <= (h + 1) / 2; ++ho) {   // windows with |h - 2ho| <= 1
+      if (ho < 0 || ho >= Ho) continue;
+      int r = h - (ho * 2 - 1);
+      if (r < 0 || r > 2) continue;
+      for (int wo = w / 2; wo <= (w + 1) / 2; ++wo) {
+        if (wo < 0 || wo >= Wo) continue;
+        int s = w - (wo * 2 - 1);
+        if (s < 0 || s > 2) continue;
+        long mo = (n * Ho + ho) * Wo + wo;
+        uint32_t packed = *reinterpret_cast<const uint32_t*>(idx + mo * C + cg * 4);
+        float g[4];
+        load4<T>(dy + mo * C + cg * 4, g);
+        int code = r * 3 + s;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if ((int)((packed >> (8 * j)) & 0xff) == code) acc[j] += g[j];
+      }
+    }
+    store4<T>(dx + m * C + cg * 4, acc);
+  }
+}
+
+// out[n, hp, wp, :] for the padded (2h+2)x(2w+2) grid = cat(up2(a), b) at the replicate-clamped pixel
+template <typename T>
+__global__ __launch_bounds__(256) void upcat_pad_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                            T* __restrict__ out, int N, int h, int w, int Ca,
+                                                            int Cb) {
+  const int H = 2 * h, W = 2 * w, Hp = H + 2, Wp = W + 2, C = Ca + Cb, CG = C / 4;
+  const long total = (long)N * Hp * Wp * CG;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int cg = (int)(i % CG); long m = i / CG;
+    int wp = (int)(m % Wp); long q = m / Wp; int hp = (int)(q % Hp); long n = q / Hp;
+    int hi = min(max(hp - 1, 0), H - 1), wi = min(max(wp - 1, 0), W - 1);
+    int c = cg * 4;
+    float v[4];
+    if (c < Ca) load4<T>(a + ((n * h + (hi >> 1)) * w + (wi >> 1)) * Ca + c, v);
+    else load4<T>(b + ((n * H + hi) * W + wi) * Cb + (c - Ca), v);
+    store4<T>(out + m * C + c, v);
+  }
+}
+
+// folded value of the padded gradient at interior pixel (hi, wi)
+template <typename T>
+__device__ inline void fold_load(const T* dpad, long n, int hi, int wi, int H, int W, int C, int c, float g[4]) {
+  const int Hp = H + 2, Wp = W + 2;
+  int hs[2] = {hi + 1, 0}, ws[2] = {wi + 1, 0};
+  int nh = 1, nw = 1;
+  if (hi == 0) { hs[1] = 0; nh = 2; } else if (hi == H - 1) { hs[1] = H + 1; nh = 2; }
+  if (wi == 0) { ws[1] = 0; nw = 2; } else if (wi == W - 1) { ws[1] = W + 1; nw = 2; }
+  g[0] = g[1] = g[2] = g[3] = 0.f;
+  for (int x = 0; x < nh; ++x)
+    for (int y = 0; y < nw; ++y) {
+      float t[4];
+      load4<T>(dpad + ((n * Hp + hs[x]) * Wp + ws[y]) * C + c, t);
+      g[0] += t[0]; g[1] += t[1]; g[2] += t[2]; g[3] += t[3];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upcat_pad_bwd_kernel(const T* __restrict__ dpad, T* __restrict__ da,
+                                                            T* __restrict__ db, int N, int h, int w, int Ca,
+                                                            int Cb) {
+  const int H = 2 * h, W = 2 * w, C = Ca + Cb;
+  const int CGa = Ca / 4, CGb = Cb / 4;
+  const long ta = (long)N * h * w * CGa, tb = (long)N * H * W * CGb;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < ta + tb; i += (long)gridDim.x * 256) {
+    if (i < ta) {
+      int cg = (int)(i % CGa); long m = i / CGa;
+      int x = (int)(m % w); long q = m / w; int y = (int)(q % h); long n = q / h;
+      float acc[4] = {0, 0, 0, 0};
+      for (int dy = 0; dy < 2; ++dy)
+        for (int dx = 0; dx < 2; ++dx) {
+          float g[4];
+          fold_load<T>(dpad, n, 2 * y + dy, 2 * x + dx, H, W, C, cg * 4, g);
+          acc[0] += g[0]; acc[1] += g[1]; acc[2] += g[2]; acc[3] += g[3];
+        }
+      store4<T>(da + m * Ca + cg * 4, acc);
+    } else {
+      long k = i - ta;
+      int cg = (int)(k % CGb); long m = k / CGb;
+      int x = (int)(m % W); long q = m / W; int y = (int)(q % H); long n = q / H;
+      float g[4];
+      fold_load<T>(dpad, n, y, x, H, W, C, Ca + cg * 4, g);
+      store4<T>(db + m * Cb + cg * 4, g);
+    }
+  }
+}
+
+// out[c] += sum_m x[m][c]   (x dense [M][C], fp32 accumulate, one atomic per channel per block)
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ x, float* __restrict__ out, long M,
+                                                          int C, int Creal) {
+  __shared__ float red[4][256];
+  const int CG = C / 4;
+  const int CGB = CG < 64 ? (CG < 16 ? 4 : 16) : 64;
+  const int PL = 256 / CGB;
+  const int cgl = threadIdx.x % CGB, pl = threadIdx.x / CGB;
+  const int cg = blockIdx.y * CGB + cgl;
+  float s[4] = {0, 0, 0, 0};
+  if (cg < CG) {
+    for (long m = (long)blockIdx.x * PL + pl; m < M; m += (long)gridDim.x * PL) {
+      float v[4];
+      load4<T>(x + m * C + cg * 4, v);
+      s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) red[j][threadIdx.x] = s[j];
+  __syncthreads();
+  if (pl == 0 && cg < CG) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = 0.f;
+      for (int k = 0; k < PL; ++k) a += red[j][k * CGB + cgl];
+      if (cg * 4 + j < Creal) atomicAdd(out + cg * 4 + j, a);
+    }
+  }
+}
+
+int grid_for(long items) {
+  long b = (items + 255) / 256;
+  return (int)std::max<long>(1, std::min<long>(b, 8192));
+}
+
+}  // namespace
+
+#define DISPATCH(KERNEL, GRID, ...)                                                                   \
+  if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(KERNEL<bf16>, GRID, dim3(256), 0, st, __VA_ARGS__);  \
+  else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(KERNEL<float>, GRID, dim3(256), 0, st, __VA_ARGS__); \
+  else return FS_EINVAL;
+
+extern "C" int fs_maxpool_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int dtype,
+                              void* stream) {
+  if (!x || !y || !idx || C % 4 != 0) return FS_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  dim3 grid(grid_for((long)N * Ho * Wo * (C / 4)));
+  if (dtype == FS_DTYPE_BF16)
+    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, (bf16*)y, idx, N, H, W, C, Ho, Wo);
+  else if (dtype == FS_DTYPE_F32)
+    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (float*)y, idx, N, H, W, C, Ho, Wo);
+  else return FS_EINVAL;
+  return fs_launch_status();
+}
+
+extern "C" int fs_maxpool_bwd(const void* dy, const uint8_t* idx, const void* addend, void* dx, int N, int H, int W,
+                              int C, int dtype, void* stream) {
+  if (!dy || !dx || !idx || C % 4 != 0) return FS_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  dim3 grid(grid_for((long)N * H * W * (C / 4)));
+  if (dtype == FS_DTYPE_BF16)
+    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)dy, idx, (const bf16*)addend, (bf16*)dx, N, H, W, C, Ho, Wo);
+  else if (dtype == FS_DTYPE_F32)
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)dy, idx, (const float*)addend, (float*)dx, N, H, W, C, Ho, Wo);
+  else return FS_EINVAL;
+  return fs_launch_status();
+}
+
+extern "C" int fs_upcat_pad_fwd(const void* a, const void* b, void* out, int N, int h, int w, int Ca, int Cb,
+                                int dtype, void* stream) {
+  if (!a || !out || (Cb > 0 && !b) || Ca % 4 != 0 || Cb % 4 != 0) return FS_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(grid_for((long)N * (2 * h + 2) * (2 * w + 2) * ((Ca + Cb) / 4)));
+  if (dtype == FS_DTYPE_BF16)
+    hipLaunchKernelGGL(upcat_pad_fwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)a, (const bf16*)b, (bf16*)out, N, h, w, Ca, Cb);
+  else if (dtype == FS_DTYPE_F32)
+    hipLaunchKernelGGL(upcat_pad_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, N, h, w, Ca, Cb);
+  else return FS_EINVAL;
+  return fs_launch_status();
+}
+
+extern "C" int fs_upcat_pad_bwd(const void* dpad, void* da, void* db, int N, int h, int w, int Ca, int Cb, int dtype,
+                                void* stream) {
+  if (!dpad || !da || (Cb > 0 && !db) || Ca % 4 != 0 || Cb % 4 != 0) return FS_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(grid_for((long)N * h * w * (Ca / 4) + (long)N * 4 * h * w * (Cb / 4)));
+  if (dtype == FS_DTYPE_BF16)
+    hipLaunchKernelGGL(upcat_pad_bwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)dpad, (bf16*)da, (bf16*)db, N, h, w, Ca, Cb);
+  else if (dtype == FS_DTYPE_F32)
+    hipLaunchKernelGGL(upcat_pad_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)dpad, (float*)da, (float*)db, N, h, w, Ca, Cb);
+  else return FS_EINVAL;
+  return fs_launch_status();
+}
+
+extern "C" int fs_channel_sum(const void* x, float* out, int64_t M, int C, int Creal, int dtype, void* stream) {
+  if (!x || !out || C % 4 != 0 || M <= 0) return FS_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int CG = C / 4;
+  const int CGB = CG < 64 ? (CG < 16 ? 4 : 16) : 64;
+  const int PL = 256 / CGB;
+  dim3 grid((unsigned)std::max<long>(1, std::min<long>((M + PL - 1) / PL / 8 + 1, 1024)), (CG + CGB - 1) / CGB);
+  if (dtype == FS_DTYPE_BF16)
+    hipLaunchKernelGGL(channel_sum_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, out, (long)M, C, Creal);
+  else if (dtype == FS_DTYPE_F32)
+    hipLaunchKernelGGL(channel_sum_kernel<float>, grid, dim3(256), 0, st, (const float*)x, out, (long)M, C, Creal);
+  else return FS_EINVAL;
+  return fs_launch_status();
+}

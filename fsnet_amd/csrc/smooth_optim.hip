@@ -1,0 +1,234 @@
+// Edge-aware smoothness loss (fwd + bwd, all scales per launch), the final loss assembly, and the
+// fused gradient-norm / clip / Adam update over a flat parameter arena.
+// Replaces:
+//   get_smooth_loss + mean-normalised disparity        monodepth_utils.py:168-181, monodepth2_decoder.py:294-299
+//   F.adaptive_avg_pool2d(original_image_0, (h, w))     monodepth2_decoder.py:214-219
+//   loss bookkeeping (loss/s, smooth_loss/s, total)     monodepth2_decoder.py:292-304, 343
+//   clip_grad_norm_ + torch.optim.Adam.step             base_training_hooks.py:46-49, optimizers.py:7-8
+#include "common.h"
+#include "fsnet_hip_internal.h"
+#include <algorithm>
+
+namespace {
+
+// colour pyramid: out_s[b][c][y][x] = mean of the (H/h)x(W/w) block (adaptive_avg_pool2d with integer ratio)
+__global__ __launch_bounds__(256) void color_pyramid_kernel(const float* __restrict__ img, float* __restrict__ out,
+                                                            int B, int H, int W, int h, int w) {
+  const int ry = H / h, rx = W / w;
+  const long total = (long)B * 3 * h * w;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int x = (int)(i % w); long q = i / w; int y = (int)(q % h); long bc = q / h;
+    const float* src = img + bc * H * W;
+    float s = 0.f;
+    for (int a = 0; a < ry; ++a)
+      for (int c = 0; c < rx; ++c) s += src[(long)(y * ry + a) * W + x * rx + c];
+    out[i] = s / (float)(ry * rx);
+  }
+}
+
+// per (scale, batch) sum of disp -> sums[s][b]  (mean = sums / (h*w))
+__global__ __launch_bounds__(256) void smooth_mean_kernel(const FsSmoothArgs p) {
+  const int s = blockIdx.z, b = blockIdx.y;
+  const long hw = (long)p.h[s] * p.w[s];
+  const float* d = p.disp[s] + (long)b * hw;
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < hw; i += (long)gridDim.x * 256) acc += d[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) atomicAdd(p.disp_sum + s * p.B + b, (double)acc);
+}
+
+__device__ __forceinline__ float edge_w(const float* __restrict__ col, long hw, long i0, long i1) {
+  float g = fabsf(col[i0] - col[i1]) + fabsf(col[hw + i0] - col[hw + i1]) + fabsf(col[2 * hw + i0] - col[2 * hw + i1]);
+  return expf(-g * (1.f / 3.f));
+}
+
+// forward: sx[s] = sum |nd(x)-nd(x+1)| e^{-gx},  sy[s] likewise (nd = disp / (mean + 1e-7))
+__global__ __launch_bounds__(256) void smooth_fwd_kernel(const FsSmoothArgs p) {
+  const int s = blockIdx.z, b = blockIdx.y;
+  const int h = p.h[s], w = p.w[s];
+  const long hw = (long)h * w;
+  const float* d = p.disp[s] + (long)b * hw;
+  const float* col = p.color[s] + (long)b * 3 * hw;
+  const float inv = 1.f / ((float)(p.disp_sum[s * p.B + b] / (double)hw) + 1e-7f);
+  float ax = 0.f, ay = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < hw; i += (long)gridDim.x * 256) {
+    int x = (int)(i % w), y = (int)(i / w);
+    float v = d[i] * inv;
+    if (x + 1 < w) ax += fabsf(v - d[i + 1] * inv) * edge_w(col, hw, i, i + 1);
+    if (y + 1 < h) ay += fabsf(v - d[i + w] * inv) * edge_w(col, hw, i, i + w);
+  }
+  ax = wave_sum(ax); ay = wave_sum(ay);
+  if ((threadIdx.x & 63) == 0) { atomicAdd(p.sm_sums + s * 2, (double)ax); atomicAdd(p.sm_sums + s * 2 + 1, (double)ay); }
+}
+
+// d loss / d nd at pixel i (both neighbours on each axis), scaled by the loss weights
+__device__ __forceinline__ float smooth_dnd(const float* __restrict__ d, const float* __restrict__ col, long hw, int h,
+                                            int w, int y, int x, float inv, float kx, float ky) {
+  long i = (long)y * w + x;
+  float v = d[i] * inv, g = 0.f;
+  auto sgn = [](float a) { return a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f); };
+  if (x + 1 < w) g += kx * sgn(v - d[i + 1] * inv) * edge_w(col, hw, i, i + 1);
+  if (x > 0) g -= kx * sgn(d[i - 1] * inv - v) * edge_w(col, hw, i - 1, i);
+  if (y + 1 < h) g += ky * sgn(v - d[i + w] * inv) * edge_w(col, hw, i, i + w);
+  if (y > 0) g -= ky * sgn(d[i - w] * inv - v) * edge_w(col, hw, i - w, i);
+  return g;
+}
+
+// backward pass 1: dot[s][b] = sum_i dnd(i) * disp(i)   (coupling through the mean normalisation)
+__global__ __launch_bounds__(256) void smooth_bwd_dot_kernel(const FsSmoothArgs p) {
+  const int s = blockIdx.z, b = blockIdx.y;
+  const int h = p.h[s], w = p.w[s];
+  const long hw = (long)h * w;
+  const float* d = p.disp[s] + (long)b * hw;
+  const float* col = p.color[s] + (long)b * 3 * hw;
+  const float inv = 1.f / ((float)(p.disp_sum[s * p.B + b] / (double)hw) + 1e-7f);
+  const float gout = p.gout ? (float)*p.gout : 1.f;
+  const float wgt = gout * 1e-5f / (float)(1 << p.scale_id[s]) / (float)p.S;
+  const float kx = wgt / (float)((long)p.B * h * (w - 1)), ky = wgt / (float)((long)p.B * (h - 1) * w);
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < hw; i += (long)gridDim.x * 256) {
+    int x = (int)(i % w), y = (int)(i / w);
+    acc += smooth_dnd(d, col, hw, h, w, y, x, inv, kx, ky) * d[i];
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) atomicAdd(p.dot + s * p.B + b, (double)acc);
+}
+
+// backward pass 2: d_disp(i) = dnd(i)*inv - dot * inv^2 / (h*w)
+__global__ __launch_bounds__(256) void smooth_bwd_apply_kernel(const FsSmoothArgs p) {
+  const int s = blockIdx.z, b = blockIdx.y;
+  const int h = p.h[s], w = p.w[s];
+  const long hw = (long)h * w;
+  const float* d = p.disp[s] + (long)b * hw;
+  const float* col = p.color[s] + (long)b * 3 * hw;
+  float* dd = p.d_disp[s] + (long)b * hw;
+  const float inv = 1.f / ((float)(p.disp_sum[s * p.B + b] / (double)hw) + 1e-7f);
+  const float gout = p.gout ? (float)*p.gout : 1.f;
+  const float wgt = gout * 1e-5f / (float)(1 << p.scale_id[s]) / (float)p.S;
+  const float kx = wgt / (float)((long)p.B * h * (w - 1)), ky = wgt / (float)((long)p.B * (h - 1) * w);
+  const float corr = (float)p.dot[s * p.B + b] * inv * inv / (float)hw;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < hw; i += (long)gridDim.x * 256) {
+    int x = (int)(i % w), y = (int)(i / w);
+    dd[i] = smooth_dnd(d, col, hw, h, w, y, x, inv, kx, ky) * inv - corr;
+  }
+}
+
+// loss assembly: out[0..S) = loss/s (f64), out[S..2S) = smooth_loss/s, out[2S] = total
+__global__ void loss_finalize_kernel(const double* __restrict__ loss_sums, const double* __restrict__ mask_sum,
+                                     const double* __restrict__ sm_sums, const FsSmoothArgs p, double* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double total = 0.0;
+  for (int s = 0; s < p.S; ++s) {
+    const int h = p.h[s], w = p.w[s];
+    float sx = (float)(sm_sums[s * 2] / (double)((long)p.B * h * (w - 1)));
+    float sy = (float)(sm_sums[s * 2 + 1] / (double)((long)p.B * (h - 1) * w));
+    float sm = (sx + sy) * 1e-5f / (float)(1 << p.scale_id[s]);   // fp32 like the reference's smooth_loss
+    double l = loss_sums[s] / (*mask_sum + 1e-6) + (double)sm;
+    out[s] = l; out[p.S + s] = (double)sm;
+    total += l;
+  }
+  out[2 * p.S] = total / (double)p.S;
+}
+
+// ---------------------------------------------------------------------------------------------
+// optimizer
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, double* __restrict__ out) {
+  double acc = 0.0;
+  long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * 256 * 4;
+  for (; i + 3 < n; i += stride) {
+    float4 v = *reinterpret_cast<const float4*>(g + i);
+    acc += (double)(v.x * v.x + v.y * v.y) + (double)(v.z * v.z + v.w * v.w);
+  }
+  if (i < n) for (long k = i; k < n && k < i + 4; ++k) acc += (double)g[k] * g[k];
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n, float lr,
+                                                   float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                   float max_norm, const double* __restrict__ sumsq,
+                                                   float grad_scale) {
+  float coef = grad_scale;
+  if (sumsq && max_norm > 0.f) {
+    float norm = (float)sqrt(*sumsq) * grad_scale;
+    coef *= fminf(max_norm / (norm + 1e-6f), 1.f);
+  }
+  const float step = lr / bc1;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float gi = g[i] * coef;
+    float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] = pi - step * mi / (sqrtf(vi) / bc2_sqrt + eps);
+  }
+}
+
+}  // namespace
+
+extern "C" int fs_color_pyramid(const float* img, float* out, int B, int H, int W, int h, int w, void* stream) {
+  if (!img || !out || h <= 0 || w <= 0 || H % h != 0 || W % w != 0) return FS_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  long total = (long)B * 3 * h * w;
+  hipLaunchKernelGGL(color_pyramid_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, img, out, B, H, W, h, w);
+  return fs_launch_status();
+}
+
+static bool smooth_valid(const FsSmoothArgs* a) {
+  if (!a || a->S < 1 || a->S > 4 || a->B < 1 || !a->disp_sum) return false;
+  for (int s = 0; s < a->S; ++s) if (!a->disp[s] || !a->color[s] || a->h[s] < 2 || a->w[s] < 2) return false;
+  return true;
+}
+static dim3 smooth_grid(const FsSmoothArgs* a) {
+  long hw = (long)a->h[0] * a->w[0];
+  for (int s = 1; s < a->S; ++s) hw = std::max<long>(hw, (long)a->h[s] * a->w[s]);
+  return dim3((unsigned)std::min<long>((hw + 255) / 256, 512), a->B, a->S);
+}
+
+extern "C" int fs_smooth_mean(const FsSmoothArgs* a, void* stream) {
+  if (!smooth_valid(a)) return FS_EINVAL;
+  hipLaunchKernelGGL(smooth_mean_kernel, smooth_grid(a), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a);
+  return fs_launch_status();
+}
+extern "C" int fs_smooth_fwd(const FsSmoothArgs* a, void* stream) {
+  if (!smooth_valid(a) || !a->sm_sums) return FS_EINVAL;
+  hipLaunchKernelGGL(smooth_fwd_kernel, smooth_grid(a), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a);
+  return fs_launch_status();
+}
+extern "C" int fs_smooth_bwd(const FsSmoothArgs* a, void* stream) {
+  if (!smooth_valid(a) || !a->dot) return FS_EINVAL;
+  for (int s = 0; s < a->S; ++s) if (!a->d_disp[s]) return FS_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(smooth_bwd_dot_kernel, smooth_grid(a), dim3(256), 0, st, *a);
+  hipLaunchKernelGGL(smooth_bwd_apply_kernel, smooth_grid(a), dim3(256), 0, st, *a);
+  return fs_launch_status();
+}
+extern "C" int fs_loss_finalize(const double* loss_sums, const double* mask_sum, const double* sm_sums,
+                                const FsSmoothArgs* a, double* out, void* stream) {
+  if (!loss_sums || !mask_sum || !sm_sums || !a || !out) return FS_EINVAL;
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), loss_sums, mask_sum, sm_sums, *a, out);
+  return fs_launch_status();
+}
+
+extern "C" int fs_sumsq(const float* g, int64_t n, double* out, void* stream) {
+  if (!g || !out || n <= 0) return FS_EINVAL;
+  long blocks = std::min<long>((n / 4 + 255) / 256 + 1, 2048);
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g, (long)n, out);
+  return fs_launch_status();
+}
+
+extern "C" int fs_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, int step, float max_norm, const double* sumsq,
+                            float grad_scale, void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || step < 1) return FS_EINVAL;
+  float bc1 = 1.f - (float)pow((double)beta1, (double)step);
+  float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  long blocks = std::min<long>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v,
+                     (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, max_norm, sumsq, grad_scale);
+  return fs_launch_status();
+}

@@ -40,6 +40,59 @@ class FsWgradArgs(C.Structure):
     ]
 
 
+class FsBnApplyArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("res", C.c_void_p), ("y", C.c_void_p),
+        ("stats", C.c_void_p), ("stats2", C.c_void_p),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p), ("gamma2", C.c_void_p), ("beta2", C.c_void_p),
+        ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+        ("running_mean2", C.c_void_p), ("running_var2", C.c_void_p),
+        ("num_batches_tracked", C.c_void_p), ("num_batches_tracked2", C.c_void_p),
+        ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p),
+        ("save_mean2", C.c_void_p), ("save_invstd2", C.c_void_p),
+        ("count", C.c_double), ("eps", C.c_float), ("momentum", C.c_float),
+        ("yN", C.c_int64), ("yH", C.c_int64), ("yW", C.c_int64),
+        ("M", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("relu", C.c_int32), ("pad_out", C.c_int32),
+    ]
+
+
+class FsBnBwdArgs(C.Structure):
+    _fields_ = [
+        ("dout", C.c_void_p), ("y", C.c_void_p), ("x", C.c_void_p), ("dx", C.c_void_p), ("g_out", C.c_void_p),
+        ("sums", C.c_void_p), ("sums_local", C.c_void_p),
+        ("gamma", C.c_void_p), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p),
+        ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
+        ("count", C.c_double),
+        ("gN", C.c_int64), ("gH", C.c_int64), ("gW", C.c_int64),
+        ("yN", C.c_int64), ("yH", C.c_int64), ("yW", C.c_int64),
+        ("M", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("relu", C.c_int32), ("fold", C.c_int32),
+    ]
+
+
+class FsPhotoArgs(C.Structure):
+    _fields_ = [
+        ("img0", C.c_void_p), ("img_src", C.c_void_p * 2), ("patched_mask", C.c_void_p),
+        ("depth", C.c_void_p * 4), ("geo", C.c_void_p),
+        ("pred", C.c_void_p), ("ov", C.c_void_p), ("ident", C.c_void_p), ("sel", C.c_void_p),
+        ("loss_sums", C.c_void_p), ("mask_sum", C.c_void_p),
+        ("d_depth", C.c_void_p * 4), ("dP", C.c_void_p), ("gout", C.c_void_p),
+        ("dh", C.c_int32 * 4), ("dw", C.c_int32 * 4),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("S", C.c_int32),
+        ("noise_seed", C.c_int32),
+    ]
+
+
+class FsSmoothArgs(C.Structure):
+    _fields_ = [
+        ("disp", C.c_void_p * 4), ("color", C.c_void_p * 4), ("d_disp", C.c_void_p * 4),
+        ("disp_sum", C.c_void_p), ("sm_sums", C.c_void_p), ("dot", C.c_void_p), ("gout", C.c_void_p),
+        ("h", C.c_int32 * 4), ("w", C.c_int32 * 4), ("scale_id", C.c_int32 * 4),
+        ("B", C.c_int32), ("S", C.c_int32),
+    ]
+
+
 _lib = None
 
 

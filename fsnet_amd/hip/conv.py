@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from .lib import lib, check, stream_ptr, FsConvArgs, FsWgradArgs, FS_DTYPE_BF16, FS_DTYPE_F32
+from .binding import lib, check, stream_ptr, FsConvArgs, FsWgradArgs, FS_DTYPE_BF16, FS_DTYPE_F32
 
 
 def dtype_code(dtype):

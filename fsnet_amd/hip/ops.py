@@ -1,0 +1,290 @@
+"""Thin host wrappers (ctypes -> libfsnet_hip.so) for the non-conv kernels.  torch tensors are used
+only as device memory + stream ordering; every arithmetic step runs in the HIP library."""
+import ctypes as C
+
+import torch
+
+from .binding import (lib, check, stream_ptr, FsBnApplyArgs, FsBnBwdArgs, FsPhotoArgs, FsSmoothArgs)
+from .conv import dtype_code
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def nchw_to_nhwc(a, b, cp, dtype):
+    """a (and optionally b, concatenated along C): NCHW fp32 -> NHWC [N,H,W,cp] in `dtype`."""
+    a = a.contiguous()
+    N, Ca, H, W = a.shape
+    Cb = 0
+    if b is not None:
+        b = b.contiguous()
+        Cb = b.shape[1]
+    out = torch.empty(N, H, W, cp, dtype=dtype, device=a.device)
+    check(lib.fs_nchw_to_nhwc(a.data_ptr(), _p(b), out.data_ptr(), N, Ca, Cb, H, W, cp, dtype_code(dtype),
+                              stream_ptr()), "nchw_to_nhwc")
+    return out
+
+
+class BnState:
+    """Device-side state of one BatchNorm invocation (saved for backward)."""
+    __slots__ = ("mean", "invstd", "count")
+
+    def __init__(self, C, device):
+        self.mean = torch.empty(C, dtype=torch.float32, device=device)
+        self.invstd = torch.empty(C, dtype=torch.float32, device=device)
+        self.count = 0.0
+
+
+def bn_apply(x, stats, bn, st, y, H, W, count, relu=True, pad_out=False, res=None, stats2=None, bn2=None, st2=None,
+             track=True):
+    """x: dense [N,H,W,C] raw conv output.  bn/bn2: dict(weight,bias,running_mean,running_var,nbt)."""
+    a = FsBnApplyArgs()
+    Cc = x.shape[-1]
+    a.x, a.res, a.y = x.data_ptr(), _p(res), y.data_ptr()
+    a.stats, a.stats2 = stats.data_ptr(), _p(stats2)
+    a.gamma, a.beta = bn["weight"].data_ptr(), bn["bias"].data_ptr()
+    if track:
+        a.running_mean, a.running_var = bn["running_mean"].data_ptr(), bn["running_var"].data_ptr()
+        a.num_batches_tracked = bn["num_batches_tracked"].data_ptr()
+    a.save_mean, a.save_invstd = st.mean.data_ptr(), st.invstd.data_ptr()
+    st.count = float(count)
+    if bn2 is not None:
+        a.gamma2, a.beta2 = bn2["weight"].data_ptr(), bn2["bias"].data_ptr()
+        if track:
+            a.running_mean2, a.running_var2 = bn2["running_mean"].data_ptr(), bn2["running_var"].data_ptr()
+            a.num_batches_tracked2 = bn2["num_batches_tracked"].data_ptr()
+        a.save_mean2, a.save_invstd2 = st2.mean.data_ptr(), st2.invstd.data_ptr()
+        st2.count = float(count)
+    a.count, a.eps, a.momentum = float(count), BN_EPS, BN_MOMENTUM
+    if pad_out:
+        assert y.shape[1] == H + 2 and y.shape[2] == W + 2
+    a.yN, a.yH, a.yW = y.stride(0), y.stride(1), y.stride(2)
+    a.M, a.C, a.H, a.W = x.shape[0] * H * W, Cc, H, W
+    a.relu, a.pad_out = int(relu), int(pad_out)
+    check(lib.fs_bn_apply(C.byref(a), dtype_code(x.dtype), stream_ptr()), "bn_apply")
+    return y
+
+
+def bn_backward(dout, y, x, gamma, st, dx, dgamma, dbeta, H, W, relu=True, fold=False, g_out=None, sums=None,
+                allreduce=None):
+    """Two-pass BN backward.  dout: grad w.r.t. the block output (strided view, or the padded buffer
+    when fold=True); y: saved output activation (interior view) for the ReLU mask."""
+    Cc = x.shape[-1]
+    a = FsBnBwdArgs()
+    if sums is None:
+        sums = torch.zeros(2, Cc, dtype=torch.float64, device=x.device)
+    else:
+        sums.zero_()
+    a.dout, a.y, a.x, a.dx, a.g_out = dout.data_ptr(), _p(y), x.data_ptr(), dx.data_ptr(), _p(g_out)
+    a.sums = sums.data_ptr()
+    a.gamma, a.save_mean, a.save_invstd = gamma.data_ptr(), st.mean.data_ptr(), st.invstd.data_ptr()
+    a.dgamma, a.dbeta = _p(dgamma), _p(dbeta)
+    a.count = st.count
+    a.gN, a.gH, a.gW = dout.stride(0), dout.stride(1), dout.stride(2)
+    if y is not None:
+        a.yN, a.yH, a.yW = y.stride(0), y.stride(1), y.stride(2)
+    a.M, a.C, a.H, a.W = x.shape[0] * H * W, Cc, H, W
+    a.relu, a.fold = int(relu), int(fold)
+    code = dtype_code(x.dtype)
+    check(lib.fs_bn_bwd_reduce(C.byref(a), code, stream_ptr()), "bn_bwd_reduce")
+    if allreduce is not None:
+        local = sums.clone()
+        a.sums_local = local.data_ptr()
+        allreduce(sums)
+    check(lib.fs_bn_bwd_apply(C.byref(a), code, stream_ptr()), "bn_bwd_apply")
+    return dx
+
+
+def maxpool_fwd(x):
+    N, H, W, Cc = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty(N, Ho, Wo, Cc, dtype=x.dtype, device=x.device)
+    idx = torch.empty(N, Ho, Wo, Cc, dtype=torch.uint8, device=x.device)
+    check(lib.fs_maxpool_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr(), N, H, W, Cc, dtype_code(x.dtype),
+                             stream_ptr()), "maxpool_fwd")
+    return y, idx
+
+
+def maxpool_bwd(dy, idx, H, W, addend=None):
+    N, Ho, Wo, Cc = dy.shape
+    dx = torch.empty(N, H, W, Cc, dtype=dy.dtype, device=dy.device)
+    check(lib.fs_maxpool_bwd(dy.data_ptr(), idx.data_ptr(), _p(addend), dx.data_ptr(), N, H, W, Cc,
+                             dtype_code(dy.dtype), stream_ptr()), "maxpool_bwd")
+    return dx
+
+
+def upcat_pad_fwd(a, b):
+    N, h, w, Ca = a.shape
+    Cb = b.shape[3] if b is not None else 0
+    out = torch.empty(N, 2 * h + 2, 2 * w + 2, Ca + Cb, dtype=a.dtype, device=a.device)
+    check(lib.fs_upcat_pad_fwd(a.data_ptr(), _p(b), out.data_ptr(), N, h, w, Ca, Cb, dtype_code(a.dtype),
+                               stream_ptr()), "upcat_pad_fwd")
+    return out
+
+
+def upcat_pad_bwd(dpad, h, w, Ca, Cb):
+    N = dpad.shape[0]
+    da = torch.empty(N, h, w, Ca, dtype=dpad.dtype, device=dpad.device)
+    db = torch.empty(N, 2 * h, 2 * w, Cb, dtype=dpad.dtype, device=dpad.device) if Cb else None
+    check(lib.fs_upcat_pad_bwd(dpad.data_ptr(), da.data_ptr(), _p(db), N, h, w, Ca, Cb, dtype_code(dpad.dtype),
+                               stream_ptr()), "upcat_pad_bwd")
+    return da, db
+
+
+def channel_sum(x, out, creal):
+    """out[c] += sum over rows of dense x [..., C]."""
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    check(lib.fs_channel_sum(x.data_ptr(), out.data_ptr(), M, Cc, creal, dtype_code(x.dtype), stream_ptr()),
+          "channel_sum")
+
+
+def depth_head_fwd(logits, bins, K, min_depth, max_depth):
+    N, H, W, Cl = logits.shape
+    depth = torch.empty(N, 1, H, W, dtype=torch.float32, device=logits.device)
+    disp = torch.empty(N, 1, H, W, dtype=torch.float32, device=logits.device)
+    check(lib.fs_depth_head_fwd(logits.data_ptr(), bins.data_ptr(), depth.data_ptr(), disp.data_ptr(), N * H * W, K,
+                                Cl, float(min_depth), float(max_depth), stream_ptr()), "depth_head_fwd")
+    return depth, disp
+
+
+def depth_head_bwd(logits, bins, d_depth, d_disp, K, min_depth, max_depth, dtype):
+    N, H, W, Cl = logits.shape
+    dl = torch.empty(N, H, W, Cl, dtype=dtype, device=logits.device)
+    check(lib.fs_depth_head_bwd(logits.data_ptr(), bins.data_ptr(), _p(d_depth), _p(d_disp), dl.data_ptr(),
+                                N * H * W, K, Cl, float(min_depth), float(max_depth), dtype_code(dtype),
+                                stream_ptr()), "depth_head_bwd")
+    return dl
+
+
+def pose_tail_fwd(x, nframes, invert):
+    B, h, w, Cx = x.shape
+    aa = torch.empty(B, nframes, 1, 3, dtype=torch.float32, device=x.device)
+    tr = torch.empty(B, nframes, 1, 3, dtype=torch.float32, device=x.device)
+    T = torch.empty(B, 4, 4, dtype=torch.float32, device=x.device)
+    check(lib.fs_pose_tail_fwd(x.data_ptr(), aa.data_ptr(), tr.data_ptr(), T.data_ptr(), B, h * w, Cx, nframes,
+                               int(invert), stream_ptr()), "pose_tail_fwd")
+    return aa, tr, T
+
+
+def pose_tail_bwd(x, dT, nframes, invert, dtype):
+    B, h, w, Cx = x.shape
+    dx = torch.empty(B, h, w, Cx, dtype=dtype, device=x.device)
+    check(lib.fs_pose_tail_bwd(x.data_ptr(), dT.data_ptr(), dx.data_ptr(), B, h * w, Cx, nframes, int(invert),
+                               dtype_code(dtype), stream_ptr()), "pose_tail_bwd")
+    return dx
+
+
+class PhotometricLoss:
+    """Fused loss chain for one batch geometry (B, H, W, scales).  forward() returns the loss
+    vector (f64 [2S+1]: loss/s, smooth_loss/s, total); backward() returns d depth_s and dT_f."""
+
+    def __init__(self, B, H, W, scales, device, min_depth, max_depth):
+        self.B, self.H, self.W = B, H, W
+        self.scales = list(scales)
+        S = self.S = len(self.scales)
+        self.device = device
+        f32, f64, u8 = torch.float32, torch.float64, torch.uint8
+        self.geo = torch.zeros(B, 48, dtype=f32, device=device)
+        self.pred = torch.empty(S, 2, B, 3, H, W, dtype=f32, device=device)
+        self.ov = torch.empty(S, 2, B, H, W, dtype=u8, device=device)
+        self.ident = torch.empty(B, 2, H, W, dtype=f32, device=device)
+        self.sel = torch.empty(S, B, H, W, dtype=u8, device=device)
+        # accumulators zeroed every step in one memset: loss_sums[S] mask_sum[1] disp_sum[S*B] sm_sums[2S] dot[S*B]
+        self.n_acc = S + 1 + S * B + 2 * S + S * B
+        self.acc = torch.zeros(self.n_acc, dtype=f64, device=device)
+        o = 0
+        self.loss_sums = self.acc[o:o + S]; o += S
+        self.mask_sum = self.acc[o:o + 1]; o += 1
+        self.disp_sum = self.acc[o:o + S * B]; o += S * B
+        self.sm_sums = self.acc[o:o + 2 * S]; o += 2 * S
+        self.dot = self.acc[o:o + S * B]
+        self.out = torch.zeros(2 * S + 1, dtype=f64, device=device)
+        self.hw = [(H >> s, W >> s) for s in self.scales]
+        self.color = [None] * S
+        self.dP = torch.zeros(B, 2, 12, dtype=f32, device=device)
+        self.d_depth = [torch.zeros(B, 1, h, w, dtype=f32, device=device) for (h, w) in self.hw]
+        self.d_disp = [torch.empty(B, 1, h, w, dtype=f32, device=device) for (h, w) in self.hw]
+        self.dT = [torch.zeros(B, 4, 4, dtype=f32, device=device) for _ in range(2)]
+        self.pyr = [None if s == 0 else torch.empty(B, 3, H >> s, W >> s, dtype=f32, device=device)
+                    for s in self.scales]
+        self._pa = FsPhotoArgs()
+        self._sa = FsSmoothArgs()
+
+    def _fill(self, img0, srcs, patched_mask, depths, disps, noise_seed, gout):
+        pa, sa = self._pa, self._sa
+        pa.img0 = img0.data_ptr()
+        pa.img_src[0], pa.img_src[1] = srcs[0].data_ptr(), srcs[1].data_ptr()
+        pa.patched_mask = _p(patched_mask)
+        pa.geo = self.geo.data_ptr()
+        pa.pred, pa.ov, pa.ident, pa.sel = self.pred.data_ptr(), self.ov.data_ptr(), self.ident.data_ptr(), self.sel.data_ptr()
+        pa.loss_sums, pa.mask_sum = self.loss_sums.data_ptr(), self.mask_sum.data_ptr()
+        pa.dP = self.dP.data_ptr()
+        pa.gout = _p(gout)
+        pa.B, pa.H, pa.W, pa.S, pa.noise_seed = self.B, self.H, self.W, self.S, int(noise_seed)
+        sa.disp_sum, sa.sm_sums, sa.dot = self.disp_sum.data_ptr(), self.sm_sums.data_ptr(), self.dot.data_ptr()
+        sa.gout = _p(gout)
+        sa.B, sa.S = self.B, self.S
+        for i, (h, w) in enumerate(self.hw):
+            pa.depth[i] = depths[i].data_ptr()
+            pa.dh[i], pa.dw[i] = h, w
+            pa.d_depth[i] = self.d_depth[i].data_ptr()
+            sa.disp[i] = disps[i].data_ptr()
+            sa.color[i] = (img0 if self.scales[i] == 0 else self.pyr[i]).data_ptr()
+            sa.d_disp[i] = self.d_disp[i].data_ptr()
+            sa.h[i], sa.w[i], sa.scale_id[i] = h, w, self.scales[i]
+
+    def forward(self, img0, srcs, P2, Ts, patched_mask, depths, disps, noise_seed=-1):
+        """img0, srcs[2]: NCHW fp32; P2 [B,3,4] fp32; Ts[2]: [B,4,4] fp32; patched_mask f64 [B,H,W] or None;
+        depths/disps: per scale [B,1,h,w] fp32 contiguous."""
+        st = stream_ptr()
+        assert img0.is_contiguous() and all(s.is_contiguous() for s in srcs)
+        if patched_mask is not None:
+            assert patched_mask.dtype == torch.float64 and patched_mask.is_contiguous()
+        self._keep = (img0, srcs, patched_mask, depths, disps, noise_seed)
+        self._fill(img0, srcs, patched_mask, depths, disps, noise_seed, None)
+        self.acc.zero_()
+        pa, sa = C.byref(self._pa), C.byref(self._sa)
+        check(lib.fs_photo_setup(P2.data_ptr(), Ts[0].data_ptr(), Ts[1].data_ptr(), self.geo.data_ptr(), self.B, st),
+              "photo_setup")
+        for i, s in enumerate(self.scales):
+            if s != 0:
+                check(lib.fs_color_pyramid(img0.data_ptr(), self.pyr[i].data_ptr(), self.B, self.H, self.W,
+                                           self.hw[i][0], self.hw[i][1], st), "color_pyramid")
+        check(lib.fs_photo_identity(pa, st), "photo_identity")
+        check(lib.fs_photo_warp(pa, st), "photo_warp")
+        check(lib.fs_photo_loss_fwd(pa, st), "photo_loss_fwd")
+        check(lib.fs_smooth_mean(sa, st), "smooth_mean")
+        check(lib.fs_smooth_fwd(sa, st), "smooth_fwd")
+        check(lib.fs_loss_finalize(self.loss_sums.data_ptr(), self.mask_sum.data_ptr(), self.sm_sums.data_ptr(), sa,
+                                   self.out.data_ptr(), st), "loss_finalize")
+        return self.out
+
+    def backward(self, gout=None):
+        """gout: device f64 scalar (upstream grad of total loss) or None (=1)."""
+        st = stream_ptr()
+        img0, srcs, patched_mask, depths, disps, noise_seed = self._keep
+        self._fill(img0, srcs, patched_mask, depths, disps, noise_seed, gout)
+        pa, sa = C.byref(self._pa), C.byref(self._sa)
+        for d in self.d_depth:
+            d.zero_()
+        self.dP.zero_()
+        check(lib.fs_photo_loss_bwd(pa, st), "photo_loss_bwd")
+        check(lib.fs_photo_pose_grad(self.geo.data_ptr(), self.dP.data_ptr(), self.dT[0].data_ptr(),
+                                     self.dT[1].data_ptr(), self.B, st), "photo_pose_grad")
+        check(lib.fs_smooth_bwd(sa, st), "smooth_bwd")
+        return self.d_depth, self.d_disp, self.dT
+
+
+def sumsq(g, out):
+    check(lib.fs_sumsq(g.data_ptr(), g.numel(), out.data_ptr(), stream_ptr()), "sumsq")
+
+
+def adam_step(p, g, m, v, lr, b1, b2, eps, wd, step, max_norm=0.0, sumsq_buf=None, grad_scale=1.0):
+    check(lib.fs_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(b1),
+                           float(b2), float(eps), float(wd), int(step), float(max_norm or 0.0), _p(sumsq_buf),
+                           float(grad_scale), stream_ptr()), "adam_step")

@@ -15,6 +15,31 @@ SIGNATURES = {
     "fs_conv_wgrad": (C.c_int, [P, I, P]),
     "fs_pack_weights": (C.c_int, [P, P, I, I, I, I, I, I, L, I, I, P]),
     "fs_nchw_to_nhwc": (C.c_int, [P, P, P, I, I, I, I, I, I, I, P]),
+    "fs_bn_apply": (C.c_int, [P, I, P]),
+    "fs_bn_bwd_reduce": (C.c_int, [P, I, P]),
+    "fs_bn_bwd_apply": (C.c_int, [P, I, P]),
+    "fs_maxpool_fwd": (C.c_int, [P, P, P, I, I, I, I, I, P]),
+    "fs_maxpool_bwd": (C.c_int, [P, P, P, P, I, I, I, I, I, P]),
+    "fs_upcat_pad_fwd": (C.c_int, [P, P, P, I, I, I, I, I, I, P]),
+    "fs_upcat_pad_bwd": (C.c_int, [P, P, P, I, I, I, I, I, I, P]),
+    "fs_channel_sum": (C.c_int, [P, P, L, I, I, I, P]),
+    "fs_depth_head_fwd": (C.c_int, [P, P, P, P, L, I, I, F, F, P]),
+    "fs_depth_head_bwd": (C.c_int, [P, P, P, P, P, L, I, I, F, F, I, P]),
+    "fs_pose_tail_fwd": (C.c_int, [P, P, P, P, I, I, I, I, I, P]),
+    "fs_pose_tail_bwd": (C.c_int, [P, P, P, I, I, I, I, I, I, P]),
+    "fs_photo_setup": (C.c_int, [P, P, P, P, I, P]),
+    "fs_photo_identity": (C.c_int, [P, P]),
+    "fs_photo_warp": (C.c_int, [P, P]),
+    "fs_photo_loss_fwd": (C.c_int, [P, P]),
+    "fs_photo_loss_bwd": (C.c_int, [P, P]),
+    "fs_photo_pose_grad": (C.c_int, [P, P, P, P, I, P]),
+    "fs_color_pyramid": (C.c_int, [P, P, I, I, I, I, I, P]),
+    "fs_smooth_mean": (C.c_int, [P, P]),
+    "fs_smooth_fwd": (C.c_int, [P, P]),
+    "fs_smooth_bwd": (C.c_int, [P, P]),
+    "fs_loss_finalize": (C.c_int, [P, P, P, P, P, P]),
+    "fs_sumsq": (C.c_int, [P, L, P, P]),
+    "fs_adam_step": (C.c_int, [P, P, P, P, L, F, F, F, F, F, I, F, P, F, P]),
 }
 
 

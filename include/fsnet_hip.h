@@ -103,6 +103,164 @@ int fs_pack_weights(const float* w_oihw, void* dst, int Co, int Ci, int R, int S
 int fs_nchw_to_nhwc(const float* a, const float* b, void* dst, int N, int Ca, int Cb, int H, int W,
                     int Cp, int dtype, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Train-mode BatchNorm forward: y = relu?( bn(x) [+ res | + bn2(res)] ).
+ * Replaces nn.BatchNorm2d(train)+relu+residual at resnet.py:33-50,70-89,201-203 and
+ * blocks.py:44-52.  stats = f64 [2][C] (sum, sumsq) from fs_conv_igemm; count = elements per
+ * channel (global count under SyncBatchNorm, scripts/train.py:101).  Block 0 updates the running
+ * statistics (momentum, unbiased variance) and num_batches_tracked and saves mean / invstd.
+ * pad_out: y is [N,H+2,W+2,C] and receives a replicated border (consumer conv pads 'replicate',
+ * depth_encoder.py:59,62).
+ */
+typedef struct FsBnApplyArgs {
+  const void* x;        /* dense [M][C] raw conv output */
+  const void* res;      /* dense [M][C] residual (or raw downsample conv output when stats2) */
+  void* y;
+  const double* stats;  const double* stats2;
+  const float* gamma;   const float* beta;
+  const float* gamma2;  const float* beta2;
+  float* running_mean;  float* running_var;
+  float* running_mean2; float* running_var2;
+  int64_t* num_batches_tracked; int64_t* num_batches_tracked2;
+  float* save_mean;  float* save_invstd;
+  float* save_mean2; float* save_invstd2;
+  double count;
+  float eps, momentum;
+  int64_t yN, yH, yW;
+  int32_t M, C, H, W;
+  int32_t relu, pad_out;
+} FsBnApplyArgs;
+int fs_bn_apply(const FsBnApplyArgs* args, int dtype, void* stream);
+
+/* BatchNorm backward, two passes (the data-parallel host all-reduces `sums` in between):
+ *   reduce: sums[0][c] = sum g, sums[1][c] = sum g*xhat, g = dout * (y > 0 if relu)
+ *   apply : dx = gamma*invstd*(g - sums0/count - xhat*sums1/count); dgamma += sums1, dbeta += sums0
+ *           (from sums_local when given); optional g_out = g (gradient of the residual branch).
+ * fold: dout is a replicate-padded [N,H+2,W+2,C] gradient whose border folds onto the edge pixels.
+ */
+typedef struct FsBnBwdArgs {
+  const void* dout; const void* y; const void* x;
+  void* dx; void* g_out;
+  double* sums; const double* sums_local;
+  const float* gamma; const float* save_mean; const float* save_invstd;
+  float* dgamma; float* dbeta;
+  double count;
+  int64_t gN, gH, gW;
+  int64_t yN, yH, yW;
+  int32_t M, C, H, W;
+  int32_t relu, fold;
+} FsBnBwdArgs;
+int fs_bn_bwd_reduce(const FsBnBwdArgs* args, int dtype, void* stream);
+int fs_bn_bwd_apply(const FsBnBwdArgs* args, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Pooling / upsampling / concat (NHWC, dense).
+ * fs_maxpool_*: nn.MaxPool2d(3,2,1), resnet.py:122,206 (idx = argmax code r*3+s per element;
+ *   backward adds `addend`, the gradient of the un-pooled skip feature).
+ * fs_upcat_pad_*: F.interpolate(nearest, x2) + torch.cat(skip) (depth_encoder.py:126-133),
+ *   written once into a replicate-padded [N,2h+2,2w+2,Ca+Cb] buffer for the 'replicate' conv
+ *   that follows (depth_encoder.py:59); backward folds the border and splits the channels.
+ * fs_channel_sum: out[c] += sum over rows (conv bias gradient).
+ */
+int fs_maxpool_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int dtype, void* stream);
+int fs_maxpool_bwd(const void* dy, const uint8_t* idx, const void* addend, void* dx, int N, int H, int W, int C,
+                   int dtype, void* stream);
+int fs_upcat_pad_fwd(const void* a, const void* b, void* out, int N, int h, int w, int Ca, int Cb, int dtype,
+                     void* stream);
+int fs_upcat_pad_bwd(const void* dpad, void* da, void* db, int N, int h, int w, int Ca, int Cb, int dtype,
+                     void* stream);
+int fs_channel_sum(const void* x, float* out, int64_t M, int C, int Creal, int dtype, void* stream);
+
+/* Depth-bin head: logits fp32 [M][Cl] (first K used) -> depth, disp (fp32 [M]).
+ * Replaces MultiChannelDepthDecoder._gather_activation / gather_output (depth_encoder.py:76-88,
+ * 114-121) and depth_to_disp (monodepth_utils.py:19-24).  Backward takes dL/d depth and dL/d disp
+ * (either may be NULL) and writes dL/d logits in `dtype`.
+ */
+int fs_depth_head_fwd(const float* logits, const float* bins, float* depth, float* disp, int64_t M, int K, int Cl,
+                      float min_depth, float max_depth, void* stream);
+int fs_depth_head_bwd(const float* logits, const float* bins, const float* d_depth, const float* d_disp,
+                      void* dlogits, int64_t M, int K, int Cl, float min_depth, float max_depth, int dtype,
+                      void* stream);
+
+/* Pose tail: x = last pose conv output fp32 [B][hw][Cx]; mean over hw, x0.01, split into
+ * axisangle / translation [B][nframes][3] (pose_decoder.py:39-45) and the 4x4 transform of frame 0
+ * (transformation_from_parameters, monodepth_utils.py:31-63,298-337; invert for negative frame ids,
+ * monodepth2_model.py:42-43).  Backward: dT [B][4][4] -> dx in `dtype`.
+ */
+int fs_pose_tail_fwd(const float* x, float* axisangle, float* translation, float* T, int B, int hw, int Cx,
+                     int nframes, int invert, void* stream);
+int fs_pose_tail_bwd(const float* x, const float* dT, void* dx, int B, int hw, int Cx, int nframes, int invert,
+                     int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Photometric loss chain (monodepth2_decoder.py:61-128,205-292; monodepth_utils.py:101-165,184-215).
+ * Images are planar NCHW fp32; all S scales are processed per launch.
+ *   fs_photo_setup     K, K^-1 (f64), P_f = (K T_f)[:3] per batch element -> geo [B][48]
+ *   fs_photo_identity  identity reprojection losses ident[B][2][H][W]; mask_sum += sum(patched_mask)
+ *   fs_photo_warp      pred[S][2][B][3][H][W], ov[S][2][B][H][W] (bilinear/border + nearest/zeros)
+ *   fs_photo_loss_fwd  sel[S][B][H][W] (argmin: 0,1 identity; 2,3 reprojection), loss_sums[s] += masked sum
+ *   fs_photo_loss_bwd  d_depth[s] += dL/d depth_s (low-res), dP[B][2][12] += dL/dP
+ *   fs_photo_pose_grad dT_f[B][4][4] = K^T dP_f
+ * noise_seed < 0 disables the tie-break noise (reference: randn*1e-5, :258-259).
+ */
+typedef struct FsPhotoArgs {
+  const float* img0;
+  const float* img_src[2];
+  const double* patched_mask;   /* [B][H][W] or NULL (= ones) */
+  const float* depth[4];        /* per scale [B][dh][dw] */
+  const float* geo;
+  float* pred;
+  uint8_t* ov;
+  float* ident;
+  uint8_t* sel;
+  double* loss_sums;
+  double* mask_sum;
+  float* d_depth[4];
+  float* dP;
+  const double* gout;           /* upstream gradient of the total loss (device scalar) or NULL = 1 */
+  int32_t dh[4], dw[4];
+  int32_t B, H, W, S;
+  int32_t noise_seed;
+} FsPhotoArgs;
+int fs_photo_setup(const float* P2, const float* T0, const float* T1, float* geo, int B, void* stream);
+int fs_photo_identity(const FsPhotoArgs* args, void* stream);
+int fs_photo_warp(const FsPhotoArgs* args, void* stream);
+int fs_photo_loss_fwd(const FsPhotoArgs* args, void* stream);
+int fs_photo_loss_bwd(const FsPhotoArgs* args, void* stream);
+int fs_photo_pose_grad(const float* geo, const float* dP, float* dT0, float* dT1, int B, void* stream);
+
+/* Edge-aware smoothness (monodepth_utils.py:168-181; monodepth2_decoder.py:214-219,294-299) and
+ * loss assembly (:292-304).  fs_color_pyramid = adaptive_avg_pool2d with an integer ratio.
+ * fs_loss_finalize: out[0..S) loss/s, out[S..2S) smooth_loss/s, out[2S] total_loss (f64).
+ */
+typedef struct FsSmoothArgs {
+  const float* disp[4];
+  const float* color[4];
+  float* d_disp[4];
+  double* disp_sum;    /* [S][B] */
+  double* sm_sums;     /* [S][2] */
+  double* dot;         /* [S][B] */
+  const double* gout;
+  int32_t h[4], w[4], scale_id[4];
+  int32_t B, S;
+} FsSmoothArgs;
+int fs_color_pyramid(const float* img, float* out, int B, int H, int W, int h, int w, void* stream);
+int fs_smooth_mean(const FsSmoothArgs* args, void* stream);
+int fs_smooth_fwd(const FsSmoothArgs* args, void* stream);
+int fs_smooth_bwd(const FsSmoothArgs* args, void* stream);
+int fs_loss_finalize(const double* loss_sums, const double* mask_sum, const double* sm_sums,
+                     const FsSmoothArgs* args, double* out, void* stream);
+
+/* Optimizer over a flat fp32 arena: global grad sum-of-squares, then clip + Adam in one pass
+ * (clip_grad_norm_ + torch.optim.Adam.step, base_training_hooks.py:46-49; optimizers.py:7-8).
+ * grad_scale multiplies every gradient first (1/world_size after a SUM all-reduce).
+ * max_norm <= 0 or sumsq == NULL disables clipping.
+ */
+int fs_sumsq(const float* g, int64_t n, double* out, void* stream);
+int fs_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, int step, float max_norm, const double* sumsq, float grad_scale,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif
