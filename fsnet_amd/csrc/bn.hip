@@ -16,11 +16,12 @@ constexpr int MAXC = 2048;
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-__device__ inline void bn_channel_coeffs(const double* stats, int C, int c, double count, float eps, float gamma,
-                                         float beta, float& mean, float& invstd, float& var_b, float& scale,
-                                         float& shift) {
-  double m = stats[c] / count;
-  double v = stats[C + c] / count - m * m;
+__device__ inline void bn_channel_coeffs(const double* stats, const float* rmean, const float* rvar, int C, int c,
+                                         double count, float eps, float gamma, float beta, float& mean,
+                                         float& invstd, float& var_b, float& scale, float& shift) {
+  double m, v;
+  if (stats) { m = stats[c] / count; v = stats[C + c] / count - m * m; }
+  else { m = rmean[c]; v = rvar[c]; }  // eval mode: running statistics
   if (v < 0) v = 0;
   mean = (float)m;
   var_b = (float)v;
@@ -34,25 +35,26 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const FsBnApplyArgs p) {
   __shared__ float s_scale[MAXC], s_shift[MAXC];
   __shared__ float s_scale2[MAXC], s_shift2[MAXC];
   const int C = p.C;
-  const bool has2 = p.stats2 != nullptr;
+  const bool has2 = p.gamma2 != nullptr;
+  const bool train = p.stats != nullptr;
   for (int c = threadIdx.x; c < C; c += 256) {
     float mean, invstd, varb, sc, sh;
-    bn_channel_coeffs(p.stats, C, c, p.count, p.eps, p.gamma[c], p.beta[c], mean, invstd, varb, sc, sh);
+    bn_channel_coeffs(p.stats, p.running_mean, p.running_var, C, c, p.count, p.eps, p.gamma[c], p.beta[c], mean, invstd, varb, sc, sh);
     s_scale[c] = sc; s_shift[c] = sh;
     if (blockIdx.x == 0) {
       p.save_mean[c] = mean; p.save_invstd[c] = invstd;
-      if (p.running_mean) {
+      if (train && p.running_mean) {
         double unb = p.count > 1.0 ? (double)varb * p.count / (p.count - 1.0) : (double)varb;
         p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * mean;
         p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unb;
       }
     }
     if (has2) {
-      bn_channel_coeffs(p.stats2, C, c, p.count, p.eps, p.gamma2[c], p.beta2[c], mean, invstd, varb, sc, sh);
+      bn_channel_coeffs(p.stats2, p.running_mean2, p.running_var2, C, c, p.count, p.eps, p.gamma2[c], p.beta2[c], mean, invstd, varb, sc, sh);
       s_scale2[c] = sc; s_shift2[c] = sh;
       if (blockIdx.x == 0) {
         p.save_mean2[c] = mean; p.save_invstd2[c] = invstd;
-        if (p.running_mean2) {
+        if (train && p.running_mean2) {
           double unb = p.count > 1.0 ? (double)varb * p.count / (p.count - 1.0) : (double)varb;
           p.running_mean2[c] = (1.f - p.momentum) * p.running_mean2[c] + p.momentum * mean;
           p.running_var2[c] = (1.f - p.momentum) * p.running_var2[c] + p.momentum * (float)unb;
@@ -61,8 +63,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const FsBnApplyArgs p) {
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (p.num_batches_tracked) *p.num_batches_tracked += 1;
-    if (p.num_batches_tracked2) *p.num_batches_tracked2 += 1;
+    if (train && p.num_batches_tracked) *p.num_batches_tracked += 1;
+    if (train && p.num_batches_tracked2) *p.num_batches_tracked2 += 1;
   }
   __syncthreads();
 
@@ -241,9 +243,11 @@ int grid_for(long items) {
 }  // namespace
 
 extern "C" int fs_bn_apply(const FsBnApplyArgs* a, int dtype, void* stream) {
-  if (!a || !a->x || !a->y || !a->stats || !a->gamma || !a->beta || !a->save_mean || !a->save_invstd) return FS_EINVAL;
+  if (!a || !a->x || !a->y || !a->gamma || !a->beta || !a->save_mean || !a->save_invstd) return FS_EINVAL;
+  if (!a->stats && (!a->running_mean || !a->running_var)) return FS_EINVAL;
   if (a->C % 4 != 0 || a->C > MAXC || a->M <= 0) return FS_EINVAL;
-  if (a->stats2 && (!a->res || !a->gamma2 || !a->beta2 || !a->save_mean2 || !a->save_invstd2)) return FS_EINVAL;
+  if (a->gamma2 && (!a->res || !a->beta2 || !a->save_mean2 || !a->save_invstd2)) return FS_EINVAL;
+  if (a->gamma2 && !a->stats2 && (!a->running_mean2 || !a->running_var2)) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int grid = grid_for((long)a->M * (a->C / 4));
   if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(grid), dim3(256), 0, st, *a);

@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
     if (mok) { x = m % p.Wd; int q = m / p.Wd; y = q % p.Hd; n = q / p.Hd; }
     long doff = (long)n * p.dN + (long)y * p.dH + (long)x * p.dW;
     long aoff = (long)n * p.aN + (long)y * p.aH + (long)x * p.aW;
+    long moff = (long)n * p.mN + (long)y * p.mH + (long)x * p.mW;
 #pragma unroll
     for (int a = 0; a < TC; ++a) {
       int co = co0 + wc * WCO + a * 16 + lg * 4;
@@ -184,6 +185,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
       if (p.relu) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      if (p.mask) {  // ReLU backward of the producing layer: pass the gradient where its output was > 0
+        float mv[4];
+        load4<T>(reinterpret_cast<const T*>(p.mask) + moff + co, mv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = mv[j] > 0.f ? v[j] : 0.f;
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) { s1[a][j] += v[j]; s2[a][j] += v[j] * v[j]; }

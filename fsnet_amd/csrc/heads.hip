@@ -129,7 +129,7 @@ __device__ inline void pose_matrix(const float in[6], int invert, Dual M[3][4]) 
 // one block (64 lanes) per batch element; x is the last pose conv output fp32 [B, hw, Cx]
 __global__ __launch_bounds__(64) void pose_tail_fwd_kernel(const float* __restrict__ x, float* __restrict__ axisangle,
                                                            float* __restrict__ translation, float* __restrict__ Tm,
-                                                           int hw, int Cx, int nframes, int invert) {
+                                                           int hw, int Cx, int nframes, int invert, float scale) {
   const int b = blockIdx.x, lane = threadIdx.x;
   const int nout = 6 * nframes;
   __shared__ float mean[64];
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64) void pose_tail_fwd_kernel(const float* __restri
     float s = 0.f;
     for (int i = lane; i < hw; i += 64) s += x[((long)b * hw + i) * Cx + c];
     s = wave_sum(s);
-    if (lane == 0) mean[c] = 0.01f * (s / (float)hw);
+    if (lane == 0) mean[c] = scale * (s / (float)hw);
   }
   __syncthreads();
   if (lane < nout) {
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64) void pose_tail_fwd_kernel(const float* __restri
 template <typename T>
 __global__ __launch_bounds__(64) void pose_tail_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dT,
                                                            T* __restrict__ dx, int hw, int Cx, int nframes,
-                                                           int invert) {
+                                                           int invert, float scale) {
   const int b = blockIdx.x, lane = threadIdx.x;
   __shared__ float mean[8];
   __shared__ float gin[8];
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64) void pose_tail_bwd_kernel(const float* __restri
     float s = 0.f;
     for (int i = lane; i < hw; i += 64) s += x[((long)b * hw + i) * Cx + c];
     s = wave_sum(s);
-    if (lane == 0) mean[c] = 0.01f * (s / (float)hw);
+    if (lane == 0) mean[c] = scale * (s / (float)hw);
   }
   __syncthreads();
   if (lane == 0) {
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64) void pose_tail_bwd_kernel(const float* __restri
     for (int k = 0; k < 6; ++k) {
       float a = 0.f;
       for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) a += g[i * 4 + j] * M[i][j].d[k];
-      gin[k] = a * 0.01f / (float)hw;
+      gin[k] = a * scale / (float)hw;
     }
   }
   __syncthreads();
@@ -225,19 +225,19 @@ extern "C" int fs_depth_head_bwd(const float* logits, const float* bins, const f
 }
 
 extern "C" int fs_pose_tail_fwd(const float* x, float* axisangle, float* translation, float* T, int B, int hw, int Cx,
-                                int nframes, int invert, void* stream) {
+                                int nframes, int invert, float scale, void* stream) {
   if (!x || !axisangle || !translation || !T || nframes < 1 || 6 * nframes > Cx || 6 * nframes > 64) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(pose_tail_fwd_kernel, dim3(B), dim3(64), 0, st, x, axisangle, translation, T, hw, Cx, nframes, invert);
+  hipLaunchKernelGGL(pose_tail_fwd_kernel, dim3(B), dim3(64), 0, st, x, axisangle, translation, T, hw, Cx, nframes, invert, scale);
   return fs_launch_status();
 }
 
 extern "C" int fs_pose_tail_bwd(const float* x, const float* dT, void* dx, int B, int hw, int Cx, int nframes,
-                                int invert, int dtype, void* stream) {
+                                int invert, float scale, int dtype, void* stream) {
   if (!x || !dT || !dx || 6 * nframes > Cx) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(pose_tail_bwd_kernel<bf16>, dim3(B), dim3(64), 0, st, x, dT, (bf16*)dx, hw, Cx, nframes, invert);
-  else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(pose_tail_bwd_kernel<float>, dim3(B), dim3(64), 0, st, x, dT, (float*)dx, hw, Cx, nframes, invert);
+  if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(pose_tail_bwd_kernel<bf16>, dim3(B), dim3(64), 0, st, x, dT, (bf16*)dx, hw, Cx, nframes, invert, scale);
+  else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(pose_tail_bwd_kernel<float>, dim3(B), dim3(64), 0, st, x, dT, (float*)dx, hw, Cx, nframes, invert, scale);
   else return FS_EINVAL;
   return fs_launch_status();
 }

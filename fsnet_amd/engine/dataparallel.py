@@ -1,0 +1,57 @@
+"""Data parallelism, one process per GPU over RCCL (torch.distributed backend 'nccl' on ROCm).
+
+What the reference gets implicitly from SyncBatchNorm + DistributedDataParallel
+(scripts/train.py:100-102), restated explicitly for the HIP engine:
+  * BatchNorm batch statistics / backward sums: all-reduce(SUM) of the small f64 buffers between the
+    two kernels that produce and consume them (global-batch statistics, count x world).
+  * parameter gradients: each network's slice of the flat gradient arena is all-reduced (SUM, async)
+    as soon as that network's backward has finished, overlapping the remaining backward; the
+    1/world average is folded into the optimizer kernel (grad_scale).
+  * rank 0's buffers (BN running stats, depth_bins) are broadcast once at start (DDP's
+    broadcast_buffers) — afterwards every rank computes identical running statistics.
+"""
+import torch
+import torch.distributed as dist
+
+
+class DataParallelContext:
+    def __init__(self, meta_arch, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.handles = []
+        self.meta = meta_arch
+        self.bucket_of = {}
+        self._synced = False
+
+    # ---- small latency-bound exchanges (BN) ------------------------------------------------
+    def allreduce_small(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    # ---- gradient buckets --------------------------------------------------------------------
+    def begin_step(self, meta_arch):
+        if not self._synced:
+            with torch.no_grad():
+                arena = meta_arch._arena
+                dist.broadcast(arena.data, src=0, group=self.group)
+                for b in meta_arch.buffers():
+                    dist.broadcast(b, src=0, group=self.group)
+            self._synced = True
+        self.handles = []
+
+    def grads_ready(self, module):
+        """called by a network's autograd Function when its last pending backward has finished."""
+        arena = self.meta._arena
+        params = [p for p in module.parameters()]
+        if not params:
+            return
+        lo, hi = arena.slice_of(params)
+        h = dist.all_reduce(arena.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.handles.append(h)
+
+    def finish(self):
+        """wait for the outstanding gradient all-reduces; returns the scale that turns SUM into MEAN."""
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        return 1.0 / self.world

@@ -1,0 +1,394 @@
+"""Manual forward/backward runners for the three networks on the hot path, written against the HIP
+library only (conv igemm / wgrad, BN, pooling, upcat, heads).  The nn.Modules that own these
+runners are pure parameter containers with the reference's state_dict names; autograd sees one
+custom Function per network invocation.
+
+Reference structure followed:
+  ResNetRunner        vision_base/networks/models/backbone/resnet.py:21-50,53-89,199-213
+  DepthDecoderRunner  monodepth/networks/models/heads/depth_encoder.py:45-66,119-139
+  PoseDecoderRunner   monodepth/networks/models/heads/pose_decoder.py:26-45
+"""
+import torch
+
+from ..hip import ops
+from ..hip.conv import ConvOp
+from .runtime import RT, grad_of
+
+
+class StatsPool:
+    """f64 scratch for BatchNorm batch statistics: one memset per network forward."""
+
+    def __init__(self, device, capacity=1 << 16):
+        self.buf = torch.zeros(capacity, dtype=torch.float64, device=device)
+        self.off = 0
+
+    def reset(self):
+        self.buf.zero_()
+        self.off = 0
+
+    def take(self, C):
+        n = 2 * C
+        if self.off + n > self.buf.numel():
+            return torch.zeros(2, C, dtype=torch.float64, device=self.buf.device)
+        v = self.buf[self.off:self.off + n].view(2, C)
+        self.off += n
+        return v
+
+
+class ConvLayer:
+    """Binds an nn.Conv2d parameter container to its device plan (ConvOp)."""
+
+    def __init__(self, conv, valid_over_padded=False, need_dgrad=True):
+        self.m = conv
+        k = conv.kernel_size
+        self.R, self.S = int(k[0]), int(k[1])
+        s = conv.stride
+        self.stride = int(s[0]) if isinstance(s, (tuple, list)) else int(s)
+        p = conv.padding
+        pad = int(p[0]) if isinstance(p, (tuple, list)) else int(p)
+        # 'replicate' convs run as a valid conv over a buffer the producer already padded
+        self.pad = 0 if valid_over_padded else pad
+        self.need_dgrad = need_dgrad
+        self._op = None
+        self._key = None
+        self._packed = None
+        self._bias = None
+
+    def ready(self, dtype, device):
+        key = (dtype, device)
+        if self._key != key:
+            w = self.m.weight
+            self._op = ConvOp(w.shape[1], w.shape[0], self.R, self.S, self.stride, self.pad, dtype, device,
+                              need_dgrad=self.need_dgrad)
+            self._key, self._packed = key, None
+        w = self.m.weight
+        ver = (w._version, RT.weights_epoch, w.data_ptr())
+        if ver != self._packed:
+            self._op.pack(w.data if w.data.is_contiguous() else w.data.contiguous())
+            b = self.m.bias
+            if b is not None:
+                if self._op.Co_p == b.numel():
+                    self._bias = b.data
+                else:
+                    self._bias = torch.zeros(self._op.Co_p, dtype=torch.float32, device=device)
+                    self._bias[: b.numel()].copy_(b.data)
+            self._packed = ver
+        return self._op
+
+    @property
+    def bias(self):
+        return self._bias
+
+    def accumulate_param_grads(self, op, dc, x):
+        """wgrad + bias grad into the parameters' gradient buffers."""
+        op.wgrad(dc, x, grad_of(self.m.weight))
+        if self.m.bias is not None:
+            ops.channel_sum(dc, grad_of(self.m.bias), self.m.bias.numel())
+
+
+def bn_tensors(bn):
+    return {"weight": bn.weight.data, "bias": bn.bias.data, "running_mean": bn.running_mean,
+            "running_var": bn.running_var, "num_batches_tracked": bn.num_batches_tracked}
+
+
+def _dp_stats(stats):
+    if RT.dp is not None:
+        RT.dp.allreduce_small(stats)
+        return RT.dp.world
+    return 1
+
+
+def _bn_bwd(dout, y, c, bn, st, H, W, relu=True, fold=False, g_out=None):
+    dc = torch.empty_like(c)
+    ops.bn_backward(dout, y, c, bn.weight.data, st, dc, grad_of(bn.weight), grad_of(bn.bias), H, W, relu=relu,
+                    fold=fold, g_out=g_out, allreduce=(RT.dp.allreduce_small if RT.dp is not None else None))
+    return dc
+
+
+def _check_train_bn(bn, what):
+    if not bn.training:
+        raise NotImplementedError(
+            "%s: BatchNorm in eval mode inside a training step (norm_eval / frozen stages) is not implemented "
+            "in the HIP engine yet" % what)
+
+
+# ==============================================================================================
+# ResNet encoder
+# ==============================================================================================
+class ResNetRunner:
+    def __init__(self, module):
+        self.m = module
+        self.stem = ConvLayer(module.conv1, need_dgrad=False)
+        self.stages = []
+        for i in range(module.num_stages):
+            blocks = []
+            for blk in getattr(module, "layer%d" % (i + 1)):
+                if hasattr(blk, "conv3"):
+                    units = [(ConvLayer(blk.conv1), blk.bn1), (ConvLayer(blk.conv2), blk.bn2),
+                             (ConvLayer(blk.conv3), blk.bn3)]
+                else:
+                    units = [(ConvLayer(blk.conv1), blk.bn1), (ConvLayer(blk.conv2), blk.bn2)]
+                ds = None
+                if blk.downsample is not None:
+                    ds = (ConvLayer(blk.downsample[0]), blk.downsample[1])
+                blocks.append((units, ds))
+            self.stages.append(blocks)
+        self.pool = None
+
+    # ------------------------------------------------------------------ forward
+    def _unit_fwd(self, cl, bn, x, train, relu=True, res=None, ds_c=None, ds_stats=None, ds_bn=None):
+        op = cl.ready(x.dtype, x.device)
+        N, H, W, _ = x.shape
+        Ho, Wo = op.out_hw(H, W)
+        stats = self.pool.take(op.Co_p) if train else None
+        c = op.forward(x, stats=stats)
+        world = _dp_stats(stats) if train else 1
+        y = torch.empty(N, Ho, Wo, op.Co_p, dtype=x.dtype, device=x.device)
+        st = ops.BnState(op.Co_p, x.device)
+        st2 = ops.BnState(op.Co_p, x.device) if ds_bn is not None else None
+        ops.bn_apply(c, stats, bn_tensors(bn), st, y, Ho, Wo, N * Ho * Wo * world, relu=relu,
+                     res=(ds_c if ds_bn is not None else res), stats2=ds_stats,
+                     bn2=(bn_tensors(ds_bn) if ds_bn is not None else None), st2=st2, track=train)
+        return c, y, st, st2
+
+    def forward(self, x, train):
+        """x: NHWC [N,H,W,Ci_p] in the compute dtype.  Returns (features NHWC x5, ctx)."""
+        if self.pool is None or self.pool.buf.device != x.device:
+            self.pool = StatsPool(x.device)
+        self.pool.reset()
+        if train:
+            _check_train_bn(self.m.bn1, "ResNet")
+        ctx = {"x": x, "blocks": []}
+        c0, y0, st0, _ = self._unit_fwd(self.stem, self.m.bn1, x, train)
+        pooled, idx = ops.maxpool_fwd(y0)
+        ctx.update(c0=c0, y0=y0, st0=st0, idx=idx)
+        feats = [y0]
+        cur = pooled
+        for blocks in self.stages:
+            for units, ds in blocks:
+                bctx = {"x": cur, "u": []}
+                inp = cur
+                for j, (cl, bn) in enumerate(units):
+                    if j < len(units) - 1:
+                        c, y, st, _ = self._unit_fwd(cl, bn, inp, train)
+                        bctx["u"].append((inp, c, y, st))
+                        inp = y
+                    else:
+                        if ds is not None:
+                            dop = ds[0].ready(cur.dtype, cur.device)
+                            dstats = self.pool.take(dop.Co_p) if train else None
+                            c_ds = dop.forward(cur, stats=dstats)
+                            if train:
+                                _dp_stats(dstats)
+                            c, y, st, st2 = self._unit_fwd(cl, bn, inp, train, ds_c=c_ds, ds_stats=dstats, ds_bn=ds[1])
+                            bctx["ds"] = (c_ds, st2)
+                        else:
+                            c, y, st, _ = self._unit_fwd(cl, bn, inp, train, res=cur)
+                        bctx["u"].append((inp, c, y, st))
+                        inp = y
+                ctx["blocks"].append(bctx)
+                cur = inp
+            feats.append(cur)
+        return feats, ctx
+
+    # ------------------------------------------------------------------ backward
+    def _block_bwd(self, units, ds, bctx, dout, extra):
+        x = bctx["x"]
+        N, H, W, _ = x.shape
+        k = len(units)
+        inp, c, y, st = bctx["u"][k - 1]
+        Ho, Wo = y.shape[1], y.shape[2]
+        g = torch.empty_like(c)
+        dc = _bn_bwd(dout, y, c, units[k - 1][1], st, Ho, Wo, relu=True, g_out=g)
+        if ds is not None:
+            c_ds, st2 = bctx["ds"]
+            dop = ds[0].ready(x.dtype, x.device)
+            dc_ds = _bn_bwd(g, None, c_ds, ds[1], st2, Ho, Wo, relu=False)
+            ds[0].accumulate_param_grads(dop, dc_ds, x)
+            dres = dop.dgrad(dc_ds, H, W, addend=extra)
+        else:
+            assert extra is None
+            dres = g
+        for j in range(k - 1, 0, -1):
+            cl = units[j][0]
+            op = cl.ready(x.dtype, x.device)
+            cl.accumulate_param_grads(op, dc, inp)
+            dy_prev = op.dgrad(dc, inp.shape[1], inp.shape[2])
+            inp, c, y, st = bctx["u"][j - 1]
+            dc = _bn_bwd(dy_prev, y, c, units[j - 1][1], st, y.shape[1], y.shape[2], relu=True)
+        cl = units[0][0]
+        op = cl.ready(x.dtype, x.device)
+        cl.accumulate_param_grads(op, dc, x)
+        return op.dgrad(dc, H, W, addend=dres)
+
+    def backward(self, ctx, gfeats):
+        """gfeats: list of 5 NHWC dense gradients (or None).  Accumulates parameter gradients."""
+        nst = len(self.stages)
+        dout = gfeats[nst]
+        last = ctx["blocks"][-1]["u"][-1][2]
+        if dout is None:
+            dout = torch.zeros_like(last)
+        bi = len(ctx["blocks"])
+        for si in range(nst - 1, -1, -1):
+            blocks = self.stages[si]
+            for b in range(len(blocks) - 1, -1, -1):
+                bi -= 1
+                units, ds = blocks[b]
+                extra = gfeats[si] if (b == 0 and si > 0) else None
+                if extra is not None and ds is None:
+                    raise NotImplementedError("feature gradient into a block without downsample")
+                dout = self._block_bwd(units, ds, ctx["blocks"][bi], dout, extra)
+        y0 = ctx["y0"]
+        d0 = ops.maxpool_bwd(dout, ctx["idx"], y0.shape[1], y0.shape[2], addend=gfeats[0])
+        dc0 = _bn_bwd(d0, y0, ctx["c0"], self.m.bn1, ctx["st0"], y0.shape[1], y0.shape[2], relu=True)
+        op = self.stem.ready(y0.dtype, y0.device)
+        self.stem.accumulate_param_grads(op, dc0, ctx["x"])
+
+
+# ==============================================================================================
+# Depth decoder (MultiChannelDepthDecoder)
+# ==============================================================================================
+class DepthDecoderRunner:
+    def __init__(self, module):
+        self.m = module
+        self.up0, self.up1, self.disp = {}, {}, {}
+        for i in range(4, -1, -1):
+            b0 = module.convs[("upconv", i, 0)]
+            b1 = module.convs[("upconv", i, 1)]
+            self.up0[i] = (ConvLayer(b0.sequence[0]), b0.sequence[1])
+            self.up1[i] = (ConvLayer(b1.sequence[0], valid_over_padded=True), b1.sequence[1])
+        for s in module.scales:
+            self.disp[s] = ConvLayer(module.convs[("dispconv", s)], valid_over_padded=True)
+        self.pool = None
+
+    def forward(self, feats, train, depth_scale=None):
+        """feats: 5 NHWC dense tensors.  Returns ({scale: (logits, depth, disp)}, ctx)."""
+        m = self.m
+        dev, dt = feats[-1].device, feats[-1].dtype
+        if self.pool is None or self.pool.buf.device != dev:
+            self.pool = StatsPool(dev)
+        self.pool.reset()
+        if train:
+            _check_train_bn(self.up0[4][1], "DepthDecoder")
+        ctx = {"lv": {}, "feats": feats}
+        outs = {}
+        x = feats[-1]
+        K = int(m.num_output_channels)
+        for i in range(4, -1, -1):
+            cl0, bn0 = self.up0[i]
+            op0 = cl0.ready(dt, dev)
+            N, h, w, _ = x.shape
+            st_a = self.pool.take(op0.Co_p) if train else None
+            c0 = op0.forward(x, bias=cl0.bias, stats=st_a)
+            world = _dp_stats(st_a) if train else 1
+            y0 = torch.empty(N, h, w, op0.Co_p, dtype=dt, device=dev)
+            s0 = ops.BnState(op0.Co_p, dev)
+            ops.bn_apply(c0, st_a, bn_tensors(bn0), s0, y0, h, w, N * h * w * world, relu=True, track=train)
+            skip = feats[i - 1] if (m.use_skips and i > 0) else None
+            xcat = ops.upcat_pad_fwd(y0, skip)
+            cl1, bn1 = self.up1[i]
+            op1 = cl1.ready(dt, dev)
+            H2, W2 = 2 * h, 2 * w
+            st_b = self.pool.take(op1.Co_p) if train else None
+            c1 = op1.forward(xcat, bias=cl1.bias, stats=st_b)
+            world = _dp_stats(st_b) if train else 1
+            y1p = torch.empty(N, H2 + 2, W2 + 2, op1.Co_p, dtype=dt, device=dev)
+            s1 = ops.BnState(op1.Co_p, dev)
+            ops.bn_apply(c1, st_b, bn_tensors(bn1), s1, y1p, H2, W2, N * H2 * W2 * world, relu=True, pad_out=True,
+                         track=train)
+            lv = dict(x=x, c0=c0, y0=y0, s0=s0, xcat=xcat, c1=c1, y1p=y1p, s1=s1, h=h, w=w,
+                      Cs=(skip.shape[3] if skip is not None else 0))
+            if i in m.scales:
+                cld = self.disp[i]
+                opd = cld.ready(dt, dev)
+                logits = opd.forward(y1p, bias=cld.bias, out_f32=True)
+                depth, disp = ops.depth_head_fwd(logits, m.depth_bins, K, m.min_depth, m.max_depth)
+                lv["logits"] = logits
+                outs[i] = (logits, depth, disp)
+            ctx["lv"][i] = lv
+            x = y1p[:, 1:-1, 1:-1]
+        return outs, ctx
+
+    def backward(self, ctx, g_depth, g_disp):
+        """g_depth / g_disp: {scale: [N,1,H,W] fp32 or None}.  Returns the 5 feature gradients (NHWC)."""
+        m = self.m
+        feats = ctx["feats"]
+        dev, dt = feats[-1].device, feats[-1].dtype
+        K = int(m.num_output_channels)
+        gfeats = [None] * 5
+
+        def disp_grad(i):
+            """padded-domain gradient of y1p_i from its dispconv (or zeros)."""
+            lv = ctx["lv"][i]
+            y1p = lv["y1p"]
+            if i in m.scales and (g_depth.get(i) is not None or g_disp.get(i) is not None):
+                cld = self.disp[i]
+                opd = cld.ready(dt, dev)
+                dl = ops.depth_head_bwd(lv["logits"], m.depth_bins, g_depth.get(i), g_disp.get(i), K, m.min_depth,
+                                        m.max_depth, dt)
+                cld.accumulate_param_grads(opd, dl, y1p)
+                return opd.dgrad(dl, y1p.shape[1], y1p.shape[2])
+            return torch.zeros_like(y1p)
+
+        Gp = disp_grad(0)
+        for i in range(0, 5):
+            lv = ctx["lv"][i]
+            h, w = lv["h"], lv["w"]
+            H2, W2 = 2 * h, 2 * w
+            cl1, bn1 = self.up1[i]
+            op1 = cl1.ready(dt, dev)
+            y1_int = lv["y1p"][:, 1:-1, 1:-1]
+            dc1 = _bn_bwd(Gp, y1_int, lv["c1"], bn1, lv["s1"], H2, W2, relu=True, fold=True)
+            cl1.accumulate_param_grads(op1, dc1, lv["xcat"])
+            dxcat = op1.dgrad(dc1, H2 + 2, W2 + 2)
+            cl0, bn0 = self.up0[i]
+            op0 = cl0.ready(dt, dev)
+            d_y0, d_skip = ops.upcat_pad_bwd(dxcat, h, w, op0.Co_p, lv["Cs"])
+            if i > 0 and lv["Cs"]:
+                gfeats[i - 1] = d_skip
+            dc0 = _bn_bwd(d_y0, lv["y0"], lv["c0"], bn0, lv["s0"], h, w, relu=True)
+            cl0.accumulate_param_grads(op0, dc0, lv["x"])
+            if i < 4:
+                Gp = disp_grad(i + 1)
+                interior = Gp[:, 1:-1, 1:-1]
+                op0.dgrad(dc0, h, w, out=interior, addend=interior)
+            else:
+                gfeats[4] = op0.dgrad(dc0, h, w)
+        return gfeats
+
+
+# ==============================================================================================
+# Pose decoder (+ fused pose tail / transform)
+# ==============================================================================================
+class PoseDecoderRunner:
+    def __init__(self, module):
+        self.m = module
+        self.cl = [ConvLayer(module.convs["squeeze"]), ConvLayer(module.convs[("pose", 0)]),
+                   ConvLayer(module.convs[("pose", 1)]), ConvLayer(module.convs[("pose", 2)])]
+
+    def forward(self, feat, invert):
+        """feat: NHWC last encoder feature.  Returns (axisangle, translation, T, ctx)."""
+        dt, dev = feat.dtype, feat.device
+        acts = [feat]
+        x = feat
+        for j in range(3):
+            op = self.cl[j].ready(dt, dev)
+            x = op.forward(x, bias=self.cl[j].bias, relu=True)
+            acts.append(x)
+        op = self.cl[3].ready(dt, dev)
+        x3 = op.forward(x, bias=self.cl[3].bias, out_f32=True)
+        nf = int(self.m.num_frames_to_predict_for)
+        aa, tr, T = ops.pose_tail_fwd(x3, nf, invert)
+        return aa, tr, T, {"acts": acts, "x3": x3, "invert": invert, "nf": nf}
+
+    def backward(self, ctx, dT):
+        acts, x3 = ctx["acts"], ctx["x3"]
+        dt, dev = acts[0].dtype, acts[0].device
+        d = ops.pose_tail_bwd(x3, dT, ctx["nf"], ctx["invert"], dt)
+        for j in range(3, -1, -1):
+            op = self.cl[j].ready(dt, dev)
+            xin = acts[j]
+            self.cl[j].accumulate_param_grads(op, d, xin)
+            # gradient w.r.t. the input activation, masked by the producing ReLU (none for the encoder feature)
+            d = op.dgrad(d, xin.shape[1], xin.shape[2], mask=(xin if j > 0 else None))
+        return d

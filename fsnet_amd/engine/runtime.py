@@ -1,0 +1,110 @@
+"""Process-wide runtime state of the HIP engine: compute dtype policy, the weight-repack epoch,
+the flat parameter/gradient arena and the data-parallel context (one process per GPU)."""
+import os
+
+import torch
+
+
+class _Runtime:
+    def __init__(self):
+        name = os.environ.get("FSNET_AMD_DTYPE", "bf16").lower()
+        self.compute_dtype = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32,
+                              "float32": torch.float32}[name]
+        self.weights_epoch = 0     # bumped whenever parameters change outside torch's version counter
+        self.dp = None             # DataParallelContext or None
+        self.noise_step = 0        # seed stream for the photometric tie-break noise
+        self.tie_noise = os.environ.get("FSNET_AMD_TIE_NOISE", "1") != "0"
+
+    def set_compute_dtype(self, dtype):
+        if isinstance(dtype, str):
+            dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[dtype.lower()]
+        assert dtype in (torch.bfloat16, torch.float32)
+        self.compute_dtype = dtype
+
+    def bump_weights(self):
+        self.weights_epoch += 1
+
+
+RT = _Runtime()
+
+
+def require_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(
+            "%s: fsnet_amd runs on MI355X through libfsnet_hip.so only — there is no CPU path. "
+            "Move the module and its inputs to a ROCm device (.cuda())." % what)
+
+
+class ParamArena:
+    """Flat fp32 storage for all parameters of a meta-arch (+ a same-shaped gradient arena), so that
+    clip + Adam is one launch and the data-parallel all-reduce works on a few large contiguous
+    buckets.  Parameters keep their identity (state_dict names, optimizer references): only
+    `.data` / `.grad` are re-pointed to views."""
+
+    def __init__(self, named_params, device):
+        self.names = [n for n, _ in named_params]
+        self.params = [p for _, p in named_params]
+        sizes = [p.numel() for p in self.params]
+        # 16-byte aligned slots so vector loads in the optimizer never straddle tensors
+        self.offsets = []
+        off = 0
+        for s in sizes:
+            self.offsets.append(off)
+            off += (s + 3) // 4 * 4
+        self.total = off
+        self.data = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.views = []
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                v = self.data[o:o + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+                g = self.grad[o:o + p.numel()].view(p.shape)
+                self.views.append(g)
+                p.grad = g
+        self._by_id = {id(p): i for i, p in enumerate(self.params)}
+        RT.bump_weights()
+
+    def owns(self, p):
+        return id(p) in self._by_id
+
+    def intact(self):
+        """False if something (e.g. module.to(), load with assign) replaced the parameter storage."""
+        return all(p.data.data_ptr() == self.data.data_ptr() + 4 * o for p, o in zip(self.params, self.offsets))
+
+    def attach_grads(self, zero=True):
+        if zero:
+            self.grad.zero_()
+        for p, g in zip(self.params, self.views):
+            p.grad = g
+
+    def zero_grads(self):
+        self.attach_grads(zero=True)
+
+    def slice_of(self, params):
+        """[lo, hi) element range of the arena covering the given parameters (must be contiguous)."""
+        idx = sorted(self._by_id[id(p)] for p in params)
+        assert idx == list(range(idx[0], idx[-1] + 1)), "parameters are not contiguous in the arena"
+        lo = self.offsets[idx[0]]
+        last = idx[-1]
+        hi = self.offsets[last] + (self.params[last].numel() + 3) // 4 * 4
+        return lo, hi
+
+
+_ARENAS = []
+
+
+def register_arena(a):
+    _ARENAS.append(a)
+
+
+def grad_of(p):
+    """Gradient buffer to accumulate into (kernels write/accumulate through raw pointers)."""
+    if p.grad is None:
+        for a in _ARENAS:
+            if a.owns(p):
+                a.attach_grads(zero=True)   # optimizer.zero_grad(set_to_none=True) happened: one memset
+                return p.grad
+        p.grad = torch.zeros_like(p)
+    return p.grad

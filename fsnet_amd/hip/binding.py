@@ -17,10 +17,11 @@ class FsError(RuntimeError):
 class FsConvArgs(C.Structure):
     _fields_ = [
         ("src", C.c_void_p), ("wgt", C.c_void_p), ("dst", C.c_void_p), ("bias", C.c_void_p),
-        ("addend", C.c_void_p), ("stats", C.c_void_p), ("ktab", C.c_void_p),
+        ("addend", C.c_void_p), ("mask", C.c_void_p), ("stats", C.c_void_p), ("ktab", C.c_void_p),
         ("sN", C.c_int64), ("sH", C.c_int64), ("sW", C.c_int64),
         ("dN", C.c_int64), ("dH", C.c_int64), ("dW", C.c_int64),
         ("aN", C.c_int64), ("aH", C.c_int64), ("aW", C.c_int64),
+        ("mN", C.c_int64), ("mH", C.c_int64), ("mW", C.c_int64),
         ("Hs", C.c_int32), ("Ws", C.c_int32), ("Hd", C.c_int32), ("Wd", C.c_int32),
         ("M", C.c_int32), ("Co", C.c_int32), ("Co_p", C.c_int32), ("nchunks", C.c_int32),
         ("hb_mul", C.c_int32), ("hb_add", C.c_int32), ("sgn", C.c_int32), ("dshift", C.c_int32),

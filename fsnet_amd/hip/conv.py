@@ -110,7 +110,7 @@ class ConvOp:
         check(lib.fs_conv_igemm(C.byref(a), self.code, stream_ptr()), "conv_fwd")
         return out
 
-    def dgrad(self, dy, H, W, out=None, addend=None):
+    def dgrad(self, dy, H, W, out=None, addend=None, mask=None):
         """dy: [N,Ho,Wo,Co_p] -> dx [N,H,W,Ci_p] (out may be a strided view; addend is summed in)."""
         N, Ho, Wo, Cd = dy.shape
         assert Cd == self.Co_p and dy.dtype == self.dtype and self.need_dgrad
@@ -125,6 +125,9 @@ class ConvOp:
         a.dN, a.dH, a.dW = _nhwc_strides(out)
         if addend is not None:
             a.aN, a.aH, a.aW = _nhwc_strides(addend)
+        if mask is not None:
+            a.mask = mask.data_ptr()
+            a.mN, a.mH, a.mW = _nhwc_strides(mask)
         a.Hs, a.Ws, a.Hd, a.Wd = Ho, Wo, H, W
         a.M = N * H * W
         a.Co, a.Co_p, a.nchunks = out.shape[3], self.rows_d, self.nch_d

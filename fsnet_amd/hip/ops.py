@@ -45,18 +45,18 @@ def bn_apply(x, stats, bn, st, y, H, W, count, relu=True, pad_out=False, res=Non
     a = FsBnApplyArgs()
     Cc = x.shape[-1]
     a.x, a.res, a.y = x.data_ptr(), _p(res), y.data_ptr()
-    a.stats, a.stats2 = stats.data_ptr(), _p(stats2)
+    a.stats, a.stats2 = _p(stats), _p(stats2)
     a.gamma, a.beta = bn["weight"].data_ptr(), bn["bias"].data_ptr()
-    if track:
+    if track or stats is None:
         a.running_mean, a.running_var = bn["running_mean"].data_ptr(), bn["running_var"].data_ptr()
         a.num_batches_tracked = bn["num_batches_tracked"].data_ptr()
     a.save_mean, a.save_invstd = st.mean.data_ptr(), st.invstd.data_ptr()
     st.count = float(count)
     if bn2 is not None:
         a.gamma2, a.beta2 = bn2["weight"].data_ptr(), bn2["bias"].data_ptr()
-        if track:
+        if track or stats2 is None:
             a.running_mean2, a.running_var2 = bn2["running_mean"].data_ptr(), bn2["running_var"].data_ptr()
-            a.num_batches_tracked2 = bn2["num_batches_tracked"].data_ptr()
+            a.num_batches_tracked2 = bn2["num_batches_tracked"].data_ptr() if track else None
         a.save_mean2, a.save_invstd2 = st2.mean.data_ptr(), st2.invstd.data_ptr()
         st2.count = float(count)
     a.count, a.eps, a.momentum = float(count), BN_EPS, BN_MOMENTUM
@@ -161,21 +161,21 @@ def depth_head_bwd(logits, bins, d_depth, d_disp, K, min_depth, max_depth, dtype
     return dl
 
 
-def pose_tail_fwd(x, nframes, invert):
+def pose_tail_fwd(x, nframes, invert, scale=0.01):
     B, h, w, Cx = x.shape
     aa = torch.empty(B, nframes, 1, 3, dtype=torch.float32, device=x.device)
     tr = torch.empty(B, nframes, 1, 3, dtype=torch.float32, device=x.device)
     T = torch.empty(B, 4, 4, dtype=torch.float32, device=x.device)
     check(lib.fs_pose_tail_fwd(x.data_ptr(), aa.data_ptr(), tr.data_ptr(), T.data_ptr(), B, h * w, Cx, nframes,
-                               int(invert), stream_ptr()), "pose_tail_fwd")
+                               int(invert), float(scale), stream_ptr()), "pose_tail_fwd")
     return aa, tr, T
 
 
-def pose_tail_bwd(x, dT, nframes, invert, dtype):
+def pose_tail_bwd(x, dT, nframes, invert, dtype, scale=0.01):
     B, h, w, Cx = x.shape
     dx = torch.empty(B, h, w, Cx, dtype=dtype, device=x.device)
     check(lib.fs_pose_tail_bwd(x.data_ptr(), dT.data_ptr(), dx.data_ptr(), B, h * w, Cx, nframes, int(invert),
-                               dtype_code(dtype), stream_ptr()), "pose_tail_bwd")
+                               float(scale), dtype_code(dtype), stream_ptr()), "pose_tail_bwd")
     return dx
 
 

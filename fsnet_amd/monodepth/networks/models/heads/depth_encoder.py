@@ -1,0 +1,112 @@
+"""Depth decoder heads with the reference's constructor and state_dict names
+(monodepth/networks/models/heads/depth_encoder.py:17-139), executed by the HIP engine."""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from fsnet_amd.engine.nets import DepthDecoderRunner
+from fsnet_amd.engine.runtime import RT, require_gpu
+from fsnet_amd.vision_base.networks.blocks.blocks import ConvBnReLU
+from fsnet_amd.vision_base.networks.models.backbone.resnet import nhwc_dense
+
+
+class _DepthDecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, nfeat, *args):
+        ctx.set_materialize_grads(False)
+        feats = [nhwc_dense(f, f.dtype) for f in args[:nfeat]]
+        outs, c = mod._runner.forward(feats, train=True)
+        ctx.mod, ctx.c, ctx.nfeat, ctx.nparam = mod, c, nfeat, len(args) - nfeat
+        mod._pending += 1
+        flat = []
+        for s in mod.scales:
+            logits, depth, disp = outs[s]
+            flat += [logits.permute(0, 3, 1, 2)[:, : mod.num_output_channels], depth, disp]
+        return tuple(flat)
+
+    @staticmethod
+    def backward(ctx, *g):
+        mod = ctx.mod
+        g_depth, g_disp = {}, {}
+        for k, s in enumerate(mod.scales):
+            if g[3 * k] is not None:
+                raise NotImplementedError("gradient w.r.t. ('logits', s) is not supported by the HIP decoder")
+            g_depth[s] = None if g[3 * k + 1] is None else g[3 * k + 1].contiguous().float()
+            g_disp[s] = None if g[3 * k + 2] is None else g[3 * k + 2].contiguous().float()
+        gfeats = mod._runner.backward(ctx.c, g_depth, g_disp)
+        ctx.c = None
+        mod._pending -= 1
+        if mod._pending == 0 and RT.dp is not None:
+            RT.dp.grads_ready(mod)
+        gf = tuple(None if t is None else t.permute(0, 3, 1, 2) for t in gfeats[: ctx.nfeat])
+        return (None, None) + gf + (None,) * ctx.nparam
+
+
+class DepthDecoder(nn.Module):
+    def __init__(self, num_ch_enc, scales=range(4), num_output_channels=1, use_skips=True, min_depth=0.1,
+                 max_depth=100, base_fx=None):
+        super().__init__()
+        self.num_output_channels = num_output_channels
+        self.use_skips = use_skips
+        self.upsample_mode = 'nearest'
+        self.scales = list(scales)
+        self.base_fx = base_fx
+        self.num_ch_enc = num_ch_enc
+        self.num_ch_dec = np.array([16, 32, 64, 128, 256])
+        self.min_depth, self.max_depth = min_depth, max_depth
+        self._build_depth_bins(min_depth, max_depth, num_output_channels)
+        self._init_layers()
+        self._runner = DepthDecoderRunner(self)
+        self._pending = 0
+        self._plist = None
+
+    def _init_layers(self):
+        self.convs = OrderedDict()
+        for i in range(4, -1, -1):
+            cin = int(self.num_ch_enc[-1] if i == 4 else self.num_ch_dec[i + 1])
+            cout = int(self.num_ch_dec[i])
+            self.convs[("upconv", i, 0)] = ConvBnReLU(cin, cout, kernel_size=(3, 3))
+            cin = cout + (int(self.num_ch_enc[i - 1]) if (self.use_skips and i > 0) else 0)
+            self.convs[("upconv", i, 1)] = ConvBnReLU(cin, cout, kernel_size=(3, 3), padding_mode='replicate')
+        for s in self.scales:
+            self.convs[("dispconv", s)] = nn.Conv2d(int(self.num_ch_dec[s]), self.num_output_channels, kernel_size=3,
+                                                    padding=1, padding_mode='replicate')
+        self.decoder = nn.ModuleList(list(self.convs.values()))
+        self.sigmoid = nn.Sigmoid()
+
+    def _build_depth_bins(self, min_depth, max_depth, num_bins):
+        lo, hi = np.log(min_depth), np.log(max_depth)
+        self.register_buffer("depth_bins", torch.exp(torch.arange(lo, hi, (hi - lo) / num_bins)))
+
+    def forward(self, input_features, P2=None):
+        raise NotImplementedError("the sigmoid-disparity DepthDecoder is not on the shipped monodepth path; "
+                                  "use MultiChannelDepthDecoder (configs/*_example)")
+
+
+class MultiChannelDepthDecoder(DepthDecoder):
+    """softmax-over-log-spaced-depth-bins head (depth_encoder.py:114-139)."""
+
+    def forward(self, input_features, P2=None):
+        require_gpu(input_features[-1], "MultiChannelDepthDecoder.forward")
+        if self.base_fx is not None:
+            raise NotImplementedError("base_fx focal-length depth scaling (multi-dataset config) is not implemented yet")
+        if self.num_output_channels not in (16, 32, 64):
+            raise NotImplementedError("depth-bin head supports 16/32/64 bins")
+        feats = list(input_features)
+        outputs = {}
+        if torch.is_grad_enabled() and self.training:
+            if self._plist is None:
+                self._plist = list(self.parameters())
+            flat = _DepthDecoderFn.apply(self, len(feats), *feats, *self._plist)
+            for k, s in enumerate(self.scales):
+                outputs[('logits', s)], outputs[('depth', s, s)], outputs[('disp', s)] = flat[3 * k: 3 * k + 3]
+            return outputs
+        with torch.no_grad():
+            outs, _ = self._runner.forward([nhwc_dense(f, f.dtype) for f in feats], train=self.decoder[0].sequence[1].training)
+        for s in self.scales:
+            logits, depth, disp = outs[s]
+            outputs[('logits', s)] = logits.permute(0, 3, 1, 2)[:, : self.num_output_channels]
+            outputs[('depth', s, s)], outputs[('disp', s)] = depth, disp
+        return outputs

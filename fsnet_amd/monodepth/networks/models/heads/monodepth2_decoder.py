@@ -1,0 +1,138 @@
+"""MonoDepth2Decoder with the reference's constructor and method names
+(monodepth/networks/models/heads/monodepth2_decoder.py:19-347).  loss() runs the fused HIP
+photometric chain (backproject -> project -> grid_sample -> SSIM+L1 -> per-pixel min -> masked mean,
+plus edge-aware smoothness), forward and backward, for the option set the shipped configs use;
+every other option raises instead of silently taking a different path."""
+import torch
+import torch.nn as nn
+
+from fsnet_amd.engine.runtime import RT, require_gpu
+from fsnet_amd.hip import ops
+from fsnet_amd.vision_base.utils.builder import build
+
+_UNSUPPORTED_FLAGS = ("is_residual_flow", "is_light_compensate", "learnable_photometric_uncertain", "is_ssim_weight")
+
+
+class _PhotoLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pl, S, img0, src_a, src_b, P2, patched_mask, T_a, T_b, *dd):
+        ctx.set_materialize_grads(False)
+        depths = [d.contiguous().float() for d in dd[:S]]
+        disps = [d.contiguous().float() for d in dd[S:]]
+        seed = -1
+        if RT.tie_noise:
+            RT.noise_step += 1
+            seed = RT.noise_step & 0x3fffffff
+        out = pl.forward(img0.contiguous().float(), [src_a.contiguous().float(), src_b.contiguous().float()],
+                         P2.contiguous().float(), [T_a.contiguous().float(), T_b.contiguous().float()], patched_mask,
+                         depths, disps, noise_seed=seed)
+        ctx.pl, ctx.S = pl, S
+        vec = out.clone()
+        ctx.mark_non_differentiable(vec)
+        return vec[2 * S].clone(), vec
+
+    @staticmethod
+    def backward(ctx, g_total, _g_vec):
+        pl, S = ctx.pl, ctx.S
+        gout = None
+        if g_total is not None:
+            gout = g_total.detach().double().contiguous()
+        d_depth, d_disp, dT = pl.backward(gout)
+        return (None, None, None, None, None, None, None, dT[0], dT[1]) + tuple(d_depth) + tuple(d_disp)
+
+
+class MonoDepth2Decoder(nn.Module):
+    def __init__(self, scales, height, width, frame_ids, depth_decoder_cfg, pose_decoder_cfg=None,
+                 multiscale_head_cfg=None, **kwargs):
+        super().__init__()
+        self.scales = list(scales)
+        self.num_scales = len(self.scales)
+        self.height, self.width = height, width
+        self.frame_ids = list(frame_ids)
+        self.depth_decoder = build(**depth_decoder_cfg)
+        if pose_decoder_cfg is not None:
+            self.pose_decoder = build(**pose_decoder_cfg)
+        if multiscale_head_cfg is not None:
+            raise NotImplementedError("multiscale_head_cfg (residual flow head) is outside the monodepth hot path")
+        for key in kwargs:           # min_depth, max_depth, overlapped_mask, is_log_image, ... (reference :48-49)
+            setattr(self, key, kwargs[key])
+        self._pl = None
+
+    # ---- network heads -------------------------------------------------------------------
+    def forward_pose(self, *args, **kwargs):
+        return self.pose_decoder(*args, **kwargs)
+
+    def forward_pose_transform(self, features, invert):
+        """fused (axisangle, translation, cam_T_cam): pose_decoder.py:26-45 + monodepth2_model.py:42-43."""
+        return self.pose_decoder.forward_with_transform(features, invert)
+
+    def forward_depth(self, features, *args, **kwargs):
+        return self.depth_decoder(features, *args, **kwargs)
+
+    def get_prediction(self, input_dict, output_dict):
+        return dict(depth=output_dict[("depth", 0, 0)])
+
+    # ---- loss ---------------------------------------------------------------------------------
+    def _check_options(self, input_dict):
+        for flag in _UNSUPPORTED_FLAGS:
+            if getattr(self, flag, False):
+                raise NotImplementedError("MonoDepth2Decoder option %s is not implemented in the HIP loss chain" % flag)
+        for w in ("pose_loss_weight", "distillation_loss_weight", "residualflow_weight"):
+            if getattr(self, w, 0) > 0:
+                raise NotImplementedError("MonoDepth2Decoder term %s > 0 is not implemented in the HIP loss chain" % w)
+        if not getattr(self, "overlapped_mask", False):
+            raise NotImplementedError("overlapped_mask=False is not implemented (all shipped configs enable it)")
+        if "motion_mask" in input_dict:
+            raise NotImplementedError("precomputed motion_mask branch is not implemented in the HIP loss chain")
+        if len(self.frame_ids) != 3 or "s" in self.frame_ids:
+            raise NotImplementedError("the HIP loss chain handles frame_ids=[0, a, b] (two temporal source frames)")
+
+    def compute_total_reprojection_loss(self, output_dict, input_dict):
+        self._check_options(input_dict)
+        img0 = input_dict[("original_image", 0)]
+        require_gpu(img0, "MonoDepth2Decoder.loss")
+        B, _, H, W = img0.shape
+        S = self.num_scales
+        for s in self.scales:
+            d = output_dict[("depth", s, s)]
+            if d.shape[2] != (H >> s) or d.shape[3] != (W >> s):
+                raise NotImplementedError("depth at scale %d must be %dx%d" % (s, H >> s, W >> s))
+        key = (B, H, W, tuple(self.scales), img0.device)
+        if self._pl is None or self._pl_key != key:
+            self._pl = ops.PhotometricLoss(B, H, W, self.scales, img0.device, self.min_depth, self.max_depth)
+            self._pl_key = key
+        fa, fb = self.frame_ids[1], self.frame_ids[2]
+        pm = input_dict.get("patched_mask", None)
+        if pm is not None and pm.dtype != torch.float64:
+            pm = pm.double()
+        if pm is not None:
+            pm = pm.contiguous()
+        depths = [output_dict[("depth", s, s)] for s in self.scales]
+        disps = [output_dict[("disp", s)] for s in self.scales]
+        total, vec = _PhotoLossFn.apply(self._pl, S, img0, input_dict[("original_image", fa)],
+                                        input_dict[("original_image", fb)], input_dict["P2"], pm,
+                                        output_dict[("cam_T_cam", fa)], output_dict[("cam_T_cam", fb)],
+                                        *depths, *disps)
+        losses = {}
+        for k, s in enumerate(self.scales):
+            losses["loss/%d" % s] = vec[k]
+            losses["smooth_loss/%d" % s] = vec[S + k].float()
+        # warped images / masks the reference leaves in output_dict (_generate_images_pred :98-116)
+        for k, s in enumerate(self.scales):
+            for j, f in enumerate((fa, fb)):
+                output_dict[("original_image", f, s)] = self._pl.pred[k, j]
+                output_dict[("overlapped_mask", f, s)] = self._pl.ov[k, j].bool()
+        hm = {}
+        if getattr(self, "is_log_image", True):
+            hm["original_image"] = img0[0:1]
+            for j, f in enumerate((fa, fb)):
+                hm["predicted_image_%s" % f] = self._pl.pred[0, j, 0:1]
+            hm["loss_mask_%d" % self.scales[0]] = dict(data=(self._pl.sel[0, 0:1] >= 2).unsqueeze(1))
+        return losses, hm, total
+
+    def loss(self, output_dict, input_dict):
+        losses, hm, total = self.compute_total_reprojection_loss(output_dict, input_dict)
+        losses["total_loss"] = total.detach()
+        if not getattr(self, "is_log_image", True):
+            hm = {}
+        return {"loss": total, "loss_dict": losses, "hm": hm}

@@ -1,0 +1,103 @@
+"""Meta-archs with the reference's constructor contract (monodepth2_model.py:8-148):
+MonoDepthMeta (learned pose, "depth+pose") and MonoDepthWPose (dataset pose).  Sub-networks are built
+through build(**cfg) exactly like the reference, so configs only change `name=` strings."""
+import torch
+
+from fsnet_amd.engine.runtime import RT, ParamArena, register_arena
+from fsnet_amd.vision_base.networks.models.meta_archs.base_meta import BaseMetaArch
+from fsnet_amd.vision_base.utils.builder import build
+
+
+class _HipMetaArch(BaseMetaArch):
+    """shared plumbing: flat parameter arena, data-parallel context, compute dtype."""
+
+    def _post_init(self, kwargs):
+        if "compute_dtype" in kwargs:
+            RT.set_compute_dtype(kwargs["compute_dtype"])
+        self._arena = None
+
+    def ensure_arena(self):
+        """Flatten all parameters into one fp32 arena (lazily, once they live on the GPU)."""
+        p0 = next(self.parameters())
+        if not p0.is_cuda:
+            raise RuntimeError("fsnet_amd meta-archs run on MI355X only: call .cuda() before the first forward")
+        if self._arena is None or not self._arena.intact():
+            self._arena = ParamArena(list(self.named_parameters()), p0.device)
+            register_arena(self._arena)
+        return self._arena
+
+    def _begin_train(self):
+        self.ensure_arena()
+        if RT.dp is None and torch.distributed.is_available() and torch.distributed.is_initialized() \
+                and torch.distributed.get_world_size() > 1:
+            from fsnet_amd.engine.dataparallel import DataParallelContext
+            RT.dp = DataParallelContext(self)
+        if RT.dp is not None:
+            RT.dp.begin_step(self)
+
+    def dummy_forward(self, image):
+        features = self.depth_backbone(image)
+        outputs = self.head.forward_depth(features)
+        return self.head.get_prediction(None, outputs)
+
+
+class MonoDepthMeta(_HipMetaArch):
+    def __init__(self, depth_backbone_cfg, pose_backbone_cfg, head_cfg, train_cfg, test_cfg, **kwargs):
+        super().__init__()
+        self.depth_backbone = build(**depth_backbone_cfg)
+        self.pose_backbone = build(**pose_backbone_cfg)
+        self.head = build(frame_ids=train_cfg.frame_ids, **head_cfg)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self._post_init(kwargs)
+
+    def forward_train(self, data, meta):
+        self._begin_train()
+        image_0 = data[('image', 0)]
+        features = self.depth_backbone(image_0)
+        outputs = self.head.forward_depth(features)
+        for f_i in self.train_cfg.frame_ids[1:]:
+            pair = (data[('image', f_i)], image_0) if f_i < 0 else (image_0, data[('image', f_i)])
+            if hasattr(self.pose_backbone, "forward_pair"):
+                pose_feats = [self.pose_backbone.forward_pair(*pair)]
+            else:
+                pose_feats = [self.pose_backbone(torch.cat(pair, 1))]
+            axisangle, translation, T = self.head.forward_pose_transform(pose_feats, invert=(f_i < 0))
+            outputs[("axisangle", f_i)] = axisangle
+            outputs[("translation", f_i)] = translation
+            outputs[("cam_T_cam", f_i)] = T
+        return self.head.loss(outputs, data)
+
+    def forward_test(self, data, meta):
+        features = self.depth_backbone(data[('image', 0)])
+        outputs = self.head.forward_depth(features)
+        return self.head.get_prediction(data, outputs)
+
+
+class MonoDepthWPose(_HipMetaArch):
+    def __init__(self, depth_backbone_cfg, head_cfg, train_cfg, test_cfg, pose_backbone_cfg=None, **kwargs):
+        super().__init__()
+        self.depth_backbone = build(**depth_backbone_cfg)
+        self.head = build(frame_ids=train_cfg.frame_ids, **head_cfg)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.is_use_res_pose = pose_backbone_cfg is not None
+        if self.is_use_res_pose:
+            raise NotImplementedError("MonoDepthWPose residual-pose branch (pose_backbone_cfg) is not implemented; "
+                                      "no shipped config uses it")
+        self._post_init(kwargs)
+
+    def forward_train(self, data, meta):
+        self._begin_train()
+        if list(getattr(self.train_cfg, 'depth_production_frames', [0])) != [0]:
+            raise NotImplementedError("depth_production_frames other than [0]")
+        features = self.depth_backbone(data[('image', 0)])
+        outputs = self.head.forward_depth(features, None if getattr(self.head.depth_decoder, "base_fx", None) is None
+                                          else data['P2'])
+        for f_i in self.train_cfg.frame_ids[1:]:
+            outputs[("cam_T_cam", f_i)] = data[('relative_pose', f_i)]
+        return self.head.loss(outputs, data)
+
+    def forward_test(self, data, meta):
+        features = self.depth_backbone(data[('image', 0)])
+        outputs = self.head.forward_depth(features, None if getattr(self.head.depth_decoder, "base_fx", None) is None
+                                          else data['P2'])
+        return self.head.get_prediction(data, outputs)

@@ -42,7 +42,7 @@ const char* fs_target_arch(void);
  * zero padding of K.  Forward: src = input, rows = output pixels, hb = y*hb_mul + hb_add
  * (stride, -pad), sgn=+1.  Dgrad: src = dY, rows = input pixels, hb_mul=1, hb_add=+pad, sgn=-1,
  * dshift = log2(stride) with a parity test.  Epilogue: + bias, + addend, relu, optional
- * per-channel f64 sum / sum-of-squares (BatchNorm batch statistics).
+ * per-channel f64 sum / sum-of-squares (BatchNorm batch statistics), ReLU-backward mask.
  */
 typedef struct FsConvArgs {
   const void* src;
@@ -50,11 +50,13 @@ typedef struct FsConvArgs {
   void* dst;
   const float* bias;    /* [Co] or NULL */
   const void* addend;   /* same dtype as src, or NULL */
+  const void* mask;     /* same dtype as src, or NULL: out = mask > 0 ? out : 0 (ReLU backward) */
   double* stats;        /* [2][Co] or NULL */
   const int* ktab;      /* [nchunks*4] */
   int64_t sN, sH, sW;   /* src strides (elements) */
   int64_t dN, dH, dW;   /* dst strides */
   int64_t aN, aH, aW;   /* addend strides */
+  int64_t mN, mH, mW;   /* mask strides */
   int32_t Hs, Ws;       /* src spatial size */
   int32_t Hd, Wd;       /* row-domain (dst) spatial size */
   int32_t M;            /* N*Hd*Wd */
@@ -109,6 +111,7 @@ int fs_nchw_to_nhwc(const float* a, const float* b, void* dst, int N, int Ca, in
  * blocks.py:44-52.  stats = f64 [2][C] (sum, sumsq) from fs_conv_igemm; count = elements per
  * channel (global count under SyncBatchNorm, scripts/train.py:101).  Block 0 updates the running
  * statistics (momentum, unbiased variance) and num_batches_tracked and saves mean / invstd.
+ * stats == NULL selects eval mode: normalise with running_mean / running_var (no updates).
  * pad_out: y is [N,H+2,W+2,C] and receives a replicated border (consumer conv pads 'replicate',
  * depth_encoder.py:59,62).
  */
@@ -185,12 +188,13 @@ int fs_depth_head_bwd(const float* logits, const float* bins, const float* d_dep
 /* Pose tail: x = last pose conv output fp32 [B][hw][Cx]; mean over hw, x0.01, split into
  * axisangle / translation [B][nframes][3] (pose_decoder.py:39-45) and the 4x4 transform of frame 0
  * (transformation_from_parameters, monodepth_utils.py:31-63,298-337; invert for negative frame ids,
- * monodepth2_model.py:42-43).  Backward: dT [B][4][4] -> dx in `dtype`.
+ * monodepth2_model.py:42-43).  `scale` is the 0.01 of pose_decoder.py:41 (1.0 with hw = 1 turns the
+ * pair into a plain transformation_from_parameters).  Backward: dT [B][4][4] -> dx in `dtype`.
  */
 int fs_pose_tail_fwd(const float* x, float* axisangle, float* translation, float* T, int B, int hw, int Cx,
-                     int nframes, int invert, void* stream);
+                     int nframes, int invert, float scale, void* stream);
 int fs_pose_tail_bwd(const float* x, const float* dT, void* dx, int B, int hw, int Cx, int nframes, int invert,
-                     int dtype, void* stream);
+                     float scale, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Photometric loss chain (monodepth2_decoder.py:61-128,205-292; monodepth_utils.py:101-165,184-215).

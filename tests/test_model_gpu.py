@@ -1,0 +1,183 @@
+"""End-to-end GPU parity of the HIP training path, built through the FSNet registry surface
+(build(**cfg) with repointed name= strings), against the golden vectors of the REAL reference and the
+CPU oracle.  fp32 compute: reference-level tolerances; bf16: stated mixed-precision tolerances."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fsnet_oracle as O
+
+gpu = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def to_dev(data, dev):
+    return {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in data.items()}
+
+
+def build_model(with_pose, H, W, dev, dtype, sd0):
+    from fsnet_amd.configs import meta_arch_cfg
+    from fsnet_amd.engine.runtime import RT
+    from fsnet_amd.vision_base.utils.builder import build
+    RT.set_compute_dtype(dtype)
+    RT.tie_noise = False
+    m = build(**meta_arch_cfg(H, W, with_pose=with_pose))
+    missing = m.load_state_dict({k: v.clone() for k, v in sd0.items()}, strict=True)
+    return m.to(dev).train()
+
+
+@pytest.mark.parametrize("tag,with_pose", [("depthpose", True), ("wpose", False)])
+def test_state_dict_names_match_reference(tag, with_pose):
+    from fsnet_amd.configs import meta_arch_cfg
+    from fsnet_amd.vision_base.utils.builder import build
+    m = build(**meta_arch_cfg(64, 128, with_pose=with_pose))
+    sd0 = O.init_state(seed=1, with_pose=with_pose)   # key list validated against the reference (gen_golden strict load)
+    assert set(m.state_dict().keys()) == set(sd0.keys()) and len(m.state_dict()) == len(sd0)
+    assert [k for k, _ in m.named_parameters()] == [k for k in sd0 if O.is_param(k)]
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(sd0[k].shape), k
+
+
+@gpu
+@pytest.mark.parametrize("tag,with_pose", [("depthpose", True), ("wpose", False)])
+def test_fp32_forward_matches_reference_golden(dev, tag, with_pose):
+    g = np.load(os.path.join(GOLD, "model_%s.npz" % tag))
+    B, H, W = int(g["B"]), int(g["H"]), int(g["W"])
+    sd0 = O.init_state(seed=int(g["init_seed"]), with_pose=with_pose)
+    m = build_model(with_pose, H, W, dev, torch.float32, sd0)
+    data = to_dev(O.synthetic_batch(B, H, W, seed=100), dev)
+    feats = m.depth_backbone(data[("image", 0)])
+    outs = m.head.forward_depth(feats)
+    torch.cuda.synchronize()
+    assert (feats[4].float().cpu() - torch.from_numpy(g["feat4"])).abs().max() < 2e-3
+    for s in range(4):
+        ref = torch.from_numpy(g["disp_%d" % s])
+        rel = ((outs[("disp", s)].cpu() - ref).abs() / ref.abs().clamp_min(1e-6)).max()
+        assert float(rel) < 1e-3, (s, float(rel))          # BASELINE north_star: disparity within 1e-3 rel
+    if with_pose:
+        pf = m.pose_backbone.forward_pair(data[("image", 0)], data[("image", 1)])
+        aa, tr = m.head.forward_pose([pf])
+        torch.cuda.synchronize()
+        assert (aa.cpu() - torch.from_numpy(g["axisangle_p"])).abs().max() < 1e-6
+        assert (tr.cpu() - torch.from_numpy(g["translation_p"])).abs().max() < 1e-6
+
+
+@gpu
+@pytest.mark.parametrize("tag,with_pose", [("depthpose", True), ("wpose", False)])
+def test_fp32_training_steps_match_reference_golden(dev, tag, with_pose):
+    from fsnet_amd.configs import training_cfg
+    from fsnet_amd.vision_base.networks.optimizers.optimizers import build_optimizer
+    from fsnet_amd.vision_base.utils.builder import build
+    g = np.load(os.path.join(GOLD, "model_%s.npz" % tag))
+    B, H, W = int(g["B"]), int(g["H"]), int(g["W"])
+    sd0 = O.init_state(seed=int(g["init_seed"]), with_pose=with_pose)
+    m = build_model(with_pose, H, W, dev, torch.float32, sd0)
+    tc = training_cfg()
+    opt = build_optimizer(m, **tc.optimizer)
+    hook = build(**tc.training_hook)
+    names = [k for k, _ in m.named_parameters()]
+    for it in range(3):
+        data = O.synthetic_batch(B, H, W, seed=100 + it)
+        out = hook(dict(data), m, opt)
+        torch.cuda.synchronize()
+        loss = float(out["loss"])
+        assert out["loss"].dtype == torch.float64
+        ref = float(g["loss_%d" % it])
+        assert abs(loss - ref) < 2e-4 * abs(ref), (it, loss, ref)
+        for k in ("loss/0", "smooth_loss/0", "total_loss"):
+            assert k in out["loss_dict"]
+        tn = float(opt.grad_norm())
+        assert abs(tn - float(g["totalnorm_%d" % it])) < 3e-2 * float(g["totalnorm_%d" % it]), (it, tn)
+        if it == 0:
+            gn = torch.stack([p.grad.norm() for p in m.parameters()]).cpu()
+            refn = torch.from_numpy(g["gradnorm_0"])
+            big = refn > 1e-3 * refn.max()
+            worst = ((gn - refn).abs() / refn)[big].max()
+            assert float(worst) < 3e-2, float(worst)
+    # parameters after 3 Adam steps: compare sums of |p| (robust to the sign-noise of zero-gradient biases)
+    pabs = torch.stack([p.double().abs().sum() for p in m.parameters()]).cpu()
+    ref = torch.from_numpy(g["pabs_2"])
+    assert float(((pabs - ref).abs() / ref.clamp_min(1e-9)).max()) < 5e-3
+    rm = torch.cat([v.flatten() for k, v in m.state_dict().items() if k.endswith("running_mean")]).cpu()
+    assert (rm - torch.from_numpy(g["bn_rm_final"])).abs().max() < 5e-3
+
+
+@gpu
+def test_fp32_gradients_match_oracle(dev):
+    """per-parameter gradients of one depth+pose step vs the CPU oracle (autograd) on the same batch."""
+    B, H, W = 2, 64, 128
+    sd0 = O.init_state(seed=3, with_pose=True)
+    m = build_model(True, H, W, dev, torch.float32, sd0)
+    data = O.synthetic_batch(B, H, W, seed=7)
+    out = m(to_dev(data, dev), dict(is_training=True))
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    tr = O.OracleTrainer(sd0, with_pose=True, clip=None)
+    total, ld, _, raw, _ = tr.step(data)
+    assert abs(float(out["loss"]) - float(total)) < 1e-5 * abs(float(total))
+    worst = 0.0
+    for k, p in m.named_parameters():
+        ref = raw[k]
+        if ref.norm() < 1e-7:
+            continue
+        rel = float((p.grad.cpu() - ref).norm() / ref.norm())
+        worst = max(worst, rel)
+        assert rel < 2e-2, (k, rel)
+    print("worst per-parameter gradient rel-L2 deviation:", worst)
+
+
+@gpu
+def test_bf16_training_step_close_to_fp32_oracle(dev):
+    """bf16 policy: conv operands / activations bf16, fp32 accumulate, fp32 BN statistics, fp32 depth head,
+    geometry and loss.  Stated tolerances vs the fp32 oracle on the same batch (DESIGN.md "bf16"):
+    loss 2e-2 rel; disparity 4e-2 mean-rel / 0.35 max-rel; parameter gradients cosine > 0.8.
+    (Per-parameter gradient L2 deviations of 0.05 (un-rectified heads) .. 0.45 (encoder) are expected: the
+    ~3 % forward perturbation flips ~1-2 % of the BN-centred ReLU masks per layer, and each flipped mask
+    is an O(1) change of that element's gradient.  fp32 compute matches the oracle to 2e-3.)"""
+    B, H, W = 4, 96, 320
+    sd0 = O.init_state(seed=3, with_pose=True)
+    m = build_model(True, H, W, dev, torch.bfloat16, sd0)
+    data = O.synthetic_batch(B, H, W, seed=7)
+    feats = m.depth_backbone(data[("image", 0)].to(dev))
+    outs = m.head.forward_depth(feats)
+    assert feats[4].dtype == torch.bfloat16
+    sd = {k: v.clone() for k, v in sd0.items()}
+    fo = O.resnet_forward(sd, "depth_backbone.", data[("image", 0)])
+    oo = O.depth_decoder_forward(sd, "head.depth_decoder.", fo, 0.5, 100.0)
+    for s in range(4):
+        ref = oo[("disp", s)].detach()
+        rel = (outs[("disp", s)].detach().cpu() - ref).abs() / ref.abs()
+        assert float(rel.mean()) < 4e-2 and float(rel.max()) < 0.35, (s, float(rel.mean()), float(rel.max()))
+    m2 = build_model(True, H, W, dev, torch.bfloat16, sd0)
+    out = m2(to_dev(data, dev), dict(is_training=True))
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    tr = O.OracleTrainer(sd0, with_pose=True, clip=None)
+    total, ld, _, raw, _ = tr.step(data)
+    assert abs(float(out["loss"].detach()) - float(total)) < 2e-2 * abs(float(total))
+    gmax = max(float(r.norm()) for r in raw.values())
+    for k, p in m2.named_parameters():
+        ref = raw[k]
+        if float(ref.norm()) < 1e-3 * gmax or ref.dim() != 4:
+            continue
+        g = p.grad.cpu()
+        cos = float((g * ref).sum() / (g.norm() * ref.norm()))
+        assert cos > 0.8, (k, cos)
+        assert 0.6 < float(g.norm() / ref.norm()) < 1.6, k
+
+
+@gpu
+def test_eval_forward_uses_running_stats(dev):
+    B, H, W = 2, 64, 128
+    sd0 = O.init_state(seed=5, with_pose=False)
+    m = build_model(False, H, W, dev, torch.float32, sd0).eval()
+    data = O.synthetic_batch(B, H, W, seed=9)
+    with torch.no_grad():
+        pred = m(to_dev(data, dev), dict(is_training=False))
+    sd = {k: v.clone() for k, v in sd0.items()}
+    fo = O.resnet_forward(sd, "depth_backbone.", data[("image", 0)], train=False)
+    oo = O.depth_decoder_forward(sd, "head.depth_decoder.", fo, 0.5, 100.0, train=False)
+    ref = oo[("depth", 0, 0)]
+    assert float(((pred["depth"].cpu() - ref).abs() / ref).max()) < 1e-3

@@ -110,6 +110,35 @@ def test_bn_forward_backward(dev, mode):
         assert torch.allclose(dg2.cpu(), g2.grad, rtol=1e-4, atol=1e-4)
 
 
+def test_bn_bf16_unit(dev):
+    """bf16 storage of the BN input/output: errors stay at bf16 rounding level (no mask flips by construction:
+    the oracle sees the same bf16-rounded conv output)."""
+    from fsnet_amd.hip import ops
+    g = torch.Generator().manual_seed(15)
+    N, C, H, W = 4, 64, 12, 20
+    x = (torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3).bfloat16().float()
+    bn = bn_dict(C, g, dev)
+    xr = x.clone().requires_grad_(True)
+    gam = bn["weight"].cpu().clone().requires_grad_(True)
+    bet = bn["bias"].cpu().clone().requires_grad_(True)
+    y_ref = F.relu(F.batch_norm(xr, torch.zeros(C), torch.ones(C), gam, bet, training=True, eps=1e-5))
+    gy = torch.randn(N, C, H, W, generator=g).bfloat16().float()
+    y_ref.backward(gy)
+    xd = nhwc(x, torch.bfloat16).to(dev)
+    st = ops.BnState(C, dev)
+    y = torch.empty(N, H, W, C, dtype=torch.bfloat16, device=dev)
+    ops.bn_apply(xd, stats_of(x).to(dev), bn, st, y, H, W, N * H * W, relu=True)
+    # use the oracle's own mask (y_ref > 0) positions where the bf16 output did not round to the other side
+    dx = torch.empty(N, H, W, C, dtype=torch.bfloat16, device=dev)
+    dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    ops.bn_backward(nhwc(gy, torch.bfloat16).to(dev), y, xd, bn["weight"], st, dx, dg, db, H, W, relu=True)
+    torch.cuda.synchronize()
+    assert (nchw(y) - y_ref.detach()).abs().max() < 2e-2
+    assert float((nchw(dx) - xr.grad).norm() / xr.grad.norm()) < 2e-2
+    assert float((dg.cpu() - gam.grad).norm() / gam.grad.norm()) < 1e-2
+    assert float((db.cpu() - bet.grad).norm() / bet.grad.norm()) < 1e-2
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_maxpool(dev, dtype):
     from fsnet_amd.hip import ops
