@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""Headline benchmark: self-supervised monodepth TRAINING samples/s at 192x640, ResNet-18 depth+pose
+(BASELINE.json metric / configs[1]: bf16, batch 12 per GPU), full optimisation step
+(forward, photometric loss, backward, global-norm clip, Adam) on synthetic 3-frame triplets.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement): value = whole-job samples/s, plus
+`roofline` (dominant kernel family = implicit-GEMM conv on MFMA, timed live with HIP events) and, at
+N=1, `cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def synthetic_device_batches(B, H, W, dev, rank, n=4):
+    """SURVEY §8(d) synthetic triplets, generated once and kept resident in HBM."""
+    from oracle import fsnet_oracle as O   # data generator only (shared with the tests); not on the timed path
+    out = []
+    for i in range(n):
+        d = O.synthetic_batch(B, H, W, seed=1000 * rank + i)
+        out.append({k: v.to(dev) for k, v in d.items()})
+    return out
+
+
+def cpu_baseline(max_seconds=25.0):
+    """Oracle (CPU restatement of the reference path, parity-pinned to the reference) on this box's host
+    cores: BASELINE config[0] (B=2, 192x640, depth+pose, fp32), full step incl. clip + Adam."""
+    from oracle import fsnet_oracle as O
+    ncores = os.cpu_count() or 1
+    try:
+        import psutil
+        ncores = psutil.cpu_count(logical=False) or ncores
+    except Exception:
+        pass
+    torch.set_num_threads(ncores)
+    B, H, W = 2, 192, 640
+    tr = O.OracleTrainer(O.init_state(seed=0, with_pose=True), with_pose=True)
+    data = O.synthetic_batch(B, H, W, seed=0)
+    tr.step(data)                      # warm-up
+    t0 = time.time()
+    n = 0
+    while n < 3 or (time.time() - t0 < max_seconds and n < 12):
+        tr.step(data)
+        n += 1
+    dt = (time.time() - t0) / n
+    return {"value": round(B / dt, 4), "unit": "samples/s", "cores": ncores, "kind": "port",
+            "sample": "%d full training steps, B=2, 192x640, R18 depth+pose, fp32 torch-CPU oracle (%.2f s/step)" % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=12)
+    ap.add_argument("--height", type=int, default=192)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--depth", type=int, default=18)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        torch.distributed.init_process_group(backend="nccl", init_method="env://")
+
+    from fsnet_amd.configs import meta_arch_cfg, training_cfg
+    from fsnet_amd.engine.runtime import RT
+    from fsnet_amd.hip.conv import LaunchProfile
+    from fsnet_amd.vision_base.networks.optimizers.optimizers import build_optimizer
+    from fsnet_amd.vision_base.utils.builder import build
+    from fsnet_amd.vision_base.utils.utils import set_random_seed
+
+    set_random_seed(123)
+    RT.set_compute_dtype(args.dtype)
+    B, H, W = args.batch, args.height, args.width
+    model = build(**meta_arch_cfg(H, W, with_pose=True, depth=args.depth)).to(dev).train()
+    tc = training_cfg(clip_gradients=35.0, lr=1e-4)
+    optimizer = build_optimizer(model, **tc.optimizer)
+    hook = build(**tc.training_hook)
+    batches = synthetic_device_batches(B, H, W, dev, rank)
+
+    def run_steps(n, start):
+        for i in range(n):
+            hook(dict(batches[(start + i) % len(batches)]), model, optimizer, global_step=start + i)
+
+    run_steps(args.warmup, 0)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(args.steps, args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+    loss = float(model.head._pl.out[-1])
+    assert loss == loss and abs(loss) < 1e3, "training diverged (loss=%r)" % loss
+
+    # ---- live kernel timing for the roofline object (extra steps, outside the timed region) ----
+    roofline, extra = None, {}
+    if not args.no_kernel_profile:
+        LaunchProfile.begin()
+        nprof = 3
+        run_steps(nprof, args.warmup + args.steps)
+        rec = LaunchProfile.end()
+        agg = {}
+        for kind, work, dt in rec:
+            a = agg.setdefault(kind, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += work; a[2] += dt
+        cg = agg["conv_igemm"]
+        ach = cg[1] / cg[2] / 1e12
+        roofline = {"kernel": "conv_igemm_kernel (fwd+dgrad, %d launches/step)" % (cg[0] // nprof), "bound": "mfma",
+                    "achieved": round(ach, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                    "avg_launch_us": round(cg[2] / cg[0] * 1e6, 2)}
+        wg = agg["conv_wgrad"]
+        extra["conv_wgrad"] = {"achieved_tflops": round(wg[1] / wg[2] / 1e12, 2), "launches_per_step": wg[0] // nprof,
+                               "avg_launch_us": round(wg[2] / wg[0] * 1e6, 2)}
+        for k in ("photo_warp", "photo_loss_fwd", "photo_loss_bwd"):
+            a = agg[k]
+            extra[k] = {"algorithmic_GBps": round(a[1] / a[2] / 1e9, 1), "frac_hbm_peak": round(a[1] / a[2] / 1e9 / PEAK_HBM_GBS, 4),
+                        "avg_launch_us": round(a[2] / a[0] * 1e6, 2)}
+        conv_time = (cg[2] + wg[2]) / nprof
+        extra["conv_time_ms_per_step"] = round(conv_time * 1e3, 3)
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        line = {
+            "metric": "training samples/sec (3-frame triplets) at %dx%d, ResNet-%d depth+pose" % (H, W, args.depth),
+            "value": round(B * world * args.steps / elapsed, 2), "unit": "samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "KITTI Eigen-Zhou-shaped synthetic triplets, ResNet-%d depth+pose, %dx%d, %s, "
+                                   "batch %d/GPU, full step (fwd+loss+bwd+clip35+Adam)" % (args.depth, H, W, args.dtype, B),
+                       "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(loss, 6)},
+            "roofline": roofline, "kernels": extra,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

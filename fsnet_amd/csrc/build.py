@@ -20,8 +20,8 @@ def _digest(paths):
     h = hashlib.sha256()
     for p in sorted(paths):
         with open(p, "rb") as f:
-            h.update(p.encode() + b"\0" + f.read())
-    h.update(" ".join(FLAGS).encode())
+            h.update(os.path.basename(p).encode() + b"\0" + f.read())
+    h.update(" ".join(f for f in FLAGS if not f.startswith("/")).encode())
     return h.hexdigest()
 
 

@@ -102,6 +102,9 @@ def load_library(path=None):
     if _lib is not None:
         return _lib
     path = path or os.environ.get("FSNET_HIP_LIB", LIB_PATH)
+    # torch bundles its own libamdhip64; it must be the HIP runtime of this process BEFORE our library is
+    # dlopen'ed (same SONAME), otherwise kernels register with a second runtime and every launch fails.
+    import torch  # noqa: F401
     if not os.path.exists(path):
         raise FsError(
             "libfsnet_hip.so not found at %s — the HIP kernel library is required (no CPU fallback). "

@@ -9,6 +9,36 @@ import torch
 from .binding import lib, check, stream_ptr, FsConvArgs, FsWgradArgs, FS_DTYPE_BF16, FS_DTYPE_F32
 
 
+class LaunchProfile:
+    """Optional per-launch timing with HIP events recorded on the stream the kernels are launched on
+    (torch's current stream).  bench.py enables it for a few extra steps after the timed region."""
+    active = False
+    records = []   # (kind, flops, start_event, end_event)
+
+    @classmethod
+    def begin(cls):
+        cls.active, cls.records = True, []
+
+    @classmethod
+    def end(cls):
+        cls.active = False
+        torch.cuda.synchronize()
+        out = [(k, f, s.elapsed_time(e) * 1e-3) for (k, f, s, e) in cls.records]
+        cls.records = []
+        return out
+
+
+def _timed(kind, flops, fn):
+    if not LaunchProfile.active:
+        return fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    r = fn()
+    e.record()
+    LaunchProfile.records.append((kind, flops, s, e))
+    return r
+
+
 def dtype_code(dtype):
     if dtype == torch.bfloat16:
         return FS_DTYPE_BF16
@@ -107,7 +137,8 @@ class ConvOp:
         a.Co, a.Co_p, a.nchunks = out.shape[3], self.Co_p, self.nch_f
         a.hb_mul, a.hb_add, a.sgn, a.dshift = self.stride, -self.pad, 1, 0
         a.relu, a.out_f32 = int(relu), int(out_f32)
-        check(lib.fs_conv_igemm(C.byref(a), self.code, stream_ptr()), "conv_fwd")
+        flops = 2.0 * a.M * self.Co * self.R * self.S * self.Ci
+        _timed("conv_igemm", flops, lambda: check(lib.fs_conv_igemm(C.byref(a), self.code, stream_ptr()), "conv_fwd"))
         return out
 
     def dgrad(self, dy, H, W, out=None, addend=None, mask=None):
@@ -133,7 +164,8 @@ class ConvOp:
         a.Co, a.Co_p, a.nchunks = out.shape[3], self.rows_d, self.nch_d
         a.hb_mul, a.hb_add, a.sgn, a.dshift = 1, self.pad, -1, (1 if self.stride == 2 else 0)
         a.relu, a.out_f32 = 0, 0
-        check(lib.fs_conv_igemm(C.byref(a), self.code, stream_ptr()), "conv_dgrad")
+        flops = 2.0 * N * Ho * Wo * self.Co * self.R * self.S * self.Ci
+        _timed("conv_igemm", flops, lambda: check(lib.fs_conv_igemm(C.byref(a), self.code, stream_ptr()), "conv_dgrad"))
         return out
 
     def wgrad(self, dy, x, dw):
@@ -148,5 +180,6 @@ class ConvOp:
         a.M, a.Cd = N * Ho * Wo, Cd
         a.Co, a.Ci, a.R, a.S = self.Co, self.Ci, self.R, self.S
         a.stride, a.pad, a.ncolgroups, a.pix_per_split = self.stride, self.pad, self.ncolgroups, 0
-        check(lib.fs_conv_wgrad(C.byref(a), self.code, stream_ptr()), "conv_wgrad")
+        flops = 2.0 * a.M * self.Co * self.R * self.S * self.Ci
+        _timed("conv_wgrad", flops, lambda: check(lib.fs_conv_wgrad(C.byref(a), self.code, stream_ptr()), "conv_wgrad"))
         return dw

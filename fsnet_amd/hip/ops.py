@@ -5,7 +5,7 @@ import ctypes as C
 import torch
 
 from .binding import (lib, check, stream_ptr, FsBnApplyArgs, FsBnBwdArgs, FsPhotoArgs, FsSmoothArgs)
-from .conv import dtype_code
+from .conv import dtype_code, _timed
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -256,8 +256,11 @@ class PhotometricLoss:
                 check(lib.fs_color_pyramid(img0.data_ptr(), self.pyr[i].data_ptr(), self.B, self.H, self.W,
                                            self.hw[i][0], self.hw[i][1], st), "color_pyramid")
         check(lib.fs_photo_identity(pa, st), "photo_identity")
-        check(lib.fs_photo_warp(pa, st), "photo_warp")
-        check(lib.fs_photo_loss_fwd(pa, st), "photo_loss_fwd")
+        N_px = float(self.B * self.H * self.W)
+        # algorithmic bytes: per scale, target 12N + 2 sources 24N + depth 4N/4^s + result 4N
+        fwd_bytes = sum(40.0 * N_px + 4.0 * N_px / (4 ** s) for s in self.scales)
+        _timed("photo_warp", fwd_bytes * 0.5, lambda: check(lib.fs_photo_warp(pa, st), "photo_warp"))
+        _timed("photo_loss_fwd", fwd_bytes * 0.5, lambda: check(lib.fs_photo_loss_fwd(pa, st), "photo_loss_fwd"))
         check(lib.fs_smooth_mean(sa, st), "smooth_mean")
         check(lib.fs_smooth_fwd(sa, st), "smooth_fwd")
         check(lib.fs_loss_finalize(self.loss_sums.data_ptr(), self.mask_sum.data_ptr(), self.sm_sums.data_ptr(), sa,
@@ -273,7 +276,9 @@ class PhotometricLoss:
         for d in self.d_depth:
             d.zero_()
         self.dP.zero_()
-        check(lib.fs_photo_loss_bwd(pa, st), "photo_loss_bwd")
+        N_px = float(self.B * self.H * self.W)
+        bwd_bytes = sum(40.0 * N_px + 8.0 * N_px / (4 ** s) for s in self.scales)
+        _timed("photo_loss_bwd", bwd_bytes, lambda: check(lib.fs_photo_loss_bwd(pa, st), "photo_loss_bwd"))
         check(lib.fs_photo_pose_grad(self.geo.data_ptr(), self.dP.data_ptr(), self.dT[0].data_ptr(),
                                      self.dT[1].data_ptr(), self.B, st), "photo_pose_grad")
         check(lib.fs_smooth_bwd(sa, st), "smooth_bwd")
