@@ -20,7 +20,12 @@ __device__ inline void bn_channel_coeffs(const double* stats, const float* rmean
                                          double count, float eps, float gamma, float beta, float& mean,
                                          float& invstd, float& var_b, float& scale, float& shift) {
   double m, v;
-  if (stats) { m = stats[c] / count; v = stats[C + c] / count - m * m; }
+  if (stats) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < FS_STAT_SLOTS; ++k) { s1 += stats[(long)k * 2 * C + c]; s2 += stats[(long)k * 2 * C + C + c]; }
+    m = s1 / count; v = s2 / count - m * m;
+  }
   else { m = rmean[c]; v = rvar[c]; }  // eval mode: running statistics
   if (v < 0) v = 0;
   mean = (float)m;
@@ -178,8 +183,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const FsBnBwdArgs p)
     for (int j = 0; j < 4; ++j) {
       float a = 0.f, b = 0.f;
       for (int k = 0; k < PL; ++k) { a += red[0][j][k * CGB + cgl]; b += red[1][j][k * CGB + cgl]; }
-      atomicAdd(p.sums + c + j, (double)a);
-      atomicAdd(p.sums + C + c + j, (double)b);
+      double* sl = p.sums + (long)(blockIdx.x % FS_STAT_SLOTS) * 2 * C;
+      atomicAdd(sl + c + j, (double)a);
+      atomicAdd(sl + C + c + j, (double)b);
     }
   }
 }
@@ -190,7 +196,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const FsBnBwdArgs p) 
   __shared__ float s_a[MAXC], s_b[MAXC], s_k[MAXC], s_mean[MAXC], s_istd[MAXC];
   const int C = p.C;
   for (int c = threadIdx.x; c < C; c += 256) {
-    double sg = p.sums[c], sgx = p.sums[C + c];
+    double sg = 0.0, sgx = 0.0, lg = 0.0, lgx = 0.0;
+#pragma unroll
+    for (int k = 0; k < FS_STAT_SLOTS; ++k) {
+      sg += p.sums[(long)k * 2 * C + c]; sgx += p.sums[(long)k * 2 * C + C + c];
+      if (p.sums_local) { lg += p.sums_local[(long)k * 2 * C + c]; lgx += p.sums_local[(long)k * 2 * C + C + c]; }
+    }
     float istd = p.save_invstd[c];
     s_mean[c] = p.save_mean[c]; s_istd[c] = istd;
     s_k[c] = p.gamma[c] * istd;
@@ -198,8 +209,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const FsBnBwdArgs p) 
     s_b[c] = (float)(sgx / p.count);
     if (blockIdx.x == 0) {
       // dgamma / dbeta of the local shard (the data-parallel all-reduce of gradients averages them later)
-      if (p.dgamma) p.dgamma[c] += (float)(p.sums_local ? p.sums_local[C + c] : sgx);
-      if (p.dbeta) p.dbeta[c] += (float)(p.sums_local ? p.sums_local[c] : sg);
+      if (p.dgamma) p.dgamma[c] += (float)(p.sums_local ? lgx : sgx);
+      if (p.dbeta) p.dbeta[c] += (float)(p.sums_local ? lg : sg);
     }
   }
   __syncthreads();
@@ -263,12 +274,12 @@ extern "C" int fs_bn_bwd_reduce(const FsBnBwdArgs* a, int dtype, void* stream) {
   const int CG = a->C / 4;
   // channel groups per block: 64 (4 pixel lanes) for wide layers, 16 (16 pixel lanes) for narrow ones
   if (CG >= 64) {
-    dim3 grid((unsigned)std::min<long>(((long)a->M + 3) / 4, 1024), (CG + 63) / 64);
+    dim3 grid((unsigned)std::min<long>(((long)a->M + 15) / 16, 512), (CG + 63) / 64);
     if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, 64>), grid, dim3(256), 0, st, *a);
     else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 64>), grid, dim3(256), 0, st, *a);
     else return FS_EINVAL;
   } else {
-    dim3 grid((unsigned)std::min<long>(((long)a->M + 15) / 16, 2048), (CG + 15) / 16);
+    dim3 grid((unsigned)std::min<long>(((long)a->M + 63) / 64, 1024), (CG + 15) / 16);
     if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, 16>), grid, dim3(256), 0, st, *a);
     else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 16>), grid, dim3(256), 0, st, *a);
     else return FS_EINVAL;

@@ -74,3 +74,12 @@ __device__ static inline double wave_sum_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+
+// block-wide sum (blockDim.x == 256): result valid in thread 0.  `sh` = 4 doubles of LDS.
+__device__ static inline double block_sum_d(double v, double* sh) {
+  v = wave_sum_d(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}

@@ -200,7 +200,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
   }
 
   if (p.stats) {
-    // reduce over the 16 pixel lanes that share lg, then one f64 atomic per channel per wave
+    // per-channel (sum, sumsq): 16 pixel lanes by shuffle, the WP pixel-waves through LDS, then ONE f64
+    // atomic per channel per block into one of FS_STAT_SLOTS address slots (same-address atomics cost
+    // ~12 ns each on MI355X; slots + block reduce keep the chain per address short).
+    __syncthreads();                     // all waves are done reading the operand tiles
+    float* red = reinterpret_cast<float*>(&lds_p[0][0]);   // [WP][CO][2]
 #pragma unroll
     for (int a = 0; a < TC; ++a)
 #pragma unroll
@@ -208,12 +212,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
         float u = s1[a][j], w = s2[a][j];
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) { u += __shfl_xor(u, o, 64); w += __shfl_xor(w, o, 64); }
-        int co = co0 + wc * WCO + a * 16 + lg * 4 + j;
-        if (li == 0 && co < p.Co) {
-          atomicAdd(p.stats + co, (double)u);
-          atomicAdd(p.stats + p.Co + co, (double)w);
+        if (li == 0) {
+          int cl = wc * WCO + a * 16 + lg * 4 + j;
+          red[(wp * CO + cl) * 2] = u; red[(wp * CO + cl) * 2 + 1] = w;
         }
       }
+    __syncthreads();
+    if (t < CO) {
+      float u = 0.f, w = 0.f;
+#pragma unroll
+      for (int k = 0; k < WP; ++k) { u += red[(k * CO + t) * 2]; w += red[(k * CO + t) * 2 + 1]; }
+      int co = co0 + t;
+      if (co < p.Co) {
+        double* sl = p.stats + (long)(blockIdx.x % FS_STAT_SLOTS) * 2 * p.Co;
+        atomicAdd(sl + co, (double)u);
+        atomicAdd(sl + p.Co + co, (double)w);
+      }
+    }
   }
 }
 

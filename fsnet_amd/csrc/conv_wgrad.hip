@@ -6,10 +6,12 @@
 // tiles are staged in LDS in their natural [pixel][channel] layout (coalesced 16-byte loads)
 // and the MFMA fragments are fetched transposed: ds_read_b64_tr_b16 for bf16 (gfx950 LDS
 // transpose-read), plain ds_read_b32 for f32 (one scalar per lane per MFMA).  The pixel range
-// is split over blockIdx.z; partial tiles are combined with f32 atomics straight into the
-// OIHW gradient the optimizer consumes.
+// is split over blockIdx.z; an unsplit tile accumulates straight into the OIHW gradient the optimizer
+// consumes, split tiles write dense partial slabs that a second kernel reduces (no atomics: same-address
+// atomics serialise at ~12 ns each on MI355X and dominated the first version of this kernel).
 #include "common.h"
 #include "fsnet_hip_internal.h"
+#include <algorithm>
 
 namespace {
 
@@ -163,6 +165,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const FsWgradArgs p) {
   }
 
   // ---- epilogue: D rows = co (lg*4+j), cols = gemm column (li) ----
+  if (p.nsplit > 1) {
+    // split-K partial: dense slab [split][Cd_t][ncols_t] in the workspace (reduced by wgrad_reduce_kernel)
+    float* ws = p.workspace + (long)blockIdx.z * p.ws_rows * p.ws_cols;
+#pragma unroll
+    for (int b = 0; b < TB; ++b) {
+      int col = col0 + wcn * WCOL + b * 16 + li;
+#pragma unroll
+      for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int co = co0 + wr * WROW + a * 16 + lg * 4 + j;
+          ws[(long)co * p.ws_cols + col] = acc[a][b][j];
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int b = 0; b < TB; ++b) {
     int col = col0 + wcn * WCOL + b * 16 + li;
@@ -178,57 +196,65 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const FsWgradArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         int co = co0 + wr * WROW + a * 16 + lg * 4 + j;
-        if (co < p.Co) atomicAdd(p.dw + (((long)co * p.Ci + ci) * p.R + r) * p.S + s, acc[a][b][j]);
+        if (co < p.Co) p.dw[(((long)co * p.Ci + ci) * p.R + r) * p.S + s] += acc[a][b][j];  // sole owner: plain RMW
       }
   }
 }
 
+// dw[co][ci][r][s] += sum_z workspace[z][co][col]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const FsWgradArgs p, int eg) {
+  const long total = (long)p.Co * p.ncolgroups * eg;
+  const int ncols = p.ncolgroups * eg;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int col = (int)(i % ncols), co = (int)(i / ncols);
+    int e = p.ktab[col / eg];
+    if (e < 0) continue;
+    int ci = (e & 0xffff) + (col % eg);
+    if (ci >= p.Ci) continue;
+    int r = (e >> 16) & 0xff, s = (e >> 24) & 0x7f;
+    const float* ws = p.workspace + (long)co * p.ws_cols + col;
+    float acc = 0.f;
+    for (int z = 0; z < p.nsplit; ++z) acc += ws[(long)z * p.ws_rows * p.ws_cols];
+    p.dw[(((long)co * p.Ci + ci) * p.R + r) * p.S + s] += acc;
+  }
+}
+
 template <typename T, int COT, int CLT, int WR>
-int launch_tile(const FsWgradArgs& a, int splits, hipStream_t st) {
+int launch_tile(const FsWgradArgs& a, hipStream_t st) {
+  constexpr int EG = ElemTraits<T>::EG;
   FsWgradArgs b = a;
-  long chunks = (a.M + 31) / 32;
+  const int ncols = a.ncolgroups * EG;
+  const int ct = (ncols + CLT - 1) / CLT, rt = (a.Cd + COT - 1) / COT;
+  const long tiles = (long)ct * rt;
+  const long chunks = (a.M + 31) / 32;
+  // split the pixel (K) range until ~768 blocks are in flight, keeping >= 8 chunks per block and the
+  // partial slabs inside the caller's workspace
+  long splits = (768 + tiles - 1) / tiles;
+  splits = std::min<long>(splits, std::max<long>(1, chunks / 8));
+  b.ws_rows = rt * COT; b.ws_cols = ct * CLT;
+  const long slab = (long)b.ws_rows * b.ws_cols;
+  if (!a.workspace) splits = 1;
+  else splits = std::min<long>(splits, std::max<long>(1, a.workspace_elems / slab));
   long cps = (chunks + splits - 1) / splits;
   b.pix_per_split = (int)(cps * 32);
-  int nz = (int)((chunks + cps - 1) / cps);
-  int ncols = a.ncolgroups * ElemTraits<T>::EG;
-  dim3 grid((ncols + CLT - 1) / CLT, (a.Cd + COT - 1) / COT, nz);
+  b.nsplit = (int)((chunks + cps - 1) / cps);
+  dim3 grid(ct, rt, b.nsplit);
   hipLaunchKernelGGL((conv_wgrad_kernel<T, COT, CLT, WR>), grid, dim3(256), 0, st, b);
+  if (b.nsplit > 1) {
+    long total = (long)a.Co * ncols;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, st, b, EG);
+  }
   return fs_launch_status();
 }
 
 template <typename T>
 int launch_wgrad(const FsWgradArgs& a, hipStream_t st) {
-  int ncols = a.ncolgroups * ElemTraits<T>::EG;
-  long chunks = (a.M + 31) / 32;
-  auto pick_splits = [&](long tiles) {
-    long want = (1024 + tiles - 1) / tiles;          // aim for ~4 blocks per CU
-    long maxs = chunks / 8 > 0 ? chunks / 8 : 1;     // at least 8 chunks per block
-    long s = want < maxs ? want : maxs;
-    return (int)(s < 1 ? 1 : s);
-  };
   constexpr bool kBf16 = sizeof(T) == 2;  // f32 tiles are capped by the 64 KB static LDS limit
-  if constexpr (kBf16) {
-    if (a.Cd % 128 == 0 && ncols >= 128) {
-      long tiles = (long)(a.Cd / 128) * ((ncols + 127) / 128);
-      return launch_tile<T, 128, 128, 2>(a, pick_splits(tiles), st);
-    }
-  }
-  if (a.Cd % 64 == 0) {
-    long tiles = (long)(a.Cd / 64) * ((ncols + 63) / 64);
-    return launch_tile<T, 64, 64, 2>(a, pick_splits(tiles), st);
-  }
-  if (a.Cd % 32 == 0) {
-    long tiles = (long)(a.Cd / 32) * ((ncols + 127) / 128);
-    return launch_tile<T, 32, 128, 1>(a, pick_splits(tiles), st);
-  }
+  if (a.Cd % 64 == 0) return launch_tile<T, 64, 64, 2>(a, st);
+  if (a.Cd % 32 == 0) return launch_tile<T, 32, 128, 1>(a, st);
   if (a.Cd % 16 == 0) {
-    if constexpr (kBf16) {
-      long tiles = (long)(a.Cd / 16) * ((ncols + 255) / 256);
-      return launch_tile<T, 16, 256, 1>(a, pick_splits(tiles), st);
-    } else {
-      long tiles = (long)(a.Cd / 16) * ((ncols + 127) / 128);
-      return launch_tile<T, 16, 128, 1>(a, pick_splits(tiles), st);
-    }
+    if constexpr (kBf16) return launch_tile<T, 16, 256, 1>(a, st);
+    else return launch_tile<T, 16, 128, 1>(a, st);
   }
   return FS_EINVAL;
 }

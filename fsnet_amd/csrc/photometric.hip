@@ -158,8 +158,9 @@ __global__ __launch_bounds__(256) void photo_ident_kernel(const FsPhotoArgs p) {
     }
     msum += p.patched_mask ? p.patched_mask[(long)b * HW + i] : 1.0;
   }
-  msum = wave_sum_d(msum);
-  if ((threadIdx.x & 63) == 0) atomicAdd(p.mask_sum, msum);
+  __shared__ double sh[4];
+  msum = block_sum_d(msum, sh);
+  if (threadIdx.x == 0) atomicAdd(p.mask_sum + b, msum);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -233,8 +234,9 @@ __global__ __launch_bounds__(256) void photo_loss_fwd_kernel(const FsPhotoArgs p
     double pm = p.patched_mask ? p.patched_mask[(long)b * HW + i] : 1.0;
     acc += (double)best * pm;
   }
-  acc = wave_sum_d(acc);
-  if ((threadIdx.x & 63) == 0) atomicAdd(p.loss_sums + s, acc);
+  __shared__ double sh[4];
+  acc = block_sum_d(acc, sh);
+  if (threadIdx.x == 0) atomicAdd(p.loss_sums + s * p.B + b, acc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -266,7 +268,9 @@ __global__ __launch_bounds__(256) void photo_loss_bwd_kernel(const FsPhotoArgs p
   const uint8_t* sel = p.sel + ((long)s * p.B + b) * HW;
   const float* ge = p.geo + (long)b * GEO_STRIDE;
   const double gout = p.gout ? *p.gout : 1.0;
-  const float gscale = (float)(gout / ((double)p.S * (*p.mask_sum + 1e-6)));
+  double msum = 0.0;
+  for (int k = 0; k < p.B; ++k) msum += p.mask_sum[k];
+  const float gscale = (float)(gout / ((double)p.S * (msum + 1e-6)));
 
   for (int i = tid; i < 3 * R2H * R2W; i += 256) {
     int c = i / (R2H * R2W), rem = i % (R2H * R2W), ry = rem / R2W, rx = rem % R2W;
@@ -467,7 +471,7 @@ extern "C" int fs_photo_identity(const FsPhotoArgs* a, void* stream) {
   if (!valid(a) || !a->ident || !a->mask_sum) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   long HW = (long)a->H * a->W;
-  dim3 grid((unsigned)std::min<long>((HW + 255) / 256, 2048), a->B);
+  dim3 grid((unsigned)std::min<long>((HW + 255) / 256, 64), a->B);
   hipLaunchKernelGGL(photo_ident_kernel, grid, dim3(256), 0, st, *a);
   return fs_launch_status();
 }
@@ -486,7 +490,7 @@ extern "C" int fs_photo_loss_fwd(const FsPhotoArgs* a, void* stream) {
   if (!valid(a) || !a->pred || !a->ov || !a->ident || !a->sel || !a->loss_sums) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   long HW = (long)a->H * a->W;
-  dim3 grid((unsigned)std::min<long>((HW + 255) / 256, 2048), a->B, a->S);
+  dim3 grid((unsigned)std::min<long>((HW + 255) / 256, 64), a->B, a->S);
   hipLaunchKernelGGL(photo_loss_fwd_kernel, grid, dim3(256), 0, st, *a);
   return fs_launch_status();
 }

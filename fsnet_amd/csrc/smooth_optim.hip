@@ -33,8 +33,9 @@ __global__ __launch_bounds__(256) void smooth_mean_kernel(const FsSmoothArgs p) 
   const float* d = p.disp[s] + (long)b * hw;
   float acc = 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < hw; i += (long)gridDim.x * 256) acc += d[i];
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) atomicAdd(p.disp_sum + s * p.B + b, (double)acc);
+  __shared__ double sh[4];
+  double tot = block_sum_d((double)acc, sh);
+  if (threadIdx.x == 0) atomicAdd(p.disp_sum + s * p.B + b, tot);
 }
 
 __device__ __forceinline__ float edge_w(const float* __restrict__ col, long hw, long i0, long i1) {
@@ -57,8 +58,13 @@ __global__ __launch_bounds__(256) void smooth_fwd_kernel(const FsSmoothArgs p) {
     if (x + 1 < w) ax += fabsf(v - d[i + 1] * inv) * edge_w(col, hw, i, i + 1);
     if (y + 1 < h) ay += fabsf(v - d[i + w] * inv) * edge_w(col, hw, i, i + w);
   }
-  ax = wave_sum(ax); ay = wave_sum(ay);
-  if ((threadIdx.x & 63) == 0) { atomicAdd(p.sm_sums + s * 2, (double)ax); atomicAdd(p.sm_sums + s * 2 + 1, (double)ay); }
+  __shared__ double sh[4];
+  double tx = block_sum_d((double)ax, sh);
+  double ty = block_sum_d((double)ay, sh);
+  if (threadIdx.x == 0) {
+    atomicAdd(p.sm_sums + (s * p.B + b) * 2, tx);
+    atomicAdd(p.sm_sums + (s * p.B + b) * 2 + 1, ty);
+  }
 }
 
 // d loss / d nd at pixel i (both neighbours on each axis), scaled by the loss weights
@@ -90,8 +96,9 @@ __global__ __launch_bounds__(256) void smooth_bwd_dot_kernel(const FsSmoothArgs 
     int x = (int)(i % w), y = (int)(i / w);
     acc += smooth_dnd(d, col, hw, h, w, y, x, inv, kx, ky) * d[i];
   }
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) atomicAdd(p.dot + s * p.B + b, (double)acc);
+  __shared__ double sh[4];
+  double tot = block_sum_d((double)acc, sh);
+  if (threadIdx.x == 0) atomicAdd(p.dot + s * p.B + b, tot);
 }
 
 // backward pass 2: d_disp(i) = dnd(i)*inv - dot * inv^2 / (h*w)
@@ -117,13 +124,16 @@ __global__ __launch_bounds__(256) void smooth_bwd_apply_kernel(const FsSmoothArg
 __global__ void loss_finalize_kernel(const double* __restrict__ loss_sums, const double* __restrict__ mask_sum,
                                      const double* __restrict__ sm_sums, const FsSmoothArgs p, double* __restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double total = 0.0;
+  double total = 0.0, msum = 0.0;
+  for (int b = 0; b < p.B; ++b) msum += mask_sum[b];
   for (int s = 0; s < p.S; ++s) {
     const int h = p.h[s], w = p.w[s];
-    float sx = (float)(sm_sums[s * 2] / (double)((long)p.B * h * (w - 1)));
-    float sy = (float)(sm_sums[s * 2 + 1] / (double)((long)p.B * (h - 1) * w));
+    double ax = 0.0, ay = 0.0, ls = 0.0;
+    for (int b = 0; b < p.B; ++b) { ax += sm_sums[(s * p.B + b) * 2]; ay += sm_sums[(s * p.B + b) * 2 + 1]; ls += loss_sums[s * p.B + b]; }
+    float sx = (float)(ax / (double)((long)p.B * h * (w - 1)));
+    float sy = (float)(ay / (double)((long)p.B * (h - 1) * w));
     float sm = (sx + sy) * 1e-5f / (float)(1 << p.scale_id[s]);   // fp32 like the reference's smooth_loss
-    double l = loss_sums[s] / (*mask_sum + 1e-6) + (double)sm;
+    double l = ls / (msum + 1e-6) + (double)sm;
     out[s] = l; out[p.S + s] = (double)sm;
     total += l;
   }
@@ -186,7 +196,7 @@ static bool smooth_valid(const FsSmoothArgs* a) {
 static dim3 smooth_grid(const FsSmoothArgs* a) {
   long hw = (long)a->h[0] * a->w[0];
   for (int s = 1; s < a->S; ++s) hw = std::max<long>(hw, (long)a->h[s] * a->w[s]);
-  return dim3((unsigned)std::min<long>((hw + 255) / 256, 512), a->B, a->S);
+  return dim3((unsigned)std::min<long>((hw + 255) / 256, 32), a->B, a->S);
 }
 
 extern "C" int fs_smooth_mean(const FsSmoothArgs* a, void* stream) {

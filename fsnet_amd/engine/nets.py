@@ -14,11 +14,13 @@ from ..hip import ops
 from ..hip.conv import ConvOp
 from .runtime import RT, grad_of
 
+STAT_SLOTS = ops.STAT_SLOTS
+
 
 class StatsPool:
     """f64 scratch for BatchNorm batch statistics: one memset per network forward."""
 
-    def __init__(self, device, capacity=1 << 16):
+    def __init__(self, device, capacity=1 << 19):
         self.buf = torch.zeros(capacity, dtype=torch.float64, device=device)
         self.off = 0
 
@@ -27,10 +29,10 @@ class StatsPool:
         self.off = 0
 
     def take(self, C):
-        n = 2 * C
+        n = STAT_SLOTS * 2 * C
         if self.off + n > self.buf.numel():
-            return torch.zeros(2, C, dtype=torch.float64, device=self.buf.device)
-        v = self.buf[self.off:self.off + n].view(2, C)
+            return torch.zeros(STAT_SLOTS, 2, C, dtype=torch.float64, device=self.buf.device)
+        v = self.buf[self.off:self.off + n].view(STAT_SLOTS, 2, C)
         self.off += n
         return v
 
@@ -98,10 +100,24 @@ def _dp_stats(stats):
     return 1
 
 
+_BWD_POOLS = {}
+
+
+def bwd_pool_reset(device):
+    """one memset per network backward for all its BatchNorm backward sums"""
+    p = _BWD_POOLS.get(device)
+    if p is None:
+        p = _BWD_POOLS[device] = StatsPool(device)
+    p.reset()
+    return p
+
+
 def _bn_bwd(dout, y, c, bn, st, H, W, relu=True, fold=False, g_out=None):
     dc = torch.empty_like(c)
+    sums = _BWD_POOLS[c.device].take(c.shape[-1])
     ops.bn_backward(dout, y, c, bn.weight.data, st, dc, grad_of(bn.weight), grad_of(bn.bias), H, W, relu=relu,
-                    fold=fold, g_out=g_out, allreduce=(RT.dp.allreduce_small if RT.dp is not None else None))
+                    fold=fold, g_out=g_out, sums=sums, sums_zeroed=True,
+                    allreduce=(RT.dp.allreduce_small if RT.dp is not None else None))
     return dc
 
 
@@ -224,6 +240,7 @@ class ResNetRunner:
     def backward(self, ctx, gfeats):
         """gfeats: list of 5 NHWC dense gradients (or None).  Accumulates parameter gradients."""
         nst = len(self.stages)
+        bwd_pool_reset(ctx["x"].device)
         dout = gfeats[nst]
         last = ctx["blocks"][-1]["u"][-1][2]
         if dout is None:
@@ -316,6 +333,7 @@ class DepthDecoderRunner:
         dev, dt = feats[-1].device, feats[-1].dtype
         K = int(m.num_output_channels)
         gfeats = [None] * 5
+        bwd_pool_reset(dev)
 
         def disp_grad(i):
             """padded-domain gradient of y1p_i from its dispconv (or zeros)."""

@@ -69,6 +69,17 @@ def _nhwc_strides(t):
     return t.stride(0), t.stride(1), t.stride(2)
 
 
+_WGRAD_WS = {}
+
+
+def wgrad_workspace(device, elems=1 << 23):
+    """per-device fp32 scratch for split-K partial slabs (32 MB; stream-ordered reuse)."""
+    ws = _WGRAD_WS.get(device)
+    if ws is None or ws.numel() < elems:
+        ws = _WGRAD_WS[device] = torch.empty(elems, dtype=torch.float32, device=device)
+    return ws
+
+
 class ConvOp:
     def __init__(self, Ci, Co, R, S, stride, pad, dtype, device, need_dgrad=True):
         assert stride in (1, 2)
@@ -180,6 +191,8 @@ class ConvOp:
         a.M, a.Cd = N * Ho * Wo, Cd
         a.Co, a.Ci, a.R, a.S = self.Co, self.Ci, self.R, self.S
         a.stride, a.pad, a.ncolgroups, a.pix_per_split = self.stride, self.pad, self.ncolgroups, 0
+        ws = wgrad_workspace(dy.device)
+        a.workspace, a.workspace_elems = ws.data_ptr(), ws.numel()
         flops = 2.0 * a.M * self.Co * self.R * self.S * self.Ci
         _timed("conv_wgrad", flops, lambda: check(lib.fs_conv_wgrad(C.byref(a), self.code, stream_ptr()), "conv_wgrad"))
         return dw

@@ -8,6 +8,7 @@ from .binding import (lib, check, stream_ptr, FsBnApplyArgs, FsBnBwdArgs, FsPhot
 from .conv import dtype_code, _timed
 
 BN_EPS = 1e-5
+STAT_SLOTS = 8   # FS_STAT_SLOTS in include/fsnet_hip.h
 BN_MOMENTUM = 0.1
 
 
@@ -70,14 +71,14 @@ def bn_apply(x, stats, bn, st, y, H, W, count, relu=True, pad_out=False, res=Non
 
 
 def bn_backward(dout, y, x, gamma, st, dx, dgamma, dbeta, H, W, relu=True, fold=False, g_out=None, sums=None,
-                allreduce=None):
+                allreduce=None, sums_zeroed=False):
     """Two-pass BN backward.  dout: grad w.r.t. the block output (strided view, or the padded buffer
     when fold=True); y: saved output activation (interior view) for the ReLU mask."""
     Cc = x.shape[-1]
     a = FsBnBwdArgs()
     if sums is None:
-        sums = torch.zeros(2, Cc, dtype=torch.float64, device=x.device)
-    else:
+        sums = torch.zeros(STAT_SLOTS, 2, Cc, dtype=torch.float64, device=x.device)
+    elif not sums_zeroed:
         sums.zero_()
     a.dout, a.y, a.x, a.dx, a.g_out = dout.data_ptr(), _p(y), x.data_ptr(), dx.data_ptr(), _p(g_out)
     a.sums = sums.data_ptr()
@@ -194,14 +195,14 @@ class PhotometricLoss:
         self.ov = torch.empty(S, 2, B, H, W, dtype=u8, device=device)
         self.ident = torch.empty(B, 2, H, W, dtype=f32, device=device)
         self.sel = torch.empty(S, B, H, W, dtype=u8, device=device)
-        # accumulators zeroed every step in one memset: loss_sums[S] mask_sum[1] disp_sum[S*B] sm_sums[2S] dot[S*B]
-        self.n_acc = S + 1 + S * B + 2 * S + S * B
+        # accumulators zeroed every step in one memset: loss_sums[S*B] mask_sum[B] disp_sum[S*B] sm_sums[2*S*B] dot[S*B]
+        self.n_acc = S * B + B + S * B + 2 * S * B + S * B
         self.acc = torch.zeros(self.n_acc, dtype=f64, device=device)
         o = 0
-        self.loss_sums = self.acc[o:o + S]; o += S
-        self.mask_sum = self.acc[o:o + 1]; o += 1
+        self.loss_sums = self.acc[o:o + S * B]; o += S * B
+        self.mask_sum = self.acc[o:o + B]; o += B
         self.disp_sum = self.acc[o:o + S * B]; o += S * B
-        self.sm_sums = self.acc[o:o + 2 * S]; o += 2 * S
+        self.sm_sums = self.acc[o:o + 2 * S * B]; o += 2 * S * B
         self.dot = self.acc[o:o + S * B]
         self.out = torch.zeros(2 * S + 1, dtype=f64, device=device)
         self.hw = [(H >> s, W >> s) for s in self.scales]

@@ -27,6 +27,10 @@ extern "C" {
 #define FS_DTYPE_F32 0
 #define FS_DTYPE_BF16 1
 
+/* per-channel f64 reduction buffers (BatchNorm statistics / backward sums) are spread over this many
+ * address slots: layout [FS_STAT_SLOTS][2][C]; consumers add the slots up. */
+#define FS_STAT_SLOTS 8
+
 /* library/ABI version and the ISA the kernels were compiled for ("gfx950") */
 int fs_abi_version(void);
 const char* fs_target_arch(void);
@@ -51,7 +55,7 @@ typedef struct FsConvArgs {
   const float* bias;    /* [Co] or NULL */
   const void* addend;   /* same dtype as src, or NULL */
   const void* mask;     /* same dtype as src, or NULL: out = mask > 0 ? out : 0 (ReLU backward) */
-  double* stats;        /* [2][Co] or NULL */
+  double* stats;        /* [FS_STAT_SLOTS][2][Co] or NULL */
   const int* ktab;      /* [nchunks*4] */
   int64_t sN, sH, sW;   /* src strides (elements) */
   int64_t dN, dH, dW;   /* dst strides */
@@ -71,7 +75,7 @@ int fs_conv_igemm(const FsConvArgs* args, int dtype, void* stream);
 
 /* Convolution weight gradient.  Replaces convolution_backward(weight) at the same call sites.
  * dy is dense [M][Cd]; x is the forward input (strided NHWC); dw is the fp32 OIHW gradient
- * [Co][Ci][R][S] and is accumulated into (atomics) — zero it first.  ktab as above, one entry
+ * [Co][Ci][R][S] and is accumulated into (+=, deterministic).  ktab as above, one entry
  * per 16-byte group of GEMM columns (r, s, ci).
  */
 typedef struct FsWgradArgs {
@@ -87,7 +91,9 @@ typedef struct FsWgradArgs {
   int32_t Co, Ci, R, S; /* real weight dims */
   int32_t stride, pad;
   int32_t ncolgroups;   /* R*S*Cs / EG */
-  int32_t pix_per_split;/* filled by the library */
+  float* workspace;     /* split-K partial slabs (or NULL: no split) */
+  int64_t workspace_elems;
+  int32_t pix_per_split, nsplit, ws_rows, ws_cols;  /* filled by the library */
 } FsWgradArgs;
 int fs_conv_wgrad(const FsWgradArgs* args, int dtype, void* stream);
 
@@ -108,7 +114,7 @@ int fs_nchw_to_nhwc(const float* a, const float* b, void* dst, int N, int Ca, in
 /* ------------------------------------------------------------------------------------------
  * Train-mode BatchNorm forward: y = relu?( bn(x) [+ res | + bn2(res)] ).
  * Replaces nn.BatchNorm2d(train)+relu+residual at resnet.py:33-50,70-89,201-203 and
- * blocks.py:44-52.  stats = f64 [2][C] (sum, sumsq) from fs_conv_igemm; count = elements per
+ * blocks.py:44-52.  stats = f64 [FS_STAT_SLOTS][2][C] (sum, sumsq) from fs_conv_igemm; count = elements per
  * channel (global count under SyncBatchNorm, scripts/train.py:101).  Block 0 updates the running
  * statistics (momentum, unbiased variance) and num_batches_tracked and saves mean / invstd.
  * stats == NULL selects eval mode: normalise with running_mean / running_var (no updates).
@@ -136,7 +142,8 @@ typedef struct FsBnApplyArgs {
 int fs_bn_apply(const FsBnApplyArgs* args, int dtype, void* stream);
 
 /* BatchNorm backward, two passes (the data-parallel host all-reduces `sums` in between):
- *   reduce: sums[0][c] = sum g, sums[1][c] = sum g*xhat, g = dout * (y > 0 if relu)
+ *   reduce: sums[slot][0][c] += sum g, sums[slot][1][c] += sum g*xhat, g = dout * (y > 0 if relu)
+ *           (sums is f64 [FS_STAT_SLOTS][2][C], zeroed by the caller)
  *   apply : dx = gamma*invstd*(g - sums0/count - xhat*sums1/count); dgamma += sums1, dbeta += sums0
  *           (from sums_local when given); optional g_out = g (gradient of the residual branch).
  * fold: dout is a replicate-padded [N,H+2,W+2,C] gradient whose border folds onto the edge pixels.
@@ -200,9 +207,9 @@ int fs_pose_tail_bwd(const float* x, const float* dT, void* dx, int B, int hw, i
  * Photometric loss chain (monodepth2_decoder.py:61-128,205-292; monodepth_utils.py:101-165,184-215).
  * Images are planar NCHW fp32; all S scales are processed per launch.
  *   fs_photo_setup     K, K^-1 (f64), P_f = (K T_f)[:3] per batch element -> geo [B][48]
- *   fs_photo_identity  identity reprojection losses ident[B][2][H][W]; mask_sum += sum(patched_mask)
+ *   fs_photo_identity  identity reprojection losses ident[B][2][H][W]; mask_sum[b] += sum(patched_mask[b])
  *   fs_photo_warp      pred[S][2][B][3][H][W], ov[S][2][B][H][W] (bilinear/border + nearest/zeros)
- *   fs_photo_loss_fwd  sel[S][B][H][W] (argmin: 0,1 identity; 2,3 reprojection), loss_sums[s] += masked sum
+ *   fs_photo_loss_fwd  sel[S][B][H][W] (argmin: 0,1 identity; 2,3 reprojection), loss_sums[s][b] += masked sum
  *   fs_photo_loss_bwd  d_depth[s] += dL/d depth_s (low-res), dP[B][2][12] += dL/dP
  *   fs_photo_pose_grad dT_f[B][4][4] = K^T dP_f
  * noise_seed < 0 disables the tie-break noise (reference: randn*1e-5, :258-259).
@@ -217,8 +224,8 @@ typedef struct FsPhotoArgs {
   uint8_t* ov;
   float* ident;
   uint8_t* sel;
-  double* loss_sums;
-  double* mask_sum;
+  double* loss_sums;            /* [S][B] */
+  double* mask_sum;             /* [B] */
   float* d_depth[4];
   float* dP;
   const double* gout;           /* upstream gradient of the total loss (device scalar) or NULL = 1 */
@@ -242,7 +249,7 @@ typedef struct FsSmoothArgs {
   const float* color[4];
   float* d_disp[4];
   double* disp_sum;    /* [S][B] */
-  double* sm_sums;     /* [S][2] */
+  double* sm_sums;     /* [S][B][2] */
   double* dot;         /* [S][B] */
   const double* gout;
   int32_t h[4], w[4], scale_id[4];

@@ -58,7 +58,7 @@ def test_conv_fwd_bwd(dev, case, dtype):
     xd = to_nhwc(x.to(dev), op.Ci_p, dtype)
     bias = torch.zeros(op.Co_p, device=dev)
     bias[:Co] = b.to(dev)
-    stats = torch.zeros(2, op.Co_p, dtype=torch.float64, device=dev)
+    stats = torch.zeros(8, 2, op.Co_p, dtype=torch.float64, device=dev)
     y = op.forward(xd, bias=bias, stats=stats, out_f32=True)
     torch.cuda.synchronize()
     y_nchw = y[..., :Co].permute(0, 3, 1, 2).float().cpu()
@@ -70,6 +70,7 @@ def test_conv_fwd_bwd(dev, case, dtype):
     # fused batch statistics
     s1 = y_ref.detach().double().sum(dim=(0, 2, 3))
     s2 = (y_ref.detach().double() ** 2).sum(dim=(0, 2, 3))
+    stats = stats.sum(0)
     assert torch.allclose(stats[0, :Co].cpu(), s1, rtol=1e-3, atol=1e-3 * s2.max().sqrt().item())
     assert torch.allclose(stats[1, :Co].cpu(), s2, rtol=2e-3)
 

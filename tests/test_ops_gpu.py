@@ -27,9 +27,11 @@ def bn_dict(C, g, dev):
             "num_batches_tracked": torch.zeros((), dtype=torch.long, device=dev)}
 
 
-def stats_of(x):  # x NCHW cpu
+def stats_of(x):  # x NCHW cpu -> [FS_STAT_SLOTS][2][C] with everything in slot 3
     d = x.double()
-    return torch.stack([d.sum(dim=(0, 2, 3)), (d * d).sum(dim=(0, 2, 3))])
+    out = torch.zeros(8, 2, x.shape[1], dtype=torch.float64)
+    out[3] = torch.stack([d.sum(dim=(0, 2, 3)), (d * d).sum(dim=(0, 2, 3))])
+    return out
 
 
 @pytest.mark.parametrize("mode", ["plain", "res", "res_bn2", "pad_fold"])
