@@ -12,7 +12,7 @@
 // One block computes a PIX x CO output tile.  The GEMM is issued "swapped":
 // MFMA A = weights (rows = output channels), MFMA B = gathered pixels, so that
 // each lane ends up with 4 consecutive channels of one pixel (one 8/16-byte store).
-// K is walked in 64-byte chunks (32 bf16 / 16 f32 channels of one tap); both operand
+// K is walked in 64- or 128-byte stages (kg = 4 / 8 sixteen-byte groups: 32 / 64 bf16 channels); both operand
 // tiles are staged through double-buffered LDS with register prefetch of the next chunk.
 // The same kernel computes dgrad: the gather source is dY, the packed weights are
 // Wt[ci][r][s][co] and the tap walk runs with sgn=-1 (plus a parity test for stride 2).
@@ -21,19 +21,26 @@
 
 namespace {
 
-template <typename T, int PIX, int CO, int WP>
+template <int KG> __device__ __forceinline__ int lds_swz(int row) {
+  // XOR swizzle of the 16-byte group index that makes the ds_read_b128 lane groups conflict-free
+  // (64-byte rows: 2 bits from row bit 3; 128-byte rows: 3 bits from row bits 1..3)
+  return KG == 4 ? (((row >> 3) & 1) << 1) : ((row >> 1) & 7);
+}
+
+template <typename T, int PIX, int CO, int WP, int KG>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
   using TR = ElemTraits<T>;
   constexpr int EG = TR::EG;
   constexpr int WC = 4 / WP;
   constexpr int WPIX = PIX / WP, WCO = CO / WC;
   constexpr int TP = WPIX / 16, TC = WCO / 16;
-  constexpr int LP = (PIX * 4 + 255) / 256;
-  constexpr int LC = (CO * 4 + 255) / 256;
+  constexpr int LP = (PIX * KG + 255) / 256;
+  constexpr int LC = (CO * KG + 255) / 256;
+  constexpr int KGS = KG == 4 ? 2 : 3;   // log2(KG)
   static_assert(WPIX % 16 == 0 && WCO % 16 == 0, "tile");
 
-  __shared__ uint4 lds_p[2][PIX * 4];
-  __shared__ uint4 lds_c[2][CO * 4];
+  __shared__ uint4 lds_p[2][PIX * KG];
+  __shared__ uint4 lds_c[2][CO * KG];
   __shared__ int s_ktab[2048];
 
   const int t = threadIdx.x;
@@ -44,7 +51,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
   const T* __restrict__ src = reinterpret_cast<const T*>(p.src);
   const T* __restrict__ wgt = reinterpret_cast<const T*>(p.wgt);
 
-  for (int i = t; i < nch * 4; i += 256) s_ktab[i] = p.ktab[i];
+  for (int i = t; i < nch * KG; i += 256) s_ktab[i] = p.ktab[i];
 
   // ---- per-thread gather rows (fixed over the K walk) ----
   long pbase[LP]; int phb[LP], pwb[LP];
@@ -52,7 +59,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
 #pragma unroll
   for (int i = 0; i < LP; ++i) {
     int idx = t + i * 256;
-    int row = idx >> 2;
+    int row = idx >> KGS;
     int m = pix0 + row;
     if (row < PIX && m < p.M) {
       int x = m % p.Wd; int q = m / p.Wd; int y = q % p.Hd; int n = q / p.Hd;
@@ -63,7 +70,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
       pbase[i] = 0; phb[i] = -(1 << 28); pwb[i] = -(1 << 28);
     }
   }
-  const long wrow_stride = (long)nch * 4 * EG;  // elements per packed weight row
+  const long wrow_stride = (long)nch * KG * EG;  // elements per packed weight row
   const int co0 = blockIdx.y * CO;
   const int dmask = (1 << p.dshift) - 1;
 
@@ -72,8 +79,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
 #pragma unroll
     for (int i = 0; i < LP; ++i) {
       int idx = t + i * 256;
-      int q = idx & 3;
-      int e = s_ktab[kc * 4 + q];
+      int q = idx & (KG - 1);
+      int e = s_ktab[kc * KG + q];
       int c = e & 0xffff, r = (e >> 16) & 0xff, s = (e >> 24) & 0x7f;
       int h = phb[i] + p.sgn * r, w = pwb[i] + p.sgn * s;
       bool ok = (e >= 0) && (((h | w) & dmask) == 0);
@@ -86,9 +93,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
 #pragma unroll
     for (int i = 0; i < LC; ++i) {
       int idx = t + i * 256;
-      int row = idx >> 2, q = idx & 3;
+      int row = idx >> KGS, q = idx & (KG - 1);
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (row < CO) v = *reinterpret_cast<const uint4*>(wgt + (long)(co0 + row) * wrow_stride + (long)(kc * 4 + q) * EG);
+      if (row < CO) v = *reinterpret_cast<const uint4*>(wgt + (long)(co0 + row) * wrow_stride + (long)(kc * KG + q) * EG);
       rc[i] = v;
     }
   };
@@ -96,14 +103,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
 #pragma unroll
     for (int i = 0; i < LP; ++i) {
       int idx = t + i * 256;
-      int row = idx >> 2, q = idx & 3;
-      if (row < PIX) lds_p[buf][row * 4 + (q ^ (((row >> 3) & 1) << 1))] = rp[i];
+      int row = idx >> KGS, q = idx & (KG - 1);
+      if (row < PIX) lds_p[buf][row * KG + (q ^ lds_swz<KG>(row))] = rp[i];
     }
 #pragma unroll
     for (int i = 0; i < LC; ++i) {
       int idx = t + i * 256;
-      int row = idx >> 2, q = idx & 3;
-      if (row < CO) lds_c[buf][row * 4 + (q ^ (((row >> 3) & 1) << 1))] = rc[i];
+      int row = idx >> KGS, q = idx & (KG - 1);
+      if (row < CO) lds_c[buf][row * KG + (q ^ lds_swz<KG>(row))] = rc[i];
     }
   };
 
@@ -121,32 +128,35 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
   int buf = 0;
   for (int kc = 0; kc < nch; ++kc) {
     if (kc + 1 < nch) load_regs(kc + 1);
-    uint4 fa[TC], fb[TP];
 #pragma unroll
-    for (int a = 0; a < TC; ++a) {
-      int row = wc * WCO + a * 16 + li;
-      fa[a] = lds_c[buf][row * 4 + (lg ^ (((row >> 3) & 1) << 1))];
-    }
+    for (int kk = 0; kk < KG / 4; ++kk) {
+      uint4 fa[TC], fb[TP];
 #pragma unroll
-    for (int b = 0; b < TP; ++b) {
-      int row = wp * WPIX + b * 16 + li;
-      fb[b] = lds_p[buf][row * 4 + (lg ^ (((row >> 3) & 1) << 1))];
-    }
-#pragma unroll
-    for (int a = 0; a < TC; ++a)
+      for (int a = 0; a < TC; ++a) {
+        int row = wc * WCO + a * 16 + li;
+        fa[a] = lds_c[buf][row * KG + ((kk * 4 + lg) ^ lds_swz<KG>(row))];
+      }
 #pragma unroll
       for (int b = 0; b < TP; ++b) {
-        if constexpr (sizeof(T) == 2) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-              __builtin_bit_cast(bf16x8, fa[a]), __builtin_bit_cast(bf16x8, fb[b]), acc[a][b], 0, 0, 0);
-        } else {
-          f32x4 va = __builtin_bit_cast(f32x4, fa[a]);
-          f32x4 vb = __builtin_bit_cast(f32x4, fb[b]);
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[j], vb[j], acc[a][b], 0, 0, 0);
-        }
+        int row = wp * WPIX + b * 16 + li;
+        fb[b] = lds_p[buf][row * KG + ((kk * 4 + lg) ^ lds_swz<KG>(row))];
       }
+#pragma unroll
+      for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b) {
+          if constexpr (sizeof(T) == 2) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, fa[a]), __builtin_bit_cast(bf16x8, fb[b]), acc[a][b], 0, 0, 0);
+          } else {
+            f32x4 va = __builtin_bit_cast(f32x4, fa[a]);
+            f32x4 vb = __builtin_bit_cast(f32x4, fb[b]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[j], vb[j], acc[a][b], 0, 0, 0);
+          }
+        }
+    }
     if (kc + 1 < nch) store_lds(buf ^ 1);
     __syncthreads();
     buf ^= 1;
@@ -232,30 +242,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
   }
 }
 
-template <typename T, int PIX, int CO, int WP>
+template <typename T, int PIX, int CO, int WP, int KG>
 int launch_tile(const FsConvArgs& a, hipStream_t st) {
   dim3 grid((a.M + PIX - 1) / PIX, (a.Co_p + CO - 1) / CO);
-  hipLaunchKernelGGL((conv_igemm_kernel<T, PIX, CO, WP>), grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, PIX, CO, WP, KG>), grid, dim3(256), 0, st, a);
   return fs_launch_status();
 }
 
+// tile choice: channel tile = largest of {128,64,32,16} dividing Co_p; shrink the pixel tile when the
+// grid would not fill 256 CUs.  kg (16-byte K groups per stage, 4 or 8) is fixed by the caller's packing.
 template <typename T>
 int launch_conv(const FsConvArgs& a, hipStream_t st) {
-  // tile choice: channel tile = largest of {128,64,32,16} dividing Co_p; shrink the pixel
-  // tile when the grid would not fill 256 CUs.
   const int cop = a.Co_p;
-  if (cop % 128 == 0) {
+  const bool k8 = a.kg == 8;
+  if (cop % 128 == 0 && !k8) {
     long blocks = (long)((a.M + 127) / 128) * (cop / 128);
-    if (blocks >= 512) return launch_tile<T, 128, 128, 2>(a, st);
-    return launch_tile<T, 64, 64, 2>(a, st);
+    if (blocks >= 512) return launch_tile<T, 128, 128, 2, 4>(a, st);
+    return launch_tile<T, 64, 64, 2, 4>(a, st);
   }
   if (cop % 64 == 0) {
     long blocks = (long)((a.M + 127) / 128) * (cop / 64);
-    if (blocks >= 512) return launch_tile<T, 128, 64, 2>(a, st);
-    return launch_tile<T, 64, 64, 2>(a, st);
+    if (blocks >= 512) return k8 ? launch_tile<T, 128, 64, 2, 8>(a, st) : launch_tile<T, 128, 64, 2, 4>(a, st);
+    return k8 ? launch_tile<T, 64, 64, 2, 8>(a, st) : launch_tile<T, 64, 64, 2, 4>(a, st);
   }
-  if (cop % 32 == 0) return launch_tile<T, 128, 32, 4>(a, st);
-  if (cop % 16 == 0) return launch_tile<T, 256, 16, 4>(a, st);
+  if (cop % 32 == 0) return k8 ? launch_tile<T, 128, 32, 4, 8>(a, st) : launch_tile<T, 128, 32, 4, 4>(a, st);
+  if (cop % 16 == 0 && !k8) return launch_tile<T, 256, 16, 4, 4>(a, st);
   return FS_EINVAL;
 }
 
@@ -263,7 +274,8 @@ int launch_conv(const FsConvArgs& a, hipStream_t st) {
 
 extern "C" int fs_conv_igemm(const FsConvArgs* args, int dtype, void* stream) {
   if (!args || !args->src || !args->wgt || !args->dst || !args->ktab) return FS_EINVAL;
-  if (args->nchunks <= 0 || args->nchunks * 4 > 2048) return FS_EINVAL;
+  if (args->kg != 4 && args->kg != 8) return FS_EINVAL;
+  if (args->nchunks <= 0 || args->nchunks * args->kg > 2048) return FS_EINVAL;
   if (args->Co % 4 != 0 || args->Co_p % 16 != 0) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == FS_DTYPE_BF16) return launch_conv<bf16>(*args, st);

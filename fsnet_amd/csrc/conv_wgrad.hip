@@ -201,21 +201,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const FsWgradArgs p) {
   }
 }
 
-// dw[co][ci][r][s] += sum_z workspace[z][co][col]
+// dw[co][ci][r][s] += sum_z workspace[z][co][col].  64 consecutive columns x 4 split-lanes per block: each
+// lane strides the splits by 4 with independent (unrolled) loads, then the 4 lanes combine through LDS.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const FsWgradArgs p, int eg) {
-  const long total = (long)p.Co * p.ncolgroups * eg;
+  __shared__ float red[4][64];
   const int ncols = p.ncolgroups * eg;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    int col = (int)(i % ncols), co = (int)(i / ncols);
-    int e = p.ktab[col / eg];
-    if (e < 0) continue;
-    int ci = (e & 0xffff) + (col % eg);
-    if (ci >= p.Ci) continue;
-    int r = (e >> 16) & 0xff, s = (e >> 24) & 0x7f;
+  const int cblocks = (ncols + 63) / 64;
+  const int co = blockIdx.x / cblocks, col = (blockIdx.x % cblocks) * 64 + (threadIdx.x & 63);
+  const int zl = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (col < ncols) {
     const float* ws = p.workspace + (long)co * p.ws_cols + col;
-    float acc = 0.f;
-    for (int z = 0; z < p.nsplit; ++z) acc += ws[(long)z * p.ws_rows * p.ws_cols];
-    p.dw[(((long)co * p.Ci + ci) * p.R + r) * p.S + s] += acc;
+    const long slab = (long)p.ws_rows * p.ws_cols;
+    int z = zl;
+    for (; z + 12 < p.nsplit; z += 16) {
+      float a0 = ws[(long)z * slab], a1 = ws[(long)(z + 4) * slab], a2 = ws[(long)(z + 8) * slab], a3 = ws[(long)(z + 12) * slab];
+      acc += (a0 + a1) + (a2 + a3);
+    }
+    for (; z < p.nsplit; z += 4) acc += ws[(long)z * slab];
+  }
+  red[zl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (zl == 0 && col < ncols) {
+    float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    int e = p.ktab[col / eg];
+    if (e >= 0) {
+      int ci = (e & 0xffff) + (col % eg);
+      if (ci < p.Ci) {
+        int r = (e >> 16) & 0xff, s = (e >> 24) & 0x7f;
+        p.dw[(((long)co * p.Ci + ci) * p.R + r) * p.S + s] += v;
+      }
+    }
   }
 }
 
@@ -229,7 +245,7 @@ int launch_tile(const FsWgradArgs& a, hipStream_t st) {
   const long chunks = (a.M + 31) / 32;
   // split the pixel (K) range until ~768 blocks are in flight, keeping >= 8 chunks per block and the
   // partial slabs inside the caller's workspace
-  long splits = (768 + tiles - 1) / tiles;
+  long splits = (640 + tiles - 1) / tiles;
   splits = std::min<long>(splits, std::max<long>(1, chunks / 8));
   b.ws_rows = rt * COT; b.ws_cols = ct * CLT;
   const long slab = (long)b.ws_rows * b.ws_cols;
@@ -241,8 +257,7 @@ int launch_tile(const FsWgradArgs& a, hipStream_t st) {
   dim3 grid(ct, rt, b.nsplit);
   hipLaunchKernelGGL((conv_wgrad_kernel<T, COT, CLT, WR>), grid, dim3(256), 0, st, b);
   if (b.nsplit > 1) {
-    long total = (long)a.Co * ncols;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, st, b, EG);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(a.Co * ((ncols + 63) / 64))), dim3(256), 0, st, b, EG);
   }
   return fs_launch_status();
 }

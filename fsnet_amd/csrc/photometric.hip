@@ -424,17 +424,35 @@ __global__ __launch_bounds__(256) void photo_loss_bwd_kernel(const FsPhotoArgs p
       if (v != 0.f) atomicAdd(p.dP + ((long)b * 2 + f) * 12 + tid, v);
     }
   }
-  // ---- transpose of the bilinear depth upsample ----
-  if (qin && dD_total != 0.f) {
-    Geo g;
-    upsample_taps(qy, qx, H, W, p.dh[s], p.dw[s], g);
-    float* dd = p.d_depth[s] + (long)b * p.dh[s] * p.dw[s];
-    const int w = p.dw[s];
-    float w00 = (1.f - g.ly) * (1.f - g.lx), w01 = (1.f - g.ly) * g.lx, w10 = g.ly * (1.f - g.lx), w11 = g.ly * g.lx;
-    if (w00 != 0.f) atomicAdd(dd + g.y0 * w + g.x0, w00 * dD_total);
-    if (w01 != 0.f) atomicAdd(dd + g.y0 * w + g.x1, w01 * dD_total);
-    if (w10 != 0.f) atomicAdd(dd + g.y1 * w + g.x0, w10 * dD_total);
-    if (w11 != 0.f) atomicAdd(dd + g.y1 * w + g.x1, w11 * dD_total);
+  // ---- transpose of the bilinear depth upsample: accumulate the tile's contributions in LDS first, then
+  //      one global atomic per touched low-res pixel (scale-3 maps receive 256 full-res pixels each) ----
+  {
+    __shared__ float s_dd[(TH + 2) * (TW + 2)];
+    const int h = p.dh[s], w = p.dw[s];
+    Geo g0;
+    upsample_taps(ty0, tx0, H, W, h, w, g0);
+    const int by = g0.y0, bx = g0.x0;
+    for (int i = tid; i < (TH + 2) * (TW + 2); i += 256) s_dd[i] = 0.f;
+    __syncthreads();
+    if (qin && dD_total != 0.f) {
+      Geo g;
+      upsample_taps(qy, qx, H, W, h, w, g);
+      float w00 = (1.f - g.ly) * (1.f - g.lx), w01 = (1.f - g.ly) * g.lx, w10 = g.ly * (1.f - g.lx), w11 = g.ly * g.lx;
+      int ly0 = g.y0 - by, ly1 = g.y1 - by, lx0 = g.x0 - bx, lx1 = g.x1 - bx;
+      if (w00 != 0.f) atomicAdd(&s_dd[ly0 * (TW + 2) + lx0], w00 * dD_total);
+      if (w01 != 0.f) atomicAdd(&s_dd[ly0 * (TW + 2) + lx1], w01 * dD_total);
+      if (w10 != 0.f) atomicAdd(&s_dd[ly1 * (TW + 2) + lx0], w10 * dD_total);
+      if (w11 != 0.f) atomicAdd(&s_dd[ly1 * (TW + 2) + lx1], w11 * dD_total);
+    }
+    __syncthreads();
+    float* dd = p.d_depth[s] + (long)b * h * w;
+    for (int i = tid; i < (TH + 2) * (TW + 2); i += 256) {
+      float v = s_dd[i];
+      if (v != 0.f) {
+        int yy = by + i / (TW + 2), xx = bx + i % (TW + 2);
+        if (yy < h && xx < w) atomicAdd(dd + yy * w + xx, v);
+      }
+    }
   }
 }
 

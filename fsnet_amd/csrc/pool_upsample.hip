@@ -246,7 +246,7 @@ extern "C" int fs_channel_sum(const void* x, float* out, int64_t M, int C, int C
   const int CG = C / 4;
   const int CGB = CG < 64 ? (CG < 16 ? 4 : 16) : 64;
   const int PL = 256 / CGB;
-  dim3 grid((unsigned)std::max<long>(1, std::min<long>((M + PL - 1) / PL / 8 + 1, 1024)), (CG + CGB - 1) / CGB);
+  dim3 grid((unsigned)std::max<long>(1, std::min<long>((M + PL - 1) / PL / 8 + 1, 96)), (CG + CGB - 1) / CGB);
   if (dtype == FS_DTYPE_BF16)
     hipLaunchKernelGGL(channel_sum_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, out, (long)M, C, Creal);
   else if (dtype == FS_DTYPE_F32)

@@ -23,7 +23,7 @@ class FsConvArgs(C.Structure):
         ("aN", C.c_int64), ("aH", C.c_int64), ("aW", C.c_int64),
         ("mN", C.c_int64), ("mH", C.c_int64), ("mW", C.c_int64),
         ("Hs", C.c_int32), ("Ws", C.c_int32), ("Hd", C.c_int32), ("Wd", C.c_int32),
-        ("M", C.c_int32), ("Co", C.c_int32), ("Co_p", C.c_int32), ("nchunks", C.c_int32),
+        ("M", C.c_int32), ("Co", C.c_int32), ("Co_p", C.c_int32), ("nchunks", C.c_int32), ("kg", C.c_int32),
         ("hb_mul", C.c_int32), ("hb_add", C.c_int32), ("sgn", C.c_int32), ("dshift", C.c_int32),
         ("relu", C.c_int32), ("out_f32", C.c_int32),
     ]

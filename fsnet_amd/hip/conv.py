@@ -91,19 +91,25 @@ class ConvOp:
         eg = self.EG
         self.Ci_p = roundup(Ci, eg)      # channels of the input activation buffer
         self.Co_p = roundup(Co, 16)      # channels of the output activation buffer
-        chunk = 4 * eg
-        # forward operand
+        # forward operand.  Stage depth kg (16-byte K groups per LDS stage): 8 (= 64 bf16 channels) when the
+        # K walk is long enough to profit and the channel tile allows it, else 4.
+        def pick_kg(ktot, rows_p):
+            return 8 if (ktot >= 64 * eg and rows_p % 32 == 0) else 4
+        self.kg_f = pick_kg(R * S * self.Ci_p, self.Co_p)
+        chunk = self.kg_f * eg
         self.nch_f = (R * S * self.Ci_p + chunk - 1) // chunk
         self.kf_p = self.nch_f * chunk
-        self.ktab_f = torch.from_numpy(make_ktab(R, S, self.Ci_p, eg, self.nch_f * 4)).to(device)
+        self.ktab_f = torch.from_numpy(make_ktab(R, S, self.Ci_p, eg, self.nch_f * self.kg_f)).to(device)
         self.w_f = torch.zeros(self.Co_p, self.kf_p, dtype=dtype, device=device)
         # dgrad operand: rows = ci, K = (r, s, co)
         self.need_dgrad = need_dgrad
         if need_dgrad:
             self.rows_d = roundup(self.Ci_p, 16)
+            self.kg_d = pick_kg(R * S * self.Co_p, self.rows_d)
+            chunk = self.kg_d * eg
             self.nch_d = (R * S * self.Co_p + chunk - 1) // chunk
             self.kd_p = self.nch_d * chunk
-            self.ktab_d = torch.from_numpy(make_ktab(R, S, self.Co_p, eg, self.nch_d * 4)).to(device)
+            self.ktab_d = torch.from_numpy(make_ktab(R, S, self.Co_p, eg, self.nch_d * self.kg_d)).to(device)
             self.w_d = torch.zeros(self.rows_d, self.kd_p, dtype=dtype, device=device)
         # wgrad columns (r, s, ci): same grouping as the forward K walk without chunk padding
         self.ncolgroups = R * S * self.Ci_p // eg
@@ -145,7 +151,7 @@ class ConvOp:
             a.aN, a.aH, a.aW = _nhwc_strides(addend)
         a.Hs, a.Ws, a.Hd, a.Wd = H, W, Ho, Wo
         a.M = N * Ho * Wo
-        a.Co, a.Co_p, a.nchunks = out.shape[3], self.Co_p, self.nch_f
+        a.Co, a.Co_p, a.nchunks, a.kg = out.shape[3], self.Co_p, self.nch_f, self.kg_f
         a.hb_mul, a.hb_add, a.sgn, a.dshift = self.stride, -self.pad, 1, 0
         a.relu, a.out_f32 = int(relu), int(out_f32)
         flops = 2.0 * a.M * self.Co * self.R * self.S * self.Ci
@@ -172,7 +178,7 @@ class ConvOp:
             a.mN, a.mH, a.mW = _nhwc_strides(mask)
         a.Hs, a.Ws, a.Hd, a.Wd = Ho, Wo, H, W
         a.M = N * H * W
-        a.Co, a.Co_p, a.nchunks = out.shape[3], self.rows_d, self.nch_d
+        a.Co, a.Co_p, a.nchunks, a.kg = out.shape[3], self.rows_d, self.nch_d, self.kg_d
         a.hb_mul, a.hb_add, a.sgn, a.dshift = 1, self.pad, -1, (1 if self.stride == 2 else 0)
         a.relu, a.out_f32 = 0, 0
         flops = 2.0 * N * Ho * Wo * self.Co * self.R * self.S * self.Ci

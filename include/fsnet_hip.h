@@ -50,13 +50,13 @@ const char* fs_target_arch(void);
  */
 typedef struct FsConvArgs {
   const void* src;
-  const void* wgt;      /* packed [Co_p][nchunks*64 bytes], K contiguous */
+  const void* wgt;      /* packed [Co_p][nchunks*kg*16 bytes], K contiguous */
   void* dst;
   const float* bias;    /* [Co] or NULL */
   const void* addend;   /* same dtype as src, or NULL */
   const void* mask;     /* same dtype as src, or NULL: out = mask > 0 ? out : 0 (ReLU backward) */
   double* stats;        /* [FS_STAT_SLOTS][2][Co] or NULL */
-  const int* ktab;      /* [nchunks*4] */
+  const int* ktab;      /* [nchunks*kg] */
   int64_t sN, sH, sW;   /* src strides (elements) */
   int64_t dN, dH, dW;   /* dst strides */
   int64_t aN, aH, aW;   /* addend strides */
@@ -66,7 +66,8 @@ typedef struct FsConvArgs {
   int32_t M;            /* N*Hd*Wd */
   int32_t Co;           /* dst channels (multiple of 4) */
   int32_t Co_p;         /* packed weight rows (multiple of 16) */
-  int32_t nchunks;
+  int32_t nchunks;      /* K stages; packed weight row = nchunks*kg*16 bytes */
+  int32_t kg;           /* 16-byte K groups per stage: 4 or 8 (8 needs Co_p % 32 == 0) */
   int32_t hb_mul, hb_add, sgn, dshift;
   int32_t relu;
   int32_t out_f32;      /* store fp32 regardless of dtype */
