@@ -12,10 +12,17 @@
 // One block computes a PIX x CO output tile.  The GEMM is issued "swapped":
 // MFMA A = weights (rows = output channels), MFMA B = gathered pixels, so that
 // each lane ends up with 4 consecutive channels of one pixel (one 8/16-byte store).
-// K is walked in 64- or 128-byte stages (kg = 4 / 8 sixteen-byte groups: 32 / 64 bf16 channels); both operand
-// tiles are staged through double-buffered LDS with register prefetch of the next chunk.
-// The same kernel computes dgrad: the gather source is dY, the packed weights are
-// Wt[ci][r][s][co] and the tap walk runs with sgn=-1 (plus a parity test for stride 2).
+// K is walked in 64- or 128-byte stages (kg = 4 / 8 sixteen-byte groups); both operand
+// tiles are staged through double-buffered, XOR-swizzled LDS with register prefetch.
+//
+// The gather is the VALU-critical part (first version: 16 VALU per MFMA, MFMA pipe 15 % busy):
+//   * operands are fetched with raw buffer loads: an out-of-range offset returns zeros in hardware,
+//     so zero padding / ragged tiles need no exec-mask branches;
+//   * the host supplies, per K unit, the byte delta of the tap (r*sH + s*sW + c) and the signed
+//     (r, s) pair, so a lane adds one table value to its per-pixel base offset (32-bit);
+//   * with kg = 8 one address computation feeds four 16-byte loads (a 64-byte unit of one tap).
+// The same kernel computes dgrad: source = dY, packed weights Wt[ci][r][s][co], taps walked with
+// sgn = -1, plus a parity test and halved strides for stride 2.
 #include "common.h"
 #include "fsnet_hip_internal.h"
 
@@ -27,90 +34,123 @@ template <int KG> __device__ __forceinline__ int lds_swz(int row) {
   return KG == 4 ? (((row >> 3) & 1) << 1) : ((row >> 1) & 7);
 }
 
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, int voff) {
+  return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+}
+
 template <typename T, int PIX, int CO, int WP, int KG>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
   using TR = ElemTraits<T>;
-  constexpr int EG = TR::EG;
   constexpr int WC = 4 / WP;
   constexpr int WPIX = PIX / WP, WCO = CO / WC;
   constexpr int TP = WPIX / 16, TC = WCO / 16;
-  constexpr int LP = (PIX * KG + 255) / 256;
-  constexpr int LC = (CO * KG + 255) / 256;
-  constexpr int KGS = KG == 4 ? 2 : 3;   // log2(KG)
+  constexpr int UG = KG == 8 ? 4 : 1;          // 16-byte groups fetched per address computation
+  constexpr int UPR = KG / UG;                 // units per tile row per stage
+  constexpr int LPU = (PIX * UPR + 255) / 256;
+  constexpr int LCU = (CO * UPR + 255) / 256;
+  constexpr int UPRS = UPR == 1 ? 0 : (UPR == 2 ? 1 : 2);
   static_assert(WPIX % 16 == 0 && WCO % 16 == 0, "tile");
 
   __shared__ uint4 lds_p[2][PIX * KG];
   __shared__ uint4 lds_c[2][CO * KG];
-  __shared__ int s_ktab[2048];
+  __shared__ int2 s_ktab[1024];
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int wp = wave % WP, wc = wave / WP;
   const int li = lane & 15, lg = lane >> 4;
   const int nch = p.nchunks;
-  const T* __restrict__ src = reinterpret_cast<const T*>(p.src);
-  const T* __restrict__ wgt = reinterpret_cast<const T*>(p.wgt);
 
-  for (int i = t; i < nch * KG; i += 256) s_ktab[i] = p.ktab[i];
+  // XCD-aware tile mapping (block b runs on XCD b % 8, each XCD has a private 4 MB L2): all pixel tiles of one
+  // channel tile go to the same XCD(s), so a weight tile is fetched from HBM/MALL once per XCD and then hit in L2.
+  int px, cy;
+  {
+    const int npix = (p.M + PIX - 1) / PIX, nco = p.Co_p / CO;
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    if (nco % 8 == 0) { const int g = nco >> 3; cy = xcd + 8 * (slot % g); px = slot / g; }
+    else if (8 % nco == 0) { const int g = 8 / nco; cy = xcd % nco; px = slot * g + xcd / nco; }
+    else { cy = id % nco; px = id / nco; }
+    if (px >= npix) return;
+  }
 
-  // ---- per-thread gather rows (fixed over the K walk) ----
-  long pbase[LP]; int phb[LP], pwb[LP];
-  const int pix0 = blockIdx.x * PIX;
+  for (int i = t; i < nch * UPR; i += 256) s_ktab[i] = reinterpret_cast<const int2*>(p.ktab)[i];
+
+  const __amdgpu_buffer_rsrc_t rs_src =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, (int)p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wgt =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, (int)p.wgt_bytes, 0x00020000);
+
+  // ---- per-thread gather units (fixed over the K walk) ----
+  int pvoff[LPU], phb[LPU], pwb[LPU];
+  const int pix0 = px * PIX;
+  const int sHe = (int)(p.sH >> p.dshift), sWe = (int)(p.sW >> p.dshift);
 #pragma unroll
-  for (int i = 0; i < LP; ++i) {
+  for (int i = 0; i < LPU; ++i) {
     int idx = t + i * 256;
-    int row = idx >> KGS;
+    int row = idx >> UPRS;
     int m = pix0 + row;
     if (row < PIX && m < p.M) {
       int x = m % p.Wd; int q = m / p.Wd; int y = q % p.Hd; int n = q / p.Hd;
-      pbase[i] = (long)n * p.sN;
       phb[i] = y * p.hb_mul + p.hb_add;
       pwb[i] = x * p.hb_mul + p.hb_add;
+      pvoff[i] = (int)((n * p.sN + (long)phb[i] * sHe + (long)pwb[i] * sWe) * (long)sizeof(T));
     } else {
-      pbase[i] = 0; phb[i] = -(1 << 28); pwb[i] = -(1 << 28);
+      pvoff[i] = 0; phb[i] = -(1 << 28); pwb[i] = -(1 << 28);
     }
   }
-  const long wrow_stride = (long)nch * KG * EG;  // elements per packed weight row
-  const int co0 = blockIdx.y * CO;
+  const int stage_bytes = KG * 16;
+  const int co0 = cy * CO;
+  const int OOB = 0x7fffffff;
+  int wvoff[LCU];
+#pragma unroll
+  for (int i = 0; i < LCU; ++i) {
+    int idx = t + i * 256;
+    int row = idx >> UPRS, qu = idx & (UPR - 1);
+    wvoff[i] = row < CO ? ((co0 + row) * nch * stage_bytes + qu * UG * 16) : OOB;
+  }
   const int dmask = (1 << p.dshift) - 1;
 
-  uint4 rp[LP], rc[LC];
-  auto load_regs = [&](int kc) {
+  // two register sets: up to two K stages are in flight behind the one being multiplied
+  uint4 rpA[LPU][UG], rcA[LCU][UG], rpB[LPU][UG], rcB[LCU][UG];
+  auto load_regs = [&](int kc, uint4 (&rp)[LPU][UG], uint4 (&rc)[LCU][UG]) {
 #pragma unroll
-    for (int i = 0; i < LP; ++i) {
+    for (int i = 0; i < LPU; ++i) {
       int idx = t + i * 256;
-      int q = idx & (KG - 1);
-      int e = s_ktab[kc * KG + q];
-      int c = e & 0xffff, r = (e >> 16) & 0xff, s = (e >> 24) & 0x7f;
-      int h = phb[i] + p.sgn * r, w = pwb[i] + p.sgn * s;
-      bool ok = (e >= 0) && (((h | w) & dmask) == 0);
-      h >>= p.dshift; w >>= p.dshift;
-      ok = ok && ((unsigned)h < (unsigned)p.Hs) && ((unsigned)w < (unsigned)p.Ws);
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) v = *reinterpret_cast<const uint4*>(src + pbase[i] + (long)h * p.sH + (long)w * p.sW + c);
-      rp[i] = v;
+      int qu = idx & (UPR - 1);
+      int2 e = s_ktab[kc * UPR + qu];
+      int r = (int)(short)(e.y & 0xffff), s = e.y >> 16;
+      int h = phb[i] + r, w = pwb[i] + s;
+      bool ok = (e.x != (int)0x80000000) && (((h | w) & dmask) == 0) &&
+                ((unsigned)(h >> p.dshift) < (unsigned)p.Hs) && ((unsigned)(w >> p.dshift) < (unsigned)p.Ws);
+      int voff = ok ? pvoff[i] + e.x : OOB;
+#pragma unroll
+      for (int j = 0; j < UG; ++j) rp[i][j] = buf_load16(rs_src, voff + j * 16);
     }
 #pragma unroll
-    for (int i = 0; i < LC; ++i) {
-      int idx = t + i * 256;
-      int row = idx >> KGS, q = idx & (KG - 1);
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (row < CO) v = *reinterpret_cast<const uint4*>(wgt + (long)(co0 + row) * wrow_stride + (long)(kc * KG + q) * EG);
-      rc[i] = v;
+    for (int i = 0; i < LCU; ++i) {
+      int voff = wvoff[i] == OOB ? OOB : wvoff[i] + kc * stage_bytes;
+#pragma unroll
+      for (int j = 0; j < UG; ++j) rc[i][j] = buf_load16(rs_wgt, voff + j * 16);
     }
   };
-  auto store_lds = [&](int buf) {
+  auto store_lds = [&](int buf, const uint4 (&rp)[LPU][UG], const uint4 (&rc)[LCU][UG]) {
 #pragma unroll
-    for (int i = 0; i < LP; ++i) {
+    for (int i = 0; i < LPU; ++i) {
       int idx = t + i * 256;
-      int row = idx >> KGS, q = idx & (KG - 1);
-      if (row < PIX) lds_p[buf][row * KG + (q ^ lds_swz<KG>(row))] = rp[i];
+      int row = idx >> UPRS, qu = idx & (UPR - 1);
+      if (row < PIX) {
+#pragma unroll
+        for (int j = 0; j < UG; ++j) lds_p[buf][row * KG + ((qu * UG + j) ^ lds_swz<KG>(row))] = rp[i][j];
+      }
     }
 #pragma unroll
-    for (int i = 0; i < LC; ++i) {
+    for (int i = 0; i < LCU; ++i) {
       int idx = t + i * 256;
-      int row = idx >> KGS, q = idx & (KG - 1);
-      if (row < CO) lds_c[buf][row * KG + (q ^ lds_swz<KG>(row))] = rc[i];
+      int row = idx >> UPRS, qu = idx & (UPR - 1);
+      if (row < CO) {
+#pragma unroll
+        for (int j = 0; j < UG; ++j) lds_c[buf][row * KG + ((qu * UG + j) ^ lds_swz<KG>(row))] = rc[i][j];
+      }
     }
   };
 
@@ -120,14 +160,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
 #pragma unroll
     for (int b = 0; b < TP; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  __syncthreads();  // s_ktab visible
-  load_regs(0);
-  store_lds(0);
-  __syncthreads();
-
-  int buf = 0;
-  for (int kc = 0; kc < nch; ++kc) {
-    if (kc + 1 < nch) load_regs(kc + 1);
+  auto compute = [&](int buf) {
 #pragma unroll
     for (int kk = 0; kk < KG / 4; ++kk) {
       uint4 fa[TC], fb[TP];
@@ -157,9 +190,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
           }
         }
     }
-    if (kc + 1 < nch) store_lds(buf ^ 1);
+  };
+
+  __syncthreads();  // s_ktab visible
+  load_regs(0, rpA, rcA);
+  if (nch > 1) load_regs(1, rpB, rcB);
+  store_lds(0, rpA, rcA);
+  __syncthreads();
+
+  // stage kc lives in LDS[kc & 1]; set A carries even stages, set B odd stages.  While stage kc is
+  // multiplied, stage kc+1 is landing in its register set and stage kc+2 is being requested.
+  for (int kc = 0; kc < nch; kc += 2) {
+    if (kc + 2 < nch) load_regs(kc + 2, rpA, rcA);
+    compute(0);
+    if (kc + 1 < nch) store_lds(1, rpB, rcB);
     __syncthreads();
-    buf ^= 1;
+    if (kc + 1 >= nch) break;
+    if (kc + 3 < nch) load_regs(kc + 3, rpB, rcB);
+    compute(1);
+    if (kc + 2 < nch) store_lds(0, rpA, rcA);
+    __syncthreads();
   }
 
   // ---- epilogue: lane holds, for pixel (tile b, li), channels lg*4..lg*4+3 of channel tile a ----
@@ -234,7 +284,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
       for (int k = 0; k < WP; ++k) { u += red[(k * CO + t) * 2]; w += red[(k * CO + t) * 2 + 1]; }
       int co = co0 + t;
       if (co < p.Co) {
-        double* sl = p.stats + (long)(blockIdx.x % FS_STAT_SLOTS) * 2 * p.Co;
+        double* sl = p.stats + (long)(px % FS_STAT_SLOTS) * 2 * p.Co;
         atomicAdd(sl + co, (double)u);
         atomicAdd(sl + p.Co + co, (double)w);
       }
@@ -244,8 +294,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
 
 template <typename T, int PIX, int CO, int WP, int KG>
 int launch_tile(const FsConvArgs& a, hipStream_t st) {
-  dim3 grid((a.M + PIX - 1) / PIX, (a.Co_p + CO - 1) / CO);
-  hipLaunchKernelGGL((conv_igemm_kernel<T, PIX, CO, WP, KG>), grid, dim3(256), 0, st, a);
+  const int npix = (a.M + PIX - 1) / PIX, nco = a.Co_p / CO;
+  int blocks = npix * nco;
+  if (nco % 8 != 0 && 8 % nco == 0) { const int g = 8 / nco; blocks = 8 * ((npix + g - 1) / g); }
+  hipLaunchKernelGGL((conv_igemm_kernel<T, PIX, CO, WP, KG>), dim3(blocks), dim3(256), 0, st, a);
   return fs_launch_status();
 }
 
@@ -275,8 +327,13 @@ int launch_conv(const FsConvArgs& a, hipStream_t st) {
 extern "C" int fs_conv_igemm(const FsConvArgs* args, int dtype, void* stream) {
   if (!args || !args->src || !args->wgt || !args->dst || !args->ktab) return FS_EINVAL;
   if (args->kg != 4 && args->kg != 8) return FS_EINVAL;
-  if (args->nchunks <= 0 || args->nchunks * args->kg > 2048) return FS_EINVAL;
+  const int units = args->nchunks * (args->kg == 8 ? 2 : 4);
+  if (args->nchunks <= 0 || units > 1024) return FS_EINVAL;
   if (args->Co % 4 != 0 || args->Co_p % 16 != 0) return FS_EINVAL;
+  if (args->src_bytes <= 0 || args->src_bytes > 0x7fffffffLL || args->wgt_bytes <= 0 ||
+      args->wgt_bytes > 0x7fffffffLL)
+    return FS_EINVAL;
+  if (args->dshift && ((args->sH | args->sW) & 1)) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == FS_DTYPE_BF16) return launch_conv<bf16>(*args, st);
   if (dtype == FS_DTYPE_F32) return launch_conv<float>(*args, st);

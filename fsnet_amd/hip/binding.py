@@ -22,6 +22,7 @@ class FsConvArgs(C.Structure):
         ("dN", C.c_int64), ("dH", C.c_int64), ("dW", C.c_int64),
         ("aN", C.c_int64), ("aH", C.c_int64), ("aW", C.c_int64),
         ("mN", C.c_int64), ("mH", C.c_int64), ("mW", C.c_int64),
+        ("src_bytes", C.c_int64), ("wgt_bytes", C.c_int64),
         ("Hs", C.c_int32), ("Ws", C.c_int32), ("Hd", C.c_int32), ("Wd", C.c_int32),
         ("M", C.c_int32), ("Co", C.c_int32), ("Co_p", C.c_int32), ("nchunks", C.c_int32), ("kg", C.c_int32),
         ("hb_mul", C.c_int32), ("hb_add", C.c_int32), ("sgn", C.c_int32), ("dshift", C.c_int32),

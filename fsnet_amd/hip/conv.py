@@ -64,6 +64,25 @@ def make_ktab(R, S, cs_p, eg, ngroups):
     return tab
 
 
+def make_unit_table(R, S, cs_p, eg, ug, nunits, sgn, sH, sW, elem_bytes):
+    """int2 per K unit (ug consecutive 16-byte groups of one tap): byte delta of the tap + channel, and the
+    signed (r, s) pair.  INT32_MIN marks K padding."""
+    tab = np.zeros((nunits, 2), dtype=np.int32)
+    tab[:, 0] = np.iinfo(np.int32).min
+    real = R * S * cs_p // (eg * ug)
+    k0 = np.arange(min(real, nunits), dtype=np.int64) * eg * ug
+    tap, c = k0 // cs_p, k0 % cs_p
+    r, s = sgn * (tap // S), sgn * (tap % S)
+    tab[: len(k0), 0] = ((r * sH + s * sW + c) * elem_bytes).astype(np.int32)
+    tab[: len(k0), 1] = ((r & 0xffff) | (s << 16)).astype(np.int64).astype(np.int32)
+    return tab
+
+
+def _span_bytes(t):
+    n, h, w, c = t.shape
+    return ((n - 1) * t.stride(0) + (h - 1) * t.stride(1) + (w - 1) * t.stride(2) + c) * t.element_size()
+
+
 def _nhwc_strides(t):
     assert t.dim() == 4 and t.stride(3) == 1, "activation must be NHWC with contiguous channels"
     return t.stride(0), t.stride(1), t.stride(2)
@@ -93,27 +112,43 @@ class ConvOp:
         self.Co_p = roundup(Co, 16)      # channels of the output activation buffer
         # forward operand.  Stage depth kg (16-byte K groups per LDS stage): 8 (= 64 bf16 channels) when the
         # K walk is long enough to profit and the channel tile allows it, else 4.
-        def pick_kg(ktot, rows_p):
-            return 8 if (ktot >= 64 * eg and rows_p % 32 == 0) else 4
-        self.kg_f = pick_kg(R * S * self.Ci_p, self.Co_p)
+        def pick_kg(ktot, rows_p, cs):
+            return 8 if (ktot >= 64 * eg and rows_p % 32 == 0 and cs % (4 * eg) == 0) else 4
+        self.kg_f = pick_kg(R * S * self.Ci_p, self.Co_p, self.Ci_p)
         chunk = self.kg_f * eg
         self.nch_f = (R * S * self.Ci_p + chunk - 1) // chunk
         self.kf_p = self.nch_f * chunk
-        self.ktab_f = torch.from_numpy(make_ktab(R, S, self.Ci_p, eg, self.nch_f * self.kg_f)).to(device)
         self.w_f = torch.zeros(self.Co_p, self.kf_p, dtype=dtype, device=device)
         # dgrad operand: rows = ci, K = (r, s, co)
         self.need_dgrad = need_dgrad
         if need_dgrad:
             self.rows_d = roundup(self.Ci_p, 16)
-            self.kg_d = pick_kg(R * S * self.Co_p, self.rows_d)
+            self.kg_d = pick_kg(R * S * self.Co_p, self.rows_d, self.Co_p)
             chunk = self.kg_d * eg
             self.nch_d = (R * S * self.Co_p + chunk - 1) // chunk
             self.kd_p = self.nch_d * chunk
-            self.ktab_d = torch.from_numpy(make_ktab(R, S, self.Co_p, eg, self.nch_d * self.kg_d)).to(device)
             self.w_d = torch.zeros(self.rows_d, self.kd_p, dtype=dtype, device=device)
+        self._tabs = {}
         # wgrad columns (r, s, ci): same grouping as the forward K walk without chunk padding
         self.ncolgroups = R * S * self.Ci_p // eg
         self.ktab_w = torch.from_numpy(make_ktab(R, S, self.Ci_p, eg, self.ncolgroups)).to(device)
+
+    def _table(self, mode, sH, sW):
+        """K-unit table for (forward | dgrad) over a source with row/pixel strides (sH, sW) [elements]."""
+        key = (mode, sH, sW)
+        t = self._tabs.get(key)
+        if t is None:
+            eb = 2 if self.dtype == torch.bfloat16 else 4
+            if mode == "f":
+                ug = 4 if self.kg_f == 8 else 1
+                tab = make_unit_table(self.R, self.S, self.Ci_p, self.EG, ug, self.nch_f * self.kg_f // ug, 1, sH, sW, eb)
+            else:
+                ug = 4 if self.kg_d == 8 else 1
+                sh = 1 if self.stride == 2 else 0
+                tab = make_unit_table(self.R, self.S, self.Co_p, self.EG, ug, self.nch_d * self.kg_d // ug, -1,
+                                      sH >> sh, sW >> sh, eb)
+            t = self._tabs[key] = torch.from_numpy(tab).to(self.device)
+        return t
 
     # ------------------------------------------------------------------
     def pack(self, weight):
@@ -144,8 +179,9 @@ class ConvOp:
         a.bias = bias.data_ptr() if bias is not None else None
         a.addend = addend.data_ptr() if addend is not None else None
         a.stats = stats.data_ptr() if stats is not None else None
-        a.ktab = self.ktab_f.data_ptr()
         a.sN, a.sH, a.sW = _nhwc_strides(x)
+        a.ktab = self._table("f", a.sH, a.sW).data_ptr()
+        a.src_bytes, a.wgt_bytes = _span_bytes(x), self.w_f.numel() * self.w_f.element_size()
         a.dN, a.dH, a.dW = _nhwc_strides(out)
         if addend is not None:
             a.aN, a.aH, a.aW = _nhwc_strides(addend)
@@ -168,8 +204,9 @@ class ConvOp:
         a.src, a.wgt, a.dst = dy.data_ptr(), self.w_d.data_ptr(), out.data_ptr()
         a.bias, a.stats = None, None
         a.addend = addend.data_ptr() if addend is not None else None
-        a.ktab = self.ktab_d.data_ptr()
         a.sN, a.sH, a.sW = _nhwc_strides(dy)
+        a.ktab = self._table("d", a.sH, a.sW).data_ptr()
+        a.src_bytes, a.wgt_bytes = _span_bytes(dy), self.w_d.numel() * self.w_d.element_size()
         a.dN, a.dH, a.dW = _nhwc_strides(out)
         if addend is not None:
             a.aN, a.aH, a.aW = _nhwc_strides(addend)

@@ -42,10 +42,12 @@ const char* fs_target_arch(void);
  *   vision_base/networks/blocks/blocks.py:41-54
  *   monodepth/networks/models/heads/depth_encoder.py:45-63,123-139
  *   monodepth/networks/models/heads/pose_decoder.py:17-21,26-37
- * ktab: one int per 16-byte K group (8 bf16 / 4 f32 channels): c | r<<16 | s<<24, or -1 for
- * zero padding of K.  Forward: src = input, rows = output pixels, hb = y*hb_mul + hb_add
- * (stride, -pad), sgn=+1.  Dgrad: src = dY, rows = input pixels, hb_mul=1, hb_add=+pad, sgn=-1,
- * dshift = log2(stride) with a parity test.  Epilogue: + bias, + addend, relu, optional
+ * ktab: one int2 per K *unit* (kg=4: one 16-byte group = 8 bf16 / 4 f32 channels; kg=8: four groups =
+ * 64 bytes of one tap): { byte delta = (r'*(sH>>dshift) + s'*(sW>>dshift) + c) * sizeof(T)  (INT32_MIN = K
+ * padding),  (r' & 0xffff) | s' << 16 } with (r', s') = sgn*(r, s).  Forward: src = input, rows = output
+ * pixels, hb = y*hb_mul + hb_add (stride, -pad), sgn=+1.  Dgrad: src = dY, rows = input pixels, hb_mul=1,
+ * hb_add=+pad, sgn=-1, dshift = log2(stride) with a parity test.  Operands are fetched with raw buffer
+ * loads bounded by src_bytes / wgt_bytes (out-of-range = zero padding).  Epilogue: + bias, + addend, relu, optional
  * per-channel f64 sum / sum-of-squares (BatchNorm batch statistics), ReLU-backward mask.
  */
 typedef struct FsConvArgs {
@@ -56,11 +58,13 @@ typedef struct FsConvArgs {
   const void* addend;   /* same dtype as src, or NULL */
   const void* mask;     /* same dtype as src, or NULL: out = mask > 0 ? out : 0 (ReLU backward) */
   double* stats;        /* [FS_STAT_SLOTS][2][Co] or NULL */
-  const int* ktab;      /* [nchunks*kg] */
+  const int* ktab;      /* int2 [nchunks * (kg==8 ? 2 : 4)] */
   int64_t sN, sH, sW;   /* src strides (elements) */
   int64_t dN, dH, dW;   /* dst strides */
   int64_t aN, aH, aW;   /* addend strides */
   int64_t mN, mH, mW;   /* mask strides */
+  int64_t src_bytes;    /* addressable span from src (< 2 GiB) */
+  int64_t wgt_bytes;    /* bytes of the packed weight operand */
   int32_t Hs, Ws;       /* src spatial size */
   int32_t Hd, Wd;       /* row-domain (dst) spatial size */
   int32_t M;            /* N*Hd*Wd */
