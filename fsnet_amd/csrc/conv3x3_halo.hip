@@ -1,0 +1,308 @@
+// 3x3 / stride-1 convolution (forward and data-gradient) with an LDS-resident input halo tile.
+//
+// Same call sites as conv_igemm.hip (the 3x3 stride-1 family is ~85 % of the conv FLOPs of the monodepth
+// step: every BasicBlock conv, all decoder convs, the pose convs).  The generic implicit-GEMM kernel
+// re-fetches every input pixel once per tap (9x) and synchronises every 8 MFMAs; measured, it is bound by
+// operand delivery (texture-addresser busy 74 %, ~8 TB/s L2->LDS) at the 32 FLOP/B of its 64x64 tile.
+// Here one block owns a TH x TW pixel tile x CO channels and walks the input channels in chunks of 64 bytes
+// (32 bf16 / 16 f32):
+//   * the (TH+2) x (TW+2) input halo of the chunk is fetched ONCE (raw buffer loads, OOB = zero padding)
+//     and reused by all 9 taps straight from LDS (MFMA B fragments are read at shifted halo positions);
+//   * the 9 taps' weights of the chunk ([tap][co][64 B]) are staged together, so a wave issues
+//     9 * TP * TC MFMAs (72 for the 128x64 tile) between two barriers;
+//   * the next chunk's halo + weights are prefetched into registers while the current one is multiplied.
+// Arithmetic intensity of the 128x64 tile: 98 FLOP per fetched byte (3x the generic kernel).
+// Dgrad = same kernel on dY with Wt[ci][r][s][co] and the taps mirrored (sgn = -1).
+// The epilogue (bias / addend / ReLU / ReLU-mask / fp32 out / fused BN statistics) matches conv_igemm.hip.
+#include "common.h"
+#include "fsnet_hip_internal.h"
+#include <algorithm>
+
+namespace {
+
+__device__ __forceinline__ int swz64(int row) { return ((row >> 3) & 1) << 1; }
+
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, int voff) {
+  return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+}
+
+struct HaloGeom {
+  int TH, TW;        // pixel tile
+  int tiles_x, tiles_y;
+};
+
+template <typename T, int PIX, int CO, int WP>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, const HaloGeom g) {
+  constexpr int WC = 4 / WP;
+  constexpr int WPIX = PIX / WP, WCO = CO / WC;
+  constexpr int TP = WPIX / 16, TC = WCO / 16;
+  constexpr int HMAX = PIX == 128 ? 208 : 120;       // halo pixels that fit the LDS budget
+  constexpr int LH = (HMAX * 4 + 255) / 256;         // halo 16-byte units per thread
+  constexpr int LW = (9 * CO * 4 + 255) / 256;       // weight 16-byte units per thread
+  constexpr int OOB = 0x7fffffff;
+
+  __shared__ uint4 lds_h[HMAX * 4];
+  __shared__ uint4 lds_w[9 * CO * 4];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wp = wave % WP, wc = wave / WP;
+  const int li = lane & 15, lg = lane >> 4;
+  const int HW = g.TW + 2, HH = g.TH + 2;
+  const int nhalo = HH * HW;
+  const int ntile = g.TH * g.TW;
+
+  // ---- tile mapping: XCD-aware over the channel tiles (see conv_igemm.hip) ----
+  const int npix = p.N * g.tiles_y * g.tiles_x, nco = p.Co_p / CO;
+  int px, cy;
+  {
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    if (nco % 8 == 0) { const int q = nco >> 3; cy = xcd + 8 * (slot % q); px = slot / q; }
+    else if (8 % nco == 0) { const int q = 8 / nco; cy = xcd % nco; px = slot * q + xcd / nco; }
+    else { cy = id % nco; px = id / nco; }
+    if (px >= npix) return;
+  }
+  const int tx_i = px % g.tiles_x; const int tq = px / g.tiles_x;
+  const int ty_i = tq % g.tiles_y; const int n = tq / g.tiles_y;
+  const int y0 = ty_i * g.TH, x0 = tx_i * g.TW;
+  const int co0 = cy * CO;
+  const int fwd = p.sgn > 0;
+  // halo origin in the source image: forward rows y0 - pad ..; dgrad rows y0 + pad - 2 ..
+  const int oy = y0 + p.hb_add + (fwd ? 0 : -2), ox = x0 + p.hb_add + (fwd ? 0 : -2);
+
+  const __amdgpu_buffer_rsrc_t rs_src =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, (int)p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wgt =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, (int)p.wgt_bytes, 0x00020000);
+
+  // ---- per-thread load units (fixed over the channel walk) ----
+  int hvoff[LH], wvoff[LW];
+#pragma unroll
+  for (int i = 0; i < LH; ++i) {
+    int idx = t + i * 256;
+    int hp = idx >> 2, q = idx & 3;
+    int hy = hp / HW, hx = hp - hy * HW;
+    int sy = oy + hy, sx = ox + hx;
+    bool ok = hp < nhalo && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
+    hvoff[i] = ok ? (int)(((long)n * p.sN + (long)sy * p.sH + (long)sx * p.sW) * (long)sizeof(T)) + q * 16 : OOB;
+  }
+  const int wrow_bytes = p.nchunks * p.kg * 16;    // packed weight row stride (as packed for conv_igemm)
+  const int tap_bytes = p.Cs * (int)sizeof(T);
+#pragma unroll
+  for (int i = 0; i < LW; ++i) {
+    int idx = t + i * 256;
+    int q = idx & 3, rt = idx >> 2;
+    int tap = rt / CO, row = rt - tap * CO;
+    wvoff[i] = (tap < 9) ? (co0 + row) * wrow_bytes + tap * tap_bytes + q * 16 : OOB;
+  }
+
+  uint4 rh[LH], rw[LW];
+  auto load_regs = [&](int cc) {
+    const int coff = cc * 64;
+#pragma unroll
+    for (int i = 0; i < LH; ++i) rh[i] = buf_load16(rs_src, hvoff[i] == OOB ? OOB : hvoff[i] + coff);
+#pragma unroll
+    for (int i = 0; i < LW; ++i) rw[i] = buf_load16(rs_wgt, wvoff[i] == OOB ? OOB : wvoff[i] + coff);
+  };
+  auto store_lds = [&]() {
+#pragma unroll
+    for (int i = 0; i < LH; ++i) {
+      int idx = t + i * 256;
+      int hp = idx >> 2, q = idx & 3;
+      if (hp < HMAX) lds_h[hp * 4 + (q ^ swz64(hp))] = rh[i];
+    }
+#pragma unroll
+    for (int i = 0; i < LW; ++i) {
+      int idx = t + i * 256;
+      int q = idx & 3, rt = idx >> 2;
+      if (rt < 9 * CO) lds_w[rt * 4 + (q ^ swz64(rt))] = rw[i];   // CO % 16 == 0 -> swizzle follows the co row
+    }
+  };
+
+  // ---- per-lane halo base rows of the TP pixel tiles this wave multiplies ----
+  int hbase[TP];
+#pragma unroll
+  for (int b = 0; b < TP; ++b) {
+    int pi = wp * WPIX + b * 16 + li;
+    if (pi >= ntile) pi = 0;                       // padding lanes read a valid halo row; results are discarded
+    int ty = pi / g.TW, tx = pi - ty * g.TW;
+    hbase[b] = ty * HW + tx;
+  }
+
+  f32x4 acc[TC][TP];
+#pragma unroll
+  for (int a = 0; a < TC; ++a)
+#pragma unroll
+    for (int b = 0; b < TP; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nchunk = p.Cs * (int)sizeof(T) / 64;
+  load_regs(0);
+  for (int cc = 0; cc < nchunk; ++cc) {
+    __syncthreads();                 // previous chunk fully multiplied
+    store_lds();
+    __syncthreads();
+    if (cc + 1 < nchunk) load_regs(cc + 1);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int r = tap / 3, s = tap - r * 3;
+      const int hoff = fwd ? (r * HW + s) : ((2 - r) * HW + (2 - s));
+      uint4 fa[TC], fb[TP];
+#pragma unroll
+      for (int a = 0; a < TC; ++a) {
+        int row = tap * CO + wc * WCO + a * 16 + li;
+        fa[a] = lds_w[row * 4 + (lg ^ swz64(row))];
+      }
+#pragma unroll
+      for (int b = 0; b < TP; ++b) {
+        int row = hbase[b] + hoff;
+        fb[b] = lds_h[row * 4 + (lg ^ swz64(row))];
+      }
+#pragma unroll
+      for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b) {
+          if constexpr (sizeof(T) == 2) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, fa[a]), __builtin_bit_cast(bf16x8, fb[b]), acc[a][b], 0, 0, 0);
+          } else {
+            f32x4 va = __builtin_bit_cast(f32x4, fa[a]);
+            f32x4 vb = __builtin_bit_cast(f32x4, fb[b]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[j], vb[j], acc[a][b], 0, 0, 0);
+          }
+        }
+    }
+  }
+
+  // ---- epilogue ----
+  float s1[TC][4], s2[TC][4];
+#pragma unroll
+  for (int a = 0; a < TC; ++a)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s1[a][j] = 0.f; s2[a][j] = 0.f; }
+#pragma unroll
+  for (int b = 0; b < TP; ++b) {
+    int pi = wp * WPIX + b * 16 + li;
+    int ty = pi / g.TW, tx = pi - ty * g.TW;
+    int y = y0 + ty, x = x0 + tx;
+    bool mok = pi < ntile && y < p.Hd && x < p.Wd;
+    long doff = (long)n * p.dN + (long)y * p.dH + (long)x * p.dW;
+    long aoff = (long)n * p.aN + (long)y * p.aH + (long)x * p.aW;
+    long moff = (long)n * p.mN + (long)y * p.mH + (long)x * p.mW;
+#pragma unroll
+    for (int a = 0; a < TC; ++a) {
+      int co = co0 + wc * WCO + a * 16 + lg * 4;
+      if (!mok || co >= p.Co) continue;
+      float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+      if (p.bias) {
+        float4 bv = *reinterpret_cast<const float4*>(p.bias + co);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+      }
+      if (p.addend) {
+        float av[4];
+        load4<T>(reinterpret_cast<const T*>(p.addend) + aoff + co, av);
+        v[0] += av[0]; v[1] += av[1]; v[2] += av[2]; v[3] += av[3];
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      if (p.mask) {
+        float mv[4];
+        load4<T>(reinterpret_cast<const T*>(p.mask) + moff + co, mv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = mv[j] > 0.f ? v[j] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s1[a][j] += v[j]; s2[a][j] += v[j] * v[j]; }
+      if (p.out_f32) store4<float>(reinterpret_cast<float*>(p.dst) + doff + co, v);
+      else store4<T>(reinterpret_cast<T*>(p.dst) + doff + co, v);
+    }
+  }
+  if (p.stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(&lds_w[0]);   // [WP][CO][2]
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float u = s1[a][j], w = s2[a][j];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { u += __shfl_xor(u, o, 64); w += __shfl_xor(w, o, 64); }
+        if (li == 0) {
+          int cl = wc * WCO + a * 16 + lg * 4 + j;
+          red[(wp * CO + cl) * 2] = u; red[(wp * CO + cl) * 2 + 1] = w;
+        }
+      }
+    __syncthreads();
+    if (t < CO) {
+      float u = 0.f, w = 0.f;
+#pragma unroll
+      for (int k = 0; k < WP; ++k) { u += red[(k * CO + t) * 2]; w += red[(k * CO + t) * 2 + 1]; }
+      int co = co0 + t;
+      if (co < p.Co) {
+        double* sl = p.stats + (long)(px % FS_STAT_SLOTS) * 2 * p.Co;
+        atomicAdd(sl + co, (double)u);
+        atomicAdd(sl + p.Co + co, (double)w);
+      }
+    }
+  }
+}
+
+// pick the pixel tile (TH x TW <= PIX, halo <= hmax) that wastes the fewest lanes, preferring wide tiles
+HaloGeom pick_geom(int Hd, int Wd, int PIX, int hmax) {
+  HaloGeom best{0, 0, 0, 0};
+  double best_cost = 1e30;
+  for (int tw = 4; tw <= std::min(Wd, 64); ++tw) {
+    int th = std::min(PIX / tw, Hd);
+    if (th < 1 || (th + 2) * (tw + 2) > hmax) continue;
+    int tx = (Wd + tw - 1) / tw, ty = (Hd + th - 1) / th;
+    double waste = (double)tx * ty * PIX / ((double)Hd * Wd);          // MFMA lanes spent per useful pixel
+    double halo = (double)(th + 2) * (tw + 2) / ((double)th * tw);     // fetch overhead
+    double cost = waste * (1.0 + 0.15 * halo);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = HaloGeom{th, tw, tx, ty}; }
+  }
+  return best;
+}
+
+template <typename T, int PIX, int CO, int WP>
+int launch_halo(const FsConvArgs& a, hipStream_t st) {
+  HaloGeom g = pick_geom(a.Hd, a.Wd, PIX, PIX == 128 ? 208 : 120);
+  if (g.TH == 0) return FS_EINVAL;
+  const int npix = a.N * g.tiles_x * g.tiles_y, nco = a.Co_p / CO;
+  int blocks = npix * nco;
+  if (nco % 8 != 0 && 8 % nco == 0) { const int q = 8 / nco; blocks = 8 * ((npix + q - 1) / q); }
+  hipLaunchKernelGGL((conv3x3_halo_kernel<T, PIX, CO, WP>), dim3(blocks), dim3(256), 0, st, a, g);
+  return fs_launch_status();
+}
+
+template <typename T>
+int dispatch(const FsConvArgs& a, hipStream_t st) {
+  const int cop = a.Co_p;
+  auto blocks_for = [&](int PIX, int CO) {
+    HaloGeom g = pick_geom(a.Hd, a.Wd, PIX, PIX == 128 ? 208 : 120);
+    return g.TH == 0 ? 0L : (long)a.N * g.tiles_x * g.tiles_y * (cop / CO);
+  };
+  if (cop % 64 == 0) {
+    if (blocks_for(128, 64) >= 256) return launch_halo<T, 128, 64, 2>(a, st);
+    return launch_halo<T, 64, 64, 2>(a, st);
+  }
+  if (cop % 32 == 0) return launch_halo<T, 128, 32, 4>(a, st);
+  return FS_EINVAL;
+}
+
+}  // namespace
+
+extern "C" int fs_conv3x3_halo(const FsConvArgs* args, int dtype, void* stream) {
+  if (!args || !args->src || !args->wgt || !args->dst) return FS_EINVAL;
+  const int es = dtype == FS_DTYPE_BF16 ? 2 : 4;
+  if (args->Cs <= 0 || (args->Cs * es) % 64 != 0 || args->dshift != 0 || args->hb_mul != 1) return FS_EINVAL;
+  if (args->Co % 4 != 0 || args->Co_p % 32 != 0 || args->N <= 0) return FS_EINVAL;
+  if (args->src_bytes <= 0 || args->src_bytes > 0x7fffffffLL || args->wgt_bytes <= 0 ||
+      args->wgt_bytes > 0x7fffffffLL)
+    return FS_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == FS_DTYPE_BF16) return dispatch<bf16>(*args, st);
+  if (dtype == FS_DTYPE_F32) return dispatch<float>(*args, st);
+  return FS_EINVAL;
+}

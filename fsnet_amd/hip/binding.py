@@ -26,7 +26,7 @@ class FsConvArgs(C.Structure):
         ("Hs", C.c_int32), ("Ws", C.c_int32), ("Hd", C.c_int32), ("Wd", C.c_int32),
         ("M", C.c_int32), ("Co", C.c_int32), ("Co_p", C.c_int32), ("nchunks", C.c_int32), ("kg", C.c_int32),
         ("hb_mul", C.c_int32), ("hb_add", C.c_int32), ("sgn", C.c_int32), ("dshift", C.c_int32),
-        ("relu", C.c_int32), ("out_f32", C.c_int32),
+        ("relu", C.c_int32), ("out_f32", C.c_int32), ("N", C.c_int32), ("Cs", C.c_int32),
     ]
 
 

@@ -88,6 +88,9 @@ def _nhwc_strides(t):
     return t.stride(0), t.stride(1), t.stride(2)
 
 
+import os
+
+USE_HALO = os.environ.get("FSNET_AMD_HALO", "1") != "0"   # 3x3/s1 LDS-halo kernel (conv3x3_halo.hip)
 _WGRAD_WS = {}
 
 
@@ -129,6 +132,10 @@ class ConvOp:
             self.kd_p = self.nch_d * chunk
             self.w_d = torch.zeros(self.rows_d, self.kd_p, dtype=dtype, device=device)
         self._tabs = {}
+        eb = 2 if dtype == torch.bfloat16 else 4
+        halo_ok = (R == 3 and S == 3 and stride == 1)
+        self.halo_f = halo_ok and (self.Ci_p * eb) % 64 == 0 and self.Co_p % 32 == 0
+        self.halo_d = halo_ok and need_dgrad and (self.Co_p * eb) % 64 == 0 and roundup(self.Ci_p, 16) % 32 == 0
         # wgrad columns (r, s, ci): same grouping as the forward K walk without chunk padding
         self.ncolgroups = R * S * self.Ci_p // eg
         self.ktab_w = torch.from_numpy(make_ktab(R, S, self.Ci_p, eg, self.ncolgroups)).to(device)
@@ -190,8 +197,10 @@ class ConvOp:
         a.Co, a.Co_p, a.nchunks, a.kg = out.shape[3], self.Co_p, self.nch_f, self.kg_f
         a.hb_mul, a.hb_add, a.sgn, a.dshift = self.stride, -self.pad, 1, 0
         a.relu, a.out_f32 = int(relu), int(out_f32)
+        a.N, a.Cs = N, self.Ci_p
         flops = 2.0 * a.M * self.Co * self.R * self.S * self.Ci
-        _timed("conv_igemm", flops, lambda: check(lib.fs_conv_igemm(C.byref(a), self.code, stream_ptr()), "conv_fwd"))
+        fn = lib.fs_conv3x3_halo if (self.halo_f and USE_HALO) else lib.fs_conv_igemm
+        _timed("conv_igemm", flops, lambda: check(fn(C.byref(a), self.code, stream_ptr()), "conv_fwd"))
         return out
 
     def dgrad(self, dy, H, W, out=None, addend=None, mask=None):
@@ -218,8 +227,10 @@ class ConvOp:
         a.Co, a.Co_p, a.nchunks, a.kg = out.shape[3], self.rows_d, self.nch_d, self.kg_d
         a.hb_mul, a.hb_add, a.sgn, a.dshift = 1, self.pad, -1, (1 if self.stride == 2 else 0)
         a.relu, a.out_f32 = 0, 0
+        a.N, a.Cs = N, self.Co_p
         flops = 2.0 * N * Ho * Wo * self.Co * self.R * self.S * self.Ci
-        _timed("conv_igemm", flops, lambda: check(lib.fs_conv_igemm(C.byref(a), self.code, stream_ptr()), "conv_dgrad"))
+        fn = lib.fs_conv3x3_halo if (self.halo_d and USE_HALO) else lib.fs_conv_igemm
+        _timed("conv_igemm", flops, lambda: check(fn(C.byref(a), self.code, stream_ptr()), "conv_dgrad"))
         return out
 
     def wgrad(self, dy, x, dw):

@@ -12,6 +12,7 @@ SIGNATURES = {
     "fs_abi_version": (C.c_int, []),
     "fs_target_arch": (C.c_char_p, []),
     "fs_conv_igemm": (C.c_int, [P, I, P]),
+    "fs_conv3x3_halo": (C.c_int, [P, I, P]),
     "fs_conv_wgrad": (C.c_int, [P, I, P]),
     "fs_pack_weights": (C.c_int, [P, P, I, I, I, I, I, I, L, I, I, P]),
     "fs_nchw_to_nhwc": (C.c_int, [P, P, P, I, I, I, I, I, I, I, P]),

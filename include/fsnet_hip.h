@@ -75,8 +75,16 @@ typedef struct FsConvArgs {
   int32_t hb_mul, hb_add, sgn, dshift;
   int32_t relu;
   int32_t out_f32;      /* store fp32 regardless of dtype */
+  int32_t N;            /* batch size (fs_conv3x3_halo) */
+  int32_t Cs;           /* source channels per tap (fs_conv3x3_halo) */
 } FsConvArgs;
 int fs_conv_igemm(const FsConvArgs* args, int dtype, void* stream);
+
+/* 3x3 / stride-1 specialisation (forward: hb_mul=1, hb_add=-pad, sgn=+1; dgrad: hb_add=+pad, sgn=-1) with an
+ * LDS-resident input halo tile reused by all nine taps.  Same arguments, packed weights and epilogue as
+ * fs_conv_igemm (ktab is not used); requires Cs*sizeof(T) % 64 == 0 and Co_p % 32 == 0.
+ */
+int fs_conv3x3_halo(const FsConvArgs* args, int dtype, void* stream);
 
 /* Convolution weight gradient.  Replaces convolution_backward(weight) at the same call sites.
  * dy is dense [M][Cd]; x is the forward input (strided NHWC); dw is the fp32 OIHW gradient
