@@ -262,9 +262,211 @@ int launch_tile(const FsWgradArgs& a, hipStream_t st) {
   return fs_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------
+// 3x3 / stride-1 weight gradient with an LDS-resident input halo (bf16).  One block owns a
+// COT x (9 taps x CIT) slice of dW and walks pixel tiles (TH x TW = 128 pixels): the dY tile and the
+// (TH+2) x (TW+2) input halo are fetched once and all nine taps multiply out of LDS (transposed fragment
+// reads at shifted halo rows), i.e. 9x fewer input fetches and 72 MFMAs per wave between barriers; the
+// generic kernel above re-gathers the input per tap and synchronises every 4 MFMAs.
+// ---------------------------------------------------------------------------------------------
+struct WGeom { int TH, TW, tiles_x, tiles_y, N, Cs, nsplit; };
+
+__device__ __forceinline__ uint4 wg_buf_load16(__amdgpu_buffer_rsrc_t rsrc, int voff) {
+  return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+}
+
+template <int COT, int CIT>
+__global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const FsWgradArgs p, const WGeom g) {
+  typedef bf16 T;
+  constexpr int PIXT = 128, HMAX = 208, OOB = 0x7fffffff;
+  constexpr int SA = COT + 8, SB = CIT + 8;
+  constexpr int TA = COT / 32, TB = CIT / 32;          // per-wave 16x16 sub-tiles (2 x 2 waves)
+  constexpr int UA = COT / 8, UB = CIT / 8;            // 16-byte units per pixel row
+  constexpr int LA = (PIXT * UA + 255) / 256, LB = (HMAX * UB + 255) / 256;
+  __shared__ __attribute__((aligned(16))) T lds_a[PIXT * SA];
+  __shared__ __attribute__((aligned(16))) T lds_b[HMAX * SB];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wr = wave & 1, wcn = wave >> 1;
+  const int li = lane & 15, lg = lane >> 4;
+  const int HW = g.TW + 2, nhalo = (g.TH + 2) * HW, ntile = g.TH * g.TW;
+  const int ci0 = blockIdx.x * CIT, co0 = blockIdx.y * COT;
+  const int npix = g.N * g.tiles_y * g.tiles_x;
+
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.dy), 0, (int)((long)p.M * p.Cd * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+
+  // per-thread load units: tile-relative coordinates are fixed, only (n, y0, x0) changes per tile
+  int aty[LA], atx[LA], bhy[LB], bhx[LB];
+#pragma unroll
+  for (int i = 0; i < LA; ++i) {
+    int pix = (t + i * 256) / UA;
+    aty[i] = pix < ntile ? pix / g.TW : -1; atx[i] = pix < ntile ? pix % g.TW : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < LB; ++i) {
+    int hp = (t + i * 256) / UB;
+    bhy[i] = hp < nhalo ? hp / HW : -1; bhx[i] = hp < nhalo ? hp % HW : 0;
+  }
+  uint4 ra[LA], rb[LB];
+  auto load_regs = [&](int pt) {
+    int tx_i = pt % g.tiles_x; int q = pt / g.tiles_x; int ty_i = q % g.tiles_y; int n = q / g.tiles_y;
+    int y0 = ty_i * g.TH, x0 = tx_i * g.TW;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      int u = (t + i * 256) % UA;
+      int y = y0 + aty[i], x = x0 + atx[i];
+      bool ok = aty[i] >= 0 && y < p.Hd && x < p.Wd;
+      int voff = ok ? (int)((((long)n * p.Hd + y) * p.Wd + x) * p.Cd + co0 + u * 8) * 2 : OOB;
+      ra[i] = wg_buf_load16(rs_dy, voff);
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+      int u = (t + i * 256) % UB;
+      int sy = y0 - p.pad + bhy[i], sx = x0 - p.pad + bhx[i];
+      bool ok = bhy[i] >= 0 && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
+      int voff = ok ? (int)(((long)n * p.sN + (long)sy * p.sH + (long)sx * p.sW + ci0 + u * 8) * 2) : OOB;
+      rb[i] = wg_buf_load16(rs_x, voff);
+    }
+  };
+  auto store_lds = [&]() {
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      int idx = t + i * 256; int pix = idx / UA, u = idx % UA;
+      if (pix < PIXT) *reinterpret_cast<uint4*>(&lds_a[pix * SA + u * 8]) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+      int idx = t + i * 256; int hp = idx / UB, u = idx % UB;
+      if (hp < HMAX) *reinterpret_cast<uint4*>(&lds_b[hp * SB + u * 8]) = rb[i];
+    }
+  };
+
+  // transposed-fragment row offsets: lane (li, lg) supplies pixel k = ks*32 + lg*8 + (li>>2) (+4)
+  int arow[4][2], brow[4][2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      int pk = ks * 32 + lg * 8 + (li >> 2) + hf * 4;
+      arow[ks][hf] = pk * SA + wr * (COT / 2) + (li & 3) * 4;
+      int pv = pk < ntile ? pk : 0;
+      brow[ks][hf] = ((pv / g.TW) * HW + (pv % g.TW)) * SB + wcn * (CIT / 2) + (li & 3) * 4;
+    }
+
+  f32x4 acc[9][TA][TB];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+      for (int b = 0; b < TB; ++b) acc[tp][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int pt = blockIdx.z;
+  if (pt < npix) load_regs(pt);
+  for (; pt < npix; pt += g.nsplit) {
+    __syncthreads();
+    store_lds();
+    __syncthreads();
+    if (pt + g.nsplit < npix) load_regs(pt + g.nsplit);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 fa[TA];
+#pragma unroll
+      for (int a = 0; a < TA; ++a) {
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(&lds_a[arow[ks][0] + a * 16]));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(&lds_a[arow[ks][1] + a * 16]));
+        uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+        fa[a] = __builtin_bit_cast(bf16x8, make_uint4(l2.x, l2.y, h2.x, h2.y));
+      }
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        const int toff = ((tp / 3) * HW + (tp % 3)) * SB;
+#pragma unroll
+        for (int b = 0; b < TB; ++b) {
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(&lds_b[brow[ks][0] + toff + b * 16]));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(&lds_b[brow[ks][1] + toff + b * 16]));
+          uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+          bf16x8 fb = __builtin_bit_cast(bf16x8, make_uint4(l2.x, l2.y, h2.x, h2.y));
+#pragma unroll
+          for (int a = 0; a < TA; ++a)
+            acc[tp][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb, acc[tp][a][b], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: D rows = co (lg*4 + j), cols = ci (li) ----
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int b = 0; b < TB; ++b) {
+      int ci = ci0 + wcn * (CIT / 2) + b * 16 + li;
+#pragma unroll
+      for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int co = co0 + wr * (COT / 2) + a * 16 + lg * 4 + j;
+          float v = acc[tp][a][b][j];
+          if (g.nsplit > 1) {
+            p.workspace[((long)blockIdx.z * p.ws_rows + co) * p.ws_cols + tp * g.Cs + ci] = v;
+          } else if (co < p.Co && ci < p.Ci) {
+            p.dw[(((long)co * p.Ci + ci) * 3 + tp / 3) * 3 + tp % 3] += v;
+          }
+        }
+    }
+}
+
+WGeom wgrad_pick_geom(int Hd, int Wd) {
+  WGeom best{0, 0, 0, 0, 0, 0, 1};
+  double best_cost = 1e30;
+  for (int tw = 4; tw <= std::min(Wd, 64); ++tw) {
+    int th = std::min(128 / tw, Hd);
+    if (th < 1 || (th + 2) * (tw + 2) > 208) continue;
+    int tx = (Wd + tw - 1) / tw, ty = (Hd + th - 1) / th;
+    double waste = (double)tx * ty * 128 / ((double)Hd * Wd);
+    double halo = (double)(th + 2) * (tw + 2) / ((double)th * tw);
+    double cost = waste * (1.0 + 0.15 * halo);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best.TH = th; best.TW = tw; best.tiles_x = tx; best.tiles_y = ty; }
+  }
+  return best;
+}
+
+int launch_wgrad_halo(const FsWgradArgs& a, hipStream_t st) {
+  constexpr int COT = 64, CIT = 32;
+  FsWgradArgs b = a;
+  const int Cs = a.ncolgroups * 8 / 9;
+  WGeom g = wgrad_pick_geom(a.Hd, a.Wd);
+  if (g.TH == 0) return FS_EINVAL;
+  g.N = a.M / (a.Hd * a.Wd); g.Cs = Cs;
+  const int out_tiles = (a.Cd / COT) * (Cs / CIT);
+  const int npix = g.N * g.tiles_x * g.tiles_y;
+  b.ws_rows = a.Cd; b.ws_cols = 9 * Cs;
+  const long slab = (long)b.ws_rows * b.ws_cols;
+  long splits = std::max<long>(1, std::min<long>(npix, (512 + out_tiles - 1) / out_tiles));
+  if (!a.workspace) splits = 1;
+  else splits = std::min<long>(splits, std::max<long>(1, a.workspace_elems / slab));
+  g.nsplit = (int)splits; b.nsplit = g.nsplit;
+  dim3 grid(Cs / CIT, a.Cd / COT, g.nsplit);
+  hipLaunchKernelGGL((wgrad3x3_halo_kernel<COT, CIT>), grid, dim3(256), 0, st, b, g);
+  if (b.nsplit > 1) {
+    const int ncols = 9 * Cs;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(a.Co * ((ncols + 63) / 64))), dim3(256), 0, st, b, 8);
+  }
+  return fs_launch_status();
+}
+
 template <typename T>
 int launch_wgrad(const FsWgradArgs& a, hipStream_t st) {
   constexpr bool kBf16 = sizeof(T) == 2;  // f32 tiles are capped by the 64 KB static LDS limit
+  if constexpr (kBf16) {
+    const int Cs = a.ncolgroups * 8 / (a.R * a.S);
+    if (a.use_halo && a.R == 3 && a.S == 3 && a.stride == 1 && a.Cd % 64 == 0 && Cs % 32 == 0 && a.x_bytes > 0 &&
+        a.x_bytes <= 0x7fffffffLL && (long)a.M * a.Cd * 2 <= 0x7fffffffLL && a.M >= 4096)
+      return launch_wgrad_halo(a, st);   // (tiny pixel counts: too few tiles to split, the generic kernel wins)
+  }
   if (a.Cd % 64 == 0) return launch_tile<T, 64, 64, 2>(a, st);
   if (a.Cd % 32 == 0) return launch_tile<T, 32, 128, 1>(a, st);
   if (a.Cd % 16 == 0) {

@@ -38,7 +38,7 @@ class FsWgradArgs(C.Structure):
         ("M", C.c_int32), ("Cd", C.c_int32),
         ("Co", C.c_int32), ("Ci", C.c_int32), ("R", C.c_int32), ("S", C.c_int32),
         ("stride", C.c_int32), ("pad", C.c_int32), ("ncolgroups", C.c_int32),
-        ("workspace", C.c_void_p), ("workspace_elems", C.c_int64),
+        ("workspace", C.c_void_p), ("workspace_elems", C.c_int64), ("x_bytes", C.c_int64), ("use_halo", C.c_int32),
         ("pix_per_split", C.c_int32), ("nsplit", C.c_int32), ("ws_rows", C.c_int32), ("ws_cols", C.c_int32),
     ]
 

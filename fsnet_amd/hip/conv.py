@@ -247,6 +247,7 @@ class ConvOp:
         a.stride, a.pad, a.ncolgroups, a.pix_per_split = self.stride, self.pad, self.ncolgroups, 0
         ws = wgrad_workspace(dy.device)
         a.workspace, a.workspace_elems = ws.data_ptr(), ws.numel()
+        a.x_bytes, a.use_halo = _span_bytes(x), int(USE_HALO)
         flops = 2.0 * a.M * self.Co * self.R * self.S * self.Ci
         _timed("conv_wgrad", flops, lambda: check(lib.fs_conv_wgrad(C.byref(a), self.code, stream_ptr()), "conv_wgrad"))
         return dw

@@ -106,6 +106,8 @@ typedef struct FsWgradArgs {
   int32_t ncolgroups;   /* R*S*Cs / EG */
   float* workspace;     /* split-K partial slabs (or NULL: no split) */
   int64_t workspace_elems;
+  int64_t x_bytes;      /* addressable span from x (< 2 GiB) — enables the 3x3/s1 LDS-halo path */
+  int32_t use_halo;     /* 1: allow the 3x3/s1 LDS-halo kernel (bf16) */
   int32_t pix_per_split, nsplit, ws_rows, ws_cols;  /* filled by the library */
 } FsWgradArgs;
 int fs_conv_wgrad(const FsWgradArgs* args, int dtype, void* stream);
