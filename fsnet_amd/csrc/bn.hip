@@ -76,32 +76,33 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const FsBnApplyArgs p) {
   const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
   const T* __restrict__ res = reinterpret_cast<const T*>(p.res);
   T* __restrict__ y = reinterpret_cast<T*>(p.y);
-  const int CG = C / 4;
+  constexpr int V = VecN<T>::N;
+  const int CG = C / V;
   const long total = (long)p.M * CG;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     int cg = (int)(i % CG); long m = i / CG;
-    int c = cg * 4;
-    float v[4];
-    load4<T>(x + m * C + c, v);
+    int c = cg * V;
+    float v[V];
+    loadv<T>(x + m * C + c, v);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = v[j] * s_scale[c + j] + s_shift[c + j];
+    for (int j = 0; j < V; ++j) v[j] = v[j] * s_scale[c + j] + s_shift[c + j];
     if (res) {
-      float r[4];
-      load4<T>(res + m * C + c, r);
+      float r[V];
+      loadv<T>(res + m * C + c, r);
       if (has2) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = r[j] * s_scale2[c + j] + s_shift2[c + j];
+        for (int j = 0; j < V; ++j) r[j] = r[j] * s_scale2[c + j] + s_shift2[c + j];
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] += r[j];
+      for (int j = 0; j < V; ++j) v[j] += r[j];
     }
     if (p.relu) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+      for (int j = 0; j < V; ++j) v[j] = fmaxf(v[j], 0.f);
     }
     int w = (int)(m % p.W); long q = m / p.W; int h = (int)(q % p.H); long n = q / p.H;
     if (!p.pad_out) {
-      store4<T>(y + n * p.yN + (long)h * p.yH + (long)w * p.yW + c, v);
+      storev<T>(y + n * p.yN + (long)h * p.yH + (long)w * p.yW + c, v);
     } else {
       // output buffer is [N, H+2, W+2, C] with a replicated border (consumer uses replicate padding)
       // (H, W >= 2: decoder maps are never a single row/column)
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const FsBnApplyArgs p) {
       if (w == 0) { ws[1] = 0; nw = 2; } else if (w == p.W - 1) { ws[1] = p.W + 1; nw = 2; }
       for (int a = 0; a < nh; ++a)
         for (int b = 0; b < nw; ++b)
-          store4<T>(y + n * p.yN + (long)hs[a] * p.yH + (long)ws[b] * p.yW + c, v);
+          storev<T>(y + n * p.yN + (long)hs[a] * p.yH + (long)ws[b] * p.yW + c, v);
     }
   }
 }
@@ -119,73 +120,95 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const FsBnApplyArgs p) {
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
-// gradient w.r.t. the block output at interior pixel (n,h,w), channels c..c+3.  `fold`: dout is a
+// gradient w.r.t. the block output at interior pixel (n,h,w), channels c..c+V-1.  `fold`: dout is a
 // replicate-padded buffer [N,H+2,W+2,C]; the border copies fold back onto the edge pixel.
 template <typename T>
-__device__ inline void load_dout(const FsBnBwdArgs& p, const T* dout, long n, int h, int w, int c, float g[4]) {
+__device__ inline void load_dout(const FsBnBwdArgs& p, const T* dout, long n, int h, int w, int c, float* g) {
+  constexpr int V = VecN<T>::N;
   if (!p.fold) {
-    load4<T>(dout + n * p.gN + (long)h * p.gH + (long)w * p.gW + c, g);
+    loadv<T>(dout + n * p.gN + (long)h * p.gH + (long)w * p.gW + c, g);
     return;
   }
-  g[0] = g[1] = g[2] = g[3] = 0.f;
+#pragma unroll
+  for (int j = 0; j < V; ++j) g[j] = 0.f;
   int hs[2] = {h + 1, 0}, ws[2] = {w + 1, 0};
   int nh = 1, nw = 1;
   if (h == 0) { hs[1] = 0; nh = 2; } else if (h == p.H - 1) { hs[1] = p.H + 1; nh = 2; }
   if (w == 0) { ws[1] = 0; nw = 2; } else if (w == p.W - 1) { ws[1] = p.W + 1; nw = 2; }
   for (int a = 0; a < nh; ++a)
     for (int b = 0; b < nw; ++b) {
-      float t[4];
-      load4<T>(dout + n * p.gN + (long)hs[a] * p.gH + (long)ws[b] * p.gW + c, t);
-      g[0] += t[0]; g[1] += t[1]; g[2] += t[2]; g[3] += t[3];
+      float t[V];
+      loadv<T>(dout + n * p.gN + (long)hs[a] * p.gH + (long)ws[b] * p.gW + c, t);
+#pragma unroll
+      for (int j = 0; j < V; ++j) g[j] += t[j];
     }
 }
 
-// pass 1: per-channel sum(g), sum(g * xhat) with g = dout * (y > 0)
+template <typename T>
+__device__ inline void masked_grad(const FsBnBwdArgs& p, const T* dout, const T* yv, long m, int c, float* g) {
+  constexpr int V = VecN<T>::N;
+  int w = (int)(m % p.W); long q = m / p.W; int h = (int)(q % p.H); long n = q / p.H;
+  load_dout<T>(p, dout, n, h, w, c, g);
+  if (p.relu) {
+    float yy[V];
+    loadv<T>(yv + n * p.yN + (long)h * p.yH + (long)w * p.yW + c, yy);
+#pragma unroll
+    for (int j = 0; j < V; ++j) g[j] = yy[j] > 0.f ? g[j] : 0.f;
+  }
+}
+
+// pass 1: per-channel sum(g), sum(g * xhat) with g = dout * (y > 0).  A block covers CGB channel groups
+// (16-byte lanes) x PL pixel lanes; two rows per iteration keep more loads in flight.
 template <typename T, int CGB>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const FsBnBwdArgs p) {
+  constexpr int V = VecN<T>::N;
   constexpr int PL = 256 / CGB;
-  __shared__ float red[2][4][256];
-  const int C = p.C, CG = C / 4;
+  __shared__ float red[2][V][256];
+  const int C = p.C, CG = C / V;
   const int cgl = threadIdx.x % CGB, pl = threadIdx.x / CGB;
   const int cg = blockIdx.y * CGB + cgl;
   const bool act = cg < CG;
-  const int c = cg * 4;
+  const int c = cg * V;
   const T* __restrict__ dout = reinterpret_cast<const T*>(p.dout);
   const T* __restrict__ yv = reinterpret_cast<const T*>(p.y);
   const T* __restrict__ xv = reinterpret_cast<const T*>(p.x);
-  float mean[4], istd[4];
-  if (act) {
+  float mean[V], istd[V], s1[V], s2[V];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { mean[j] = p.save_mean[c + j]; istd[j] = p.save_invstd[c + j]; }
-  }
-  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  for (int j = 0; j < V; ++j) { mean[j] = act ? p.save_mean[c + j] : 0.f; istd[j] = act ? p.save_invstd[c + j] : 0.f; s1[j] = 0.f; s2[j] = 0.f; }
   if (act) {
-    for (long m = (long)blockIdx.x * PL + pl; m < p.M; m += (long)gridDim.x * PL) {
-      int w = (int)(m % p.W); long q = m / p.W; int h = (int)(q % p.H); long n = q / p.H;
-      float g[4], xr[4];
-      load_dout<T>(p, dout, n, h, w, c, g);
-      if (p.relu) {
-        float yy[4];
-        load4<T>(yv + n * p.yN + (long)h * p.yH + (long)w * p.yW + c, yy);
+    const long stride = (long)gridDim.x * PL;
+    long m = (long)blockIdx.x * PL + pl;
+    for (; m + stride < p.M; m += 2 * stride) {
+      float g0[V], g1[V], x0[V], x1[V];
+      masked_grad<T>(p, dout, yv, m, c, g0);
+      masked_grad<T>(p, dout, yv, m + stride, c, g1);
+      loadv<T>(xv + m * C + c, x0);
+      loadv<T>(xv + (m + stride) * C + c, x1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) g[j] = yy[j] > 0.f ? g[j] : 0.f;
+      for (int j = 0; j < V; ++j) {
+        s1[j] += g0[j] + g1[j];
+        s2[j] += g0[j] * (x0[j] - mean[j]) * istd[j] + g1[j] * (x1[j] - mean[j]) * istd[j];
       }
-      load4<T>(xv + m * C + c, xr);
+    }
+    for (; m < p.M; m += stride) {
+      float g0[V], x0[V];
+      masked_grad<T>(p, dout, yv, m, c, g0);
+      loadv<T>(xv + m * C + c, x0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { s1[j] += g[j]; s2[j] += g[j] * (xr[j] - mean[j]) * istd[j]; }
+      for (int j = 0; j < V; ++j) { s1[j] += g0[j]; s2[j] += g0[j] * (x0[j] - mean[j]) * istd[j]; }
     }
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { red[0][j][threadIdx.x] = s1[j]; red[1][j][threadIdx.x] = s2[j]; }
+  for (int j = 0; j < V; ++j) { red[0][j][threadIdx.x] = s1[j]; red[1][j][threadIdx.x] = s2[j]; }
   __syncthreads();
-  if (pl == 0 && act) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float a = 0.f, b = 0.f;
-      for (int k = 0; k < PL; ++k) { a += red[0][j][k * CGB + cgl]; b += red[1][j][k * CGB + cgl]; }
+  // threads (pl < 2*V) of each channel group finish one (kind, j) pair each
+  if (act && pl < 2 * V && pl < PL) {
+    for (int kj = pl; kj < 2 * V; kj += PL) {
+      int kind = kj / V, j = kj % V;
+      float a = 0.f;
+      for (int k = 0; k < PL; ++k) a += red[kind][j][k * CGB + cgl];
       double* sl = p.sums + (long)(blockIdx.x % FS_STAT_SLOTS) * 2 * C;
-      atomicAdd(sl + c + j, (double)a);
-      atomicAdd(sl + C + c + j, (double)b);
+      atomicAdd(sl + kind * C + c + j, (double)a);
     }
   }
 }
@@ -219,28 +242,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const FsBnBwdArgs p) 
   const T* __restrict__ xv = reinterpret_cast<const T*>(p.x);
   T* __restrict__ dx = reinterpret_cast<T*>(p.dx);
   T* __restrict__ gout = reinterpret_cast<T*>(p.g_out);
-  const int CG = C / 4;
+  constexpr int V = VecN<T>::N;
+  const int CG = C / V;
   const long total = (long)p.M * CG;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     int cg = (int)(i % CG); long m = i / CG;
-    int c = cg * 4;
-    int w = (int)(m % p.W); long q = m / p.W; int h = (int)(q % p.H); long n = q / p.H;
-    float g[4], xr[4], o[4];
-    load_dout<T>(p, dout, n, h, w, c, g);
-    if (p.relu) {
-      float yy[4];
-      load4<T>(yv + n * p.yN + (long)h * p.yH + (long)w * p.yW + c, yy);
+    int c = cg * V;
+    float g[V], xr[V], o[V];
+    masked_grad<T>(p, dout, yv, m, c, g);
+    loadv<T>(xv + m * C + c, xr);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) g[j] = yy[j] > 0.f ? g[j] : 0.f;
-    }
-    load4<T>(xv + m * C + c, xr);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < V; ++j) {
       float xh = (xr[j] - s_mean[c + j]) * s_istd[c + j];
       o[j] = s_k[c + j] * (g[j] - s_a[c + j] - xh * s_b[c + j]);
     }
-    store4<T>(dx + m * C + c, o);
-    if (gout) store4<T>(gout + m * C + c, g);
+    storev<T>(dx + m * C + c, o);
+    if (gout) storev<T>(gout + m * C + c, g);
   }
 }
 
@@ -256,11 +273,11 @@ int grid_for(long items) {
 extern "C" int fs_bn_apply(const FsBnApplyArgs* a, int dtype, void* stream) {
   if (!a || !a->x || !a->y || !a->gamma || !a->beta || !a->save_mean || !a->save_invstd) return FS_EINVAL;
   if (!a->stats && (!a->running_mean || !a->running_var)) return FS_EINVAL;
-  if (a->C % 4 != 0 || a->C > MAXC || a->M <= 0) return FS_EINVAL;
+  if (a->C % 8 != 0 || a->C > MAXC || a->M <= 0) return FS_EINVAL;
   if (a->gamma2 && (!a->res || !a->beta2 || !a->save_mean2 || !a->save_invstd2)) return FS_EINVAL;
   if (a->gamma2 && !a->stats2 && (!a->running_mean2 || !a->running_var2)) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  int grid = grid_for((long)a->M * (a->C / 4));
+  int grid = grid_for((long)a->M * (a->C / (dtype == FS_DTYPE_BF16 ? 8 : 4)));
   if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(grid), dim3(256), 0, st, *a);
   else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, st, *a);
   else return FS_EINVAL;
@@ -269,19 +286,19 @@ extern "C" int fs_bn_apply(const FsBnApplyArgs* a, int dtype, void* stream) {
 
 extern "C" int fs_bn_bwd_reduce(const FsBnBwdArgs* a, int dtype, void* stream) {
   if (!a || !a->dout || !a->x || !a->sums || !a->save_mean || !a->save_invstd) return FS_EINVAL;
-  if (a->C % 4 != 0 || a->C > MAXC || a->M <= 0 || (a->relu && !a->y)) return FS_EINVAL;
+  if (a->C % 8 != 0 || a->C > MAXC || a->M <= 0 || (a->relu && !a->y)) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int CG = a->C / 4;
-  // channel groups per block: 64 (4 pixel lanes) for wide layers, 16 (16 pixel lanes) for narrow ones
-  if (CG >= 64) {
-    dim3 grid((unsigned)std::min<long>(((long)a->M + 15) / 16, 512), (CG + 63) / 64);
-    if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, 64>), grid, dim3(256), 0, st, *a);
-    else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 64>), grid, dim3(256), 0, st, *a);
+  const int CG = a->C / (dtype == FS_DTYPE_BF16 ? 8 : 4);
+  // channel groups per block: 32 (8 pixel lanes) for wide layers, 8 (32 pixel lanes) for narrow ones
+  if (CG >= 32) {
+    dim3 grid((unsigned)std::min<long>(((long)a->M + 15) / 16, 512), (CG + 31) / 32);
+    if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, 32>), grid, dim3(256), 0, st, *a);
+    else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 32>), grid, dim3(256), 0, st, *a);
     else return FS_EINVAL;
   } else {
-    dim3 grid((unsigned)std::min<long>(((long)a->M + 63) / 64, 1024), (CG + 15) / 16);
-    if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, 16>), grid, dim3(256), 0, st, *a);
-    else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 16>), grid, dim3(256), 0, st, *a);
+    dim3 grid((unsigned)std::min<long>(((long)a->M + 63) / 64, 1024), (CG + 7) / 8);
+    if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, 8>), grid, dim3(256), 0, st, *a);
+    else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 8>), grid, dim3(256), 0, st, *a);
     else return FS_EINVAL;
   }
   return fs_launch_status();
@@ -289,9 +306,9 @@ extern "C" int fs_bn_bwd_reduce(const FsBnBwdArgs* a, int dtype, void* stream) {
 
 extern "C" int fs_bn_bwd_apply(const FsBnBwdArgs* a, int dtype, void* stream) {
   if (!a || !a->dout || !a->x || !a->sums || !a->dx || !a->gamma || !a->save_mean || !a->save_invstd) return FS_EINVAL;
-  if (a->C % 4 != 0 || a->C > MAXC || a->M <= 0 || (a->relu && !a->y)) return FS_EINVAL;
+  if (a->C % 8 != 0 || a->C > MAXC || a->M <= 0 || (a->relu && !a->y)) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  int grid = grid_for((long)a->M * (a->C / 4));
+  int grid = grid_for((long)a->M * (a->C / (dtype == FS_DTYPE_BF16 ? 8 : 4)));
   if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(grid), dim3(256), 0, st, *a);
   else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, *a);
   else return FS_EINVAL;

@@ -83,3 +83,28 @@ __device__ static inline double block_sum_d(double v, double* sh) {
   __syncthreads();
   return sh[0] + sh[1] + sh[2] + sh[3];
 }
+
+// 16-byte per-lane vectors: VecN<T>::N consecutive channel values (4 f32 / 8 bf16) as floats
+template <typename T> struct VecN { static constexpr int N = 16 / sizeof(T); };
+template <typename T> __device__ inline void loadv(const T* p, float* v);
+template <> __device__ inline void loadv<float>(const float* p, float* v) {
+  float4 t = *reinterpret_cast<const float4*>(p);
+  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ inline void loadv<bf16>(const bf16* p, float* v) {
+  uint4 t = *reinterpret_cast<const uint4*>(p);
+  v[0] = bf16_bits_to_f(t.x & 0xffffu); v[1] = bf16_bits_to_f(t.x >> 16);
+  v[2] = bf16_bits_to_f(t.y & 0xffffu); v[3] = bf16_bits_to_f(t.y >> 16);
+  v[4] = bf16_bits_to_f(t.z & 0xffffu); v[5] = bf16_bits_to_f(t.z >> 16);
+  v[6] = bf16_bits_to_f(t.w & 0xffffu); v[7] = bf16_bits_to_f(t.w >> 16);
+}
+template <typename T> __device__ inline void storev(T* p, const float* v);
+template <> __device__ inline void storev<float>(float* p, const float* v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ inline void storev<bf16>(bf16* p, const float* v) {
+  uint4 t;
+  t.x = pack_bf16x2(v[0], v[1]); t.y = pack_bf16x2(v[2], v[3]);
+  t.z = pack_bf16x2(v[4], v[5]); t.w = pack_bf16x2(v[6], v[7]);
+  *reinterpret_cast<uint4*>(p) = t;
+}

@@ -40,7 +40,48 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ a, const float* __
   }
 }
 
+// all convolutions of a model in ONE launch: a block finds its descriptor by binary search over block_start
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const FsPackDesc* __restrict__ descs, int n) {
+  int lo = 0, hi = n - 1;
+  const long bid = blockIdx.x;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].block_start <= bid) lo = mid; else hi = mid - 1;
+  }
+  const FsPackDesc d = descs[lo];
+  const long i = (bid - d.block_start) * 256 + threadIdx.x;
+  const long nf = (long)d.rows_f * d.k_f, nd = (long)d.rows_d * d.k_d;
+  if (i >= nf + nd) return;
+  const bool tr = i >= nf;
+  const long j = tr ? i - nf : i;
+  const long kp = tr ? d.k_d : d.k_f;
+  const int csp = tr ? d.cs_d : d.cs_f;
+  const long row = j / kp; const int k = (int)(j % kp);
+  const int tap = k / csp, c = k % csp;
+  const int rows = tr ? d.Ci : d.Co, cs = tr ? d.Co : d.Ci;
+  float v = 0.f;
+  if (row < rows && c < cs && tap < d.R * d.S) {
+    int r = tap / d.S, s = tap % d.S;
+    int co = tr ? c : (int)row, ci = tr ? (int)row : c;
+    v = d.w[(((long)co * d.Ci + ci) * d.R + r) * d.S + s];
+  }
+  T* dst = reinterpret_cast<T*>(tr ? d.dst_d : d.dst_f);
+  dst[j] = ElemTraits<T>::from_f(v);
+}
+
 }  // namespace
+
+extern "C" int fs_pack_weights_multi(const FsPackDesc* descs_dev, int n, int64_t total_blocks, int dtype, void* stream) {
+  if (!descs_dev || n <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffffLL) return FS_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == FS_DTYPE_BF16)
+    hipLaunchKernelGGL(pack_weights_multi_kernel<bf16>, dim3((unsigned)total_blocks), dim3(256), 0, st, descs_dev, n);
+  else if (dtype == FS_DTYPE_F32)
+    hipLaunchKernelGGL(pack_weights_multi_kernel<float>, dim3((unsigned)total_blocks), dim3(256), 0, st, descs_dev, n);
+  else return FS_EINVAL;
+  return fs_launch_status();
+}
 
 extern "C" int fs_pack_weights(const float* w_oihw, void* dst, int Co, int Ci, int R, int S, int rows_p,
                                int cs_p, int64_t ktot_p, int transpose, int dtype, void* stream) {

@@ -37,6 +37,48 @@ class StatsPool:
         return v
 
 
+_PACK_REGISTRY = {}     # (dtype, device) -> [ConvLayer]
+_PACK_TABLES = {}       # (dtype, device, tuple of pointers) -> (device table, n, total_blocks)
+
+
+def pack_all(key):
+    """Re-pack the MFMA weight operands of every registered conv whose master weights changed, in ONE launch
+    (fs_pack_weights_multi).  The descriptor table is cached while the pointers stay the same."""
+    import ctypes as C
+    from ..hip.binding import FsPackDesc, lib, check, stream_ptr
+    from ..hip.conv import dtype_code
+    dtype, device = key
+    layers = [l for l in _PACK_REGISTRY.get(key, []) if l._version() != l._packed and l.m.weight.is_cuda]
+    if not layers:
+        return
+    sig = tuple((l.m.weight.data_ptr(), l._op.w_f.data_ptr()) for l in layers)
+    ent = _PACK_TABLES.get((key, sig))
+    if ent is None:
+        arr = (FsPackDesc * len(layers))()
+        blocks = 0
+        for d, l in zip(arr, layers):
+            op, w = l._op, l.m.weight
+            assert w.dtype == torch.float32 and w.data.is_contiguous()
+            d.w, d.dst_f = w.data_ptr(), op.w_f.data_ptr()
+            d.Co, d.Ci, d.R, d.S = op.Co, op.Ci, op.R, op.S
+            d.rows_f, d.cs_f, d.k_f = op.Co_p, op.Ci_p, op.kf_p
+            if op.need_dgrad:
+                d.dst_d, d.rows_d, d.cs_d, d.k_d = op.w_d.data_ptr(), op.rows_d, op.Co_p, op.kd_p
+            else:
+                d.dst_d, d.rows_d, d.cs_d, d.k_d = None, 0, 1, 1
+            d.block_start = blocks
+            blocks += (d.rows_f * d.k_f + d.rows_d * d.k_d + 255) // 256
+        raw = bytes(arr)
+        tab = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        if len(_PACK_TABLES) > 64:
+            _PACK_TABLES.clear()
+        ent = _PACK_TABLES[(key, sig)] = (tab, len(layers), blocks)
+    tab, n, blocks = ent
+    check(lib.fs_pack_weights_multi(tab.data_ptr(), n, blocks, dtype_code(dtype), stream_ptr()), "pack_weights_multi")
+    for l in layers:
+        l._after_pack(device)
+
+
 class ConvLayer:
     """Binds an nn.Conv2d parameter container to its device plan (ConvOp)."""
 
@@ -63,19 +105,25 @@ class ConvLayer:
             self._op = ConvOp(w.shape[1], w.shape[0], self.R, self.S, self.stride, self.pad, dtype, device,
                               need_dgrad=self.need_dgrad)
             self._key, self._packed = key, None
-        w = self.m.weight
-        ver = (w._version, RT.weights_epoch, w.data_ptr())
-        if ver != self._packed:
-            self._op.pack(w.data if w.data.is_contiguous() else w.data.contiguous())
-            b = self.m.bias
-            if b is not None:
-                if self._op.Co_p == b.numel():
-                    self._bias = b.data
-                else:
-                    self._bias = torch.zeros(self._op.Co_p, dtype=torch.float32, device=device)
-                    self._bias[: b.numel()].copy_(b.data)
-            self._packed = ver
+            _PACK_REGISTRY.setdefault(key, []).append(self)
+        if self._version() != self._packed:
+            pack_all(key)          # one launch for every stale conv of the model
         return self._op
+
+    def _version(self):
+        w = self.m.weight
+        return (w._version, RT.weights_epoch, w.data_ptr())
+
+    def _after_pack(self, device):
+        b = self.m.bias
+        if b is not None:
+            if self._op.Co_p == b.numel():
+                self._bias = b.data
+            else:
+                if self._bias is None or self._bias.numel() != self._op.Co_p or self._bias.data_ptr() == b.data_ptr():
+                    self._bias = torch.zeros(self._op.Co_p, dtype=torch.float32, device=device)
+                self._bias[: b.numel()].copy_(b.data)
+        self._packed = self._version()
 
     @property
     def bias(self):

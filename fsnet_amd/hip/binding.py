@@ -43,6 +43,15 @@ class FsWgradArgs(C.Structure):
     ]
 
 
+class FsPackDesc(C.Structure):
+    _fields_ = [
+        ("w", C.c_void_p), ("dst_f", C.c_void_p), ("dst_d", C.c_void_p),
+        ("k_f", C.c_int64), ("k_d", C.c_int64), ("block_start", C.c_int64),
+        ("Co", C.c_int32), ("Ci", C.c_int32), ("R", C.c_int32), ("S", C.c_int32),
+        ("rows_f", C.c_int32), ("cs_f", C.c_int32), ("rows_d", C.c_int32), ("cs_d", C.c_int32),
+    ]
+
+
 class FsBnApplyArgs(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("res", C.c_void_p), ("y", C.c_void_p),

@@ -120,6 +120,21 @@ int fs_conv_wgrad(const FsWgradArgs* args, int dtype, void* stream);
 int fs_pack_weights(const float* w_oihw, void* dst, int Co, int Ci, int R, int S, int rows_p,
                     int cs_p, int64_t ktot_p, int transpose, int dtype, void* stream);
 
+/* The same for every convolution of a model in ONE launch.  descs lives in device memory; block_start is the
+ * exclusive prefix sum of ceil((rows_f*k_f + rows_d*k_d) / 256); dst_d may be NULL with rows_d = 0.
+ */
+typedef struct FsPackDesc {
+  const float* w;
+  void* dst_f;
+  void* dst_d;
+  int64_t k_f, k_d;       /* padded K of the forward / dgrad operand */
+  int64_t block_start;
+  int32_t Co, Ci, R, S;
+  int32_t rows_f, cs_f;   /* forward operand: padded rows (co), padded channels per tap (ci) */
+  int32_t rows_d, cs_d;   /* dgrad operand:  padded rows (ci), padded channels per tap (co) */
+} FsPackDesc;
+int fs_pack_weights_multi(const FsPackDesc* descs_dev, int n, int64_t total_blocks, int dtype, void* stream);
+
 /* Batch images NCHW fp32 (one tensor, or two concatenated along C as the pose encoder input,
  * monodepth2_model.py:29-35) -> NHWC with Cp >= Ca+Cb zero-padded channels.
  */
