@@ -445,7 +445,8 @@ int launch_wgrad_halo(const FsWgradArgs& a, hipStream_t st) {
   const int npix = g.N * g.tiles_x * g.tiles_y;
   b.ws_rows = a.Cd; b.ws_cols = 9 * Cs;
   const long slab = (long)b.ws_rows * b.ws_cols;
-  long splits = std::max<long>(1, std::min<long>(npix, (512 + out_tiles - 1) / out_tiles));
+  // ~256-320 blocks: every extra split adds a Cd x 9Cs fp32 slab to write and re-read
+  long splits = std::max<long>(1, std::min<long>(npix / 2 > 0 ? npix / 2 : 1, (288 + out_tiles - 1) / out_tiles));
   if (!a.workspace) splits = 1;
   else splits = std::min<long>(splits, std::max<long>(1, a.workspace_elems / slab));
   g.nsplit = (int)splits; b.nsplit = g.nsplit;

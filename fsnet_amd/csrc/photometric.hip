@@ -211,41 +211,90 @@ __device__ __forceinline__ float tie_noise(int seed, uint32_t key) {
   return 1e-5f * sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2);
 }
 
+constexpr int TW = 32, TH = 8;
+constexpr int R2W = TW + 4, R2H = TH + 4;   // pred / target region of the backward
+constexpr int R1W = TW + 2, R1H = TH + 2;   // coefficient region (= stencil region of the forward)
+
+// SSIM + L1 of one pixel from LDS planes [3][R1H][R1W]; (ly, lx) = position inside the region
+__device__ __forceinline__ float reproj_lds(const float (*xs)[R1H][R1W], const float (*ts)[R1H][R1W], int ly, int lx) {
+  float ssim_sum = 0.f, l1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+#pragma unroll
+    for (int a = -1; a <= 1; ++a)
+#pragma unroll
+      for (int bb = -1; bb <= 1; ++bb) {
+        float xv = xs[c][ly + a][lx + bb], tv = ts[c][ly + a][lx + bb];
+        sx += xv; sy += tv; sxx += xv * xv; syy += tv * tv; sxy += xv * tv;
+      }
+    const float k = 1.f / 9.f;
+    float mux = sx * k, muy = sy * k;
+    float sgx = sxx * k - mux * mux, sgy = syy * k - muy * muy, sgxy = sxy * k - mux * muy;
+    float n = (2.f * mux * muy + C1) * (2.f * sgxy + C2);
+    float d = (mux * mux + muy * muy + C1) * (sgx + sgy + C2);
+    ssim_sum += fminf(fmaxf((1.f - n / d) * 0.5f, 0.f), 1.f);
+    l1 += fabsf(ts[c][ly][lx] - xs[c][ly][lx]);
+  }
+  return 0.85f * (ssim_sum / 3.f) + 0.15f * (l1 / 3.f);
+}
+
+// LDS-tiled: a block owns 32x8 pixels of one (scale, batch) plane; target and both warped images of the
+// tile (+1 halo, reflection resolved while loading) are staged once and every SSIM window reads LDS.
 __global__ __launch_bounds__(256) void photo_loss_fwd_kernel(const FsPhotoArgs p) {
-  const int b = blockIdx.y, s = blockIdx.z;
-  const long HW = (long)p.H * p.W;
-  const float* t = p.img0 + (long)b * 3 * HW;
+  __shared__ float s_t[3][R1H][R1W];
+  __shared__ float s_x[2][3][R1H][R1W];
+  __shared__ double sh[4];
+  const int s = blockIdx.z / p.B, b = blockIdx.z % p.B;
+  const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+  const int H = p.H, W = p.W, tid = threadIdx.x;
+  const long HW = (long)H * W;
+  const float* timg = p.img0 + (long)b * 3 * HW;
+  const float* pr0 = p.pred + (((long)s * 2 + 0) * p.B + b) * 3 * HW;
+  const float* pr1 = p.pred + (((long)s * 2 + 1) * p.B + b) * 3 * HW;
+  for (int i = tid; i < R1H * R1W; i += 256) {
+    int ry = i / R1W, rx = i - ry * R1W;
+    int y = min(max(refl(ty0 - 1 + ry, H), 0), H - 1), x = min(max(refl(tx0 - 1 + rx, W), 0), W - 1);
+    long o = (long)y * W + x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      s_t[c][ry][rx] = timg[c * HW + o];
+      s_x[0][c][ry][rx] = pr0[c * HW + o];
+      s_x[1][c][ry][rx] = pr1[c * HW + o];
+    }
+  }
+  __syncthreads();
+  const int lx = tid % TW, ly = tid / TW;
+  const int qx = tx0 + lx, qy = ty0 + ly;
   double acc = 0.0;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
-    int y = (int)(i / p.W), x = (int)(i % p.W);
+  if (qx < W && qy < H) {
+    const long i = (long)qy * W + qx;
     float best = 0.f; int bi = 0;
+#pragma unroll
     for (int f = 0; f < 2; ++f) {
       uint32_t key = (uint32_t)((((long)s * 2 + f) * p.B + b) * HW + i);
       float v = p.ident[((long)b * 2 + f) * HW + i] + tie_noise(p.noise_seed, key);
       if (f == 0 || v < best) { best = v; bi = f; }
     }
+#pragma unroll
     for (int f = 0; f < 2; ++f) {
       long o = (((long)s * 2 + f) * p.B + b);
       float v = 100.f;
-      if (p.ov[o * HW + i]) v = reproj_at(p.pred + o * 3 * HW, t, y, x, p.H, p.W);
+      if (p.ov[o * HW + i]) v = reproj_lds(s_x[f], s_t, ly + 1, lx + 1);
       if (v < best) { best = v; bi = 2 + f; }
     }
     p.sel[((long)s * p.B + b) * HW + i] = (uint8_t)bi;
     double pm = p.patched_mask ? p.patched_mask[(long)b * HW + i] : 1.0;
-    acc += (double)best * pm;
+    acc = (double)best * pm;
   }
-  __shared__ double sh[4];
   acc = block_sum_d(acc, sh);
-  if (threadIdx.x == 0) atomicAdd(p.loss_sums + s * p.B + b, acc);
+  if (tid == 0) atomicAdd(p.loss_sums + s * p.B + b, acc);
 }
 
 // ---------------------------------------------------------------------------------------------
-// loss backward, LDS tiled: tile 32x8 pixels q; coefficients of p in tile(+)1 from pred/target in tile(+)2
+// loss backward, LDS tiled: tile 32x8 pixels q; coefficients of p in tile(+)1 from pred/target in tile(+)2.
+// 512 threads: the two source frames run concurrently (threads 0-255 frame 0, 256-511 frame 1).
 // ---------------------------------------------------------------------------------------------
-constexpr int TW = 32, TH = 8;
-constexpr int R2W = TW + 4, R2H = TH + 4;   // pred / target region
-constexpr int R1W = TW + 2, R1H = TH + 2;   // coefficient region
-
 __device__ __forceinline__ int refl_mult(int pc, int qc, int n) {
   // how many taps delta in {-1,0,1} of window centre pc land (after reflection) on pixel qc
   int m = 0;
@@ -254,16 +303,18 @@ __device__ __forceinline__ int refl_mult(int pc, int qc, int n) {
   return m;
 }
 
-__global__ __launch_bounds__(256) void photo_loss_bwd_kernel(const FsPhotoArgs p) {
+__global__ __launch_bounds__(512) void photo_loss_bwd_kernel(const FsPhotoArgs p) {
   __shared__ float s_t[3][R2H][R2W];
-  __shared__ float s_x[3][R2H][R2W];
-  __shared__ float s_coef[9][R1H][R1W];   // [c*3 + {A,B,C}]
-  __shared__ float s_red[12][4];
+  __shared__ float s_x[2][3][R2H][R2W];
+  __shared__ float s_coef[2][9][R1H][R1W];   // [frame][c*3 + {A,B,C}]
+  __shared__ float s_red[2][12][4];
+  __shared__ float s_dD[TH * TW];
+  __shared__ float s_dd[(TH + 2) * (TW + 2)];
   const int s = blockIdx.z / p.B, b = blockIdx.z % p.B;
   const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
   const int H = p.H, W = p.W;
   const long HW = (long)H * W;
-  const int tid = threadIdx.x;
+  const int f = threadIdx.x >> 8, tid = threadIdx.x & 255;
   const float* timg = p.img0 + (long)b * 3 * HW;
   const uint8_t* sel = p.sel + ((long)s * p.B + b) * HW;
   const float* ge = p.geo + (long)b * GEO_STRIDE;
@@ -271,89 +322,117 @@ __global__ __launch_bounds__(256) void photo_loss_bwd_kernel(const FsPhotoArgs p
   double msum = 0.0;
   for (int k = 0; k < p.B; ++k) msum += p.mask_sum[k];
   const float gscale = (float)(gout / ((double)p.S * (msum + 1e-6)));
+  const float* pred = p.pred + (((long)s * 2 + f) * p.B + b) * 3 * HW;
+  // tiles whose 2-pixel halo lies inside the image need no reflection bookkeeping (the common case)
+  const bool interior = ty0 >= 2 && tx0 >= 2 && ty0 + TH + 2 <= H && tx0 + TW + 2 <= W;
 
-  for (int i = tid; i < 3 * R2H * R2W; i += 256) {
-    int c = i / (R2H * R2W), rem = i % (R2H * R2W), ry = rem / R2W, rx = rem % R2W;
+  for (int i = tid; i < R2H * R2W; i += 256) {
+    int ry = i / R2W, rx = i - ry * R2W;
     int y = ty0 - 2 + ry, x = tx0 - 2 + rx;
-    float v = 0.f;
-    if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) v = timg[c * HW + (long)y * W + x];
-    s_t[c][ry][rx] = v;
-  }
-
-  const int qx = tx0 + (tid % TW), qy = ty0 + (tid / TW);
-  const bool qin = qx < W && qy < H;
-  float dD_total = 0.f;
-  Geo gq; gq.y0 = gq.x0 = gq.y1 = gq.x1 = 0; gq.ly = gq.lx = 0.f;
-
-  for (int f = 0; f < 2; ++f) {
-    const long o = ((long)s * 2 + f) * p.B + b;
-    const float* pred = p.pred + o * 3 * HW;
-    __syncthreads();  // previous iteration done with s_x / s_coef
-    for (int i = tid; i < 3 * R2H * R2W; i += 256) {
-      int c = i / (R2H * R2W), rem = i % (R2H * R2W), ry = rem / R2W, rx = rem % R2W;
-      int y = ty0 - 2 + ry, x = tx0 - 2 + rx;
-      float v = 0.f;
-      if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) v = pred[c * HW + (long)y * W + x];
-      s_x[c][ry][rx] = v;
+    bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+    long o = (long)y * W + x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if (f == 0) s_t[c][ry][rx] = in ? timg[c * HW + o] : 0.f;
+      s_x[f][c][ry][rx] = in ? pred[c * HW + o] : 0.f;
     }
-    __syncthreads();
-    // ---- coefficients at p in tile(+)1 ----
-    for (int i = tid; i < R1H * R1W; i += 256) {
-      int ry = i / R1W, rx = i % R1W;
-      int y = ty0 - 1 + ry, x = tx0 - 1 + rx;
-      float wgt = 0.f;
-      bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-      if (in && sel[(long)y * W + x] == 2 + f) {
-        float pm = p.patched_mask ? (float)p.patched_mask[(long)b * HW + (long)y * W + x] : 1.f;
-        wgt = pm * gscale * (0.85f / 3.f);
-      }
-      if (wgt == 0.f) {
+  }
+  for (int i = threadIdx.x; i < (TH + 2) * (TW + 2); i += 512) s_dd[i] = 0.f;
+  __syncthreads();
+
+  // ---- coefficients at p in tile(+)1 ----
+  for (int i = tid; i < R1H * R1W; i += 256) {
+    int ry = i / R1W, rx = i - ry * R1W;
+    int y = ty0 - 1 + ry, x = tx0 - 1 + rx;
+    float wgt = 0.f;
+    bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+    if (in && sel[(long)y * W + x] == 2 + f) {
+      float pm = p.patched_mask ? (float)p.patched_mask[(long)b * HW + (long)y * W + x] : 1.f;
+      wgt = pm * gscale * (0.85f / 3.f);
+    }
+    if (wgt == 0.f) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) s_coef[k][ry][rx] = 0.f;
-        continue;
-      }
-      int ys[3] = {refl(y - 1, H) - (ty0 - 2), y - (ty0 - 2), refl(y + 1, H) - (ty0 - 2)};
-      int xs[3] = {refl(x - 1, W) - (tx0 - 2), x - (tx0 - 2), refl(x + 1, W) - (tx0 - 2)};
+      for (int k = 0; k < 9; ++k) s_coef[f][k][ry][rx] = 0.f;
+      continue;
+    }
+    int ys[3] = {ry, ry + 1, ry + 2}, xs[3] = {rx, rx + 1, rx + 2};   // interior: window = R2 rows ry..ry+2
+    if (!interior) {
+      ys[0] = refl(y - 1, H) - (ty0 - 2); ys[2] = refl(y + 1, H) - (ty0 - 2);
+      xs[0] = refl(x - 1, W) - (tx0 - 2); xs[2] = refl(x + 1, W) - (tx0 - 2);
+    }
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+    for (int c = 0; c < 3; ++c) {
+      float sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+      if (interior) {
+        const float* xb = &s_x[f][c][ry][rx];
+        const float* tb = &s_t[c][ry][rx];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
           for (int bb = 0; bb < 3; ++bb) {
-            float xv = s_x[c][ys[a]][xs[bb]], tv = s_t[c][ys[a]][xs[bb]];
+            float xv = xb[a * R2W + bb], tv = tb[a * R2W + bb];
             sx += xv; sy += tv; sxx += xv * xv; syy += tv * tv; sxy += xv * tv;
           }
-        const float k9 = 1.f / 9.f;
-        float mux = sx * k9, muy = sy * k9;
-        float sgx = sxx * k9 - mux * mux, sgy = syy * k9 - muy * muy, sgxy = sxy * k9 - mux * muy;
-        float n1 = 2.f * mux * muy + C1, n2 = 2.f * sgxy + C2;
-        float d1 = mux * mux + muy * muy + C1, d2 = sgx + sgy + C2;
-        float n = n1 * n2, d = d1 * d2;
-        float sv = (1.f - n / d) * 0.5f;
-        float A = 0.f, Bc = 0.f, Cc = 0.f;
-        if (sv >= 0.f && sv <= 1.f) {
-          // d n / d x(q) = a1 + a2 (t(q) - muy),  d d / d x(q) = b1 + b2 (x(q) - mux)   (each tap weight 1/9)
-          float a1 = 2.f * muy * n2 * k9, a2 = 2.f * n1 * k9;
-          float b1 = 2.f * mux * d2 * k9, b2 = 2.f * d1 * k9;
-          float h = -0.5f / (d * d);
-          A = h * ((a1 - a2 * muy) * d - n * (b1 - b2 * mux));
-          Bc = -h * n * b2;
-          Cc = h * a2 * d;
-        }
-        s_coef[c * 3 + 0][ry][rx] = wgt * A;
-        s_coef[c * 3 + 1][ry][rx] = wgt * Bc;
-        s_coef[c * 3 + 2][ry][rx] = wgt * Cc;
-      }
-    }
-    __syncthreads();
-    // ---- gather d loss / d pred(q), chain through the sampler and the projection ----
-    float dP[12];
+      } else {
 #pragma unroll
-    for (int k = 0; k < 12; ++k) dP[k] = 0.f;
-    if (qin) {
-      const int ly = tid / TW + 2, lx = tid % TW + 2;  // q inside the R2 arrays
-      float dpred[3] = {0.f, 0.f, 0.f};
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 3; ++bb) {
+            float xv = s_x[f][c][ys[a]][xs[bb]], tv = s_t[c][ys[a]][xs[bb]];
+            sx += xv; sy += tv; sxx += xv * xv; syy += tv * tv; sxy += xv * tv;
+          }
+      }
+      const float k9 = 1.f / 9.f;
+      float mux = sx * k9, muy = sy * k9;
+      float sgx = sxx * k9 - mux * mux, sgy = syy * k9 - muy * muy, sgxy = sxy * k9 - mux * muy;
+      float n1 = 2.f * mux * muy + C1, n2 = 2.f * sgxy + C2;
+      float d1 = mux * mux + muy * muy + C1, d2 = sgx + sgy + C2;
+      float n = n1 * n2, d = d1 * d2;
+      float sv = (1.f - n / d) * 0.5f;
+      float A = 0.f, Bc = 0.f, Cc = 0.f;
+      if (sv >= 0.f && sv <= 1.f) {
+        // d n / d x(q) = a1 + a2 (t(q) - muy),  d d / d x(q) = b1 + b2 (x(q) - mux)   (each tap weight 1/9)
+        float a1 = 2.f * muy * n2 * k9, a2 = 2.f * n1 * k9;
+        float b1 = 2.f * mux * d2 * k9, b2 = 2.f * d1 * k9;
+        float h = -0.5f / (d * d);
+        A = h * ((a1 - a2 * muy) * d - n * (b1 - b2 * mux));
+        Bc = -h * n * b2;
+        Cc = h * a2 * d;
+      }
+      s_coef[f][c * 3 + 0][ry][rx] = wgt * A;
+      s_coef[f][c * 3 + 1][ry][rx] = wgt * Bc;
+      s_coef[f][c * 3 + 2][ry][rx] = wgt * Cc;
+    }
+  }
+  __syncthreads();
+
+  // ---- gather d loss / d pred(q), chain through the sampler and the projection ----
+  const int qx = tx0 + (tid % TW), qy = ty0 + (tid / TW);
+  const bool qin = qx < W && qy < H;
+  float dD = 0.f;
+  float dP[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) dP[k] = 0.f;
+  if (qin) {
+    const int ly = tid / TW + 2, lx = tid % TW + 2;  // q inside the R2 arrays
+    float dpred[3] = {0.f, 0.f, 0.f};
+    if (interior) {
+      // every window centre in [q-1, q+1]^2 contributes exactly once
+      const int cy = tid / TW, cx = tid % TW;     // coefficient-region row/col of (qy-1, qx-1)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float sa = 0.f, sb = 0.f, sc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 3; ++bb) {
+            sa += s_coef[f][c * 3][cy + a][cx + bb];
+            sb += s_coef[f][c * 3 + 1][cy + a][cx + bb];
+            sc += s_coef[f][c * 3 + 2][cy + a][cx + bb];
+          }
+        dpred[c] = sa + sb * s_x[f][c][ly][lx] + sc * s_t[c][ly][lx];
+      }
+    } else {
       for (int py = qy - 1; py <= qy + 1; ++py) {
         if ((unsigned)py >= (unsigned)H) continue;
         int my = refl_mult(py, qy, H);
@@ -366,74 +445,74 @@ __global__ __launch_bounds__(256) void photo_loss_bwd_kernel(const FsPhotoArgs p
           int ry = py - (ty0 - 1), rx = px - (tx0 - 1);
 #pragma unroll
           for (int c = 0; c < 3; ++c)
-            dpred[c] += mult * (s_coef[c * 3][ry][rx] + s_coef[c * 3 + 1][ry][rx] * s_x[c][ly][lx] +
-                                s_coef[c * 3 + 2][ry][rx] * s_t[c][ly][lx]);
-        }
-      }
-      if (sel[(long)qy * W + qx] == 2 + f) {
-        float pm = p.patched_mask ? (float)p.patched_mask[(long)b * HW + (long)qy * W + qx] : 1.f;
-        float wl1 = pm * gscale * (0.15f / 3.f);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          float df = s_x[c][ly][lx] - s_t[c][ly][lx];
-          dpred[c] += wl1 * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
-        }
-      }
-      if (dpred[0] != 0.f || dpred[1] != 0.f || dpred[2] != 0.f) {
-        project_pixel(p.depth[s], b, qy, qx, H, W, p.dh[s], p.dw[s], ge, f, gq);
-        Taps t;
-        bilinear_taps(gq.ixu, gq.iyu, H, W, t);
-        const float* src = p.img_src[f] + (long)b * 3 * HW;
-        float gix = 0.f, giy = 0.f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float* sc = src + c * HW;
-          float v00 = sc[(long)t.y0 * W + t.x0], v01 = sc[(long)t.y0 * W + t.x1];
-          float v10 = sc[(long)t.y1 * W + t.x0], v11 = sc[(long)t.y1 * W + t.x1];
-          gix += dpred[c] * ((v01 - v00) * (1.f - t.wy) + (v11 - v10) * t.wy);
-          giy += dpred[c] * ((v10 - v00) * (1.f - t.wx) + (v11 - v01) * t.wx);
-        }
-        float du = gix * t.mx, dv = giy * t.my;   // (W-1)/2 of the sampler cancels 2/(W-1) of Project3D
-        float iz = 1.f / gq.Zp;
-        float dX = du * iz, dY = dv * iz;
-        float dZ = -(du * gq.X + dv * gq.Y) * iz * iz;
-        const float* P = ge + 18 + f * 12;
-        float pr0 = P[0] * gq.r[0] + P[1] * gq.r[1] + P[2] * gq.r[2];
-        float pr1 = P[4] * gq.r[0] + P[5] * gq.r[1] + P[6] * gq.r[2];
-        float pr2 = P[8] * gq.r[0] + P[9] * gq.r[1] + P[10] * gq.r[2];
-        dD_total += dX * pr0 + dY * pr1 + dZ * pr2;
-        float cam[3] = {gq.D * gq.r[0], gq.D * gq.r[1], gq.D * gq.r[2]};
-        float dxyz[3] = {dX, dY, dZ};
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-#pragma unroll
-          for (int j = 0; j < 3; ++j) dP[i * 4 + j] = dxyz[i] * cam[j];
-          dP[i * 4 + 3] = dxyz[i];
+            dpred[c] += mult * (s_coef[f][c * 3][ry][rx] + s_coef[f][c * 3 + 1][ry][rx] * s_x[f][c][ly][lx] +
+                                s_coef[f][c * 3 + 2][ry][rx] * s_t[c][ly][lx]);
         }
       }
     }
-    // block-reduce the 12 projection-matrix partials -> one atomic each
+    if (sel[(long)qy * W + qx] == 2 + f) {
+      float pm = p.patched_mask ? (float)p.patched_mask[(long)b * HW + (long)qy * W + qx] : 1.f;
+      float wl1 = pm * gscale * (0.15f / 3.f);
 #pragma unroll
-    for (int k = 0; k < 12; ++k) {
-      float v = wave_sum(dP[k]);
-      if ((tid & 63) == 0) s_red[k][tid >> 6] = v;
+      for (int c = 0; c < 3; ++c) {
+        float df = s_x[f][c][ly][lx] - s_t[c][ly][lx];
+        dpred[c] += wl1 * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
+      }
     }
-    __syncthreads();
-    if (tid < 12) {
-      float v = s_red[tid][0] + s_red[tid][1] + s_red[tid][2] + s_red[tid][3];
-      if (v != 0.f) atomicAdd(p.dP + ((long)b * 2 + f) * 12 + tid, v);
+    if (dpred[0] != 0.f || dpred[1] != 0.f || dpred[2] != 0.f) {
+      Geo gq;
+      project_pixel(p.depth[s], b, qy, qx, H, W, p.dh[s], p.dw[s], ge, f, gq);
+      Taps t;
+      bilinear_taps(gq.ixu, gq.iyu, H, W, t);
+      const float* src = p.img_src[f] + (long)b * 3 * HW;
+      float gix = 0.f, giy = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float* sc = src + c * HW;
+        float v00 = sc[(long)t.y0 * W + t.x0], v01 = sc[(long)t.y0 * W + t.x1];
+        float v10 = sc[(long)t.y1 * W + t.x0], v11 = sc[(long)t.y1 * W + t.x1];
+        gix += dpred[c] * ((v01 - v00) * (1.f - t.wy) + (v11 - v10) * t.wy);
+        giy += dpred[c] * ((v10 - v00) * (1.f - t.wx) + (v11 - v01) * t.wx);
+      }
+      float du = gix * t.mx, dv = giy * t.my;   // (W-1)/2 of the sampler cancels 2/(W-1) of Project3D
+      float iz = 1.f / gq.Zp;
+      float dX = du * iz, dY = dv * iz;
+      float dZ = -(du * gq.X + dv * gq.Y) * iz * iz;
+      const float* P = ge + 18 + f * 12;
+      float pr0 = P[0] * gq.r[0] + P[1] * gq.r[1] + P[2] * gq.r[2];
+      float pr1 = P[4] * gq.r[0] + P[5] * gq.r[1] + P[6] * gq.r[2];
+      float pr2 = P[8] * gq.r[0] + P[9] * gq.r[1] + P[10] * gq.r[2];
+      dD = dX * pr0 + dY * pr1 + dZ * pr2;
+      float cam[3] = {gq.D * gq.r[0], gq.D * gq.r[1], gq.D * gq.r[2]};
+      float dxyz[3] = {dX, dY, dZ};
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dP[i * 4 + j] = dxyz[i] * cam[j];
+        dP[i * 4 + 3] = dxyz[i];
+      }
     }
+  }
+  // reduce the 12 projection-matrix partials per frame -> one atomic each
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    float v = wave_sum(dP[k]);
+    if ((tid & 63) == 0) s_red[f][k][tid >> 6] = v;
+  }
+  if (f == 1) s_dD[tid] = dD;
+  __syncthreads();
+  if (tid < 12) {
+    float v = s_red[f][tid][0] + s_red[f][tid][1] + s_red[f][tid][2] + s_red[f][tid][3];
+    if (v != 0.f) atomicAdd(p.dP + ((long)b * 2 + f) * 12 + tid, v);
   }
   // ---- transpose of the bilinear depth upsample: accumulate the tile's contributions in LDS first, then
   //      one global atomic per touched low-res pixel (scale-3 maps receive 256 full-res pixels each) ----
-  {
-    __shared__ float s_dd[(TH + 2) * (TW + 2)];
-    const int h = p.dh[s], w = p.dw[s];
-    Geo g0;
-    upsample_taps(ty0, tx0, H, W, h, w, g0);
-    const int by = g0.y0, bx = g0.x0;
-    for (int i = tid; i < (TH + 2) * (TW + 2); i += 256) s_dd[i] = 0.f;
-    __syncthreads();
+  const int h = p.dh[s], w = p.dw[s];
+  Geo g0;
+  upsample_taps(ty0, tx0, H, W, h, w, g0);
+  const int by = g0.y0, bx = g0.x0;
+  if (f == 0) {
+    float dD_total = dD + s_dD[tid];
     if (qin && dD_total != 0.f) {
       Geo g;
       upsample_taps(qy, qx, H, W, h, w, g);
@@ -444,14 +523,14 @@ __global__ __launch_bounds__(256) void photo_loss_bwd_kernel(const FsPhotoArgs p
       if (w10 != 0.f) atomicAdd(&s_dd[ly1 * (TW + 2) + lx0], w10 * dD_total);
       if (w11 != 0.f) atomicAdd(&s_dd[ly1 * (TW + 2) + lx1], w11 * dD_total);
     }
-    __syncthreads();
-    float* dd = p.d_depth[s] + (long)b * h * w;
-    for (int i = tid; i < (TH + 2) * (TW + 2); i += 256) {
-      float v = s_dd[i];
-      if (v != 0.f) {
-        int yy = by + i / (TW + 2), xx = bx + i % (TW + 2);
-        if (yy < h && xx < w) atomicAdd(dd + yy * w + xx, v);
-      }
+  }
+  __syncthreads();
+  float* dd = p.d_depth[s] + (long)b * h * w;
+  for (int i = threadIdx.x; i < (TH + 2) * (TW + 2); i += 512) {
+    float v = s_dd[i];
+    if (v != 0.f) {
+      int yy = by + i / (TW + 2), xx = bx + i % (TW + 2);
+      if (yy < h && xx < w) atomicAdd(dd + yy * w + xx, v);
     }
   }
 }
@@ -508,7 +587,7 @@ extern "C" int fs_photo_loss_fwd(const FsPhotoArgs* a, void* stream) {
   if (!valid(a) || !a->pred || !a->ov || !a->ident || !a->sel || !a->loss_sums) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   long HW = (long)a->H * a->W;
-  dim3 grid((unsigned)std::min<long>((HW + 255) / 256, 64), a->B, a->S);
+  dim3 grid((a->W + TW - 1) / TW, (a->H + TH - 1) / TH, a->S * a->B);
   hipLaunchKernelGGL(photo_loss_fwd_kernel, grid, dim3(256), 0, st, *a);
   return fs_launch_status();
 }
@@ -518,7 +597,7 @@ extern "C" int fs_photo_loss_bwd(const FsPhotoArgs* a, void* stream) {
   for (int s = 0; s < a->S; ++s) if (!a->depth[s] || !a->d_depth[s]) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((a->W + TW - 1) / TW, (a->H + TH - 1) / TH, a->S * a->B);
-  hipLaunchKernelGGL(photo_loss_bwd_kernel, grid, dim3(256), 0, st, *a);
+  hipLaunchKernelGGL(photo_loss_bwd_kernel, grid, dim3(512), 0, st, *a);
   return fs_launch_status();
 }
 
