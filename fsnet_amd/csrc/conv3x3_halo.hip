@@ -41,7 +41,9 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
   constexpr int LW = (9 * CO * 4 + 255) / 256;       // weight 16-byte units per thread
   constexpr int OOB = 0x7fffffff;
 
-  __shared__ uint4 lds_h[HMAX * 4];
+  // halo rows padded to 80 bytes (5 x 16 B): 16 consecutive rows at ANY shift hit 16 distinct 16-byte slots
+  // (5 is odd), and the tap shift becomes an immediate LDS offset (no per-tap swizzle arithmetic)
+  __shared__ uint4 lds_h[HMAX * 5];
   __shared__ uint4 lds_w[9 * CO * 4];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
     for (int i = 0; i < LH; ++i) {
       int idx = t + i * 256;
       int hp = idx >> 2, q = idx & 3;
-      if (hp < HMAX) lds_h[hp * 4 + (q ^ swz64(hp))] = rh[i];
+      if (hp < HMAX) lds_h[hp * 5 + q] = rh[i];
     }
 #pragma unroll
     for (int i = 0; i < LW; ++i) {
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
     int pi = wp * WPIX + b * 16 + li;
     if (pi >= ntile) pi = 0;                       // padding lanes read a valid halo row; results are discarded
     int ty = pi / g.TW, tx = pi - ty * g.TW;
-    hbase[b] = ty * HW + tx;
+    hbase[b] = (ty * HW + tx) * 5 + lg;
   }
 
   f32x4 acc[TC][TP];
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int r = tap / 3, s = tap - r * 3;
-      const int hoff = fwd ? (r * HW + s) : ((2 - r) * HW + (2 - s));
+      const int hoff = (fwd ? (r * HW + s) : ((2 - r) * HW + (2 - s))) * 5;
       uint4 fa[TC], fb[TP];
 #pragma unroll
       for (int a = 0; a < TC; ++a) {
@@ -153,8 +155,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
       }
 #pragma unroll
       for (int b = 0; b < TP; ++b) {
-        int row = hbase[b] + hoff;
-        fb[b] = lds_h[row * 4 + (lg ^ swz64(row))];
+        fb[b] = lds_h[hbase[b] + hoff];
       }
 #pragma unroll
       for (int a = 0; a < TC; ++a)
