@@ -36,6 +36,19 @@ def synthetic_device_batches(B, H, W, dev, rank, n=4):
     return out
 
 
+def pmc_traffic(kind):
+    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
+    separate runs of this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  The passes are
+    collected offline with tools/pmc_traffic.sh and committed as profiles/pmc_traffic.json; None if absent."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path)).get(kind, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def cpu_baseline(max_seconds=25.0):
     """Oracle (CPU restatement of the reference path, parity-pinned to the reference) on this box's host
     cores: BASELINE config[0] (B=2, 192x640, depth+pose, fp32), full step incl. clip + Adam."""
@@ -134,20 +147,28 @@ def main():
         for kind, work, dt in rec:
             a = agg.setdefault(kind, [0, 0.0, 0.0])
             a[0] += 1; a[1] += work; a[2] += dt
-        cg = agg["conv_igemm"]
-        ach = cg[1] / cg[2] / 1e12
-        roofline = {"kernel": "conv_igemm_kernel (fwd+dgrad, %d launches/step)" % (cg[0] // nprof), "bound": "mfma",
-                    "achieved": round(ach, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
-                    "avg_launch_us": round(cg[2] / cg[0] * 1e6, 2)}
-        wg = agg["conv_wgrad"]
-        extra["conv_wgrad"] = {"achieved_tflops": round(wg[1] / wg[2] / 1e12, 2), "launches_per_step": wg[0] // nprof,
+        def tf(a):
+            return a[1] / a[2] / 1e12
+        ch = agg["conv3x3_halo"]            # dominant kernel family by time: 3x3/s1 fwd+dgrad (LDS halo kernel)
+        ach = tf(ch)
+        roofline = {"kernel": "conv3x3_halo_kernel (3x3/s1 fwd+dgrad, %d launches/step)" % (ch[0] // nprof),
+                    "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": pmc_traffic("conv3x3_halo"),
+                    "avg_launch_us": round(ch[2] / ch[0] * 1e6, 2),
+                    "algorithmic_flop_per_launch": round(ch[1] / ch[0])}
+        cg, wg = agg["conv_igemm"], agg["conv_wgrad"]
+        extra["conv_igemm_generic"] = {"achieved_tflops": round(tf(cg), 2), "launches_per_step": cg[0] // nprof,
+                                       "avg_launch_us": round(cg[2] / cg[0] * 1e6, 2)}
+        extra["conv_wgrad"] = {"achieved_tflops": round(tf(wg), 2), "launches_per_step": wg[0] // nprof,
                                "avg_launch_us": round(wg[2] / wg[0] * 1e6, 2)}
+        allc = [ch, cg, wg]
+        extra["conv_all"] = {"achieved_tflops": round(sum(a[1] for a in allc) / sum(a[2] for a in allc) / 1e12, 2),
+                             "frac_mfma_peak": round(sum(a[1] for a in allc) / sum(a[2] for a in allc) / 1e12 / PEAK_TFLOPS[args.dtype], 4)}
         for k in ("photo_warp", "photo_loss_fwd", "photo_loss_bwd"):
             a = agg[k]
             extra[k] = {"algorithmic_GBps": round(a[1] / a[2] / 1e9, 1), "frac_hbm_peak": round(a[1] / a[2] / 1e9 / PEAK_HBM_GBS, 4),
                         "avg_launch_us": round(a[2] / a[0] * 1e6, 2)}
-        conv_time = (cg[2] + wg[2]) / nprof
+        conv_time = (ch[2] + cg[2] + wg[2]) / nprof
         extra["conv_time_ms_per_step"] = round(conv_time * 1e3, 3)
 
     if rank == 0:

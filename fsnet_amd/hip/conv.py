@@ -199,8 +199,9 @@ class ConvOp:
         a.relu, a.out_f32 = int(relu), int(out_f32)
         a.N, a.Cs = N, self.Ci_p
         flops = 2.0 * a.M * self.Co * self.R * self.S * self.Ci
-        fn = lib.fs_conv3x3_halo if (self.halo_f and USE_HALO) else lib.fs_conv_igemm
-        _timed("conv_igemm", flops, lambda: check(fn(C.byref(a), self.code, stream_ptr()), "conv_fwd"))
+        halo = self.halo_f and USE_HALO
+        fn = lib.fs_conv3x3_halo if halo else lib.fs_conv_igemm
+        _timed("conv3x3_halo" if halo else "conv_igemm", flops, lambda: check(fn(C.byref(a), self.code, stream_ptr()), "conv_fwd"))
         return out
 
     def dgrad(self, dy, H, W, out=None, addend=None, mask=None):
@@ -229,8 +230,9 @@ class ConvOp:
         a.relu, a.out_f32 = 0, 0
         a.N, a.Cs = N, self.Co_p
         flops = 2.0 * N * Ho * Wo * self.Co * self.R * self.S * self.Ci
-        fn = lib.fs_conv3x3_halo if (self.halo_d and USE_HALO) else lib.fs_conv_igemm
-        _timed("conv_igemm", flops, lambda: check(fn(C.byref(a), self.code, stream_ptr()), "conv_dgrad"))
+        halo = self.halo_d and USE_HALO
+        fn = lib.fs_conv3x3_halo if halo else lib.fs_conv_igemm
+        _timed("conv3x3_halo" if halo else "conv_igemm", flops, lambda: check(fn(C.byref(a), self.code, stream_ptr()), "conv_dgrad"))
         return out
 
     def wgrad(self, dy, x, dw):
