@@ -41,6 +41,12 @@ _PACK_REGISTRY = {}     # (dtype, device) -> [ConvLayer]
 _PACK_TABLES = {}       # (dtype, device, tuple of pointers) -> (device table, n, total_blocks)
 
 
+def pack_everything():
+    """all registered (dtype, device) groups — called on the main stream before work is forked to a side stream"""
+    for key in list(_PACK_REGISTRY.keys()):
+        pack_all(key)
+
+
 def pack_all(key):
     """Re-pack the MFMA weight operands of every registered conv whose master weights changed, in ONE launch
     (fs_pack_weights_multi).  The descriptor table is cached while the pointers stay the same."""
@@ -153,16 +159,17 @@ _BWD_POOLS = {}
 
 def bwd_pool_reset(device):
     """one memset per network backward for all its BatchNorm backward sums"""
-    p = _BWD_POOLS.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    p = _BWD_POOLS.get(key)
     if p is None:
-        p = _BWD_POOLS[device] = StatsPool(device)
+        p = _BWD_POOLS[key] = StatsPool(device)
     p.reset()
     return p
 
 
 def _bn_bwd(dout, y, c, bn, st, H, W, relu=True, fold=False, g_out=None):
     dc = torch.empty_like(c)
-    sums = _BWD_POOLS[c.device].take(c.shape[-1])
+    sums = _BWD_POOLS[(c.device, torch.cuda.current_stream(c.device).cuda_stream)].take(c.shape[-1])
     ops.bn_backward(dout, y, c, bn.weight.data, st, dc, grad_of(bn.weight), grad_of(bn.bias), H, W, relu=relu,
                     fold=fold, g_out=g_out, sums=sums, sums_zeroed=True,
                     allreduce=(RT.dp.allreduce_small if RT.dp is not None else None))

@@ -14,6 +14,16 @@ class _Runtime:
         self.dp = None             # DataParallelContext or None
         self.noise_step = 0        # seed stream for the photometric tie-break noise
         self.tie_noise = os.environ.get("FSNET_AMD_TIE_NOISE", "1") != "0"
+        # run the pose chain on a second HIP stream next to the depth chain (they are independent until the
+        # loss): measured, ~40 % of the GPU idles in kernel boundaries / tails of the many small launches
+        self.overlap = os.environ.get("FSNET_AMD_OVERLAP", "1") != "0"
+        self._side = {}
+
+    def side_stream(self, device):
+        s = self._side.get(device)
+        if s is None:
+            s = self._side[device] = torch.cuda.Stream(device=device)
+        return s
 
     def set_compute_dtype(self, dtype):
         if isinstance(dtype, str):

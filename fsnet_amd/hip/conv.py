@@ -96,9 +96,10 @@ _WGRAD_WS = {}
 
 def wgrad_workspace(device, elems=1 << 23):
     """per-device fp32 scratch for split-K partial slabs (32 MB; stream-ordered reuse)."""
-    ws = _WGRAD_WS.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)   # one scratch per stream: no cross-stream reuse
+    ws = _WGRAD_WS.get(key)
     if ws is None or ws.numel() < elems:
-        ws = _WGRAD_WS[device] = torch.empty(elems, dtype=torch.float32, device=device)
+        ws = _WGRAD_WS[key] = torch.empty(elems, dtype=torch.float32, device=device)
     return ws
 
 

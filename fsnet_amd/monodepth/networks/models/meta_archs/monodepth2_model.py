@@ -34,6 +34,8 @@ class _HipMetaArch(BaseMetaArch):
             RT.dp = DataParallelContext(self)
         if RT.dp is not None:
             RT.dp.begin_step(self)
+        from fsnet_amd.engine.nets import pack_everything
+        pack_everything()      # re-pack stale MFMA weight operands once, on the main stream, before any fork
 
     def dummy_forward(self, image):
         features = self.depth_backbone(image)
@@ -50,11 +52,7 @@ class MonoDepthMeta(_HipMetaArch):
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
         self._post_init(kwargs)
 
-    def forward_train(self, data, meta):
-        self._begin_train()
-        image_0 = data[('image', 0)]
-        features = self.depth_backbone(image_0)
-        outputs = self.head.forward_depth(features)
+    def _pose_chain(self, data, image_0, outputs):
         for f_i in self.train_cfg.frame_ids[1:]:
             pair = (data[('image', f_i)], image_0) if f_i < 0 else (image_0, data[('image', f_i)])
             if hasattr(self.pose_backbone, "forward_pair"):
@@ -65,6 +63,29 @@ class MonoDepthMeta(_HipMetaArch):
             outputs[("axisangle", f_i)] = axisangle
             outputs[("translation", f_i)] = translation
             outputs[("cam_T_cam", f_i)] = T
+
+    def forward_train(self, data, meta):
+        self._begin_train()
+        image_0 = data[('image', 0)]
+        pose_out = {}
+        overlap = RT.overlap and image_0.is_cuda
+        if overlap:
+            # fork: pose chain (2 encoder passes + pose decoder) on the side stream, depth chain on the main one;
+            # autograd replays each chain's backward on the stream its forward ran on, so the backward overlaps too
+            main = torch.cuda.current_stream(image_0.device)
+            side = RT.side_stream(image_0.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._pose_chain(data, image_0, pose_out)
+        features = self.depth_backbone(image_0)
+        outputs = self.head.forward_depth(features)
+        if overlap:
+            main.wait_stream(side)            # join before the loss consumes cam_T_cam
+            for v in pose_out.values():
+                v.record_stream(main)
+        else:
+            self._pose_chain(data, image_0, pose_out)
+        outputs.update(pose_out)
         return self.head.loss(outputs, data)
 
     def forward_test(self, data, meta):
