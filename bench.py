@@ -139,9 +139,13 @@ def main():
     # ---- live kernel timing for the roofline object (extra steps, outside the timed region) ----
     roofline, extra = None, {}
     if not args.no_kernel_profile:
+        # per-launch HIP events need the launches to come from the host: these extra steps run the same kernels
+        # eagerly (the timed region above replays them from a hipGraph)
+        eager_hook = build(use_graph=False, **tc.training_hook)
         LaunchProfile.begin()
         nprof = 3
-        run_steps(nprof, args.warmup + args.steps)
+        for i in range(nprof):
+            eager_hook(dict(batches[i % len(batches)]), model, optimizer, global_step=args.warmup + args.steps + i)
         rec = LaunchProfile.end()
         agg = {}
         for kind, work, dt in rec:
@@ -180,7 +184,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "KITTI Eigen-Zhou-shaped synthetic triplets, ResNet-%d depth+pose, %dx%d, %s, "
                                    "batch %d/GPU, full step (fwd+loss+bwd+clip35+Adam)" % (args.depth, H, W, args.dtype, B),
-                       "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(loss, 6)},
+                       "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(loss, 6),
+                       "hipgraph_replays": hook.graph_replays},
             "roofline": roofline, "kernels": extra,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -266,6 +266,8 @@ __global__ __launch_bounds__(256) void photo_loss_fwd_kernel(const FsPhotoArgs p
   __syncthreads();
   const int lx = tid % TW, ly = tid / TW;
   const int qx = tx0 + lx, qy = ty0 + ly;
+  // device-resident seed (bumped once per step by fs_counter_incr) keeps the launch replayable from a hipGraph
+  const int seed = p.noise_seed_ptr ? (*p.noise_seed_ptr & 0x3fffffff) : p.noise_seed;
   double acc = 0.0;
   if (qx < W && qy < H) {
     const long i = (long)qy * W + qx;
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(256) void photo_loss_fwd_kernel(const FsPhotoArgs p
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
       uint32_t key = (uint32_t)((((long)s * 2 + f) * p.B + b) * HW + i);
-      float v = p.ident[((long)b * 2 + f) * HW + i] + tie_noise(p.noise_seed, key);
+      float v = p.ident[((long)b * 2 + f) * HW + i] + tie_noise(seed, key);
       if (f == 0 || v < best) { best = v; bi = f; }
     }
 #pragma unroll

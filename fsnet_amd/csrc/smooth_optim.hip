@@ -156,11 +156,20 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
 }
 
+__global__ void counter_incr_kernel(int* p) { if (threadIdx.x == 0 && blockIdx.x == 0) *p += 1; }
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n, float lr,
                                                    float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
                                                    float max_norm, const double* __restrict__ sumsq,
-                                                   float grad_scale) {
+                                                   float grad_scale, const int* __restrict__ step_ptr,
+                                                   const float* __restrict__ lr_ptr) {
+  if (step_ptr) {   // device-resident step count / learning rate: the launch can be replayed from a hipGraph
+    const float st = (float)*step_ptr;
+    bc1 = 1.f - powf(b1, st);
+    bc2_sqrt = sqrtf(1.f - powf(b2, st));
+  }
+  if (lr_ptr) lr = *lr_ptr;
   float coef = grad_scale;
   if (sumsq && max_norm > 0.f) {
     float norm = (float)sqrt(*sumsq) * grad_scale;
@@ -231,14 +240,21 @@ extern "C" int fs_sumsq(const float* g, int64_t n, double* out, void* stream) {
   return fs_launch_status();
 }
 
+extern "C" int fs_counter_incr(int* counter, void* stream) {
+  if (!counter) return FS_EINVAL;
+  hipLaunchKernelGGL(counter_incr_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), counter);
+  return fs_launch_status();
+}
+
 extern "C" int fs_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                             float beta2, float eps, float weight_decay, int step, float max_norm, const double* sumsq,
-                            float grad_scale, void* stream) {
-  if (!p || !g || !m || !v || n <= 0 || step < 1) return FS_EINVAL;
+                            float grad_scale, const int* step_ptr, const float* lr_ptr, void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || (step < 1 && !step_ptr)) return FS_EINVAL;
+  if (step < 1) step = 1;
   float bc1 = 1.f - (float)pow((double)beta1, (double)step);
   float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   long blocks = std::min<long>((n + 255) / 256, 4096);
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v,
-                     (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, max_norm, sumsq, grad_scale);
+                     (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, max_norm, sumsq, grad_scale, step_ptr, lr_ptr);
   return fs_launch_status();
 }

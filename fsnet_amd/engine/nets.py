@@ -8,6 +8,8 @@ Reference structure followed:
   DepthDecoderRunner  monodepth/networks/models/heads/depth_encoder.py:45-66,119-139
   PoseDecoderRunner   monodepth/networks/models/heads/pose_decoder.py:26-45
 """
+import weakref
+
 import torch
 
 from ..hip import ops
@@ -37,7 +39,39 @@ class StatsPool:
         return v
 
 
-_PACK_REGISTRY = {}     # (dtype, device) -> [ConvLayer]
+_PENDING_JOIN = set()   # (chain stream, companion stream) pairs with weight-gradient work in flight
+_PENDING_KEEP = []      # tensors the companion kernels still read: kept alive until the join (no record_stream
+                        # bookkeeping in the allocator, and safe inside a hipGraph capture's private pool)
+
+
+def join_companions():
+    """make every chain stream wait for its companion (end of a network's backward: gradients complete).
+    Inside a hipGraph capture the join is deferred to join_companions_final(): joining a companion into a
+    stream that is itself a fork of the capture stream and then joining that one crashes hipStreamEndCapture
+    on ROCm 7.2 (tools/probes/graph_fork_probe.py, variants C/D), joining every companion straight into the
+    capture stream does not (variant G)."""
+    if not _PENDING_JOIN:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return
+    for cur, ws in list(_PENDING_JOIN):
+        cur.wait_stream(ws)
+    _PENDING_JOIN.clear()
+    _PENDING_KEEP.clear()
+
+
+def join_companions_final():
+    """the current stream waits for every companion with work in flight (before the optimizer reads gradients)"""
+    if not _PENDING_JOIN:
+        return
+    cur = torch.cuda.current_stream()
+    for ws in {ws for _, ws in _PENDING_JOIN}:
+        cur.wait_stream(ws)
+    _PENDING_JOIN.clear()
+    _PENDING_KEEP.clear()
+
+
+_PACK_REGISTRY = {}     # (dtype, device) -> [weakref to ConvLayer]: a dropped model leaves no work behind
 _PACK_TABLES = {}       # (dtype, device, tuple of pointers) -> (device table, n, total_blocks)
 
 
@@ -54,7 +88,11 @@ def pack_all(key):
     from ..hip.binding import FsPackDesc, lib, check, stream_ptr
     from ..hip.conv import dtype_code
     dtype, device = key
-    layers = [l for l in _PACK_REGISTRY.get(key, []) if l._version() != l._packed and l.m.weight.is_cuda]
+    refs = _PACK_REGISTRY.get(key, [])
+    alive = [(r, r()) for r in refs]
+    if any(l is None for _, l in alive):
+        refs[:] = [r for r, l in alive if l is not None]
+    layers = [l for _, l in alive if l is not None and l._version() != l._packed and l.m.weight.is_cuda]
     if not layers:
         return
     sig = tuple((l.m.weight.data_ptr(), l._op.w_f.data_ptr()) for l in layers)
@@ -111,7 +149,7 @@ class ConvLayer:
             self._op = ConvOp(w.shape[1], w.shape[0], self.R, self.S, self.stride, self.pad, dtype, device,
                               need_dgrad=self.need_dgrad)
             self._key, self._packed = key, None
-            _PACK_REGISTRY.setdefault(key, []).append(self)
+            _PACK_REGISTRY.setdefault(key, []).append(weakref.ref(self))
         if self._version() != self._packed:
             pack_all(key)          # one launch for every stale conv of the model
         return self._op
@@ -136,10 +174,23 @@ class ConvLayer:
         return self._bias
 
     def accumulate_param_grads(self, op, dc, x):
-        """wgrad + bias grad into the parameters' gradient buffers."""
-        op.wgrad(dc, x, grad_of(self.m.weight))
-        if self.m.bias is not None:
-            ops.channel_sum(dc, grad_of(self.m.bias), self.m.bias.numel())
+        """wgrad + bias grad into the parameters' gradient buffers.  They feed nothing downstream in the
+        backward pass, so they run on a companion stream while the chain continues with the dgrad."""
+        gw = grad_of(self.m.weight)
+        gb = grad_of(self.m.bias) if self.m.bias is not None else None
+        if RT.overlap and RT.wgrad_streams and dc.is_cuda:
+            cur, ws = RT.companion_stream(dc.device)
+            ws.wait_stream(cur)                      # dc (and x) are complete on the chain stream
+            with torch.cuda.stream(ws):
+                op.wgrad(dc, x, gw)
+                if gb is not None:
+                    ops.channel_sum(dc, gb, self.m.bias.numel())
+            _PENDING_KEEP.append((dc, x))
+            _PENDING_JOIN.add((cur, ws))
+        else:
+            op.wgrad(dc, x, gw)
+            if gb is not None:
+                ops.channel_sum(dc, gb, self.m.bias.numel())
 
 
 def bn_tensors(bn):
@@ -315,6 +366,7 @@ class ResNetRunner:
         dc0 = _bn_bwd(d0, y0, ctx["c0"], self.m.bn1, ctx["st0"], y0.shape[1], y0.shape[2], relu=True)
         op = self.stem.ready(y0.dtype, y0.device)
         self.stem.accumulate_param_grads(op, dc0, ctx["x"])
+        join_companions()
 
 
 # ==============================================================================================
@@ -427,6 +479,7 @@ class DepthDecoderRunner:
                 op0.dgrad(dc0, h, w, out=interior, addend=interior)
             else:
                 gfeats[4] = op0.dgrad(dc0, h, w)
+        join_companions()
         return gfeats
 
 
@@ -464,4 +517,5 @@ class PoseDecoderRunner:
             self.cl[j].accumulate_param_grads(op, d, xin)
             # gradient w.r.t. the input activation, masked by the producing ReLU (none for the encoder feature)
             d = op.dgrad(d, xin.shape[1], xin.shape[2], mask=(xin if j > 0 else None))
+        join_companions()
         return d

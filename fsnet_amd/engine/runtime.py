@@ -17,6 +17,8 @@ class _Runtime:
         # run the pose chain on a second HIP stream next to the depth chain (they are independent until the
         # loss): measured, ~40 % of the GPU idles in kernel boundaries / tails of the many small launches
         self.overlap = os.environ.get("FSNET_AMD_OVERLAP", "1") != "0"
+        # weight gradients on companion streams (costs host time: events + stream switches per layer)
+        self.wgrad_streams = os.environ.get("FSNET_AMD_WGRAD_STREAMS", "0") != "0"
         self._side = {}
 
     def side_stream(self, device):
@@ -24,6 +26,15 @@ class _Runtime:
         if s is None:
             s = self._side[device] = torch.cuda.Stream(device=device)
         return s
+
+    def companion_stream(self, device):
+        """stream that runs weight-gradient kernels next to the chain stream that is current now"""
+        cur = torch.cuda.current_stream(device)
+        key = (device, cur.cuda_stream, "wgrad")
+        s = self._side.get(key)
+        if s is None:
+            s = self._side[key] = torch.cuda.Stream(device=device)
+        return cur, s
 
     def set_compute_dtype(self, dtype):
         if isinstance(dtype, str):

@@ -92,7 +92,7 @@ class FsPhotoArgs(C.Structure):
         ("d_depth", C.c_void_p * 4), ("dP", C.c_void_p), ("gout", C.c_void_p),
         ("dh", C.c_int32 * 4), ("dw", C.c_int32 * 4),
         ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("S", C.c_int32),
-        ("noise_seed", C.c_int32),
+        ("noise_seed", C.c_int32), ("noise_seed_ptr", C.c_void_p),
     ]
 
 

@@ -215,6 +215,7 @@ class PhotometricLoss:
                     for s in self.scales]
         self._pa = FsPhotoArgs()
         self._sa = FsSmoothArgs()
+        self.seed_buf = torch.zeros(1, dtype=torch.int32, device=device)   # device-resident tie-break seed
 
     def _fill(self, img0, srcs, patched_mask, depths, disps, noise_seed, gout):
         pa, sa = self._pa, self._sa
@@ -226,7 +227,9 @@ class PhotometricLoss:
         pa.loss_sums, pa.mask_sum = self.loss_sums.data_ptr(), self.mask_sum.data_ptr()
         pa.dP = self.dP.data_ptr()
         pa.gout = _p(gout)
-        pa.B, pa.H, pa.W, pa.S, pa.noise_seed = self.B, self.H, self.W, self.S, int(noise_seed)
+        pa.B, pa.H, pa.W, pa.S = self.B, self.H, self.W, self.S
+        pa.noise_seed = -1 if noise_seed is None else int(noise_seed)
+        pa.noise_seed_ptr = self.seed_buf.data_ptr() if noise_seed is None else None
         sa.disp_sum, sa.sm_sums, sa.dot = self.disp_sum.data_ptr(), self.sm_sums.data_ptr(), self.dot.data_ptr()
         sa.gout = _p(gout)
         sa.B, sa.S = self.B, self.S
@@ -249,6 +252,8 @@ class PhotometricLoss:
         self._keep = (img0, srcs, patched_mask, depths, disps, noise_seed)
         self._fill(img0, srcs, patched_mask, depths, disps, noise_seed, None)
         self.acc.zero_()
+        if noise_seed is None:
+            counter_incr(self.seed_buf)       # fresh noise every step, also when the step is a graph replay
         pa, sa = C.byref(self._pa), C.byref(self._sa)
         check(lib.fs_photo_setup(P2.data_ptr(), Ts[0].data_ptr(), Ts[1].data_ptr(), self.geo.data_ptr(), self.B, st),
               "photo_setup")
@@ -290,7 +295,13 @@ def sumsq(g, out):
     check(lib.fs_sumsq(g.data_ptr(), g.numel(), out.data_ptr(), stream_ptr()), "sumsq")
 
 
-def adam_step(p, g, m, v, lr, b1, b2, eps, wd, step, max_norm=0.0, sumsq_buf=None, grad_scale=1.0):
+def adam_step(p, g, m, v, lr, b1, b2, eps, wd, step, max_norm=0.0, sumsq_buf=None, grad_scale=1.0, step_buf=None,
+              lr_buf=None):
     check(lib.fs_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(b1),
                            float(b2), float(eps), float(wd), int(step), float(max_norm or 0.0), _p(sumsq_buf),
-                           float(grad_scale), stream_ptr()), "adam_step")
+                           float(grad_scale), _p(step_buf), _p(lr_buf), stream_ptr()), "adam_step")
+
+
+def counter_incr(buf):
+    """device int32 counter += 1 on the current stream (replayable from a hipGraph)"""
+    check(lib.fs_counter_incr(buf.data_ptr(), stream_ptr()), "counter_incr")

@@ -41,7 +41,8 @@ SIGNATURES = {
     "fs_smooth_bwd": (C.c_int, [P, P]),
     "fs_loss_finalize": (C.c_int, [P, P, P, P, P, P]),
     "fs_sumsq": (C.c_int, [P, L, P, P]),
-    "fs_adam_step": (C.c_int, [P, P, P, P, L, F, F, F, F, F, I, F, P, F, P]),
+    "fs_counter_incr": (C.c_int, [P, P]),
+    "fs_adam_step": (C.c_int, [P, P, P, P, L, F, F, F, F, F, I, F, P, F, P, P, P]),
 }
 
 

@@ -19,10 +19,7 @@ class _PhotoLossFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         depths = [d.contiguous().float() for d in dd[:S]]
         disps = [d.contiguous().float() for d in dd[S:]]
-        seed = -1
-        if RT.tie_noise:
-            RT.noise_step += 1
-            seed = RT.noise_step & 0x3fffffff
+        seed = None if RT.tie_noise else -1     # None: device-resident seed, bumped in-stream every step
         out = pl.forward(img0.contiguous().float(), [src_a.contiguous().float(), src_b.contiguous().float()],
                          P2.contiguous().float(), [T_a.contiguous().float(), T_b.contiguous().float()], patched_mask,
                          depths, disps, noise_seed=seed)

@@ -5,6 +5,7 @@ import torch
 import torch.nn as nn
 import torch.optim as optim
 
+from fsnet_amd.engine.nets import join_companions_final
 from fsnet_amd.engine.runtime import RT
 from fsnet_amd.hip import ops
 
@@ -15,8 +16,12 @@ class FusedAdam(optim.Optimizer):
         super().__init__(params, defaults)
         self._model = model
         self._arena_state = None
+        self._readopt = False
         self._sumsq = None
         self._step_count_fused = 0
+        self._step_buf = None      # device-resident step count / lr: the step kernel is hipGraph-replayable
+        self._lr_buf = None
+        self._lr_host = None
 
     # -- flat path -------------------------------------------------------------------------------
     def _arena(self):
@@ -31,9 +36,13 @@ class FusedAdam(optim.Optimizer):
         return arena
 
     def _flat_state(self, arena):
-        if self._arena_state is None or self._arena_state[0] is not arena:
-            m = torch.zeros_like(arena.data)
-            v = torch.zeros_like(arena.data)
+        if self._arena_state is None or self._arena_state[0] is not arena or self._readopt:
+            if self._arena_state is not None and self._arena_state[0] is arena:
+                m, v = self._arena_state[1].zero_(), self._arena_state[2].zero_()   # same storage: graphs stay valid
+            else:
+                m = torch.zeros_like(arena.data)
+                v = torch.zeros_like(arena.data)
+            self._readopt = False
             step0 = 0
             for p, o in zip(arena.params, arena.offsets):   # adopt state loaded from a checkpoint
                 st = self.state.get(p, None)
@@ -46,6 +55,8 @@ class FusedAdam(optim.Optimizer):
                                  "exp_avg_sq": v[o:o + p.numel()].view(p.shape)}
             self._arena_state = (arena, m, v)
             self._step_count_fused = step0
+            if self._step_buf is not None:       # keep the pointer (a captured graph holds it), reset the value
+                self._step_buf.fill_(step0)
         return self._arena_state[1], self._arena_state[2]
 
     @torch.no_grad()
@@ -57,6 +68,7 @@ class FusedAdam(optim.Optimizer):
                 loss = closure()
         arena = self._arena()
         g0 = self.param_groups[0]
+        join_companions_final()        # weight-gradient kernels still in flight on companion streams
         if arena is not None:
             m, v = self._flat_state(arena)
             dev = arena.data.device
@@ -67,12 +79,16 @@ class FusedAdam(optim.Optimizer):
                 self._sumsq.zero_()
                 ops.sumsq(arena.grad, self._sumsq)
                 sq = self._sumsq
-            self._step_count_fused += 1
+            if self._step_buf is None or self._step_buf.device != dev:
+                self._step_buf = torch.full((1,), self._step_count_fused, dtype=torch.int32, device=dev)
+                self._lr_buf = torch.full((1,), float(g0["lr"]), dtype=torch.float32, device=dev)
+                self._lr_host = float(g0["lr"])
+            self.sync_lr()
+            ops.counter_incr(self._step_buf)
             ops.adam_step(arena.data, arena.grad, m, v, g0["lr"], g0["betas"][0], g0["betas"][1], g0["eps"],
-                          g0["weight_decay"], self._step_count_fused, max_norm=max_norm or 0.0, sumsq_buf=sq,
-                          grad_scale=grad_scale)
-            for p in arena.params:
-                self.state[p]["step"] += 1
+                          g0["weight_decay"], 1, max_norm=max_norm or 0.0, sumsq_buf=sq,
+                          grad_scale=grad_scale, step_buf=self._step_buf, lr_buf=self._lr_buf)
+            self.note_step()
         else:
             params = [p for g in self.param_groups for p in g["params"] if p.grad is not None]
             sq = None
@@ -95,6 +111,37 @@ class FusedAdam(optim.Optimizer):
                                   max_norm=max_norm or 0.0, sumsq_buf=sq, grad_scale=grad_scale)
         RT.bump_weights()   # parameters changed through raw pointers: conv operands must be re-packed
         return loss
+
+    def note_step(self):
+        """host-side bookkeeping of one (eager or graph-replayed) fused step"""
+        self._step_count_fused += 1
+
+    def _refresh_steps(self):
+        if self._arena_state is not None:
+            for p in self._arena_state[0].params:
+                self.state[p]["step"].fill_(float(self._step_count_fused))
+
+    def state_dict(self):
+        self._refresh_steps()      # per-parameter "step" entries are only materialised when someone looks
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._readopt = True       # re-adopt moments / step count from the loaded per-parameter state
+
+    def prepare_replay(self):
+        """before a captured step is replayed: adopt freshly loaded state in place, push the current lr"""
+        arena = self._arena()
+        if self._readopt and arena is not None:
+            self._flat_state(arena)
+        self.sync_lr()
+
+    def sync_lr(self):
+        """push a scheduler-changed learning rate to the device scalar the (possibly captured) kernel reads"""
+        lr = float(self.param_groups[0]["lr"])
+        if self._lr_buf is not None and lr != self._lr_host:
+            self._lr_buf.fill_(lr)
+            self._lr_host = lr
 
     def grad_norm(self):
         """sqrt of the last fused sum of squares (device tensor; no host sync)."""

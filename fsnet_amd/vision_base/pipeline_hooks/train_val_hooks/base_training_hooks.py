@@ -1,7 +1,18 @@
 """One optimisation step, with the reference hook's constructor and call signature
 (vision_base/pipeline_hooks/train_val_hooks/base_training_hooks.py:9-49): zero_grad -> H2D -> forward ->
 loss.backward() -> clip_grad_norm_ -> optimizer.step().  With the HIP FusedAdam the zero/clip/step
-collapse to one memset + two kernels over the flat arena, with no host synchronisation in the step."""
+collapse to one memset + two kernels over the flat arena, with no host synchronisation in the step.
+
+hipGraph replay: the step launches ~700 small kernels on two streams and the host needs ~10 ms to issue them,
+about what the GPU needs to run them.  After `graph_warmup` eager steps the hook captures the whole step
+(zero-grad memset, weight re-pack, both forward/backward chains, clip + Adam) into one hipGraph on a private
+stream and replays it; the per-step scalars (Adam step count, learning rate, tie-break noise seed) live in
+device memory, so a replay is a real step.  Inputs are copied into static device buffers; the returned
+tensors are the graph's static outputs, valid until the next call (loss_dict entries are cloned when a logger
+is attached).  Eager execution stays in use while a data-parallel context is active, for non-fused
+optimizers, and whenever the batch signature changes."""
+import os
+
 import torch
 
 from fsnet_amd.engine.runtime import RT
@@ -9,37 +20,104 @@ from fsnet_amd.vision_base.utils.timer import profile
 
 
 class BaseTrainingHook(object):
-    def __init__(self, tensor_keys=None, clip_gradients=None, **kwargs):
+    def __init__(self, tensor_keys=None, clip_gradients=None, use_graph=None, graph_warmup=3, **kwargs):
         self.tensor_keys = tensor_keys
         self.clip_gradients = clip_gradients
+        if use_graph is None:
+            use_graph = os.environ.get("FSNET_AMD_GRAPH", "1") != "0"
+        self.use_graph = bool(use_graph)
+        self.graph_warmup = int(graph_warmup)   # eager steps before the capture (at least 2: see __call__)
+        self.graph_captures = 0
+        self._g = None            # dict(graph, sig, static, output, stream, ...) once captured
+        self._g_sig = None
+        self._g_eager = 0         # eager steps seen with the current signature
+        self._g_stream = None
+        self.graph_replays = 0
 
-    @profile('Training hook', 0, 100)
-    def __call__(self, data, meta_arch, optimizer, writer=None, training_loss_logger=None, global_step=0,
-                 epoch_num=0):
-        from fsnet_amd.vision_base.networks.optimizers.optimizers import FusedAdam
-        inner = getattr(meta_arch, "module", meta_arch)
-        arena = inner.ensure_arena() if hasattr(inner, "ensure_arena") else None
-        fused = isinstance(optimizer, FusedAdam)
+    # ------------------------------------------------------------------ graph path
+    def _signature(self, data, meta_arch, optimizer):
+        sig = [id(meta_arch), id(optimizer), self.clip_gradients]
+        for k, v in data.items():
+            if isinstance(v, torch.Tensor):
+                sig.append((k, tuple(v.shape), v.dtype))
+        return tuple(sig)
+
+    def _graph_ok(self, meta_arch, optimizer, arena, fused):
+        if not (self.use_graph and fused and arena is not None and torch.cuda.is_available()):
+            return False
+        if RT.dp is not None:
+            return False
+        if torch.distributed.is_available() and torch.distributed.is_initialized() \
+                and torch.distributed.get_world_size() > 1:
+            return False
+        if not next(meta_arch.parameters()).is_cuda:
+            return False
+        return True
+
+    def _stage(self, data, static):
+        """incoming batch -> static device buffers (H2D or D2D on the current stream)"""
+        for k, v in data.items():
+            if isinstance(v, torch.Tensor) and k in static:
+                static[k].copy_(v, non_blocking=True)
+
+    def _eager_step(self, data, meta_arch, optimizer, arena, fused, meta, logger):
         if arena is not None:
             arena.zero_grads()
         else:
             optimizer.zero_grad()
-
         for key in data:
             if isinstance(data[key], torch.Tensor):
                 if self.tensor_keys is None or key in self.tensor_keys:
                     data[key] = data[key].cuda(non_blocking=True).contiguous()
-
-        meta = dict(epoch_num=epoch_num, global_step=global_step, is_training=True)
         output = meta_arch(data, meta)
-
-        if training_loss_logger is not None:
-            training_loss_logger.update(output['loss_dict'])
-            training_loss_logger.update_hm(output.get('hm', dict()))
-
+        if logger is not None:
+            logger.update(output['loss_dict'])
+            logger.update_hm(output.get('hm', dict()))
         loss = output['loss']
         (loss if loss.dim() == 0 else loss.mean()).backward()
+        self._optim(meta_arch, optimizer, fused)
+        return output
 
+    def _capture(self, data, meta_arch, optimizer, arena, meta, sig):
+        dev = next(meta_arch.parameters()).device
+        static = {}
+        for k, v in data.items():
+            if isinstance(v, torch.Tensor):
+                static[k] = torch.empty(v.shape, dtype=v.dtype, device=dev).contiguous()
+        sdata = dict(data)
+        sdata.update(static)
+        self._stage(data, static)
+        optimizer.sync_lr()
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        steps_before = optimizer._step_count_fused
+        with torch.cuda.graph(graph, stream=self._g_stream):
+            arena.zero_grads()
+            output = meta_arch(sdata, meta)
+            loss = output['loss']
+            (loss if loss.dim() == 0 else loss.mean()).backward()
+            optimizer.step(max_norm=self.clip_gradients, grad_scale=1.0)
+        # capture records, it does not run: host bookkeeping happened once above, the first replay is that step
+        assert optimizer._step_count_fused == steps_before + 1
+        self._g = dict(graph=graph, sig=sig, static=static, output=output, arena=arena)
+        graph.replay()
+        RT.bump_weights()
+        return output
+
+    def _replay(self, data, optimizer):
+        g = self._g
+        self._stage(data, g["static"])
+        optimizer.prepare_replay()
+        g["graph"].replay()
+        optimizer.note_step()
+        RT.bump_weights()          # packed MFMA operands are one Adam step behind the arena again
+        self.graph_replays += 1
+        return g["output"]
+
+    def reset_graph(self):
+        self._g, self._g_sig, self._g_eager = None, None, 0
+
+    def _optim(self, meta_arch, optimizer, fused):
         grad_scale = RT.dp.finish() if RT.dp is not None else 1.0
         if fused:
             optimizer.step(max_norm=self.clip_gradients, grad_scale=grad_scale)
@@ -52,4 +130,56 @@ class BaseTrainingHook(object):
                 torch.nn.utils.clip_grad_norm_(meta_arch.parameters(), self.clip_gradients)
             optimizer.step()
             RT.bump_weights()
+
+    @profile('Training hook', 0, 100)
+    def __call__(self, data, meta_arch, optimizer, writer=None, training_loss_logger=None, global_step=0,
+                 epoch_num=0):
+        from fsnet_amd.vision_base.networks.optimizers.optimizers import FusedAdam
+        inner = getattr(meta_arch, "module", meta_arch)
+        arena = inner.ensure_arena() if hasattr(inner, "ensure_arena") else None
+        fused = isinstance(optimizer, FusedAdam)
+        meta = dict(epoch_num=epoch_num, global_step=global_step, is_training=True)
+        logger = training_loss_logger
+
+        if not self._graph_ok(meta_arch, optimizer, arena, fused):
+            return self._eager_step(data, meta_arch, optimizer, arena, fused, meta, logger)
+
+        sig = self._signature(data, meta_arch, optimizer)
+        if sig != self._g_sig or (self._g is not None and not self._g["arena"] is arena):
+            self._g, self._g_sig, self._g_eager = None, sig, 0
+        if self._g_stream is None:
+            self._g_stream = torch.cuda.Stream(device=next(meta_arch.parameters()).device)
+        cur = torch.cuda.current_stream()
+        if self._g is None and self._g_eager < max(2, self.graph_warmup):
+            # warm-up on the capture stream: lazy buffers, per-stream pools and tables exist before the capture
+            # (two steps at least: the one-launch weight re-pack table is first built by the second step)
+            self._g_eager += 1
+            self._g_stream.wait_stream(cur)
+            with torch.cuda.stream(self._g_stream):
+                output = self._eager_step(data, meta_arch, optimizer, arena, fused, meta, logger)
+            cur.wait_stream(self._g_stream)
+            return output
+        self._g_stream.wait_stream(cur)
+        with torch.cuda.stream(self._g_stream):
+            if self._g is None:
+                steps_before = optimizer._step_count_fused
+                try:
+                    output = self._capture(data, meta_arch, optimizer, arena, meta, sig)
+                    self.graph_captures += 1
+                except Exception as e:      # something in the step is not capturable here: stay eager, loudly
+                    import warnings
+                    warnings.warn("fsnet_amd: hipGraph capture of the training step failed (%s: %s); "
+                                  "continuing with eager launches" % (type(e).__name__, e))
+                    self.use_graph = False
+                    self._g = None
+                    optimizer._step_count_fused = steps_before
+                    torch.cuda.synchronize()
+                    output = self._eager_step(data, meta_arch, optimizer, arena, fused, meta, logger)
+                    logger = None
+            else:
+                output = self._replay(data, optimizer)
+            if logger is not None:
+                logger.update({k: v.clone() for k, v in output['loss_dict'].items()})
+                logger.update_hm(output.get('hm', dict()))
+        cur.wait_stream(self._g_stream)
         return output

@@ -262,6 +262,7 @@ typedef struct FsPhotoArgs {
   int32_t dh[4], dw[4];
   int32_t B, H, W, S;
   int32_t noise_seed;
+  const int32_t* noise_seed_ptr;  /* device-resident seed (overrides noise_seed when non-NULL; hipGraph replay) */
 } FsPhotoArgs;
 int fs_photo_setup(const float* P2, const float* T0, const float* T1, float* geo, int B, void* stream);
 int fs_photo_identity(const FsPhotoArgs* args, void* stream);
@@ -296,11 +297,14 @@ int fs_loss_finalize(const double* loss_sums, const double* mask_sum, const doub
  * (clip_grad_norm_ + torch.optim.Adam.step, base_training_hooks.py:46-49; optimizers.py:7-8).
  * grad_scale multiplies every gradient first (1/world_size after a SUM all-reduce).
  * max_norm <= 0 or sumsq == NULL disables clipping.
+ * step_ptr / lr_ptr: optional device-resident step count / learning rate (override the scalars) so that the
+ * launch can be replayed from a hipGraph; fs_counter_incr bumps such a counter on the stream.
  */
 int fs_sumsq(const float* g, int64_t n, double* out, void* stream);
+int fs_counter_incr(int32_t* counter, void* stream);
 int fs_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                  float eps, float weight_decay, int step, float max_norm, const double* sumsq, float grad_scale,
-                 void* stream);
+                 const int32_t* step_ptr, const float* lr_ptr, void* stream);
 
 #ifdef __cplusplus
 }

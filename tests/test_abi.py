@@ -101,7 +101,7 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     from fsnet_amd.hip import lib
     assert lib.fs_conv_igemm(None, 0, None) == 1
     assert lib.fs_conv_wgrad(None, 1, None) == 1
-    assert lib.fs_adam_step(None, None, None, None, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 1, 0.0, None, 1.0, None) == 1
+    assert lib.fs_adam_step(None, None, None, None, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 1, 0.0, None, 1.0, None, None, None) == 1
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -1,0 +1,79 @@
+"""hipGraph replay of the training step == eager execution of the same steps (same seeds, same device-side
+tie-break noise sequence, lr schedule changes picked up through the device-resident lr scalar)."""
+import pytest
+import torch
+
+from oracle import fsnet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(dev, use_graph, steps, dtype, tie_noise):
+    from fsnet_amd.configs import meta_arch_cfg, training_cfg
+    from fsnet_amd.engine.runtime import RT
+    from fsnet_amd.vision_base.networks.optimizers.optimizers import build_optimizer
+    from fsnet_amd.vision_base.utils.builder import build
+    RT.set_compute_dtype(dtype)
+    RT.tie_noise = tie_noise
+    B, H, W = 2, 64, 128
+    m = build(**meta_arch_cfg(H, W, with_pose=True))
+    m.load_state_dict(O.init_state(seed=3, with_pose=True), strict=True)
+    m = m.to(dev).train()
+    tc = training_cfg()
+    opt = build_optimizer(m, **tc.optimizer)
+    hook = build(use_graph=use_graph, graph_warmup=2, **tc.training_hook)
+    losses = []
+    for it in range(steps):
+        if it == 4:
+            opt.param_groups[0]["lr"] *= 0.5          # what a scheduler does between steps
+        out = hook(dict(O.synthetic_batch(B, H, W, seed=50 + it)), m, opt)
+        losses.append(out["loss"].detach().clone())
+    torch.cuda.synchronize()
+    params = torch.cat([p.detach().double().flatten() for p in m.parameters()]).cpu()
+    rm = torch.cat([v.double().flatten() for k, v in m.state_dict().items() if "running_" in k]).cpu()
+    if tie_noise:
+        assert int(m.head._pl.seed_buf.item()) == steps       # device-side seed stream advanced once per step
+    RT.tie_noise = False
+    return torch.stack(losses).cpu(), params, rm, hook, opt
+
+
+@pytest.mark.parametrize("dtype,tie", [(torch.float32, False), (torch.float32, True), (torch.bfloat16, True)])
+def test_graph_replay_matches_eager(dev, dtype, tie):
+    le, pe, re_, he, oe = _run(dev, False, 6, dtype, tie)
+    l2, p2, r2, _, _ = _run(dev, False, 6, dtype, tie)
+    lg, pg, rg, hg, og = _run(dev, True, 6, dtype, tie)
+    assert he.graph_replays == 0 and hg.graph_replays == 3          # steps 0,1 eager; 2 captured; 3..5 replayed
+    # same kernels in the same launch order; only the order of fp atomics differs run to run, and min-selection /
+    # ReLU flips amplify that over steps.  Yardstick: the spread between two EAGER runs of the same thing.
+    def d(a, b, rel_floor=0.0):
+        return float(((a - b).abs() / a.abs().clamp_min(rel_floor)).max()) if rel_floor else float((a - b).abs().max())
+    # (bf16: one reordered atomic flips a rounding and the runs decorrelate at the 1e-3 level within a few steps,
+    # eager against eager just the same — measured with tools/probes/graph_vs_eager.py)
+    f32 = dtype == torch.float32
+    assert d(le, lg, 1e-9) < max(5e-5 if f32 else 5e-3, 5 * d(le, l2, 1e-9)), (le, lg, l2)
+    assert d(pe, pg) < max(1e-4 if f32 else 2e-3, 5 * d(pe, p2)), (d(pe, pg), d(pe, p2))
+    assert d(re_, rg, 1.0) < max(1e-3 if f32 else 1e-2, 5 * d(re_, r2, 1.0)), (d(re_, rg, 1.0), d(re_, r2, 1.0))
+    assert oe._step_count_fused == og._step_count_fused == 6
+    assert int(og._step_buf.item()) == 6 and abs(float(og._lr_buf.item()) - og.param_groups[0]["lr"]) < 1e-9
+
+
+def test_graph_falls_back_on_new_batch_shape(dev):
+    from fsnet_amd.configs import meta_arch_cfg, training_cfg
+    from fsnet_amd.engine.runtime import RT
+    from fsnet_amd.vision_base.networks.optimizers.optimizers import build_optimizer
+    from fsnet_amd.vision_base.utils.builder import build
+    RT.set_compute_dtype(torch.bfloat16)
+    m = build(**meta_arch_cfg(64, 128, with_pose=True)).to(dev).train()
+    tc = training_cfg()
+    opt = build_optimizer(m, **tc.optimizer)
+    hook = build(graph_warmup=2, **tc.training_hook)
+    for it in range(4):
+        hook(dict(O.synthetic_batch(2, 64, 128, seed=it)), m, opt)
+    assert hook.graph_replays == 1 and hook.graph_captures == 1
+    out = hook(dict(O.synthetic_batch(1, 64, 128, seed=9)), m, opt)     # last, ragged batch of an epoch
+    assert hook.graph_replays == 1 and torch.isfinite(out["loss"])
+    for it in range(4):
+        out = hook(dict(O.synthetic_batch(2, 64, 128, seed=20 + it)), m, opt)
+    torch.cuda.synchronize()
+    assert hook.graph_replays == 2 and hook.graph_captures == 2 and hook.use_graph
+    assert torch.isfinite(out["loss"]) and opt._step_count_fused == 9

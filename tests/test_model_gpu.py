@@ -65,8 +65,9 @@ def test_fp32_forward_matches_reference_golden(dev, tag, with_pose):
 
 
 @gpu
+@pytest.mark.parametrize("graph_warmup", [99, 2], ids=["eager", "hipgraph"])
 @pytest.mark.parametrize("tag,with_pose", [("depthpose", True), ("wpose", False)])
-def test_fp32_training_steps_match_reference_golden(dev, tag, with_pose):
+def test_fp32_training_steps_match_reference_golden(dev, tag, with_pose, graph_warmup):
     from fsnet_amd.configs import training_cfg
     from fsnet_amd.vision_base.networks.optimizers.optimizers import build_optimizer
     from fsnet_amd.vision_base.utils.builder import build
@@ -77,6 +78,7 @@ def test_fp32_training_steps_match_reference_golden(dev, tag, with_pose):
     tc = training_cfg()
     opt = build_optimizer(m, **tc.optimizer)
     hook = build(**tc.training_hook)
+    hook.graph_warmup = graph_warmup      # 2: steps 0,1 eager, step 2 captured and executed as the first replay
     names = [k for k, _ in m.named_parameters()]
     for it in range(3):
         data = O.synthetic_batch(B, H, W, seed=100 + it)
@@ -102,6 +104,8 @@ def test_fp32_training_steps_match_reference_golden(dev, tag, with_pose):
     assert float(((pabs - ref).abs() / ref.clamp_min(1e-9)).max()) < 5e-3
     rm = torch.cat([v.flatten() for k, v in m.state_dict().items() if k.endswith("running_mean")]).cpu()
     assert (rm - torch.from_numpy(g["bn_rm_final"])).abs().max() < 5e-3
+    assert hook.graph_captures == (1 if graph_warmup == 2 else 0)
+    assert float(opt.state_dict()["state"][0]["step"]) == 3.0
 
 
 @gpu
