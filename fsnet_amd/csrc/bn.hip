@@ -42,34 +42,51 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const FsBnApplyArgs p) {
   const int C = p.C;
   const bool has2 = p.gamma2 != nullptr;
   const bool train = p.stats != nullptr;
+  // statistics groups: blockIdx.z owns the rows [z*Mg, (z+1)*Mg) and the z-th statistics / saved-state slice
+  const int G = p.groups > 1 ? p.groups : 1;
+  const int z = blockIdx.z;
+  const int Mg = p.M / G;
+  const long gstat = (long)FS_STAT_SLOTS * 2 * C;
+  const double* stats_z = p.stats ? p.stats + z * gstat : nullptr;
+  const double* stats2_z = p.stats2 ? p.stats2 + z * gstat : nullptr;
+  const bool first = blockIdx.x == 0;
   for (int c = threadIdx.x; c < C; c += 256) {
     float mean, invstd, varb, sc, sh;
-    bn_channel_coeffs(p.stats, p.running_mean, p.running_var, C, c, p.count, p.eps, p.gamma[c], p.beta[c], mean, invstd, varb, sc, sh);
+    bn_channel_coeffs(stats_z, p.running_mean, p.running_var, C, c, p.count, p.eps, p.gamma[c], p.beta[c], mean, invstd, varb, sc, sh);
     s_scale[c] = sc; s_shift[c] = sh;
-    if (blockIdx.x == 0) {
-      p.save_mean[c] = mean; p.save_invstd[c] = invstd;
-      if (train && p.running_mean) {
-        double unb = p.count > 1.0 ? (double)varb * p.count / (p.count - 1.0) : (double)varb;
-        p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * mean;
-        p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unb;
+    if (first) { p.save_mean[z * C + c] = mean; p.save_invstd[z * C + c] = invstd; }
+    if (first && z == 0 && train && p.running_mean) {
+      // one momentum update per group, in group order (= the order the reference calls the module in)
+      float rm = p.running_mean[c], rv = p.running_var[c];
+      for (int g = 0; g < G; ++g) {
+        float mg = mean, vg = varb, t0, t1, t2;
+        if (g > 0) bn_channel_coeffs(p.stats + g * gstat, nullptr, nullptr, C, c, p.count, p.eps, 1.f, 0.f, mg, t0, vg, t1, t2);
+        double unb = p.count > 1.0 ? (double)vg * p.count / (p.count - 1.0) : (double)vg;
+        rm = (1.f - p.momentum) * rm + p.momentum * mg;
+        rv = (1.f - p.momentum) * rv + p.momentum * (float)unb;
       }
+      p.running_mean[c] = rm; p.running_var[c] = rv;
     }
     if (has2) {
-      bn_channel_coeffs(p.stats2, p.running_mean2, p.running_var2, C, c, p.count, p.eps, p.gamma2[c], p.beta2[c], mean, invstd, varb, sc, sh);
+      bn_channel_coeffs(stats2_z, p.running_mean2, p.running_var2, C, c, p.count, p.eps, p.gamma2[c], p.beta2[c], mean, invstd, varb, sc, sh);
       s_scale2[c] = sc; s_shift2[c] = sh;
-      if (blockIdx.x == 0) {
-        p.save_mean2[c] = mean; p.save_invstd2[c] = invstd;
-        if (train && p.running_mean2) {
-          double unb = p.count > 1.0 ? (double)varb * p.count / (p.count - 1.0) : (double)varb;
-          p.running_mean2[c] = (1.f - p.momentum) * p.running_mean2[c] + p.momentum * mean;
-          p.running_var2[c] = (1.f - p.momentum) * p.running_var2[c] + p.momentum * (float)unb;
+      if (first) { p.save_mean2[z * C + c] = mean; p.save_invstd2[z * C + c] = invstd; }
+      if (first && z == 0 && train && p.running_mean2) {
+        float rm = p.running_mean2[c], rv = p.running_var2[c];
+        for (int g = 0; g < G; ++g) {
+          float mg = mean, vg = varb, t0, t1, t2;
+          if (g > 0) bn_channel_coeffs(p.stats2 + g * gstat, nullptr, nullptr, C, c, p.count, p.eps, 1.f, 0.f, mg, t0, vg, t1, t2);
+          double unb = p.count > 1.0 ? (double)vg * p.count / (p.count - 1.0) : (double)vg;
+          rm = (1.f - p.momentum) * rm + p.momentum * mg;
+          rv = (1.f - p.momentum) * rv + p.momentum * (float)unb;
         }
+        p.running_mean2[c] = rm; p.running_var2[c] = rv;
       }
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (train && p.num_batches_tracked) *p.num_batches_tracked += 1;
-    if (train && p.num_batches_tracked2) *p.num_batches_tracked2 += 1;
+  if (first && z == 0 && threadIdx.x == 0) {
+    if (train && p.num_batches_tracked) *p.num_batches_tracked += G;
+    if (train && p.num_batches_tracked2) *p.num_batches_tracked2 += G;
   }
   __syncthreads();
 
@@ -78,9 +95,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const FsBnApplyArgs p) {
   T* __restrict__ y = reinterpret_cast<T*>(p.y);
   constexpr int V = VecN<T>::N;
   const int CG = C / V;
-  const long total = (long)p.M * CG;
+  const long total = (long)Mg * CG;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    int cg = (int)(i % CG); long m = i / CG;
+    int cg = (int)(i % CG); long m = (long)z * Mg + i / CG;
     int c = cg * V;
     float v[V];
     loadv<T>(x + m * C + c, v);
@@ -172,13 +189,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const FsBnBwdArgs p)
   const T* __restrict__ dout = reinterpret_cast<const T*>(p.dout);
   const T* __restrict__ yv = reinterpret_cast<const T*>(p.y);
   const T* __restrict__ xv = reinterpret_cast<const T*>(p.x);
+  const int G = p.groups > 1 ? p.groups : 1;
+  const int z = blockIdx.z;
+  const long Mg = p.M / G, m_end = (z + 1) * Mg;
   float mean[V], istd[V], s1[V], s2[V];
 #pragma unroll
-  for (int j = 0; j < V; ++j) { mean[j] = act ? p.save_mean[c + j] : 0.f; istd[j] = act ? p.save_invstd[c + j] : 0.f; s1[j] = 0.f; s2[j] = 0.f; }
+  for (int j = 0; j < V; ++j) { mean[j] = act ? p.save_mean[z * C + c + j] : 0.f; istd[j] = act ? p.save_invstd[z * C + c + j] : 0.f; s1[j] = 0.f; s2[j] = 0.f; }
   if (act) {
     const long stride = (long)gridDim.x * PL;
-    long m = (long)blockIdx.x * PL + pl;
-    for (; m + stride < p.M; m += 2 * stride) {
+    long m = z * Mg + (long)blockIdx.x * PL + pl;
+    for (; m + stride < m_end; m += 2 * stride) {
       float g0[V], g1[V], x0[V], x1[V];
       masked_grad<T>(p, dout, yv, m, c, g0);
       masked_grad<T>(p, dout, yv, m + stride, c, g1);
@@ -190,7 +210,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const FsBnBwdArgs p)
         s2[j] += g0[j] * (x0[j] - mean[j]) * istd[j] + g1[j] * (x1[j] - mean[j]) * istd[j];
       }
     }
-    for (; m < p.M; m += stride) {
+    for (; m < m_end; m += stride) {
       float g0[V], x0[V];
       masked_grad<T>(p, dout, yv, m, c, g0);
       loadv<T>(xv + m * C + c, x0);
@@ -207,7 +227,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const FsBnBwdArgs p)
       int kind = kj / V, j = kj % V;
       float a = 0.f;
       for (int k = 0; k < PL; ++k) a += red[kind][j][k * CGB + cgl];
-      double* sl = p.sums + (long)(blockIdx.x % FS_STAT_SLOTS) * 2 * C;
+      double* sl = p.sums + ((long)z * FS_STAT_SLOTS + blockIdx.x % FS_STAT_SLOTS) * 2 * C;
       atomicAdd(sl + kind * C + c + j, (double)a);
     }
   }
@@ -218,22 +238,32 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const FsBnBwdArgs p) {
   __shared__ float s_a[MAXC], s_b[MAXC], s_k[MAXC], s_mean[MAXC], s_istd[MAXC];
   const int C = p.C;
+  const int G = p.groups > 1 ? p.groups : 1;
+  const int z = blockIdx.z;
+  const int Mg = p.M / G;
+  const double* sums = p.sums + (long)z * FS_STAT_SLOTS * 2 * C;
+  const double* sums_local = p.sums_local ? p.sums_local + (long)z * FS_STAT_SLOTS * 2 * C : nullptr;
   for (int c = threadIdx.x; c < C; c += 256) {
     double sg = 0.0, sgx = 0.0, lg = 0.0, lgx = 0.0;
 #pragma unroll
     for (int k = 0; k < FS_STAT_SLOTS; ++k) {
-      sg += p.sums[(long)k * 2 * C + c]; sgx += p.sums[(long)k * 2 * C + C + c];
-      if (p.sums_local) { lg += p.sums_local[(long)k * 2 * C + c]; lgx += p.sums_local[(long)k * 2 * C + C + c]; }
+      sg += sums[(long)k * 2 * C + c]; sgx += sums[(long)k * 2 * C + C + c];
+      if (sums_local) { lg += sums_local[(long)k * 2 * C + c]; lgx += sums_local[(long)k * 2 * C + C + c]; }
     }
-    float istd = p.save_invstd[c];
-    s_mean[c] = p.save_mean[c]; s_istd[c] = istd;
+    float istd = p.save_invstd[z * C + c];
+    s_mean[c] = p.save_mean[z * C + c]; s_istd[c] = istd;
     s_k[c] = p.gamma[c] * istd;
     s_a[c] = (float)(sg / p.count);
     s_b[c] = (float)(sgx / p.count);
     if (blockIdx.x == 0) {
       // dgamma / dbeta of the local shard (the data-parallel all-reduce of gradients averages them later)
-      if (p.dgamma) p.dgamma[c] += (float)(p.sums_local ? lgx : sgx);
-      if (p.dbeta) p.dbeta[c] += (float)(p.sums_local ? lg : sg);
+      if (G > 1) {       // the groups' blocks add concurrently
+        if (p.dgamma) atomicAdd(p.dgamma + c, (float)(sums_local ? lgx : sgx));
+        if (p.dbeta) atomicAdd(p.dbeta + c, (float)(sums_local ? lg : sg));
+      } else {
+        if (p.dgamma) p.dgamma[c] += (float)(sums_local ? lgx : sgx);
+        if (p.dbeta) p.dbeta[c] += (float)(sums_local ? lg : sg);
+      }
     }
   }
   __syncthreads();
@@ -244,9 +274,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const FsBnBwdArgs p) 
   T* __restrict__ gout = reinterpret_cast<T*>(p.g_out);
   constexpr int V = VecN<T>::N;
   const int CG = C / V;
-  const long total = (long)p.M * CG;
+  const long total = (long)Mg * CG;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    int cg = (int)(i % CG); long m = i / CG;
+    int cg = (int)(i % CG); long m = (long)z * Mg + i / CG;
     int c = cg * V;
     float g[V], xr[V], o[V];
     masked_grad<T>(p, dout, yv, m, c, g);
@@ -277,9 +307,11 @@ extern "C" int fs_bn_apply(const FsBnApplyArgs* a, int dtype, void* stream) {
   if (a->gamma2 && (!a->res || !a->beta2 || !a->save_mean2 || !a->save_invstd2)) return FS_EINVAL;
   if (a->gamma2 && !a->stats2 && (!a->running_mean2 || !a->running_var2)) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  int grid = grid_for((long)a->M * (a->C / (dtype == FS_DTYPE_BF16 ? 8 : 4)));
-  if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(grid), dim3(256), 0, st, *a);
-  else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, st, *a);
+  const int G = a->groups > 1 ? a->groups : 1;
+  if (a->M % G != 0 || (G > 1 && !a->stats)) return FS_EINVAL;
+  dim3 grid(grid_for((long)(a->M / G) * (a->C / (dtype == FS_DTYPE_BF16 ? 8 : 4))), 1, G);
+  if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16>, grid, dim3(256), 0, st, *a);
+  else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, st, *a);
   else return FS_EINVAL;
   return fs_launch_status();
 }
@@ -289,14 +321,17 @@ extern "C" int fs_bn_bwd_reduce(const FsBnBwdArgs* a, int dtype, void* stream) {
   if (a->C % 8 != 0 || a->C > MAXC || a->M <= 0 || (a->relu && !a->y)) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int CG = a->C / (dtype == FS_DTYPE_BF16 ? 8 : 4);
+  const int G = a->groups > 1 ? a->groups : 1;
+  if (a->M % G != 0) return FS_EINVAL;
+  const long Mg = a->M / G;
   // channel groups per block: 32 (8 pixel lanes) for wide layers, 8 (32 pixel lanes) for narrow ones
   if (CG >= 32) {
-    dim3 grid((unsigned)std::min<long>(((long)a->M + 15) / 16, 512), (CG + 31) / 32);
+    dim3 grid((unsigned)std::min<long>((Mg + 15) / 16, 512), (CG + 31) / 32, G);
     if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, 32>), grid, dim3(256), 0, st, *a);
     else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 32>), grid, dim3(256), 0, st, *a);
     else return FS_EINVAL;
   } else {
-    dim3 grid((unsigned)std::min<long>(((long)a->M + 63) / 64, 1024), (CG + 7) / 8);
+    dim3 grid((unsigned)std::min<long>((Mg + 63) / 64, 1024), (CG + 7) / 8, G);
     if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, 8>), grid, dim3(256), 0, st, *a);
     else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 8>), grid, dim3(256), 0, st, *a);
     else return FS_EINVAL;
@@ -308,9 +343,11 @@ extern "C" int fs_bn_bwd_apply(const FsBnBwdArgs* a, int dtype, void* stream) {
   if (!a || !a->dout || !a->x || !a->sums || !a->dx || !a->gamma || !a->save_mean || !a->save_invstd) return FS_EINVAL;
   if (a->C % 8 != 0 || a->C > MAXC || a->M <= 0 || (a->relu && !a->y)) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  int grid = grid_for((long)a->M * (a->C / (dtype == FS_DTYPE_BF16 ? 8 : 4)));
-  if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(grid), dim3(256), 0, st, *a);
-  else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, *a);
+  const int G = a->groups > 1 ? a->groups : 1;
+  if (a->M % G != 0) return FS_EINVAL;
+  dim3 grid(grid_for((long)(a->M / G) * (a->C / (dtype == FS_DTYPE_BF16 ? 8 : 4))), 1, G);
+  if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, grid, dim3(256), 0, st, *a);
+  else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, st, *a);
   else return FS_EINVAL;
   return fs_launch_status();
 }

@@ -242,7 +242,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
       for (int k = 0; k < WP; ++k) { u += red[(k * CO + t) * 2]; w += red[(k * CO + t) * 2 + 1]; }
       int co = co0 + t;
       if (co < p.Co) {
-        double* sl = p.stats + (long)(px % FS_STAT_SLOTS) * 2 * p.Co;
+        const long sg = p.stat_group_rows > 0 ? ((long)n * p.Hd * p.Wd) / p.stat_group_rows : 0;   // whole images
+        double* sl = p.stats + (sg * FS_STAT_SLOTS + px % FS_STAT_SLOTS) * 2 * p.Co;
         atomicAdd(sl + co, (double)u);
         atomicAdd(sl + p.Co + co, (double)w);
       }

@@ -284,7 +284,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
       for (int k = 0; k < WP; ++k) { u += red[(k * CO + t) * 2]; w += red[(k * CO + t) * 2 + 1]; }
       int co = co0 + t;
       if (co < p.Co) {
-        double* sl = p.stats + (long)(px % FS_STAT_SLOTS) * 2 * p.Co;
+        // statistics group of this tile (groups are multiples of the tile height: fs_conv_igemm checks)
+        const long sg = p.stat_group_rows > 0 ? pix0 / p.stat_group_rows : 0;
+        double* sl = p.stats + (sg * FS_STAT_SLOTS + px % FS_STAT_SLOTS) * 2 * p.Co;
         atomicAdd(sl + co, (double)u);
         atomicAdd(sl + p.Co + co, (double)w);
       }
@@ -334,6 +336,7 @@ extern "C" int fs_conv_igemm(const FsConvArgs* args, int dtype, void* stream) {
       args->wgt_bytes > 0x7fffffffLL)
     return FS_EINVAL;
   if (args->dshift && ((args->sH | args->sW) & 1)) return FS_EINVAL;
+  if (args->stats && args->stat_group_rows > 0 && args->stat_group_rows % 256 != 0) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == FS_DTYPE_BF16) return launch_conv<bf16>(*args, st);
   if (dtype == FS_DTYPE_F32) return launch_conv<float>(*args, st);

@@ -30,11 +30,13 @@ class StatsPool:
         self.buf.zero_()
         self.off = 0
 
-    def take(self, C):
-        n = STAT_SLOTS * 2 * C
+    def take(self, C, groups=1):
+        """[SLOTS][2][C] (one statistics group) or [G][SLOTS][2][C]"""
+        n = groups * STAT_SLOTS * 2 * C
+        shape = (STAT_SLOTS, 2, C) if groups == 1 else (groups, STAT_SLOTS, 2, C)
         if self.off + n > self.buf.numel():
-            return torch.zeros(STAT_SLOTS, 2, C, dtype=torch.float64, device=self.buf.device)
-        v = self.buf[self.off:self.off + n].view(STAT_SLOTS, 2, C)
+            return torch.zeros(shape, dtype=torch.float64, device=self.buf.device)
+        v = self.buf[self.off:self.off + n].view(shape)
         self.off += n
         return v
 
@@ -42,14 +44,62 @@ class StatsPool:
 _PENDING_JOIN = set()   # (chain stream, companion stream) pairs with weight-gradient work in flight
 _PENDING_KEEP = []      # tensors the companion kernels still read: kept alive until the join (no record_stream
                         # bookkeeping in the allocator, and safe inside a hipGraph capture's private pool)
+_DEFERRED = {}          # chain stream id -> (chain stream, [weight-gradient work items not yet handed over])
+_CALLBACK_QUEUED = [False]
+
+
+def _run_param_grads(op, dc, x, gw, gb, nb):
+    op.wgrad(dc, x, gw)
+    if gb is not None:
+        ops.channel_sum(dc, gb, nb)
+
+
+def _defer_param_grads(cur, item):
+    ent = _DEFERRED.get(cur.cuda_stream)
+    if ent is None:
+        ent = _DEFERRED[cur.cuda_stream] = (cur, [])
+    ent[1].append(item)
+    if not _CALLBACK_QUEUED[0]:
+        # runs once, when the autograd engine has executed every node of this backward pass and before it
+        # synchronises the streams it used with the caller's stream
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+        _CALLBACK_QUEUED[0] = True
+    if RT.wgrad_streams != 3 and len(ent[1]) >= RT.wgrad_flush:
+        flush_deferred(cur)
+
+
+def flush_deferred(cur=None):
+    """hand the collected weight-gradient work of chain stream `cur` (default: all chains) to its companion"""
+    for key in ([cur.cuda_stream] if cur is not None else list(_DEFERRED.keys())):
+        ent = _DEFERRED.get(key)
+        if ent is None or not ent[1]:
+            continue
+        chain, items = ent
+        if RT.wgrad_streams == 3:
+            # the pose chain's stream: shorter than the depth chain's, so its tail is idle GPU time
+            ws = RT.side_stream(chain.device)
+        else:
+            _, ws = RT.companion_stream(chain.device, chain)
+        ws.wait_stream(chain)                       # one cross-stream edge per batch
+        with torch.cuda.stream(ws):
+            for it in items:
+                _run_param_grads(*it)
+        _PENDING_KEEP.extend(items)
+        _PENDING_JOIN.add((chain, ws))
+        ent[1].clear()
+
+
+def _end_of_backward():
+    _CALLBACK_QUEUED[0] = False
+    flush_deferred()
+    join_companions()
 
 
 def join_companions():
-    """make every chain stream wait for its companion (end of a network's backward: gradients complete).
-    Inside a hipGraph capture the join is deferred to join_companions_final(): joining a companion into a
-    stream that is itself a fork of the capture stream and then joining that one crashes hipStreamEndCapture
-    on ROCm 7.2 (tools/probes/graph_fork_probe.py, variants C/D), joining every companion straight into the
-    capture stream does not (variant G)."""
+    """every chain stream waits for its companion.  Inside a hipGraph capture the join is left to
+    join_companions_final(): joining a companion into a stream that is itself a fork of the capture stream and
+    then joining that one crashes hipStreamEndCapture on ROCm 7.2 (tools/probes/graph_fork_probe.py, variants
+    C/D), joining every companion straight into the capture stream does not (variant G)."""
     if not _PENDING_JOIN:
         return
     if torch.cuda.is_current_stream_capturing():
@@ -62,6 +112,7 @@ def join_companions():
 
 def join_companions_final():
     """the current stream waits for every companion with work in flight (before the optimizer reads gradients)"""
+    flush_deferred()
     if not _PENDING_JOIN:
         return
     cur = torch.cuda.current_stream()
@@ -178,19 +229,20 @@ class ConvLayer:
         backward pass, so they run on a companion stream while the chain continues with the dgrad."""
         gw = grad_of(self.m.weight)
         gb = grad_of(self.m.bias) if self.m.bias is not None else None
-        if RT.overlap and RT.wgrad_streams and dc.is_cuda:
-            cur, ws = RT.companion_stream(dc.device)
-            ws.wait_stream(cur)                      # dc (and x) are complete on the chain stream
-            with torch.cuda.stream(ws):
-                op.wgrad(dc, x, gw)
-                if gb is not None:
-                    ops.channel_sum(dc, gb, self.m.bias.numel())
-            _PENDING_KEEP.append((dc, x))
-            _PENDING_JOIN.add((cur, ws))
-        else:
-            op.wgrad(dc, x, gw)
-            if gb is not None:
-                ops.channel_sum(dc, gb, self.m.bias.numel())
+        item = (op, dc, x, gw, gb, self.m.bias.numel() if gb is not None else 0)
+        mode = RT.wgrad_streams if (dc.is_cuda and RT.dp is None and RT.overlap) else 0
+        if mode:
+            cur = torch.cuda.current_stream(dc.device)
+            if mode == 3:
+                # only while the budget lasts: hand over about as much as balances the two chains
+                ent = _DEFERRED.get(cur.cuda_stream)
+                if not RT.is_side(cur) and (ent is None or len(ent[1]) < RT.wgrad_side_budget):
+                    _defer_param_grads(cur, item)
+                    return
+            elif mode == 2 or not RT.is_side(cur):
+                _defer_param_grads(cur, item)
+                return
+        _run_param_grads(*item)
 
 
 def bn_tensors(bn):
@@ -220,7 +272,7 @@ def bwd_pool_reset(device):
 
 def _bn_bwd(dout, y, c, bn, st, H, W, relu=True, fold=False, g_out=None):
     dc = torch.empty_like(c)
-    sums = _BWD_POOLS[(c.device, torch.cuda.current_stream(c.device).cuda_stream)].take(c.shape[-1])
+    sums = _BWD_POOLS[(c.device, torch.cuda.current_stream(c.device).cuda_stream)].take(c.shape[-1], st.groups)
     ops.bn_backward(dout, y, c, bn.weight.data, st, dc, grad_of(bn.weight), grad_of(bn.bias), H, W, relu=relu,
                     fold=fold, g_out=g_out, sums=sums, sums_zeroed=True,
                     allreduce=(RT.dp.allreduce_small if RT.dp is not None else None))
@@ -262,22 +314,28 @@ class ResNetRunner:
         op = cl.ready(x.dtype, x.device)
         N, H, W, _ = x.shape
         Ho, Wo = op.out_hw(H, W)
-        stats = self.pool.take(op.Co_p) if train else None
-        c = op.forward(x, stats=stats)
+        G = self.groups if train else 1
+        stats = self.pool.take(op.Co_p, G) if train else None
+        c = op.forward(x, stats=stats, stat_groups=G)
         world = _dp_stats(stats) if train else 1
         y = torch.empty(N, Ho, Wo, op.Co_p, dtype=x.dtype, device=x.device)
-        st = ops.BnState(op.Co_p, x.device)
-        st2 = ops.BnState(op.Co_p, x.device) if ds_bn is not None else None
-        ops.bn_apply(c, stats, bn_tensors(bn), st, y, Ho, Wo, N * Ho * Wo * world, relu=relu,
+        st = ops.BnState(op.Co_p, x.device, G)
+        st2 = ops.BnState(op.Co_p, x.device, G) if ds_bn is not None else None
+        ops.bn_apply(c, stats, bn_tensors(bn), st, y, Ho, Wo, (N // G) * Ho * Wo * world, relu=relu,
                      res=(ds_c if ds_bn is not None else res), stats2=ds_stats,
-                     bn2=(bn_tensors(ds_bn) if ds_bn is not None else None), st2=st2, track=train)
+                     bn2=(bn_tensors(ds_bn) if ds_bn is not None else None), st2=st2, track=train, groups=G)
         return c, y, st, st2
 
-    def forward(self, x, train):
-        """x: NHWC [N,H,W,Ci_p] in the compute dtype.  Returns (features NHWC x5, ctx)."""
+    def forward(self, x, train, groups=1):
+        """x: NHWC [N,H,W,Ci_p] in the compute dtype.  Returns (features NHWC x5, ctx).
+        groups G > 1 (training): x stacks G independent calls of the module along N — BatchNorm statistics,
+        running-statistic updates and gradients are those of G separate calls in that order, the launches are
+        shared (the pose encoder's two image pairs run as one pass)."""
         if self.pool is None or self.pool.buf.device != x.device:
             self.pool = StatsPool(x.device)
         self.pool.reset()
+        self.groups = groups if train else 1
+        assert x.shape[0] % self.groups == 0
         if train:
             _check_train_bn(self.m.bn1, "ResNet")
         ctx = {"x": x, "blocks": []}
@@ -298,8 +356,8 @@ class ResNetRunner:
                     else:
                         if ds is not None:
                             dop = ds[0].ready(cur.dtype, cur.device)
-                            dstats = self.pool.take(dop.Co_p) if train else None
-                            c_ds = dop.forward(cur, stats=dstats)
+                            dstats = self.pool.take(dop.Co_p, self.groups) if train else None
+                            c_ds = dop.forward(cur, stats=dstats, stat_groups=self.groups)
                             if train:
                                 _dp_stats(dstats)
                             c, y, st, st2 = self._unit_fwd(cl, bn, inp, train, ds_c=c_ds, ds_stats=dstats, ds_bn=ds[1])
@@ -366,7 +424,8 @@ class ResNetRunner:
         dc0 = _bn_bwd(d0, y0, ctx["c0"], self.m.bn1, ctx["st0"], y0.shape[1], y0.shape[2], relu=True)
         op = self.stem.ready(y0.dtype, y0.device)
         self.stem.accumulate_param_grads(op, dc0, ctx["x"])
-        join_companions()
+        if RT.wgrad_streams != 3:
+            flush_deferred(torch.cuda.current_stream())
 
 
 # ==============================================================================================
@@ -479,7 +538,8 @@ class DepthDecoderRunner:
                 op0.dgrad(dc0, h, w, out=interior, addend=interior)
             else:
                 gfeats[4] = op0.dgrad(dc0, h, w)
-        join_companions()
+        if RT.wgrad_streams != 3:
+            flush_deferred(torch.cuda.current_stream())
         return gfeats
 
 
@@ -517,5 +577,6 @@ class PoseDecoderRunner:
             self.cl[j].accumulate_param_grads(op, d, xin)
             # gradient w.r.t. the input activation, masked by the producing ReLU (none for the encoder feature)
             d = op.dgrad(d, xin.shape[1], xin.shape[2], mask=(xin if j > 0 else None))
-        join_companions()
+        if RT.wgrad_streams != 3:
+            flush_deferred(torch.cuda.current_stream())
         return d

@@ -17,8 +17,17 @@ class _Runtime:
         # run the pose chain on a second HIP stream next to the depth chain (they are independent until the
         # loss): measured, ~40 % of the GPU idles in kernel boundaries / tails of the many small launches
         self.overlap = os.environ.get("FSNET_AMD_OVERLAP", "1") != "0"
-        # weight gradients on companion streams (costs host time: events + stream switches per layer)
-        self.wgrad_streams = os.environ.get("FSNET_AMD_WGRAD_STREAMS", "0") != "0"
+        # weight gradients feed nothing downstream in the backward pass: 0 = inline on the chain stream,
+        # 1 = the main (depth) chain hands them to a companion stream in batches of `wgrad_flush` layers,
+        # 2 = every chain does.  Cross-stream edges are not free (host time eagerly, barrier packets in a
+        # hipGraph), hence batches rather than one fork per layer.
+        self.wgrad_streams = int(os.environ.get("FSNET_AMD_WGRAD_STREAMS", "0"))
+        self.wgrad_flush = int(os.environ.get("FSNET_AMD_WGRAD_FLUSH", "8"))
+        # 3 = the first `wgrad_side_budget` weight gradients of the main chain's backward (the decoder's, then
+        # the encoder's deepest stages) run at the tail of the pose chain's stream, which finishes earlier
+        self.wgrad_side_budget = int(os.environ.get("FSNET_AMD_WGRAD_SIDE_BUDGET", "12"))
+        # the pose encoder's image pairs as one stacked pass with per-pair BatchNorm statistics
+        self.batch_pose_pairs = os.environ.get("FSNET_AMD_BATCH_POSE", "1") != "0"
         self._side = {}
 
     def side_stream(self, device):
@@ -27,14 +36,19 @@ class _Runtime:
             s = self._side[device] = torch.cuda.Stream(device=device)
         return s
 
-    def companion_stream(self, device):
-        """stream that runs weight-gradient kernels next to the chain stream that is current now"""
-        cur = torch.cuda.current_stream(device)
+    def companion_stream(self, device, cur=None):
+        """stream that runs weight-gradient kernels next to the chain stream `cur` (default: the current one)"""
+        if cur is None:
+            cur = torch.cuda.current_stream(device)
         key = (device, cur.cuda_stream, "wgrad")
         s = self._side.get(key)
         if s is None:
             s = self._side[key] = torch.cuda.Stream(device=device)
         return cur, s
+
+    def is_side(self, stream):
+        s = self._side.get(stream.device)
+        return s is not None and s.cuda_stream == stream.cuda_stream
 
     def set_compute_dtype(self, dtype):
         if isinstance(dtype, str):

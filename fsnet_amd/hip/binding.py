@@ -27,6 +27,7 @@ class FsConvArgs(C.Structure):
         ("M", C.c_int32), ("Co", C.c_int32), ("Co_p", C.c_int32), ("nchunks", C.c_int32), ("kg", C.c_int32),
         ("hb_mul", C.c_int32), ("hb_add", C.c_int32), ("sgn", C.c_int32), ("dshift", C.c_int32),
         ("relu", C.c_int32), ("out_f32", C.c_int32), ("N", C.c_int32), ("Cs", C.c_int32),
+        ("stat_group_rows", C.c_int32),
     ]
 
 
@@ -65,7 +66,7 @@ class FsBnApplyArgs(C.Structure):
         ("count", C.c_double), ("eps", C.c_float), ("momentum", C.c_float),
         ("yN", C.c_int64), ("yH", C.c_int64), ("yW", C.c_int64),
         ("M", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-        ("relu", C.c_int32), ("pad_out", C.c_int32),
+        ("relu", C.c_int32), ("pad_out", C.c_int32), ("groups", C.c_int32),
     ]
 
 
@@ -79,7 +80,7 @@ class FsBnBwdArgs(C.Structure):
         ("gN", C.c_int64), ("gH", C.c_int64), ("gW", C.c_int64),
         ("yN", C.c_int64), ("yH", C.c_int64), ("yW", C.c_int64),
         ("M", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-        ("relu", C.c_int32), ("fold", C.c_int32),
+        ("relu", C.c_int32), ("fold", C.c_int32), ("groups", C.c_int32),
     ]
 
 

@@ -23,19 +23,20 @@ class LaunchProfile:
     def end(cls):
         cls.active = False
         torch.cuda.synchronize()
-        out = [(k, f, s.elapsed_time(e) * 1e-3) for (k, f, s, e) in cls.records]
+        out = [(k, f, s.elapsed_time(e) * 1e-3) for (k, f, s, e, _) in cls.records]
+        cls.tagged = [(k, f, s.elapsed_time(e) * 1e-3, t) for (k, f, s, e, t) in cls.records]
         cls.records = []
         return out
 
 
-def _timed(kind, flops, fn):
+def _timed(kind, flops, fn, tag=None):
     if not LaunchProfile.active:
         return fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     r = fn()
     e.record()
-    LaunchProfile.records.append((kind, flops, s, e))
+    LaunchProfile.records.append((kind, flops, s, e, tag() if callable(tag) else tag))
     return r
 
 
@@ -175,13 +176,26 @@ class ConvOp:
         return Ho, Wo
 
     # ------------------------------------------------------------------
-    def forward(self, x, out=None, bias=None, addend=None, stats=None, relu=False, out_f32=False):
+    def forward(self, x, out=None, bias=None, addend=None, stats=None, relu=False, out_f32=False, stat_groups=1):
+        """stat_groups G > 1: the batch is G stacked BatchNorm invocations; stats is [G][SLOTS][2][Co]."""
         N, H, W, Cs = x.shape
         assert Cs == self.Ci_p and x.dtype == self.dtype, (x.shape, self.Ci_p, x.dtype)
         Ho, Wo = self.out_hw(H, W)
         if out is None:
             out = torch.empty(N, Ho, Wo, self.Co_p, dtype=torch.float32 if out_f32 else self.dtype,
                               device=x.device)
+        halo = self.halo_f and USE_HALO
+        group_rows = 0
+        if stats is not None and stat_groups > 1:
+            assert N % stat_groups == 0 and addend is None
+            n = N // stat_groups
+            group_rows = n * Ho * Wo
+            if not halo and group_rows % 256 != 0:
+                # a pixel tile of the implicit-GEMM kernel could straddle two groups: one launch per group
+                for g in range(stat_groups):
+                    self.forward(x[g * n:(g + 1) * n], out=out[g * n:(g + 1) * n], bias=bias, stats=stats[g],
+                                 relu=relu, out_f32=out_f32)
+                return out
         a = FsConvArgs()
         a.src, a.wgt, a.dst = x.data_ptr(), self.w_f.data_ptr(), out.data_ptr()
         a.bias = bias.data_ptr() if bias is not None else None
@@ -199,10 +213,11 @@ class ConvOp:
         a.hb_mul, a.hb_add, a.sgn, a.dshift = self.stride, -self.pad, 1, 0
         a.relu, a.out_f32 = int(relu), int(out_f32)
         a.N, a.Cs = N, self.Ci_p
+        a.stat_group_rows = group_rows
         flops = 2.0 * a.M * self.Co * self.R * self.S * self.Ci
-        halo = self.halo_f and USE_HALO
         fn = lib.fs_conv3x3_halo if halo else lib.fs_conv_igemm
-        _timed("conv3x3_halo" if halo else "conv_igemm", flops, lambda: check(fn(C.byref(a), self.code, stream_ptr()), "conv_fwd"))
+        _timed("conv3x3_halo" if halo else "conv_igemm", flops, lambda: check(fn(C.byref(a), self.code, stream_ptr()), "conv_fwd"),
+               tag=lambda: "fwd  %s x[%d,%d,%d,%d]" % (self.describe(), N, x.shape[1], x.shape[2], x.shape[3]))
         return out
 
     def dgrad(self, dy, H, W, out=None, addend=None, mask=None):
@@ -233,8 +248,12 @@ class ConvOp:
         flops = 2.0 * N * Ho * Wo * self.Co * self.R * self.S * self.Ci
         halo = self.halo_d and USE_HALO
         fn = lib.fs_conv3x3_halo if halo else lib.fs_conv_igemm
-        _timed("conv3x3_halo" if halo else "conv_igemm", flops, lambda: check(fn(C.byref(a), self.code, stream_ptr()), "conv_dgrad"))
+        _timed("conv3x3_halo" if halo else "conv_igemm", flops, lambda: check(fn(C.byref(a), self.code, stream_ptr()), "conv_dgrad"),
+               tag=lambda: "dgrd %s dy[%d,%d,%d,%d]" % (self.describe(), N, Ho, Wo, Cd))
         return out
+
+    def describe(self):
+        return "%dx%d/s%d p%d %d->%d" % (self.R, self.S, self.stride, self.pad, self.Ci, self.Co)
 
     def wgrad(self, dy, x, dw):
         """accumulates into dw (fp32 OIHW [Co,Ci,R,S]); dy must be dense [N,Ho,Wo,Co_p]."""
@@ -252,5 +271,6 @@ class ConvOp:
         a.workspace, a.workspace_elems = ws.data_ptr(), ws.numel()
         a.x_bytes, a.use_halo = _span_bytes(x), int(USE_HALO)
         flops = 2.0 * a.M * self.Co * self.R * self.S * self.Ci
-        _timed("conv_wgrad", flops, lambda: check(lib.fs_conv_wgrad(C.byref(a), self.code, stream_ptr()), "conv_wgrad"))
+        _timed("conv_wgrad", flops, lambda: check(lib.fs_conv_wgrad(C.byref(a), self.code, stream_ptr()), "conv_wgrad"),
+               tag=lambda: "wgrd %s dy[%d,%d,%d,%d]" % (self.describe(), N, Ho, Wo, Cd))
         return dw

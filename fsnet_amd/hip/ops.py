@@ -16,7 +16,7 @@ def _p(t):
     return t.data_ptr() if t is not None else None
 
 
-def nchw_to_nhwc(a, b, cp, dtype):
+def nchw_to_nhwc(a, b, cp, dtype, out=None):
     """a (and optionally b, concatenated along C): NCHW fp32 -> NHWC [N,H,W,cp] in `dtype`."""
     a = a.contiguous()
     N, Ca, H, W = a.shape
@@ -24,7 +24,9 @@ def nchw_to_nhwc(a, b, cp, dtype):
     if b is not None:
         b = b.contiguous()
         Cb = b.shape[1]
-    out = torch.empty(N, H, W, cp, dtype=dtype, device=a.device)
+    if out is None:
+        out = torch.empty(N, H, W, cp, dtype=dtype, device=a.device)
+    assert out.shape == (N, H, W, cp) and out.is_contiguous() and out.dtype == dtype
     check(lib.fs_nchw_to_nhwc(a.data_ptr(), _p(b), out.data_ptr(), N, Ca, Cb, H, W, cp, dtype_code(dtype),
                               stream_ptr()), "nchw_to_nhwc")
     return out
@@ -32,18 +34,22 @@ def nchw_to_nhwc(a, b, cp, dtype):
 
 class BnState:
     """Device-side state of one BatchNorm invocation (saved for backward)."""
-    __slots__ = ("mean", "invstd", "count")
+    __slots__ = ("mean", "invstd", "count", "groups")
 
-    def __init__(self, C, device):
-        self.mean = torch.empty(C, dtype=torch.float32, device=device)
-        self.invstd = torch.empty(C, dtype=torch.float32, device=device)
-        self.count = 0.0
+    def __init__(self, C, device, groups=1):
+        self.mean = torch.empty(groups * C, dtype=torch.float32, device=device)
+        self.invstd = torch.empty(groups * C, dtype=torch.float32, device=device)
+        self.count = 0.0          # rows per statistics group (x world size)
+        self.groups = groups
 
 
 def bn_apply(x, stats, bn, st, y, H, W, count, relu=True, pad_out=False, res=None, stats2=None, bn2=None, st2=None,
-             track=True):
-    """x: dense [N,H,W,C] raw conv output.  bn/bn2: dict(weight,bias,running_mean,running_var,nbt)."""
+             track=True, groups=1):
+    """x: dense [N,H,W,C] raw conv output.  bn/bn2: dict(weight,bias,running_mean,running_var,nbt).
+    groups G > 1: G stacked invocations of the module (count is per group; stats are [G][SLOTS][2][C])."""
     a = FsBnApplyArgs()
+    a.groups = groups
+    assert st.groups == groups and (st2 is None or st2.groups == groups)
     Cc = x.shape[-1]
     a.x, a.res, a.y = x.data_ptr(), _p(res), y.data_ptr()
     a.stats, a.stats2 = _p(stats), _p(stats2)
@@ -66,7 +72,10 @@ def bn_apply(x, stats, bn, st, y, H, W, count, relu=True, pad_out=False, res=Non
     a.yN, a.yH, a.yW = y.stride(0), y.stride(1), y.stride(2)
     a.M, a.C, a.H, a.W = x.shape[0] * H * W, Cc, H, W
     a.relu, a.pad_out = int(relu), int(pad_out)
-    check(lib.fs_bn_apply(C.byref(a), dtype_code(x.dtype), stream_ptr()), "bn_apply")
+    nb = x.numel() * x.element_size() * (2 + (res is not None))
+    _timed("bn_apply", nb, lambda: check(lib.fs_bn_apply(C.byref(a), dtype_code(x.dtype), stream_ptr()), "bn_apply"),
+           tag=lambda: "[%d,%d,%d,%d]%s%s" % (x.shape[0], H, W, Cc, " +res" if res is not None else "",
+                                              " pad" if pad_out else ""))
     return y
 
 
@@ -77,7 +86,7 @@ def bn_backward(dout, y, x, gamma, st, dx, dgamma, dbeta, H, W, relu=True, fold=
     Cc = x.shape[-1]
     a = FsBnBwdArgs()
     if sums is None:
-        sums = torch.zeros(STAT_SLOTS, 2, Cc, dtype=torch.float64, device=x.device)
+        sums = torch.zeros(st.groups * STAT_SLOTS, 2, Cc, dtype=torch.float64, device=x.device)
     elif not sums_zeroed:
         sums.zero_()
     a.dout, a.y, a.x, a.dx, a.g_out = dout.data_ptr(), _p(y), x.data_ptr(), dx.data_ptr(), _p(g_out)
@@ -85,18 +94,23 @@ def bn_backward(dout, y, x, gamma, st, dx, dgamma, dbeta, H, W, relu=True, fold=
     a.gamma, a.save_mean, a.save_invstd = gamma.data_ptr(), st.mean.data_ptr(), st.invstd.data_ptr()
     a.dgamma, a.dbeta = _p(dgamma), _p(dbeta)
     a.count = st.count
+    a.groups = st.groups
     a.gN, a.gH, a.gW = dout.stride(0), dout.stride(1), dout.stride(2)
     if y is not None:
         a.yN, a.yH, a.yW = y.stride(0), y.stride(1), y.stride(2)
     a.M, a.C, a.H, a.W = x.shape[0] * H * W, Cc, H, W
     a.relu, a.fold = int(relu), int(fold)
     code = dtype_code(x.dtype)
-    check(lib.fs_bn_bwd_reduce(C.byref(a), code, stream_ptr()), "bn_bwd_reduce")
+    nb = x.numel() * x.element_size()
+    shp = lambda: "[%d,%d,%d,%d]%s" % (x.shape[0], H, W, Cc, " fold" if fold else "")
+    _timed("bn_bwd_reduce", nb * (2 + (y is not None)),
+           lambda: check(lib.fs_bn_bwd_reduce(C.byref(a), code, stream_ptr()), "bn_bwd_reduce"), tag=shp)
     if allreduce is not None:
         local = sums.clone()
         a.sums_local = local.data_ptr()
         allreduce(sums)
-    check(lib.fs_bn_bwd_apply(C.byref(a), code, stream_ptr()), "bn_bwd_apply")
+    _timed("bn_bwd_apply", nb * (3 + (y is not None) + (g_out is not None)),
+           lambda: check(lib.fs_bn_bwd_apply(C.byref(a), code, stream_ptr()), "bn_bwd_apply"), tag=shp)
     return dx
 
 
@@ -105,16 +119,18 @@ def maxpool_fwd(x):
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     y = torch.empty(N, Ho, Wo, Cc, dtype=x.dtype, device=x.device)
     idx = torch.empty(N, Ho, Wo, Cc, dtype=torch.uint8, device=x.device)
-    check(lib.fs_maxpool_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr(), N, H, W, Cc, dtype_code(x.dtype),
-                             stream_ptr()), "maxpool_fwd")
+    _timed("maxpool_fwd", x.numel() * x.element_size() * 1.25 + idx.numel(),
+           lambda: check(lib.fs_maxpool_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr(), N, H, W, Cc, dtype_code(x.dtype),
+                                            stream_ptr()), "maxpool_fwd"), tag=str(tuple(x.shape)))
     return y, idx
 
 
 def maxpool_bwd(dy, idx, H, W, addend=None):
     N, Ho, Wo, Cc = dy.shape
     dx = torch.empty(N, H, W, Cc, dtype=dy.dtype, device=dy.device)
-    check(lib.fs_maxpool_bwd(dy.data_ptr(), idx.data_ptr(), _p(addend), dx.data_ptr(), N, H, W, Cc,
-                             dtype_code(dy.dtype), stream_ptr()), "maxpool_bwd")
+    _timed("maxpool_bwd", dx.numel() * dx.element_size() * (1.25 + (addend is not None)) + idx.numel(),
+           lambda: check(lib.fs_maxpool_bwd(dy.data_ptr(), idx.data_ptr(), _p(addend), dx.data_ptr(), N, H, W, Cc,
+                                            dtype_code(dy.dtype), stream_ptr()), "maxpool_bwd"), tag=str(tuple(dx.shape)))
     return dx
 
 
@@ -122,8 +138,9 @@ def upcat_pad_fwd(a, b):
     N, h, w, Ca = a.shape
     Cb = b.shape[3] if b is not None else 0
     out = torch.empty(N, 2 * h + 2, 2 * w + 2, Ca + Cb, dtype=a.dtype, device=a.device)
-    check(lib.fs_upcat_pad_fwd(a.data_ptr(), _p(b), out.data_ptr(), N, h, w, Ca, Cb, dtype_code(a.dtype),
-                               stream_ptr()), "upcat_pad_fwd")
+    _timed("upcat_pad_fwd", (a.numel() + (b.numel() if b is not None else 0) + out.numel()) * a.element_size(),
+           lambda: check(lib.fs_upcat_pad_fwd(a.data_ptr(), _p(b), out.data_ptr(), N, h, w, Ca, Cb, dtype_code(a.dtype),
+                                              stream_ptr()), "upcat_pad_fwd"), tag=str(tuple(out.shape)))
     return out
 
 
@@ -131,8 +148,10 @@ def upcat_pad_bwd(dpad, h, w, Ca, Cb):
     N = dpad.shape[0]
     da = torch.empty(N, h, w, Ca, dtype=dpad.dtype, device=dpad.device)
     db = torch.empty(N, 2 * h, 2 * w, Cb, dtype=dpad.dtype, device=dpad.device) if Cb else None
-    check(lib.fs_upcat_pad_bwd(dpad.data_ptr(), da.data_ptr(), _p(db), N, h, w, Ca, Cb, dtype_code(dpad.dtype),
-                               stream_ptr()), "upcat_pad_bwd")
+    _timed("upcat_pad_bwd", (da.numel() + (db.numel() if db is not None else 0) + dpad.numel()) * da.element_size(),
+           lambda: check(lib.fs_upcat_pad_bwd(dpad.data_ptr(), da.data_ptr(), _p(db), N, h, w, Ca, Cb,
+                                              dtype_code(dpad.dtype), stream_ptr()), "upcat_pad_bwd"),
+           tag=str(tuple(dpad.shape)))
     return da, db
 
 
@@ -140,8 +159,9 @@ def channel_sum(x, out, creal):
     """out[c] += sum over rows of dense x [..., C]."""
     Cc = x.shape[-1]
     M = x.numel() // Cc
-    check(lib.fs_channel_sum(x.data_ptr(), out.data_ptr(), M, Cc, creal, dtype_code(x.dtype), stream_ptr()),
-          "channel_sum")
+    _timed("channel_sum", x.numel() * x.element_size(),
+           lambda: check(lib.fs_channel_sum(x.data_ptr(), out.data_ptr(), M, Cc, creal, dtype_code(x.dtype),
+                                            stream_ptr()), "channel_sum"), tag=str(tuple(x.shape)))
 
 
 def depth_head_fwd(logits, bins, K, min_depth, max_depth):

@@ -53,9 +53,18 @@ class MonoDepthMeta(_HipMetaArch):
         self._post_init(kwargs)
 
     def _pose_chain(self, data, image_0, outputs):
-        for f_i in self.train_cfg.frame_ids[1:]:
-            pair = (data[('image', f_i)], image_0) if f_i < 0 else (image_0, data[('image', f_i)])
-            if hasattr(self.pose_backbone, "forward_pair"):
+        fids = list(self.train_cfg.frame_ids[1:])
+        pairs = [(data[('image', f_i)], image_0) if f_i < 0 else (image_0, data[('image', f_i)]) for f_i in fids]
+        stacked = None
+        if RT.batch_pose_pairs and len(pairs) > 1 and hasattr(self.pose_backbone, "forward_pairs"):
+            # one encoder pass over all pairs, BatchNorm statistics per pair (= separate calls, in this order)
+            stacked = self.pose_backbone.forward_pairs(pairs)
+            B = image_0.shape[0]
+        for k, f_i in enumerate(fids):
+            pair = pairs[k]
+            if stacked is not None:
+                pose_feats = [[f[k * B:(k + 1) * B] for f in stacked]]
+            elif hasattr(self.pose_backbone, "forward_pair"):
                 pose_feats = [self.pose_backbone.forward_pair(*pair)]
             else:
                 pose_feats = [self.pose_backbone(torch.cat(pair, 1))]

@@ -54,9 +54,9 @@ def nhwc_dense(t, dtype):
 
 class _ResNetFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mod, x, *params):
+    def forward(ctx, mod, x, groups, *params):
         ctx.set_materialize_grads(False)
-        feats, c = mod._runner.forward(x, train=True)
+        feats, c = mod._runner.forward(x, train=True, groups=groups)
         ctx.mod, ctx.c, ctx.dtype = mod, c, x.dtype
         mod._pending += 1
         return tuple(f.permute(0, 3, 1, 2) for f in feats)
@@ -70,7 +70,7 @@ class _ResNetFn(torch.autograd.Function):
         mod._pending -= 1
         if mod._pending == 0 and RT.dp is not None:
             RT.dp.grads_ready(mod)
-        return (None, None) + (None,) * len(mod._plist)
+        return (None, None, None) + (None,) * len(mod._plist)
 
 
 class ResNet(nn.Module):
@@ -149,13 +149,13 @@ class ResNet(nn.Module):
                 layer.eval()
 
     # ---------------------------------------------------------------- execution
-    def _run(self, x):
+    def _run(self, x, groups=1):
         if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
             if self._plist is None:
                 self._plist = list(self.parameters())
-            return list(_ResNetFn.apply(self, x, *self._plist))
+            return list(_ResNetFn.apply(self, x, groups, *self._plist))
         with torch.no_grad():
-            feats, _ = self._runner.forward(x, train=self.bn1.training)
+            feats, _ = self._runner.forward(x, train=self.bn1.training, groups=groups)
         return [f.permute(0, 3, 1, 2) for f in feats]
 
     def forward(self, img_batch):
@@ -168,6 +168,20 @@ class ResNet(nn.Module):
         require_gpu(a, "ResNet.forward_pair")
         op = self._runner.stem.ready(RT.compute_dtype, a.device)
         return self._run(ops.nchw_to_nhwc(a.float(), b.float(), op.Ci_p, RT.compute_dtype))
+
+
+    def forward_pairs(self, pairs):
+        """[(a0, b0), (a1, b1), ...] -> features of the stacked batch [G*N, ...]: numerically G separate
+        forward_pair calls in list order (per-call BatchNorm batch statistics and running-statistic updates),
+        executed as ONE pass — half the launches of the pose encoder and twice the rows per launch."""
+        a0 = pairs[0][0]
+        require_gpu(a0, "ResNet.forward_pairs")
+        op = self._runner.stem.ready(RT.compute_dtype, a0.device)
+        G, N = len(pairs), a0.shape[0]
+        x = torch.empty(G * N, a0.shape[2], a0.shape[3], op.Ci_p, dtype=RT.compute_dtype, device=a0.device)
+        for g, (a, b) in enumerate(pairs):
+            ops.nchw_to_nhwc(a.float(), b.float(), op.Ci_p, RT.compute_dtype, out=x[g * N:(g + 1) * N])
+        return self._run(x, groups=G)
 
 
 _DEPTHS = {18: (BasicBlock, [2, 2, 2, 2]), 34: (BasicBlock, [3, 4, 6, 3]), 50: (Bottleneck, [3, 4, 6, 3]),

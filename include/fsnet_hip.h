@@ -77,6 +77,9 @@ typedef struct FsConvArgs {
   int32_t out_f32;      /* store fp32 regardless of dtype */
   int32_t N;            /* batch size (fs_conv3x3_halo) */
   int32_t Cs;           /* source channels per tap (fs_conv3x3_halo) */
+  int32_t stat_group_rows; /* 0: one statistics group.  >0: rows (pixels) per BatchNorm statistics group; row m
+                              adds to stats + (m / stat_group_rows) * FS_STAT_SLOTS*2*Co.  Groups are whole
+                              images and, for fs_conv_igemm, stat_group_rows % 256 == 0 (no tile straddles). */
 } FsConvArgs;
 int fs_conv_igemm(const FsConvArgs* args, int dtype, void* stream);
 
@@ -168,6 +171,10 @@ typedef struct FsBnApplyArgs {
   int64_t yN, yH, yW;
   int32_t M, C, H, W;
   int32_t relu, pad_out;
+  int32_t groups;       /* 0/1: one batch.  G>1: the batch is G independent BatchNorm invocations stacked along N
+                           (the pose encoder's two image pairs, monodepth2_model.py:29-35): statistics, save_mean /
+                           save_invstd are [G][...], count is per group, running statistics are updated G times
+                           in group order. */
 } FsBnApplyArgs;
 int fs_bn_apply(const FsBnApplyArgs* args, int dtype, void* stream);
 
@@ -189,6 +196,7 @@ typedef struct FsBnBwdArgs {
   int64_t yN, yH, yW;
   int32_t M, C, H, W;
   int32_t relu, fold;
+  int32_t groups;       /* as FsBnApplyArgs.groups: sums / save_mean / save_invstd are [G][...]; dgamma, dbeta add up */
 } FsBnBwdArgs;
 int fs_bn_bwd_reduce(const FsBnBwdArgs* args, int dtype, void* stream);
 int fs_bn_bwd_apply(const FsBnBwdArgs* args, int dtype, void* stream);
