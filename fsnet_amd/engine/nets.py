@@ -27,7 +27,8 @@ class StatsPool:
         self.off = 0
 
     def reset(self):
-        self.buf.zero_()
+        if self.off:
+            self.buf[:self.off].zero_()     # everything beyond the bump pointer was never handed out: still zero
         self.off = 0
 
     def take(self, C, groups=1):
@@ -126,13 +127,15 @@ _PACK_REGISTRY = {}     # (dtype, device) -> [weakref to ConvLayer]: a dropped m
 _PACK_TABLES = {}       # (dtype, device, tuple of pointers) -> (device table, n, total_blocks)
 
 
-def pack_everything():
-    """all registered (dtype, device) groups — called on the main stream before work is forked to a side stream"""
+def pack_everything(arena=None):
+    """all registered (dtype, device) groups — called on the main stream before work is forked to a side stream.
+    With an arena: only the convolutions whose master weights live in it (one model's step never touches, or
+    captures pointers of, another model's layers)."""
     for key in list(_PACK_REGISTRY.keys()):
-        pack_all(key)
+        pack_all(key, arena)
 
 
-def pack_all(key):
+def pack_all(key, arena=None):
     """Re-pack the MFMA weight operands of every registered conv whose master weights changed, in ONE launch
     (fs_pack_weights_multi).  The descriptor table is cached while the pointers stay the same."""
     import ctypes as C
@@ -143,7 +146,8 @@ def pack_all(key):
     alive = [(r, r()) for r in refs]
     if any(l is None for _, l in alive):
         refs[:] = [r for r, l in alive if l is not None]
-    layers = [l for _, l in alive if l is not None and l._version() != l._packed and l.m.weight.is_cuda]
+    layers = [l for _, l in alive if l is not None and l._version() != l._packed and l.m.weight.is_cuda
+              and (arena is None or arena.owns(l.m.weight))]
     if not layers:
         return
     sig = tuple((l.m.weight.data_ptr(), l._op.w_f.data_ptr()) for l in layers)
@@ -165,8 +169,7 @@ def pack_all(key):
             blocks += (d.rows_f * d.k_f + d.rows_d * d.k_d + 255) // 256
         raw = bytes(arr)
         tab = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
-        if len(_PACK_TABLES) > 64:
-            _PACK_TABLES.clear()
+        # (never evicted: a captured hipGraph may hold the table's address; a table is ~100 B per conv)
         ent = _PACK_TABLES[(key, sig)] = (tab, len(layers), blocks)
     tab, n, blocks = ent
     check(lib.fs_pack_weights_multi(tab.data_ptr(), n, blocks, dtype_code(dtype), stream_ptr()), "pack_weights_multi")
@@ -553,7 +556,9 @@ class PoseDecoderRunner:
                    ConvLayer(module.convs[("pose", 1)]), ConvLayer(module.convs[("pose", 2)])]
 
     def forward(self, feat, invert):
-        """feat: NHWC last encoder feature.  Returns (axisangle, translation, T, ctx)."""
+        """feat: NHWC last encoder feature.  Returns (axisangle, translation, T, ctx).
+        invert may be a tuple of G flags: feat then stacks G calls of the module along N (no BatchNorm here, so
+        the convolutions simply run on the stacked batch) and the outputs are G-tuples."""
         dt, dev = feat.dtype, feat.device
         acts = [feat]
         x = feat
@@ -564,13 +569,26 @@ class PoseDecoderRunner:
         op = self.cl[3].ready(dt, dev)
         x3 = op.forward(x, bias=self.cl[3].bias, out_f32=True)
         nf = int(self.m.num_frames_to_predict_for)
-        aa, tr, T = ops.pose_tail_fwd(x3, nf, invert)
+        if isinstance(invert, tuple):
+            G = len(invert)
+            B = x3.shape[0] // G
+            outs = [ops.pose_tail_fwd(x3[g * B:(g + 1) * B], nf, invert[g]) for g in range(G)]
+            aa, tr, T = (tuple(o[i] for o in outs) for i in range(3))
+        else:
+            aa, tr, T = ops.pose_tail_fwd(x3, nf, invert)
         return aa, tr, T, {"acts": acts, "x3": x3, "invert": invert, "nf": nf}
 
     def backward(self, ctx, dT):
         acts, x3 = ctx["acts"], ctx["x3"]
         dt, dev = acts[0].dtype, acts[0].device
-        d = ops.pose_tail_bwd(x3, dT, ctx["nf"], ctx["invert"], dt)
+        if isinstance(ctx["invert"], tuple):
+            G = len(ctx["invert"])
+            B = x3.shape[0] // G
+            d = torch.empty(x3.shape, dtype=dt, device=dev)
+            for g in range(G):
+                ops.pose_tail_bwd(x3[g * B:(g + 1) * B], dT[g], ctx["nf"], ctx["invert"][g], dt, out=d[g * B:(g + 1) * B])
+        else:
+            d = ops.pose_tail_bwd(x3, dT, ctx["nf"], ctx["invert"], dt)
         for j in range(3, -1, -1):
             op = self.cl[j].ready(dt, dev)
             xin = acts[j]

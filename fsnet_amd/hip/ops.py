@@ -192,9 +192,10 @@ def pose_tail_fwd(x, nframes, invert, scale=0.01):
     return aa, tr, T
 
 
-def pose_tail_bwd(x, dT, nframes, invert, dtype, scale=0.01):
+def pose_tail_bwd(x, dT, nframes, invert, dtype, scale=0.01, out=None):
     B, h, w, Cx = x.shape
-    dx = torch.empty(B, h, w, Cx, dtype=dtype, device=x.device)
+    dx = torch.empty(B, h, w, Cx, dtype=dtype, device=x.device) if out is None else out
+    assert dx.shape == x.shape and dx.is_contiguous() and dx.dtype == dtype and x.is_contiguous()
     check(lib.fs_pose_tail_bwd(x.data_ptr(), dT.data_ptr(), dx.data_ptr(), B, h * w, Cx, nframes, int(invert),
                                float(scale), dtype_code(dtype), stream_ptr()), "pose_tail_bwd")
     return dx

@@ -63,6 +63,10 @@ class MonoDepth2Decoder(nn.Module):
         """fused (axisangle, translation, cam_T_cam): pose_decoder.py:26-45 + monodepth2_model.py:42-43."""
         return self.pose_decoder.forward_with_transform(features, invert)
 
+    def forward_pose_pairs(self, features, inverts):
+        """all image pairs of the step in one pass over the stacked pose-encoder feature"""
+        return self.pose_decoder.forward_pairs_with_transform(features, inverts)
+
     def forward_depth(self, features, *args, **kwargs):
         return self.depth_decoder(features, *args, **kwargs)
 
@@ -113,12 +117,12 @@ class MonoDepth2Decoder(nn.Module):
         losses = {}
         for k, s in enumerate(self.scales):
             losses["loss/%d" % s] = vec[k]
-            losses["smooth_loss/%d" % s] = vec[S + k].float()
+            losses["smooth_loss/%d" % s] = vec[S + k]
         # warped images / masks the reference leaves in output_dict (_generate_images_pred :98-116)
         for k, s in enumerate(self.scales):
             for j, f in enumerate((fa, fb)):
                 output_dict[("original_image", f, s)] = self._pl.pred[k, j]
-                output_dict[("overlapped_mask", f, s)] = self._pl.ov[k, j].bool()
+                output_dict[("overlapped_mask", f, s)] = self._pl.ov[k, j].view(torch.bool)   # 0/1 bytes: no kernel
         hm = {}
         if getattr(self, "is_log_image", True):
             hm["original_image"] = img0[0:1]

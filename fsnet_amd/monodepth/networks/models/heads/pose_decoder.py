@@ -36,6 +36,34 @@ class _PoseFn(torch.autograd.Function):
         return (None, d.permute(0, 3, 1, 2), None) + (None,) * ctx.nparam
 
 
+class _PosePairsFn(torch.autograd.Function):
+    """G stacked calls of the pose decoder (one per image pair) as one pass over the stacked encoder feature."""
+
+    @staticmethod
+    def forward(ctx, mod, feat, inverts, *params):
+        ctx.set_materialize_grads(False)
+        aa, tr, T, c = mod._runner.forward(nhwc_dense(feat, feat.dtype), inverts)
+        ctx.mod, ctx.c, ctx.nparam, ctx.G = mod, c, len(params), len(inverts)
+        mod._pending += 1
+        return tuple(aa) + tuple(tr) + tuple(T)
+
+    @staticmethod
+    def backward(ctx, *g):
+        mod, G = ctx.mod, ctx.G
+        if any(gi is not None for gi in g[:2 * G]):
+            raise NotImplementedError("gradients w.r.t. axisangle/translation outputs (pose_loss_weight > 0) "
+                                      "are not supported by the HIP pose decoder yet")
+        x3 = ctx.c["x3"]
+        B = x3.shape[0] // G
+        dT = [gi.contiguous().float() if gi is not None else torch.zeros(B, 4, 4, device=x3.device) for gi in g[2 * G:]]
+        d = mod._runner.backward(ctx.c, dT)
+        ctx.c = None
+        mod._pending -= 1
+        if mod._pending == 0 and RT.dp is not None:
+            RT.dp.grads_ready(mod)
+        return (None, d.permute(0, 3, 1, 2), None) + (None,) * ctx.nparam
+
+
 class PoseDecoder(nn.Module):
     def __init__(self, num_ch_enc, num_input_features, num_frames_to_predict_for=None, stride=1):
         super().__init__()
@@ -68,6 +96,22 @@ class PoseDecoder(nn.Module):
         with torch.no_grad():
             aa, tr, T, _ = self._runner.forward(nhwc_dense(feat, feat.dtype), bool(invert))
         return aa, tr, T
+
+    def forward_pairs_with_transform(self, input_features, inverts):
+        """input_features[0][-1] stacks G calls along N -> [(axisangle, translation, T) per call]."""
+        feat = input_features[0][-1]
+        require_gpu(feat, "PoseDecoder")
+        inverts = tuple(bool(i) for i in inverts)
+        G = len(inverts)
+        if torch.is_grad_enabled() and self.training:
+            if self._plist is None:
+                self._plist = list(self.parameters())
+            o = _PosePairsFn.apply(self, feat, inverts, *self._plist)
+        else:
+            with torch.no_grad():
+                aa, tr, T, _ = self._runner.forward(nhwc_dense(feat, feat.dtype), inverts)
+            o = tuple(aa) + tuple(tr) + tuple(T)
+        return [(o[g], o[G + g], o[2 * G + g]) for g in range(G)]
 
     def forward(self, input_features):
         aa, tr, _ = self.forward_with_transform(input_features, False)

@@ -35,7 +35,7 @@ class _HipMetaArch(BaseMetaArch):
         if RT.dp is not None:
             RT.dp.begin_step(self)
         from fsnet_amd.engine.nets import pack_everything
-        pack_everything()      # re-pack stale MFMA weight operands once, on the main stream, before any fork
+        pack_everything(self._arena)   # re-pack stale MFMA weight operands once, on the main stream, before any fork
 
     def dummy_forward(self, image):
         features = self.depth_backbone(image)
@@ -60,6 +60,13 @@ class MonoDepthMeta(_HipMetaArch):
             # one encoder pass over all pairs, BatchNorm statistics per pair (= separate calls, in this order)
             stacked = self.pose_backbone.forward_pairs(pairs)
             B = image_0.shape[0]
+        if stacked is not None and hasattr(self.head, "forward_pose_pairs"):
+            res = self.head.forward_pose_pairs([stacked], [f_i < 0 for f_i in fids])
+            for f_i, (axisangle, translation, T) in zip(fids, res):
+                outputs[("axisangle", f_i)] = axisangle
+                outputs[("translation", f_i)] = translation
+                outputs[("cam_T_cam", f_i)] = T
+            return
         for k, f_i in enumerate(fids):
             pair = pairs[k]
             if stacked is not None:
