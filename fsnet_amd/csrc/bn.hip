@@ -37,9 +37,12 @@ __device__ inline void bn_channel_coeffs(const double* stats, const float* rmean
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const FsBnApplyArgs p) {
-  __shared__ float s_scale[MAXC], s_shift[MAXC];
-  __shared__ float s_scale2[MAXC], s_shift2[MAXC];
+  // per-channel coefficients in dynamic LDS (4*C floats): a fixed MAXC-sized array would cap the occupancy of
+  // these bandwidth-bound kernels at 4-5 blocks per CU
+  extern __shared__ float bn_smem[];
   const int C = p.C;
+  float* s_scale = bn_smem; float* s_shift = bn_smem + C;
+  float* s_scale2 = bn_smem + 2 * C; float* s_shift2 = bn_smem + 3 * C;
   const bool has2 = p.gamma2 != nullptr;
   const bool train = p.stats != nullptr;
   // statistics groups: blockIdx.z owns the rows [z*Mg, (z+1)*Mg) and the z-th statistics / saved-state slice
@@ -236,8 +239,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const FsBnBwdArgs p)
 // pass 2: dx = gamma*invstd * (g - sum_g/count - xhat * sum_gx/count); optional g output; param grads
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const FsBnBwdArgs p) {
-  __shared__ float s_a[MAXC], s_b[MAXC], s_k[MAXC], s_mean[MAXC], s_istd[MAXC];
+  extern __shared__ float bn_smem[];
   const int C = p.C;
+  float* s_a = bn_smem; float* s_b = bn_smem + C; float* s_k = bn_smem + 2 * C;
+  float* s_mean = bn_smem + 3 * C; float* s_istd = bn_smem + 4 * C;
   const int G = p.groups > 1 ? p.groups : 1;
   const int z = blockIdx.z;
   const int Mg = p.M / G;
@@ -310,8 +315,9 @@ extern "C" int fs_bn_apply(const FsBnApplyArgs* a, int dtype, void* stream) {
   const int G = a->groups > 1 ? a->groups : 1;
   if (a->M % G != 0 || (G > 1 && !a->stats)) return FS_EINVAL;
   dim3 grid(grid_for((long)(a->M / G) * (a->C / (dtype == FS_DTYPE_BF16 ? 8 : 4))), 1, G);
-  if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16>, grid, dim3(256), 0, st, *a);
-  else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, st, *a);
+  const unsigned lds = (a->gamma2 ? 4u : 2u) * a->C * sizeof(float);
+  if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16>, grid, dim3(256), lds, st, *a);
+  else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), lds, st, *a);
   else return FS_EINVAL;
   return fs_launch_status();
 }
@@ -346,8 +352,9 @@ extern "C" int fs_bn_bwd_apply(const FsBnBwdArgs* a, int dtype, void* stream) {
   const int G = a->groups > 1 ? a->groups : 1;
   if (a->M % G != 0) return FS_EINVAL;
   dim3 grid(grid_for((long)(a->M / G) * (a->C / (dtype == FS_DTYPE_BF16 ? 8 : 4))), 1, G);
-  if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, grid, dim3(256), 0, st, *a);
-  else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, st, *a);
+  const unsigned lds = 5u * a->C * sizeof(float);
+  if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, grid, dim3(256), lds, st, *a);
+  else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), lds, st, *a);
   else return FS_EINVAL;
   return fs_launch_status();
 }

@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
   for (int a = 0; a < TC; ++a)
 #pragma unroll
     for (int j = 0; j < 4; ++j) { s1[a][j] = 0.f; s2[a][j] = 0.f; }
+  const long sgoff = p.stat_group_rows > 0 ? (long)(pix0 / p.stat_group_rows) * p.Co : 0;
 
 #pragma unroll
   for (int b = 0; b < TP; ++b) {
@@ -252,8 +253,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = mv[j] > 0.f ? v[j] : 0.f;
       }
+      if (p.bnb_x) {   // BatchNorm-backward sums of the layer this gradient flows into: (sum g, sum g*xhat)
+        float cv[4];
+        load4<T>(reinterpret_cast<const T*>(p.bnb_x) + (long)m * p.Co + co, cv);
+        const float4 mu = *reinterpret_cast<const float4*>(p.bnb_mean + sgoff + co);
+        const float4 is = *reinterpret_cast<const float4*>(p.bnb_invstd + sgoff + co);
+        s1[a][0] += v[0]; s1[a][1] += v[1]; s1[a][2] += v[2]; s1[a][3] += v[3];
+        s2[a][0] += v[0] * (cv[0] - mu.x) * is.x; s2[a][1] += v[1] * (cv[1] - mu.y) * is.y;
+        s2[a][2] += v[2] * (cv[2] - mu.z) * is.z; s2[a][3] += v[3] * (cv[3] - mu.w) * is.w;
+      } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { s1[a][j] += v[j]; s2[a][j] += v[j] * v[j]; }
+        for (int j = 0; j < 4; ++j) { s1[a][j] += v[j]; s2[a][j] += v[j] * v[j]; }
+      }
       if (p.out_f32) store4<float>(reinterpret_cast<float*>(p.dst) + doff + co, v);
       else store4<T>(reinterpret_cast<T*>(p.dst) + doff + co, v);
     }

@@ -8,6 +8,7 @@ Reference structure followed:
   DepthDecoderRunner  monodepth/networks/models/heads/depth_encoder.py:45-66,119-139
   PoseDecoderRunner   monodepth/networks/models/heads/pose_decoder.py:26-45
 """
+import os
 import weakref
 
 import torch
@@ -17,6 +18,8 @@ from ..hip.conv import ConvOp
 from .runtime import RT, grad_of
 
 STAT_SLOTS = ops.STAT_SLOTS
+# BatchNorm-backward reduction pass fused into the epilogue of the data-gradient convolution that feeds it
+FUSE_BN_BWD = os.environ.get("FSNET_AMD_FUSE_BN_BWD", "1") != "0"
 
 
 class StatsPool:
@@ -273,11 +276,19 @@ def bwd_pool_reset(device):
     return p
 
 
-def _bn_bwd(dout, y, c, bn, st, H, W, relu=True, fold=False, g_out=None):
+def _bwd_sums(c, st):
+    """zeroed f64 [groups][SLOTS][2][C] from the current stream's backward pool"""
+    return _BWD_POOLS[(c.device, torch.cuda.current_stream(c.device).cuda_stream)].take(c.shape[-1], st.groups)
+
+
+def _bn_bwd(dout, y, c, bn, st, H, W, relu=True, fold=False, g_out=None, sums=None):
+    """sums given: dout is already ReLU-masked and the sums are accumulated (fused into the producing dgrad)"""
     dc = torch.empty_like(c)
-    sums = _BWD_POOLS[(c.device, torch.cuda.current_stream(c.device).cuda_stream)].take(c.shape[-1], st.groups)
+    reduced = sums is not None
+    if sums is None:
+        sums = _bwd_sums(c, st)
     ops.bn_backward(dout, y, c, bn.weight.data, st, dc, grad_of(bn.weight), grad_of(bn.bias), H, W, relu=relu,
-                    fold=fold, g_out=g_out, sums=sums, sums_zeroed=True,
+                    fold=fold, g_out=g_out, sums=sums, sums_zeroed=True, reduced=reduced,
                     allreduce=(RT.dp.allreduce_small if RT.dp is not None else None))
     return dc
 
@@ -375,14 +386,21 @@ class ResNetRunner:
         return feats, ctx
 
     # ------------------------------------------------------------------ backward
-    def _block_bwd(self, units, ds, bctx, dout, extra):
+    def _block_bwd(self, units, ds, bctx, dout, extra, dout_sums=None, prev=None):
+        """dout: gradient w.r.t. the block output.  dout_sums: set when dout came out of a data-gradient epilogue
+        that already masked it with this block's output ReLU and accumulated the BatchNorm-backward sums.
+        prev = (y, c, BnState) of the block that consumes the returned gradient (fused the same way)."""
         x = bctx["x"]
         N, H, W, _ = x.shape
         k = len(units)
         inp, c, y, st = bctx["u"][k - 1]
         Ho, Wo = y.shape[1], y.shape[2]
-        g = torch.empty_like(c)
-        dc = _bn_bwd(dout, y, c, units[k - 1][1], st, Ho, Wo, relu=True, g_out=g)
+        if dout_sums is not None:
+            g = dout
+            dc = _bn_bwd(dout, None, c, units[k - 1][1], st, Ho, Wo, sums=dout_sums)
+        else:
+            g = torch.empty_like(c)
+            dc = _bn_bwd(dout, y, c, units[k - 1][1], st, Ho, Wo, relu=True, g_out=g)
         if ds is not None:
             c_ds, st2 = bctx["ds"]
             dop = ds[0].ready(x.dtype, x.device)
@@ -396,13 +414,23 @@ class ResNetRunner:
             cl = units[j][0]
             op = cl.ready(x.dtype, x.device)
             cl.accumulate_param_grads(op, dc, inp)
-            dy_prev = op.dgrad(dc, inp.shape[1], inp.shape[2])
+            xin = inp
             inp, c, y, st = bctx["u"][j - 1]
-            dc = _bn_bwd(dy_prev, y, c, units[j - 1][1], st, y.shape[1], y.shape[2], relu=True)
+            if FUSE_BN_BWD and op.can_fuse_bn_bwd(N, xin.shape[1], xin.shape[2], st.groups):
+                sums = _bwd_sums(c, st)
+                dy_prev = op.dgrad(dc, xin.shape[1], xin.shape[2], mask=y, bn_fuse=(c, st, sums))
+                dc = _bn_bwd(dy_prev, None, c, units[j - 1][1], st, y.shape[1], y.shape[2], sums=sums)
+            else:
+                dy_prev = op.dgrad(dc, xin.shape[1], xin.shape[2])
+                dc = _bn_bwd(dy_prev, y, c, units[j - 1][1], st, y.shape[1], y.shape[2], relu=True)
         cl = units[0][0]
         op = cl.ready(x.dtype, x.device)
         cl.accumulate_param_grads(op, dc, x)
-        return op.dgrad(dc, H, W, addend=dres)
+        if prev is not None and FUSE_BN_BWD and op.can_fuse_bn_bwd(N, H, W, prev[2].groups):
+            py, pc, pst = prev
+            sums = _bwd_sums(pc, pst)
+            return op.dgrad(dc, H, W, addend=dres, mask=py, bn_fuse=(pc, pst, sums)), sums
+        return op.dgrad(dc, H, W, addend=dres), None
 
     def backward(self, ctx, gfeats):
         """gfeats: list of 5 NHWC dense gradients (or None).  Accumulates parameter gradients."""
@@ -413,6 +441,7 @@ class ResNetRunner:
         if dout is None:
             dout = torch.zeros_like(last)
         bi = len(ctx["blocks"])
+        dsums = None
         for si in range(nst - 1, -1, -1):
             blocks = self.stages[si]
             for b in range(len(blocks) - 1, -1, -1):
@@ -421,7 +450,13 @@ class ResNetRunner:
                 extra = gfeats[si] if (b == 0 and si > 0) else None
                 if extra is not None and ds is None:
                     raise NotImplementedError("feature gradient into a block without downsample")
-                dout = self._block_bwd(units, ds, ctx["blocks"][bi], dout, extra)
+                prev = None
+                if bi > 0 and not (b == 0 and gfeats[si] is not None and ds is None):
+                    pu = ctx["blocks"][bi - 1]["u"][-1]
+                    # the consumer of the returned gradient is the previous block's output BatchNorm, unless a
+                    # feature gradient still has to be added to it first (stage boundary without downsample)
+                    prev = (pu[2], pu[1], pu[3])
+                dout, dsums = self._block_bwd(units, ds, ctx["blocks"][bi], dout, extra, dout_sums=dsums, prev=prev)
         y0 = ctx["y0"]
         d0 = ops.maxpool_bwd(dout, ctx["idx"], y0.shape[1], y0.shape[2], addend=gfeats[0])
         dc0 = _bn_bwd(d0, y0, ctx["c0"], self.m.bn1, ctx["st0"], y0.shape[1], y0.shape[2], relu=True)

@@ -27,6 +27,7 @@ class FsConvArgs(C.Structure):
         ("M", C.c_int32), ("Co", C.c_int32), ("Co_p", C.c_int32), ("nchunks", C.c_int32), ("kg", C.c_int32),
         ("hb_mul", C.c_int32), ("hb_add", C.c_int32), ("sgn", C.c_int32), ("dshift", C.c_int32),
         ("relu", C.c_int32), ("out_f32", C.c_int32), ("N", C.c_int32), ("Cs", C.c_int32),
+        ("bnb_x", C.c_void_p), ("bnb_mean", C.c_void_p), ("bnb_invstd", C.c_void_p),
         ("stat_group_rows", C.c_int32),
     ]
 

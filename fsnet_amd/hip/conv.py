@@ -220,8 +220,19 @@ class ConvOp:
                tag=lambda: "fwd  %s x[%d,%d,%d,%d]" % (self.describe(), N, x.shape[1], x.shape[2], x.shape[3]))
         return out
 
-    def dgrad(self, dy, H, W, out=None, addend=None, mask=None):
-        """dy: [N,Ho,Wo,Co_p] -> dx [N,H,W,Ci_p] (out may be a strided view; addend is summed in)."""
+    def can_fuse_bn_bwd(self, N, H, W, groups):
+        """whether dgrad(..., bn_fuse=) may carry the BatchNorm-backward sums of a [N,H,W,Ci_p] gradient"""
+        if self.Ci_p != self.Ci:
+            return False
+        if groups > 1 and not (self.halo_d and USE_HALO) and ((N // groups) * H * W) % 256 != 0:
+            return False      # an implicit-GEMM tile could straddle two statistics groups
+        return True
+
+    def dgrad(self, dy, H, W, out=None, addend=None, mask=None, bn_fuse=None):
+        """dy: [N,Ho,Wo,Co_p] -> dx [N,H,W,Ci_p] (out may be a strided view; addend is summed in).
+        bn_fuse = (c, BnState, sums): dx is the gradient w.r.t. relu(BN(c)) (+ residual): the epilogue also
+        accumulates the BatchNorm-backward sums (sum g, sum g*xhat) of that BatchNorm into `sums` (zeroed f64
+        [groups][SLOTS][2][C]), i.e. fs_bn_bwd_reduce without a launch and without re-reading g and y."""
         N, Ho, Wo, Cd = dy.shape
         assert Cd == self.Co_p and dy.dtype == self.dtype and self.need_dgrad
         if out is None:
@@ -245,6 +256,13 @@ class ConvOp:
         a.hb_mul, a.hb_add, a.sgn, a.dshift = 1, self.pad, -1, (1 if self.stride == 2 else 0)
         a.relu, a.out_f32 = 0, 0
         a.N, a.Cs = N, self.Co_p
+        if bn_fuse is not None:
+            c, st, sums = bn_fuse
+            assert c.is_contiguous() and c.shape == (N, H, W, out.shape[3]) and c.dtype == self.dtype
+            assert self.can_fuse_bn_bwd(N, H, W, st.groups)
+            a.bnb_x, a.bnb_mean, a.bnb_invstd = c.data_ptr(), st.mean.data_ptr(), st.invstd.data_ptr()
+            a.stats = sums.data_ptr()
+            a.stat_group_rows = (N // st.groups) * H * W if st.groups > 1 else 0
         flops = 2.0 * N * Ho * Wo * self.Co * self.R * self.S * self.Ci
         halo = self.halo_d and USE_HALO
         fn = lib.fs_conv3x3_halo if halo else lib.fs_conv_igemm

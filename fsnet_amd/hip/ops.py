@@ -80,14 +80,19 @@ def bn_apply(x, stats, bn, st, y, H, W, count, relu=True, pad_out=False, res=Non
 
 
 def bn_backward(dout, y, x, gamma, st, dx, dgamma, dbeta, H, W, relu=True, fold=False, g_out=None, sums=None,
-                allreduce=None, sums_zeroed=False):
+                allreduce=None, sums_zeroed=False, reduced=False):
     """Two-pass BN backward.  dout: grad w.r.t. the block output (strided view, or the padded buffer
-    when fold=True); y: saved output activation (interior view) for the ReLU mask."""
+    when fold=True); y: saved output activation (interior view) for the ReLU mask.
+    reduced=True: the first pass already happened in the epilogue of the convolution that produced dout
+    (ConvOp.dgrad(bn_fuse=...)): dout is ReLU-masked and `sums` holds (sum g, sum g*xhat)."""
+    if reduced:
+        assert sums is not None and not fold and g_out is None
+        relu, y = False, None
     Cc = x.shape[-1]
     a = FsBnBwdArgs()
     if sums is None:
         sums = torch.zeros(st.groups * STAT_SLOTS, 2, Cc, dtype=torch.float64, device=x.device)
-    elif not sums_zeroed:
+    elif not sums_zeroed and not reduced:
         sums.zero_()
     a.dout, a.y, a.x, a.dx, a.g_out = dout.data_ptr(), _p(y), x.data_ptr(), dx.data_ptr(), _p(g_out)
     a.sums = sums.data_ptr()
@@ -103,8 +108,9 @@ def bn_backward(dout, y, x, gamma, st, dx, dgamma, dbeta, H, W, relu=True, fold=
     code = dtype_code(x.dtype)
     nb = x.numel() * x.element_size()
     shp = lambda: "[%d,%d,%d,%d]%s" % (x.shape[0], H, W, Cc, " fold" if fold else "")
-    _timed("bn_bwd_reduce", nb * (2 + (y is not None)),
-           lambda: check(lib.fs_bn_bwd_reduce(C.byref(a), code, stream_ptr()), "bn_bwd_reduce"), tag=shp)
+    if not reduced:
+        _timed("bn_bwd_reduce", nb * (2 + (y is not None)),
+               lambda: check(lib.fs_bn_bwd_reduce(C.byref(a), code, stream_ptr()), "bn_bwd_reduce"), tag=shp)
     if allreduce is not None:
         local = sums.clone()
         a.sums_local = local.data_ptr()

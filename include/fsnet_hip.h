@@ -77,6 +77,12 @@ typedef struct FsConvArgs {
   int32_t out_f32;      /* store fp32 regardless of dtype */
   int32_t N;            /* batch size (fs_conv3x3_halo) */
   int32_t Cs;           /* source channels per tap (fs_conv3x3_halo) */
+  const void* bnb_x;    /* NULL: stats = (sum v, sum v^2) of the outputs (BatchNorm forward statistics).
+                           Else: the raw conv output [M][Co] (dense, src dtype) of the BatchNorm whose input
+                           gradient this launch produces, and stats = (sum v, sum v*xhat), xhat =
+                           (bnb_x - bnb_mean) * bnb_invstd: the first pass of BatchNorm backward
+                           (fs_bn_bwd_reduce) fused into the data-gradient epilogue. */
+  const float* bnb_mean; const float* bnb_invstd;   /* [groups][Co] saved statistics of that BatchNorm */
   int32_t stat_group_rows; /* 0: one statistics group.  >0: rows (pixels) per BatchNorm statistics group; row m
                               adds to stats + (m / stat_group_rows) * FS_STAT_SLOTS*2*Co.  Groups are whole
                               images and, for fs_conv_igemm, stat_group_rows % 256 == 0 (no tile straddles). */

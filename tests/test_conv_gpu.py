@@ -113,3 +113,51 @@ def test_conv_addend_relu_strided(dev):
     got = outp[:, 1:-1, 1:-1].permute(0, 3, 1, 2).cpu()
     assert (got - ref).abs().max().item() < 1e-4
     assert (outp[:, 0] == -5).all() and (outp[:, :, 0] == -5).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(64, 64, 3, 1, 1, 4, 16, 32, 1), (64, 128, 3, 2, 1, 4, 16, 32, 1),
+                                  (128, 128, 3, 1, 1, 4, 12, 20, 2), (256, 256, 3, 1, 1, 12, 6, 20, 1),
+                                  (64, 128, 3, 2, 1, 4, 32, 64, 2)])
+def test_dgrad_epilogue_carries_bn_backward_sums(dev, case, dtype):
+    """ConvOp.dgrad(mask=, addend=, bn_fuse=): masked gradient and BatchNorm-backward sums (sum g, sum g*xhat)
+    == unfused dgrad followed by fs_bn_bwd_reduce (batch_norm backward's first pass, ATen via
+    vision_base/networks/models/backbone/resnet.py:17-41)."""
+    from fsnet_amd.hip import ops
+    from fsnet_amd.hip.conv import ConvOp
+    Ci, Co, k, stride, pad, N, H, W, G = case
+    g = torch.Generator().manual_seed(7 + Ci + Co + stride)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    w = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
+    op = ConvOp(Ci, Co, k, k, stride, pad, dtype, dev, need_dgrad=True)
+    op.pack(w.to(dev).contiguous())
+    if not op.can_fuse_bn_bwd(N, H, W, G):
+        pytest.skip("shape falls back to the unfused path by design")
+    dy = torch.randn(N, Ho, Wo, Co, generator=g).to(dev).to(dtype)
+    c = torch.randn(N, H, W, Ci, generator=g).to(dev).to(dtype)             # BN input (previous conv output)
+    yact = torch.randn(N, H, W, Ci, generator=g).to(dev).to(dtype)          # its activation: the ReLU mask
+    addend = torch.randn(N, H, W, Ci, generator=g).to(dev).to(dtype)
+    st = ops.BnState(Ci, dev, G)
+    st.mean.copy_(torch.randn(G * Ci, generator=g) * 0.1)
+    st.invstd.copy_(torch.rand(G * Ci, generator=g) + 0.5)
+    st.count = float(N // G * H * W)
+    # unfused: dgrad (+addend), then the reduce pass with the ReLU mask
+    d_ref = op.dgrad(dy, H, W, addend=addend)
+    sums_ref = torch.zeros(G * 8, 2, Ci, dtype=torch.float64, device=dev)
+    dx = torch.empty_like(c)
+    gamma = torch.ones(Ci, device=dev)
+    gout = torch.empty_like(c)
+    ops.bn_backward(d_ref, yact, c, gamma, st, dx, None, None, H, W, relu=True, g_out=gout, sums=sums_ref, sums_zeroed=True)
+    # fused
+    sums = torch.zeros(G * 8, 2, Ci, dtype=torch.float64, device=dev)
+    d_fused = op.dgrad(dy, H, W, addend=addend, mask=yact, bn_fuse=(c, st, sums))
+    dx2 = torch.empty_like(c)
+    ops.bn_backward(d_fused, None, c, gamma, st, dx2, None, None, H, W, sums=sums, reduced=True)
+    torch.cuda.synchronize()
+    assert torch.equal(d_fused, gout)                      # same masked gradient, bit for bit
+    a = sums.view(G, 8, 2, Ci).sum(1).cpu()
+    b = sums_ref.view(G, 8, 2, Ci).sum(1).cpu()
+    # fused sums use the fp32 accumulator before the store rounding; the reduce pass re-reads the rounded tensor
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert float((a - b).abs().max()) <= tol * float(b.abs().max()), float((a - b).abs().max() / b.abs().max())
+    assert float((dx2.float() - dx.float()).abs().max()) <= (1e-4 if dtype == torch.float32 else 5e-2) * float(dx.float().abs().max())

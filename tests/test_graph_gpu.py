@@ -47,12 +47,13 @@ def test_graph_replay_matches_eager(dev, dtype, tie):
     # ReLU flips amplify that over steps.  Yardstick: the spread between two EAGER runs of the same thing.
     def d(a, b, rel_floor=0.0):
         return float(((a - b).abs() / a.abs().clamp_min(rel_floor)).max()) if rel_floor else float((a - b).abs().max())
-    # (bf16: one reordered atomic flips a rounding and the runs decorrelate at the 1e-3 level within a few steps,
-    # eager against eager just the same — measured with tools/probes/graph_vs_eager.py)
+    # Measured with tools/probes/graph_vs_eager.py (3 eager and 3 graph runs each): the spread is bimodal — runs agree
+    # to ~1e-5 (loss) / 5e-4 (running statistics) or, when one near-tie min-selection / ReLU decision flips on a
+    # reordered fp32 atomic, differ by ~8e-5 / 5e-3 — eager against eager just like graph against eager.
     f32 = dtype == torch.float32
-    assert d(le, lg, 1e-9) < max(5e-5 if f32 else 5e-3, 5 * d(le, l2, 1e-9)), (le, lg, l2)
-    assert d(pe, pg) < max(1e-4 if f32 else 2e-3, 5 * d(pe, p2)), (d(pe, pg), d(pe, p2))
-    assert d(re_, rg, 1.0) < max(1e-3 if f32 else 1e-2, 5 * d(re_, r2, 1.0)), (d(re_, rg, 1.0), d(re_, r2, 1.0))
+    assert d(le, lg, 1e-9) < max(3e-4 if f32 else 5e-3, 5 * d(le, l2, 1e-9)), (le, lg, l2)
+    assert d(pe, pg) < max(1e-3 if f32 else 2e-3, 5 * d(pe, p2)), (d(pe, pg), d(pe, p2))
+    assert d(re_, rg, 1.0) < max(2e-2 if f32 else 3e-2, 5 * d(re_, r2, 1.0)), (d(re_, rg, 1.0), d(re_, r2, 1.0))
     assert oe._step_count_fused == og._step_count_fused == 6
     assert int(og._step_buf.item()) == 6 and abs(float(og._lr_buf.item()) - og.param_groups[0]["lr"]) < 1e-9
 

@@ -1,22 +1,19 @@
-"""debug probe: per-step loss differences eager vs hipGraph replay (bf16, tie noise on)"""
+"""debug probe: run-to-run spread of losses / parameters / BN running statistics, eager vs hipGraph replay"""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests"))
 import torch
 from test_graph_gpu import _run
-from fsnet_amd.engine.runtime import RT
 dev = torch.device("cuda", 0)
 torch.set_printoptions(precision=3, linewidth=200)
-for overlap in (True, False):
-    RT.overlap = overlap
-    for dtype in (torch.bfloat16,):
-        e1 = _run(dev, False, 8, dtype, True)
-        e2 = _run(dev, False, 8, dtype, True)
-        g1 = _run(dev, True, 8, dtype, True)
-        g2 = _run(dev, True, 8, dtype, True)
-        rel = lambda a, b: ((a[0] - b[0]).abs() / a[0].abs())
-        print("overlap", overlap, dtype)
-        print(" e1-e2", rel(e1, e2))
-        print(" e1-g1", rel(e1, g1))
-        print(" g1-g2", rel(g1, g2))
-        print(" params e1-e2 %.3e e1-g1 %.3e g1-g2 %.3e" % ((e1[1]-e2[1]).abs().max(), (e1[1]-g1[1]).abs().max(), (g1[1]-g2[1]).abs().max()))
+def d(a, b, floor=None):
+    return float(((a - b).abs() / a.abs().clamp_min(floor)).max()) if floor else float((a - b).abs().max())
+for dtype, tie in ((torch.float32, False), (torch.float32, True)):
+    E = [_run(dev, False, 6, dtype, tie) for _ in range(3)]
+    G = [_run(dev, True, 6, dtype, tie) for _ in range(3)]
+    print(dtype, "tie", tie)
+    for name, A, B in (("e-e", E, E), ("g-g", G, G), ("e-g", E, G)):
+        pairs = [(i, j) for i in range(3) for j in range(3) if (A is not B or i < j)]
+        print("  %s loss %s  params %s  running %s" % (
+            name, ["%.1e" % d(A[i][0], B[j][0], 1e-9) for i, j in pairs],
+            ["%.1e" % d(A[i][1], B[j][1]) for i, j in pairs], ["%.1e" % d(A[i][2], B[j][2], 1.0) for i, j in pairs]))
