@@ -17,7 +17,7 @@ namespace {
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-template <typename T, int COT, int CLT, int WR>
+template <typename T, int COT, int CLT, int WR, int CH>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const FsWgradArgs p) {
   using TR = ElemTraits<T>;
   constexpr int EG = TR::EG;
@@ -25,12 +25,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const FsWgradArgs p) {
   constexpr int WROW = COT / WR, WCOL = CLT / WCn;
   constexpr int TA = WROW / 16, TB = WCOL / 16;
   constexpr int GA = COT / EG, GB = CLT / EG;  // 16-byte groups per pixel row
-  constexpr int LA = (32 * GA + 255) / 256, LB = (32 * GB + 255) / 256;
+  constexpr int LA = (CH * GA + 255) / 256, LB = (CH * GB + 255) / 256;   // CH pixels per pipeline stage
   constexpr int PADE = 16 / sizeof(T);         // row padding (elements) to spread LDS banks
   constexpr int SA = COT + PADE, SB = CLT + PADE;
 
-  __shared__ __attribute__((aligned(16))) T lds_a[2][32 * SA];
-  __shared__ __attribute__((aligned(16))) T lds_b[2][32 * SB];
+  __shared__ __attribute__((aligned(16))) T lds_a[2][CH * SA];
+  __shared__ __attribute__((aligned(16))) T lds_b[2][CH * SB];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wr = wave % WR, wcn = wave / WR;
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const FsWgradArgs p) {
   const int co0 = blockIdx.y * COT;
   const long m_begin = (long)blockIdx.z * p.pix_per_split;
   long m_end = m_begin + p.pix_per_split; if (m_end > p.M) m_end = p.M;
-  const int nch = (int)((m_end - m_begin + 31) / 32);
+  const int nch = (int)((m_end - m_begin + CH - 1) / CH);
 
   // ---- B loader state: fixed column group, pixel advancing by 32 per chunk ----
   int bc[LB], br[LB], bs[LB]; bool bval[LB];
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const FsWgradArgs p) {
     int idx = t + i * 256;
     int pix = idx / GB, g = idx % GB;
     int kg = col0 / EG + g;
-    bval[i] = (pix < 32) && (kg < p.ncolgroups);
+    bval[i] = (pix < CH) && (kg < p.ncolgroups);
     int e = bval[i] ? p.ktab[kg] : -1;
     bval[i] = bval[i] && (e >= 0);
     bc[i] = e & 0xffff; br[i] = (e >> 16) & 0xff; bs[i] = (e >> 24) & 0x7f;
@@ -67,9 +67,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const FsWgradArgs p) {
     for (int i = 0; i < LA; ++i) {
       int idx = t + i * 256;
       int pix = idx / GA, g = idx % GA;
-      long m = m_begin + (long)kc * 32 + pix;
+      long m = m_begin + (long)kc * CH + pix;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (pix < 32 && m < m_end && (co0 + g * EG) < p.Cd)
+      if (pix < CH && m < m_end && (co0 + g * EG) < p.Cd)
         v = *reinterpret_cast<const uint4*>(dy + m * p.Cd + co0 + g * EG);
       ra[i] = v;
     }
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const FsWgradArgs p) {
       }
       rb[i] = v;
       // advance this loader's pixel by one chunk
-      bm[i] += 32; bx[i] += 32;
+      bm[i] += CH; bx[i] += CH;
       while (bx[i] >= p.Wd) { bx[i] -= p.Wd; by[i] += 1; }
       while (by[i] >= p.Hd) { by[i] -= p.Hd; bn[i] += 1; }
     }
@@ -94,13 +94,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const FsWgradArgs p) {
     for (int i = 0; i < LA; ++i) {
       int idx = t + i * 256;
       int pix = idx / GA, g = idx % GA;
-      if (pix < 32) *reinterpret_cast<uint4*>(&lds_a[buf][pix * SA + g * EG]) = ra[i];
+      if (pix < CH) *reinterpret_cast<uint4*>(&lds_a[buf][pix * SA + g * EG]) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
       int idx = t + i * 256;
       int pix = idx / GB, g = idx % GB;
-      if (pix < 32) *reinterpret_cast<uint4*>(&lds_b[buf][pix * SB + g * EG]) = rb[i];
+      if (pix < CH) *reinterpret_cast<uint4*>(&lds_b[buf][pix * SB + g * EG]) = rb[i];
     }
   };
 
@@ -122,10 +122,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const FsWgradArgs p) {
       // transposed fragments: lane (li, lg) supplies the 8-byte row segment
       // [pixel lg*8 + (li>>2) (+4)][channel tile0 + (li&3)*4 ..+3] and receives channel tile0+li
       // for pixels lg*8 + {0..3} (+4).
+#pragma unroll
+     for (int ks = 0; ks < CH / 32; ++ks) {
       bf16x8 fa[TA], fb[TB];
 #pragma unroll
       for (int a = 0; a < TA; ++a) {
-        const T* base = &lds_a[buf][(lg * 8 + (li >> 2)) * SA + wr * WROW + a * 16 + (li & 3) * 4];
+        const T* base = &lds_a[buf][(ks * 32 + lg * 8 + (li >> 2)) * SA + wr * WROW + a * 16 + (li & 3) * 4];
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base));
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 4 * SA));
         uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const FsWgradArgs p) {
       }
 #pragma unroll
       for (int b = 0; b < TB; ++b) {
-        const T* base = &lds_b[buf][(lg * 8 + (li >> 2)) * SB + wcn * WCOL + b * 16 + (li & 3) * 4];
+        const T* base = &lds_b[buf][(ks * 32 + lg * 8 + (li >> 2)) * SB + wcn * WCOL + b * 16 + (li & 3) * 4];
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base));
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 4 * SB));
         uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
@@ -144,9 +146,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const FsWgradArgs p) {
 #pragma unroll
         for (int b = 0; b < TB; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+     }
     } else {
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
+      for (int kk = 0; kk < CH / 4; ++kk) {
         float fa[TA], fb[TB];
 #pragma unroll
         for (int a = 0; a < TA; ++a) fa[a] = lds_a[buf][(kk * 4 + lg) * SA + wr * WROW + a * 16 + li];
@@ -238,24 +241,28 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const FsWgradArgs p, 
 template <typename T, int COT, int CLT, int WR>
 int launch_tile(const FsWgradArgs& a, hipStream_t st) {
   constexpr int EG = ElemTraits<T>::EG;
+  // pixels per pipeline stage: every stage waits one global-load latency, so bf16 tiles that fit the LDS budget
+  // take 64 pixels (two MFMA K steps) per stage
+  constexpr int CH = (sizeof(T) == 2 && (COT + CLT) <= 192) ? 64 : 32;
   FsWgradArgs b = a;
   const int ncols = a.ncolgroups * EG;
   const int ct = (ncols + CLT - 1) / CLT, rt = (a.Cd + COT - 1) / COT;
   const long tiles = (long)ct * rt;
-  const long chunks = (a.M + 31) / 32;
-  // split the pixel (K) range until ~768 blocks are in flight, keeping >= 8 chunks per block and the
-  // partial slabs inside the caller's workspace
+  const long chunks = (a.M + CH - 1) / CH;
+  // split the pixel (K) range until ~640 blocks are in flight, keeping >= 256 pixels per block and the partial
+  // slabs inside the caller's workspace.  (Measured: fewer, longer blocks lose — every stage of the pixel loop
+  // waits one global-load latency, so the kernel wants many short chains; the slab traffic is the smaller cost.)
   long splits = (640 + tiles - 1) / tiles;
-  splits = std::min<long>(splits, std::max<long>(1, chunks / 8));
+  splits = std::min<long>(splits, std::max<long>(1, chunks / (256 / CH)));
   b.ws_rows = rt * COT; b.ws_cols = ct * CLT;
   const long slab = (long)b.ws_rows * b.ws_cols;
   if (!a.workspace) splits = 1;
   else splits = std::min<long>(splits, std::max<long>(1, a.workspace_elems / slab));
   long cps = (chunks + splits - 1) / splits;
-  b.pix_per_split = (int)(cps * 32);
+  b.pix_per_split = (int)(cps * CH);
   b.nsplit = (int)((chunks + cps - 1) / cps);
   dim3 grid(ct, rt, b.nsplit);
-  hipLaunchKernelGGL((conv_wgrad_kernel<T, COT, CLT, WR>), grid, dim3(256), 0, st, b);
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, COT, CLT, WR, CH>), grid, dim3(256), 0, st, b);
   if (b.nsplit > 1) {
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(a.Co * ((ncols + 63) / 64))), dim3(256), 0, st, b, EG);
   }
@@ -465,8 +472,16 @@ int launch_wgrad(const FsWgradArgs& a, hipStream_t st) {
   if constexpr (kBf16) {
     const int Cs = a.ncolgroups * 8 / (a.R * a.S);
     if (a.use_halo && a.R == 3 && a.S == 3 && a.stride == 1 && a.Cd % 64 == 0 && Cs % 32 == 0 && a.x_bytes > 0 &&
-        a.x_bytes <= 0x7fffffffLL && (long)a.M * a.Cd * 2 <= 0x7fffffffLL && a.M >= 4096)
+        a.x_bytes <= 0x7fffffffLL && (long)a.M * a.Cd * 2 <= 0x7fffffffLL && a.M >= 1024)
       return launch_wgrad_halo(a, st);   // (tiny pixel counts: too few tiles to split, the generic kernel wins)
+  }
+  if constexpr (kBf16) {
+    // few pixels, wide dW (deep stages, pose decoder): 128x128 tiles halve the operand re-fetch per MFMA and
+    // put 16 MFMAs per wave between barriers (the 64x64 tile: 4)
+    const int ncols = a.ncolgroups * 8;
+    if (a.Cd % 128 == 0 && ncols >= 1024 && (long)(a.Cd / 128) * ((ncols + 127) / 128) >= 96)
+      return launch_tile<T, 128, 128, 2>(a, st);
+    if (a.Cd % 64 == 0 && ncols >= 256) return launch_tile<T, 64, 128, 2>(a, st);
   }
   if (a.Cd % 64 == 0) return launch_tile<T, 64, 64, 2>(a, st);
   if (a.Cd % 32 == 0) return launch_tile<T, 32, 128, 1>(a, st);
