@@ -88,6 +88,38 @@ class MonoDepth2Decoder(nn.Module):
         if len(self.frame_ids) != 3 or "s" in self.frame_ids:
             raise NotImplementedError("the HIP loss chain handles frame_ids=[0, a, b] (two temporal source frames)")
 
+    def _loss_engine(self, img0):
+        B, _, H, W = img0.shape
+        key = (B, H, W, tuple(self.scales), img0.device)
+        if self._pl is None or self._pl_key != key:
+            self._pl = ops.PhotometricLoss(B, H, W, self.scales, img0.device, self.min_depth, self.max_depth)
+            self._pl_key = key
+        return self._pl
+
+    @staticmethod
+    def _mask64(input_dict):
+        pm = input_dict.get("patched_mask", None)
+        if pm is not None and pm.dtype != torch.float64:
+            pm = pm.double()
+        return pm.contiguous() if pm is not None else None
+
+    def prefetch_loss_inputs(self, input_dict):
+        """launch the input-only part of the loss chain (identity reprojection, colour pyramid) on the current
+        stream — the meta-arch calls this on the pose stream, off the depth chain's critical path"""
+        if len(self.frame_ids) != 3 or "s" in self.frame_ids or "motion_mask" in input_dict:
+            return
+        img0 = input_dict[("original_image", 0)]
+        if not (img0.is_cuda and img0.dtype == torch.float32 and img0.is_contiguous()):
+            return
+        fa, fb = self.frame_ids[1], self.frame_ids[2]
+        srcs = [input_dict[("original_image", fa)], input_dict[("original_image", fb)]]
+        if not all(s.dtype == torch.float32 and s.is_contiguous() for s in srcs):
+            return
+        pm = input_dict.get("patched_mask", None)
+        if pm is not None and not (pm.dtype == torch.float64 and pm.is_contiguous()):
+            return                    # a converted copy would not be the tensor loss() sees
+        self._loss_engine(img0).prefetch(img0, srcs, pm)
+
     def compute_total_reprojection_loss(self, output_dict, input_dict):
         self._check_options(input_dict)
         img0 = input_dict[("original_image", 0)]
@@ -98,16 +130,9 @@ class MonoDepth2Decoder(nn.Module):
             d = output_dict[("depth", s, s)]
             if d.shape[2] != (H >> s) or d.shape[3] != (W >> s):
                 raise NotImplementedError("depth at scale %d must be %dx%d" % (s, H >> s, W >> s))
-        key = (B, H, W, tuple(self.scales), img0.device)
-        if self._pl is None or self._pl_key != key:
-            self._pl = ops.PhotometricLoss(B, H, W, self.scales, img0.device, self.min_depth, self.max_depth)
-            self._pl_key = key
+        self._loss_engine(img0)
         fa, fb = self.frame_ids[1], self.frame_ids[2]
-        pm = input_dict.get("patched_mask", None)
-        if pm is not None and pm.dtype != torch.float64:
-            pm = pm.double()
-        if pm is not None:
-            pm = pm.contiguous()
+        pm = self._mask64(input_dict)
         depths = [output_dict[("depth", s, s)] for s in self.scales]
         disps = [output_dict[("disp", s)] for s in self.scales]
         total, vec = _PhotoLossFn.apply(self._pl, S, img0, input_dict[("original_image", fa)],

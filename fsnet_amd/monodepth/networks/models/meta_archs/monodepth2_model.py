@@ -92,6 +92,8 @@ class MonoDepthMeta(_HipMetaArch):
             side = RT.side_stream(image_0.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
+                if hasattr(self.head, "prefetch_loss_inputs"):
+                    self.head.prefetch_loss_inputs(data)      # needs only the batch: off the depth chain
                 self._pose_chain(data, image_0, pose_out)
         features = self.depth_backbone(image_0)
         outputs = self.head.forward_depth(features)
