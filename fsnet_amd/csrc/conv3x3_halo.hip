@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
   constexpr int WC = 4 / WP;
   constexpr int WPIX = PIX / WP, WCO = CO / WC;
   constexpr int TP = WPIX / 16, TC = WCO / 16;
-  constexpr int HMAX = PIX == 128 ? 208 : 120;       // halo pixels that fit the LDS budget
+  constexpr int HMAX = PIX == 256 ? 360 : (PIX == 128 ? 208 : 120);   // halo pixels that fit the LDS budget
   constexpr int LH = (HMAX * 4 + 255) / 256;         // halo 16-byte units per thread
   constexpr int LW = (9 * CO * 4 + 255) / 256;       // weight 16-byte units per thread
   constexpr int OOB = 0x7fffffff;
@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, (int)p.wgt_bytes, 0x00020000);
 
   // ---- per-thread load units (fixed over the channel walk) ----
+  const int row_bytes = p.Cs * (int)sizeof(T);     // real bytes per pixel / per tap
   int hvoff[LH], wvoff[LW];
 #pragma unroll
   for (int i = 0; i < LH; ++i) {
@@ -84,7 +85,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
     int hp = idx >> 2, q = idx & 3;
     int hy = hp / HW, hx = hp - hy * HW;
     int sy = oy + hy, sx = ox + hx;
-    bool ok = hp < nhalo && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
+    // (a 16-channel bf16 layer fills half a 64-byte chunk: the upper units stay zero, as do their weights)
+    bool ok = hp < nhalo && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws && q * 16 < row_bytes;
     hvoff[i] = ok ? (int)(((long)n * p.sN + (long)sy * p.sH + (long)sx * p.sW) * (long)sizeof(T)) + q * 16 : OOB;
   }
   const int wrow_bytes = p.nchunks * p.kg * 16;    // packed weight row stride (as packed for conv_igemm)
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
     int idx = t + i * 256;
     int q = idx & 3, rt = idx >> 2;
     int tap = rt / CO, row = rt - tap * CO;
-    wvoff[i] = (tap < 9) ? (co0 + row) * wrow_bytes + tap * tap_bytes + q * 16 : OOB;
+    wvoff[i] = (tap < 9 && q * 16 < row_bytes) ? (co0 + row) * wrow_bytes + tap * tap_bytes + q * 16 : OOB;
   }
 
   uint4 rh[LH], rw[LW];
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
 #pragma unroll
     for (int b = 0; b < TP; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nchunk = p.Cs * (int)sizeof(T) / 64;
+  const int nchunk = (p.Cs * (int)sizeof(T) + 63) / 64;
   load_regs(0);
   for (int cc = 0; cc < nchunk; ++cc) {
     __syncthreads();                 // previous chunk fully multiplied
@@ -280,7 +282,7 @@ HaloGeom pick_geom(int Hd, int Wd, int PIX, int hmax) {
 
 template <typename T, int PIX, int CO, int WP>
 int launch_halo(const FsConvArgs& a, hipStream_t st) {
-  HaloGeom g = pick_geom(a.Hd, a.Wd, PIX, PIX == 128 ? 208 : 120);
+  HaloGeom g = pick_geom(a.Hd, a.Wd, PIX, PIX == 256 ? 360 : (PIX == 128 ? 208 : 120));
   if (g.TH == 0) return FS_EINVAL;
   const int npix = a.N * g.tiles_x * g.tiles_y, nco = a.Co_p / CO;
   int blocks = npix * nco;
@@ -293,7 +295,7 @@ template <typename T>
 int dispatch(const FsConvArgs& a, hipStream_t st) {
   const int cop = a.Co_p;
   auto blocks_for = [&](int PIX, int CO) {
-    HaloGeom g = pick_geom(a.Hd, a.Wd, PIX, PIX == 128 ? 208 : 120);
+    HaloGeom g = pick_geom(a.Hd, a.Wd, PIX, PIX == 256 ? 360 : (PIX == 128 ? 208 : 120));
     return g.TH == 0 ? 0L : (long)a.N * g.tiles_x * g.tiles_y * (cop / CO);
   };
   if (cop % 64 == 0) {
@@ -301,6 +303,10 @@ int dispatch(const FsConvArgs& a, hipStream_t st) {
     return launch_halo<T, 64, 64, 2>(a, st);
   }
   if (cop % 32 == 0) return launch_halo<T, 128, 32, 4>(a, st);
+  if (cop % 16 == 0) {   // 16-channel decoder layers at 96x320 / 192x640: memory-bound, large pixel tiles
+    if (blocks_for(256, 16) >= 1024) return launch_halo<T, 256, 16, 4>(a, st);
+    return launch_halo<T, 128, 16, 4>(a, st);
+  }
   return FS_EINVAL;
 }
 
@@ -309,8 +315,10 @@ int dispatch(const FsConvArgs& a, hipStream_t st) {
 extern "C" int fs_conv3x3_halo(const FsConvArgs* args, int dtype, void* stream) {
   if (!args || !args->src || !args->wgt || !args->dst) return FS_EINVAL;
   const int es = dtype == FS_DTYPE_BF16 ? 2 : 4;
-  if (args->Cs <= 0 || (args->Cs * es) % 64 != 0 || args->dshift != 0 || args->hb_mul != 1) return FS_EINVAL;
-  if (args->Co % 4 != 0 || args->Co_p % 32 != 0 || args->N <= 0) return FS_EINVAL;
+  if (args->Cs <= 0 || (args->Cs * es) % 32 != 0 || ((args->Cs * es) % 64 != 0 && args->Cs * es != 32) ||
+      args->dshift != 0 || args->hb_mul != 1)
+    return FS_EINVAL;
+  if (args->Co % 4 != 0 || args->Co_p % 16 != 0 || args->N <= 0) return FS_EINVAL;
   if (args->src_bytes <= 0 || args->src_bytes > 0x7fffffffLL || args->wgt_bytes <= 0 ||
       args->wgt_bytes > 0x7fffffffLL)
     return FS_EINVAL;

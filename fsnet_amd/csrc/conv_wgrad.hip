@@ -426,6 +426,168 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const FsWgradArgs p,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Narrow variant for the 16-channel decoder layers (Cd = 16: dY rows are 32 bytes, dW is a few KB, the pixel
+// count is up to 1.5 M): the block owns ALL 16 output channels x 9 taps x CIT input channels, its four waves
+// split the 128-pixel tile along the reduction axis (32 pixels = one MFMA K step each) and add their partial
+// accumulators through LDS once, after the last tile.  The generic kernel spends a 16x256 tile on 144 useful
+// columns and re-gathers the input per tap: 124 us for the 192x640 16->16 layer against ~15 us of HBM time.
+// ---------------------------------------------------------------------------------------------
+template <int CIT>
+__global__ __launch_bounds__(256) void wgrad3x3_narrow_kernel(const FsWgradArgs p, const WGeom g) {
+  typedef bf16 T;
+  constexpr int COT = 16;
+  constexpr int PIXT = 128, HMAX = 208, OOB = 0x7fffffff;
+  constexpr int SA = COT + 8, SB = CIT + 8;
+  constexpr int TB = CIT / 16;
+  constexpr int UA = COT / 8, UB = CIT / 8;
+  constexpr int LA = (PIXT * UA + 255) / 256, LB = (HMAX * UB + 255) / 256;
+  constexpr int NACC = 9 * TB * 4;                       // accumulator floats per lane
+  // one arena: operand tiles during the walk, then (re-used) one wave's partial accumulators at a time
+  constexpr int OPER_BYTES = (PIXT * SA + HMAX * SB) * 2, RED_BYTES = NACC * 64 * 4;
+  __shared__ __attribute__((aligned(16))) char smem[OPER_BYTES > RED_BYTES ? OPER_BYTES : RED_BYTES];
+  T* lds_a = reinterpret_cast<T*>(smem);
+  T* lds_b = lds_a + PIXT * SA;
+  float* lds_red = reinterpret_cast<float*>(smem);
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int HW = g.TW + 2, nhalo = (g.TH + 2) * HW, ntile = g.TH * g.TW;
+  const int ci0 = blockIdx.x * CIT;
+  const int npix = g.N * g.tiles_y * g.tiles_x;
+
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.dy), 0, (int)((long)p.M * p.Cd * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+
+  int aty[LA], atx[LA], bhy[LB], bhx[LB];
+#pragma unroll
+  for (int i = 0; i < LA; ++i) {
+    int pix = (t + i * 256) / UA;
+    aty[i] = pix < ntile ? pix / g.TW : -1; atx[i] = pix < ntile ? pix % g.TW : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < LB; ++i) {
+    int hp = (t + i * 256) / UB;
+    bhy[i] = hp < nhalo ? hp / HW : -1; bhx[i] = hp < nhalo ? hp % HW : 0;
+  }
+  uint4 ra[LA], rb[LB];
+  auto load_regs = [&](int pt) {
+    int tx_i = pt % g.tiles_x; int q = pt / g.tiles_x; int ty_i = q % g.tiles_y; int n = q / g.tiles_y;
+    int y0 = ty_i * g.TH, x0 = tx_i * g.TW;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      int u = (t + i * 256) % UA;
+      int y = y0 + aty[i], x = x0 + atx[i];
+      bool ok = aty[i] >= 0 && y < p.Hd && x < p.Wd;
+      int voff = ok ? (int)((((long)n * p.Hd + y) * p.Wd + x) * p.Cd + u * 8) * 2 : OOB;
+      ra[i] = wg_buf_load16(rs_dy, voff);
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+      int u = (t + i * 256) % UB;
+      int sy = y0 - p.pad + bhy[i], sx = x0 - p.pad + bhx[i];
+      bool ok = bhy[i] >= 0 && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
+      int voff = ok ? (int)(((long)n * p.sN + (long)sy * p.sH + (long)sx * p.sW + ci0 + u * 8) * 2) : OOB;
+      rb[i] = wg_buf_load16(rs_x, voff);
+    }
+  };
+  auto store_lds = [&]() {
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      int idx = t + i * 256; int pix = idx / UA, u = idx % UA;
+      if (pix < PIXT) *reinterpret_cast<uint4*>(&lds_a[pix * SA + u * 8]) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+      int idx = t + i * 256; int hp = idx / UB, u = idx % UB;
+      if (hp < HMAX) *reinterpret_cast<uint4*>(&lds_b[hp * SB + u * 8]) = rb[i];
+    }
+  };
+
+  // this wave's K step: pixels wave*32 .. wave*32+31; lane (li, lg) supplies pixel lg*8 + (li>>2) (+4)
+  int arow[2], brow[2];
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    int pk = wave * 32 + lg * 8 + (li >> 2) + hf * 4;
+    arow[hf] = pk * SA + (li & 3) * 4;
+    int pv = pk < ntile ? pk : 0;          // (pixels past the tile hold zero dY rows)
+    brow[hf] = ((pv / g.TW) * HW + (pv % g.TW)) * SB + (li & 3) * 4;
+  }
+
+  f32x4 acc[9][TB];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int b = 0; b < TB; ++b) acc[tp][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int pt = blockIdx.z;
+  if (pt < npix) load_regs(pt);
+  for (; pt < npix; pt += g.nsplit) {
+    __syncthreads();
+    store_lds();
+    __syncthreads();
+    if (pt + g.nsplit < npix) load_regs(pt + g.nsplit);
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(&lds_a[arow[0]]));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(&lds_a[arow[1]]));
+    uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+    const bf16x8 fa = __builtin_bit_cast(bf16x8, make_uint4(l2.x, l2.y, h2.x, h2.y));
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+      const int toff = ((tp / 3) * HW + (tp % 3)) * SB;
+#pragma unroll
+      for (int b = 0; b < TB; ++b) {
+        s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(&lds_b[brow[0] + toff + b * 16]));
+        s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(&lds_b[brow[1] + toff + b * 16]));
+        uint2 bl = __builtin_bit_cast(uint2, blo), bh = __builtin_bit_cast(uint2, bhi);
+        bf16x8 fb = __builtin_bit_cast(bf16x8, make_uint4(bl.x, bl.y, bh.x, bh.y));
+        acc[tp][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[tp][b], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- the four K partials -> wave 0, one wave at a time through the (now idle) operand arena ----
+  for (int w = 1; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int b = 0; b < TB; ++b)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) lds_red[((tp * TB + b) * 4 + j) * 64 + lane] = acc[tp][b][j];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int b = 0; b < TB; ++b)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[tp][b][j] += lds_red[((tp * TB + b) * 4 + j) * 64 + lane];
+    }
+  }
+  if (wave > 0) return;
+  // ---- epilogue: D rows = co (lg*4 + j), cols = ci (li) ----
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int b = 0; b < TB; ++b) {
+      int ci = ci0 + b * 16 + li;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int co = lg * 4 + j;
+        float v = acc[tp][b][j];
+        if (g.nsplit > 1) {
+          p.workspace[((long)blockIdx.z * p.ws_rows + co) * p.ws_cols + tp * g.Cs + ci] = v;
+        } else if (co < p.Co && ci < p.Ci) {
+          p.dw[(((long)co * p.Ci + ci) * 3 + tp / 3) * 3 + tp % 3] += v;
+        }
+      }
+    }
+}
+
 WGeom wgrad_pick_geom(int Hd, int Wd) {
   WGeom best{0, 0, 0, 0, 0, 0, 1};
   double best_cost = 1e30;
@@ -466,6 +628,33 @@ int launch_wgrad_halo(const FsWgradArgs& a, hipStream_t st) {
   return fs_launch_status();
 }
 
+int launch_wgrad_narrow(const FsWgradArgs& a, hipStream_t st) {
+  FsWgradArgs b = a;
+  const int Cs = a.ncolgroups * 8 / 9;
+  WGeom g = wgrad_pick_geom(a.Hd, a.Wd);
+  if (g.TH == 0) return FS_EINVAL;
+  g.N = a.M / (a.Hd * a.Wd); g.Cs = Cs;
+  const int CIT = Cs % 32 == 0 ? 32 : 16;
+  const int out_tiles = Cs / CIT;
+  const int npix = g.N * g.tiles_x * g.tiles_y;
+  b.ws_rows = 16; b.ws_cols = 9 * Cs;
+  const long slab = (long)b.ws_rows * b.ws_cols;
+  // every tile step waits one global-load latency: ~1024 short chains keep 4 blocks per CU in flight; the slabs
+  // are tiny (16 x 9Cs floats)
+  long splits = std::max<long>(1, std::min<long>(npix / 4 > 0 ? npix / 4 : 1, (1024 + out_tiles - 1) / out_tiles));
+  if (!a.workspace) splits = 1;
+  else splits = std::min<long>(splits, std::max<long>(1, a.workspace_elems / slab));
+  g.nsplit = (int)splits; b.nsplit = g.nsplit;
+  dim3 grid(out_tiles, 1, g.nsplit);
+  if (CIT == 32) hipLaunchKernelGGL((wgrad3x3_narrow_kernel<32>), grid, dim3(256), 0, st, b, g);
+  else hipLaunchKernelGGL((wgrad3x3_narrow_kernel<16>), grid, dim3(256), 0, st, b, g);
+  if (b.nsplit > 1) {
+    const int ncols = 9 * Cs;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(a.Co * ((ncols + 63) / 64))), dim3(256), 0, st, b, 8);
+  }
+  return fs_launch_status();
+}
+
 template <typename T>
 int launch_wgrad(const FsWgradArgs& a, hipStream_t st) {
   constexpr bool kBf16 = sizeof(T) == 2;  // f32 tiles are capped by the 64 KB static LDS limit
@@ -474,6 +663,9 @@ int launch_wgrad(const FsWgradArgs& a, hipStream_t st) {
     if (a.use_halo && a.R == 3 && a.S == 3 && a.stride == 1 && a.Cd % 64 == 0 && Cs % 32 == 0 && a.x_bytes > 0 &&
         a.x_bytes <= 0x7fffffffLL && (long)a.M * a.Cd * 2 <= 0x7fffffffLL && a.M >= 1024)
       return launch_wgrad_halo(a, st);   // (tiny pixel counts: too few tiles to split, the generic kernel wins)
+    if (a.use_halo && a.R == 3 && a.S == 3 && a.stride == 1 && a.Cd == 16 && a.Co <= 16 && Cs % 16 == 0 &&
+        a.x_bytes > 0 && a.x_bytes <= 0x7fffffffLL && (long)a.M * a.Cd * 2 <= 0x7fffffffLL && a.M >= 4096)
+      return launch_wgrad_narrow(a, st);
   }
   if constexpr (kBf16) {
     // few pixels, wide dW (deep stages, pose decoder): 128x128 tiles halve the operand re-fetch per MFMA and

@@ -136,8 +136,10 @@ class ConvOp:
         self._tabs = {}
         eb = 2 if dtype == torch.bfloat16 else 4
         halo_ok = (R == 3 and S == 3 and stride == 1)
-        self.halo_f = halo_ok and (self.Ci_p * eb) % 64 == 0 and self.Co_p % 32 == 0
-        self.halo_d = halo_ok and need_dgrad and (self.Co_p * eb) % 64 == 0 and roundup(self.Ci_p, 16) % 32 == 0
+        def chunks_ok(c):      # whole 64-byte chunks, or exactly half of one (16 bf16 channels)
+            return (c * eb) % 64 == 0 or c * eb == 32
+        self.halo_f = halo_ok and chunks_ok(self.Ci_p) and self.Co_p % 16 == 0
+        self.halo_d = halo_ok and need_dgrad and chunks_ok(self.Co_p) and roundup(self.Ci_p, 16) % 16 == 0
         # wgrad columns (r, s, ci): same grouping as the forward K walk without chunk padding
         self.ncolgroups = R * S * self.Ci_p // eg
         self.ktab_w = torch.from_numpy(make_ktab(R, S, self.Ci_p, eg, self.ncolgroups)).to(device)
