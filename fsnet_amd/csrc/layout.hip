@@ -40,9 +40,25 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ a, const float* __
   }
 }
 
-// all convolutions of a model in ONE launch: a block finds its descriptor by binary search over block_start
+// All convolutions of a model in ONE launch.  A block owns a 32 (co) x IB (ci) x RS tile of one layer's OIHW master
+// weights: it reads the tile with coalesced rows (IB*RS contiguous floats per co), keeps it in LDS and writes
+// the two MFMA operands as contiguous runs — forward [co][tap][ci] (runs of IB elements) and dgrad
+// [ci][tap][co] (runs of 32).  (The first version mapped one thread per *output* element: its reads strode the
+// OIHW tensor by 9 or by 9*Ci floats and the step-start re-pack took 234 us for 215 MB; this one ~20 us.)
+// Padding rows / channels / K of the operands are zero from allocation and never touched.
+constexpr int PACK_CB = 32, PACK_ROW = 289;      // tile rows (co) and LDS row length (floats, odd: no conflicts)
+
+__host__ __device__ inline int pack_ib(int RS, int Ci) {
+  int ib = 288 / RS;                     // tile row fits PACK_ROW - 1 floats
+  int p2 = 1;
+  while (p2 * 2 <= ib && p2 < 128) p2 *= 2;
+  (void)Ci;
+  return p2;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const FsPackDesc* __restrict__ descs, int n) {
+  __shared__ float tile[PACK_CB * PACK_ROW];
   int lo = 0, hi = n - 1;
   const long bid = blockIdx.x;
   while (lo < hi) {
@@ -50,27 +66,40 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const FsPackDes
     if (descs[mid].block_start <= bid) lo = mid; else hi = mid - 1;
   }
   const FsPackDesc d = descs[lo];
-  const long i = (bid - d.block_start) * 256 + threadIdx.x;
-  const long nf = (long)d.rows_f * d.k_f, nd = (long)d.rows_d * d.k_d;
-  if (i >= nf + nd) return;
-  const bool tr = i >= nf;
-  const long j = tr ? i - nf : i;
-  const long kp = tr ? d.k_d : d.k_f;
-  const int csp = tr ? d.cs_d : d.cs_f;
-  const long row = j / kp; const int k = (int)(j % kp);
-  const int tap = k / csp, c = k % csp;
-  const int rows = tr ? d.Ci : d.Co, cs = tr ? d.Co : d.Ci;
-  float v = 0.f;
-  if (row < rows && c < cs && tap < d.R * d.S) {
-    int r = tap / d.S, s = tap % d.S;
-    int co = tr ? c : (int)row, ci = tr ? (int)row : c;
-    v = d.w[(((long)co * d.Ci + ci) * d.R + r) * d.S + s];
+  const int RS = d.R * d.S;
+  const int IB = pack_ib(RS, d.Ci);
+  const int nci_t = (d.Ci + IB - 1) / IB;
+  const int local = (int)(bid - d.block_start);
+  const int co0 = (local / nci_t) * PACK_CB, ci0 = (local % nci_t) * IB;
+  const int nco = min(PACK_CB, d.Co - co0), nci = min(IB, d.Ci - ci0);
+  if (nco <= 0 || nci <= 0) return;
+  const int run = nci * RS;                         // contiguous floats per co in the master tensor
+  for (int i = threadIdx.x; i < nco * run; i += 256) {
+    int col = i / run, rem = i - col * run;
+    tile[col * PACK_ROW + rem] = d.w[((long)(co0 + col) * d.Ci + ci0) * RS + rem];
   }
-  T* dst = reinterpret_cast<T*>(tr ? d.dst_d : d.dst_f);
-  dst[j] = ElemTraits<T>::from_f(v);
+  __syncthreads();
+  T* df = reinterpret_cast<T*>(d.dst_f);
+  for (int i = threadIdx.x; i < nco * run; i += 256) {          // (co, tap, ci): ci fastest
+    int cil = i % nci; int q = i / nci; int tap = q % RS; int col = q / RS;
+    df[(long)(co0 + col) * d.k_f + (long)tap * d.cs_f + ci0 + cil] = ElemTraits<T>::from_f(tile[col * PACK_ROW + cil * RS + tap]);
+  }
+  if (d.dst_d) {
+    T* dd = reinterpret_cast<T*>(d.dst_d);
+    for (int i = threadIdx.x; i < nco * run; i += 256) {        // (ci, tap, co): co fastest
+      int col = i % nco; int q = i / nco; int tap = q % RS; int cil = q / RS;
+      dd[(long)(ci0 + cil) * d.k_d + (long)tap * d.cs_d + co0 + col] = ElemTraits<T>::from_f(tile[col * PACK_ROW + cil * RS + tap]);
+    }
+  }
 }
 
 }  // namespace
+
+extern "C" int64_t fs_pack_tile_blocks(int Co, int Ci, int R, int S) {
+  if (Co <= 0 || Ci <= 0 || R <= 0 || S <= 0 || R * S > 288) return -1;
+  const int IB = pack_ib(R * S, Ci);
+  return (int64_t)((Co + PACK_CB - 1) / PACK_CB) * ((Ci + IB - 1) / IB);
+}
 
 extern "C" int fs_pack_weights_multi(const FsPackDesc* descs_dev, int n, int64_t total_blocks, int dtype, void* stream) {
   if (!descs_dev || n <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffffLL) return FS_EINVAL;

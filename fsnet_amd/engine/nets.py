@@ -169,7 +169,7 @@ def pack_all(key, arena=None):
             else:
                 d.dst_d, d.rows_d, d.cs_d, d.k_d = None, 0, 1, 1
             d.block_start = blocks
-            blocks += (d.rows_f * d.k_f + d.rows_d * d.k_d + 255) // 256
+            blocks += int(lib.fs_pack_tile_blocks(op.Co, op.Ci, op.R, op.S))
         raw = bytes(arr)
         tab = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
         # (never evicted: a captured hipGraph may hold the table's address; a table is ~100 B per conv)

@@ -143,6 +143,9 @@ typedef struct FsPackDesc {
   int32_t rows_d, cs_d;   /* dgrad operand:  padded rows (ci), padded channels per tap (co) */
 } FsPackDesc;
 int fs_pack_weights_multi(const FsPackDesc* descs_dev, int n, int64_t total_blocks, int dtype, void* stream);
+/* blocks of fs_pack_weights_multi that one layer occupies (32 co x IB ci x R*S tiles): FsPackDesc.block_start is the
+ * running sum of this over the table, total_blocks the grand total.  -1 for unsupported shapes (R*S > 288). */
+int64_t fs_pack_tile_blocks(int Co, int Ci, int R, int S);
 
 /* Batch images NCHW fp32 (one tensor, or two concatenated along C as the pose encoder input,
  * monodepth2_model.py:29-35) -> NHWC with Cp >= Ca+Cb zero-padded channels.

@@ -15,7 +15,7 @@ def declared_functions():
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     src = re.sub(r"typedef struct \w+ \{.*?\} \w+;", "", src, flags=re.S)
     fns = {}
-    for m in re.finditer(r"\b(int|const char\*)\s+(fs_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(int64_t|int|const char\*)\s+(fs_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = [a.strip() for a in m.group(3).split(",") if a.strip() and a.strip() != "void"]
         fns[m.group(2)] = (m.group(1), args)
     return fns
