@@ -2,6 +2,8 @@
 // NCHW fp32 images -> NHWC (channel-padded) activations.
 #include "common.h"
 #include "fsnet_hip_internal.h"
+#include <algorithm>
+#include <cstdint>
 
 namespace {
 
@@ -94,6 +96,42 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const FsPackDes
 }
 
 }  // namespace
+
+namespace {
+struct CopyBatch { const char* src[FS_COPY_MAX]; char* dst[FS_COPY_MAX]; long bytes[FS_COPY_MAX]; long start[FS_COPY_MAX + 1]; int n; };
+
+// up to FS_COPY_MAX device-to-device copies in ONE launch (the batch -> static hipGraph input buffers):
+// blocks are dealt over the copies in proportion to their size; 16-byte lanes, byte tail by the last threads
+__global__ __launch_bounds__(256) void copy_multi_kernel(const CopyBatch c) {
+  int k = 0;
+  while (k + 1 < c.n && (long)blockIdx.x >= c.start[k + 1]) ++k;
+  const long nblk = c.start[k + 1] - c.start[k], lb = blockIdx.x - c.start[k];
+  const long n16 = c.bytes[k] >> 4;
+  const uint4* s = reinterpret_cast<const uint4*>(c.src[k]);
+  uint4* d = reinterpret_cast<uint4*>(c.dst[k]);
+  for (long i = lb * 256 + threadIdx.x; i < n16; i += nblk * 256) d[i] = s[i];
+  if (lb == 0) {
+    const long tail = c.bytes[k] & 15;
+    if ((long)threadIdx.x < tail) c.dst[k][n16 * 16 + threadIdx.x] = c.src[k][n16 * 16 + threadIdx.x];
+  }
+}
+}  // namespace
+
+extern "C" int fs_copy_multi(const void* const* src, void* const* dst, const int64_t* bytes, int n, void* stream) {
+  if (!src || !dst || !bytes || n <= 0 || n > FS_COPY_MAX) return FS_EINVAL;
+  CopyBatch c;
+  long blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!src[i] || !dst[i] || bytes[i] <= 0) return FS_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(src[i]) | reinterpret_cast<uintptr_t>(dst[i])) & 15) return FS_EINVAL;
+    c.src[i] = static_cast<const char*>(src[i]); c.dst[i] = static_cast<char*>(dst[i]); c.bytes[i] = bytes[i];
+    c.start[i] = blocks;
+    blocks += std::max<long>(1, std::min<long>((bytes[i] / 16 + 1023) / 1024, 512));   // ~4 lanes per thread
+  }
+  c.start[n] = blocks; c.n = n;
+  hipLaunchKernelGGL(copy_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), c);
+  return fs_launch_status();
+}
 
 extern "C" int64_t fs_pack_tile_blocks(int Co, int Ci, int R, int S) {
   if (Co <= 0 || Ci <= 0 || R <= 0 || S <= 0 || R * S > 288) return -1;

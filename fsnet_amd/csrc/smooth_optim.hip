@@ -91,10 +91,13 @@ __global__ __launch_bounds__(256) void smooth_bwd_dot_kernel(const FsSmoothArgs 
   const float gout = p.gout ? (float)*p.gout : 1.f;
   const float wgt = gout * 1e-5f / (float)(1 << p.scale_id[s]) / (float)p.S;
   const float kx = wgt / (float)((long)p.B * h * (w - 1)), ky = wgt / (float)((long)p.B * (h - 1) * w);
+  float* dd = p.d_disp[s] + (long)b * hw;
   float acc = 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < hw; i += (long)gridDim.x * 256) {
     int x = (int)(i % w), y = (int)(i / w);
-    acc += smooth_dnd(d, col, hw, h, w, y, x, inv, kx, ky) * d[i];
+    float g = smooth_dnd(d, col, hw, h, w, y, x, inv, kx, ky);
+    dd[i] = g;                 // pass 2 only rescales and shifts it (no second walk over the colour edges)
+    acc += g * d[i];
   }
   __shared__ double sh[4];
   double tot = block_sum_d((double)acc, sh);
@@ -106,18 +109,11 @@ __global__ __launch_bounds__(256) void smooth_bwd_apply_kernel(const FsSmoothArg
   const int s = blockIdx.z, b = blockIdx.y;
   const int h = p.h[s], w = p.w[s];
   const long hw = (long)h * w;
-  const float* d = p.disp[s] + (long)b * hw;
-  const float* col = p.color[s] + (long)b * 3 * hw;
   float* dd = p.d_disp[s] + (long)b * hw;
   const float inv = 1.f / ((float)(p.disp_sum[s * p.B + b] / (double)hw) + 1e-7f);
-  const float gout = p.gout ? (float)*p.gout : 1.f;
-  const float wgt = gout * 1e-5f / (float)(1 << p.scale_id[s]) / (float)p.S;
-  const float kx = wgt / (float)((long)p.B * h * (w - 1)), ky = wgt / (float)((long)p.B * (h - 1) * w);
   const float corr = (float)p.dot[s * p.B + b] * inv * inv / (float)hw;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < hw; i += (long)gridDim.x * 256) {
-    int x = (int)(i % w), y = (int)(i / w);
-    dd[i] = smooth_dnd(d, col, hw, h, w, y, x, inv, kx, ky) * inv - corr;
-  }
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < hw; i += (long)gridDim.x * 256)
+    dd[i] = dd[i] * inv - corr;        // dd holds dnd from pass 1
 }
 
 // loss assembly: out[0..S) = loss/s (f64), out[S..2S) = smooth_loss/s, out[2S] = total

@@ -350,6 +350,28 @@ def adam_step(p, g, m, v, lr, b1, b2, eps, wd, step, max_norm=0.0, sumsq_buf=Non
                            float(grad_scale), _p(step_buf), _p(lr_buf), stream_ptr()), "adam_step")
 
 
+COPY_MAX = 16
+
+
+def copy_multi(pairs):
+    """[(dst, src)] same-shape/dtype contiguous device tensors -> one launch per 16 copies (current stream);
+    pairs the kernel cannot take (unaligned views, dtype change, host source) go through Tensor.copy_."""
+    fast = []
+    for dst, src in pairs:
+        if (src.is_cuda and src.dtype == dst.dtype and src.shape == dst.shape and src.is_contiguous()
+                and dst.is_contiguous() and src.data_ptr() % 16 == 0 and dst.data_ptr() % 16 == 0 and src.numel() > 0):
+            fast.append((dst, src))
+        else:
+            dst.copy_(src, non_blocking=True)
+    for i in range(0, len(fast), COPY_MAX):
+        chunk = fast[i:i + COPY_MAX]
+        n = len(chunk)
+        srcs = (C.c_void_p * n)(*[s.data_ptr() for _, s in chunk])
+        dsts = (C.c_void_p * n)(*[d.data_ptr() for d, _ in chunk])
+        nbytes = (C.c_int64 * n)(*[s.numel() * s.element_size() for _, s in chunk])
+        check(lib.fs_copy_multi(srcs, dsts, nbytes, n, stream_ptr()), "copy_multi")
+
+
 def counter_incr(buf):
     """device int32 counter += 1 on the current stream (replayable from a hipGraph)"""
     check(lib.fs_counter_incr(buf.data_ptr(), stream_ptr()), "counter_incr")

@@ -56,9 +56,8 @@ class BaseTrainingHook(object):
 
     def _stage(self, data, static):
         """incoming batch -> static device buffers (H2D or D2D on the current stream)"""
-        for k, v in data.items():
-            if isinstance(v, torch.Tensor) and k in static:
-                static[k].copy_(v, non_blocking=True)
+        from fsnet_amd.hip import ops
+        ops.copy_multi([(static[k], v) for k, v in data.items() if isinstance(v, torch.Tensor) and k in static])
 
     def _eager_step(self, data, meta_arch, optimizer, arena, fused, meta, logger):
         if arena is not None:

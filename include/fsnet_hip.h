@@ -147,6 +147,12 @@ int fs_pack_weights_multi(const FsPackDesc* descs_dev, int n, int64_t total_bloc
  * running sum of this over the table, total_blocks the grand total.  -1 for unsupported shapes (R*S > 288). */
 int64_t fs_pack_tile_blocks(int Co, int Ci, int R, int S);
 
+/* n <= FS_COPY_MAX device-to-device copies (16-byte aligned pointers, any byte counts) in one launch: the training
+ * hook stages a batch into the static input buffers of its captured hipGraph with it
+ * (base_training_hooks.py:28-31 does one .cuda() per tensor). */
+#define FS_COPY_MAX 16
+int fs_copy_multi(const void* const* src, void* const* dst, const int64_t* bytes, int n, void* stream);
+
 /* Batch images NCHW fp32 (one tensor, or two concatenated along C as the pose encoder input,
  * monodepth2_model.py:29-35) -> NHWC with Cp >= Ca+Cb zero-padded channels.
  */
