@@ -333,18 +333,20 @@ extern "C" int fs_bn_bwd_reduce(const FsBnBwdArgs* a, int dtype, void* stream) {
   const int G = a->groups > 1 ? a->groups : 1;
   if (a->M % G != 0) return FS_EINVAL;
   const long Mg = a->M / G;
-  // channel groups per block: 32 (8 pixel lanes) for wide layers, 8 (32 pixel lanes) for narrow ones
-  if (CG >= 32) {
-    dim3 grid((unsigned)std::min<long>((Mg + 15) / 16, 512), (CG + 31) / 32, G);
-    if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, 32>), grid, dim3(256), 0, st, *a);
-    else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 32>), grid, dim3(256), 0, st, *a);
-    else return FS_EINVAL;
-  } else {
-    dim3 grid((unsigned)std::min<long>((Mg + 63) / 64, 1024), (CG + 7) / 8, G);
-    if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, 8>), grid, dim3(256), 0, st, *a);
-    else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 8>), grid, dim3(256), 0, st, *a);
-    else return FS_EINVAL;
+  // channel groups (16-byte lanes) per block: 32 for wide layers (8 pixel lanes), 8, or — for the 16 / 32-channel
+  // decoder layers, whose 2 / 4 lanes would leave three quarters of an 8-lane block idle — 4 and 2
+#define LAUNCH_REDUCE(CGB, ROWS_PER_BLOCK, MAXB)                                                               \
+  {                                                                                                             \
+    dim3 grid((unsigned)std::min<long>((Mg + (ROWS_PER_BLOCK) - 1) / (ROWS_PER_BLOCK), MAXB), (CG + CGB - 1) / CGB, G); \
+    if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, CGB>), grid, dim3(256), 0, st, *a);  \
+    else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, CGB>), grid, dim3(256), 0, st, *a); \
+    else return FS_EINVAL;                                                                                      \
   }
+  if (CG >= 32) LAUNCH_REDUCE(32, 16, 512)
+  else if (CG >= 8) LAUNCH_REDUCE(8, 64, 1024)
+  else if (CG >= 4) LAUNCH_REDUCE(4, 128, 1024)
+  else LAUNCH_REDUCE(2, 256, 1024)
+#undef LAUNCH_REDUCE
   return fs_launch_status();
 }
 

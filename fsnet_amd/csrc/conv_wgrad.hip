@@ -238,6 +238,36 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const FsWgradArgs p, 
   }
 }
 
+// few splits (deep stages: wide dW, 2-8 slabs): one thread per column, all slabs summed with independent loads —
+// the 4-lane kernel above would run 4x the blocks with most lanes idle
+__global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const FsWgradArgs p, int eg) {
+  const int ncols = p.ncolgroups * eg;
+  const int cblocks = (ncols + 255) / 256;
+  const int co = blockIdx.x / cblocks, col = (blockIdx.x % cblocks) * 256 + threadIdx.x;
+  if (col >= ncols) return;
+  const float* ws = p.workspace + (long)co * p.ws_cols + col;
+  const long slab = (long)p.ws_rows * p.ws_cols;
+  float v[8];
+#pragma unroll
+  for (int z = 0; z < 8; ++z) v[z] = z < p.nsplit ? ws[(long)z * slab] : 0.f;
+  float acc = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  int e = p.ktab[col / eg];
+  if (e >= 0) {
+    int ci = (e & 0xffff) + (col % eg);
+    if (ci < p.Ci) {
+      int r = (e >> 16) & 0xff, s = (e >> 24) & 0x7f;
+      p.dw[(((long)co * p.Ci + ci) * p.R + r) * p.S + s] += acc;
+    }
+  }
+}
+
+void launch_reduce(const FsWgradArgs& b, int Co, int ncols, int eg, hipStream_t st) {
+  if (b.nsplit <= 8 && ncols >= 256)
+    hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)(Co * ((ncols + 255) / 256))), dim3(256), 0, st, b, eg);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(Co * ((ncols + 63) / 64))), dim3(256), 0, st, b, eg);
+}
+
 template <typename T, int COT, int CLT, int WR>
 int launch_tile(const FsWgradArgs& a, hipStream_t st) {
   constexpr int EG = ElemTraits<T>::EG;
@@ -264,7 +294,7 @@ int launch_tile(const FsWgradArgs& a, hipStream_t st) {
   dim3 grid(ct, rt, b.nsplit);
   hipLaunchKernelGGL((conv_wgrad_kernel<T, COT, CLT, WR, CH>), grid, dim3(256), 0, st, b);
   if (b.nsplit > 1) {
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(a.Co * ((ncols + 63) / 64))), dim3(256), 0, st, b, EG);
+    launch_reduce(b, a.Co, ncols, EG, st);
   }
   return fs_launch_status();
 }
@@ -623,7 +653,7 @@ int launch_wgrad_halo(const FsWgradArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((wgrad3x3_halo_kernel<COT, CIT>), grid, dim3(256), 0, st, b, g);
   if (b.nsplit > 1) {
     const int ncols = 9 * Cs;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(a.Co * ((ncols + 63) / 64))), dim3(256), 0, st, b, 8);
+    launch_reduce(b, a.Co, ncols, 8, st);
   }
   return fs_launch_status();
 }
@@ -650,7 +680,7 @@ int launch_wgrad_narrow(const FsWgradArgs& a, hipStream_t st) {
   else hipLaunchKernelGGL((wgrad3x3_narrow_kernel<16>), grid, dim3(256), 0, st, b, g);
   if (b.nsplit > 1) {
     const int ncols = 9 * Cs;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(a.Co * ((ncols + 63) / 64))), dim3(256), 0, st, b, 8);
+    launch_reduce(b, a.Co, ncols, 8, st);
   }
   return fs_launch_status();
 }
