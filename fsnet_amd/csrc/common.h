@@ -40,8 +40,13 @@ __device__ static inline uint32_t f_to_bf16_bits(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return u >> 16;
 }
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+// two fp32 -> packed bf16 pair, round-to-nearest-even: ONE v_cvt_pk_bf16_f32 on gfx950 (the shift/add/mask
+// sequence above costs ~10 VALU per pair, and the conv epilogues convert 32 outputs per lane)
 __device__ static inline uint32_t pack_bf16x2(float lo, float hi) {
-  return f_to_bf16_bits(lo) | (f_to_bf16_bits(hi) << 16);
+  f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 // load / store `n<=4` consecutive channel values as float, for either element type

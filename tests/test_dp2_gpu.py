@@ -1,0 +1,97 @@
+"""Two data-parallel ranks (two processes, here sharing the one GPU of the test box, gloo transport so both may sit
+on the same device) against ONE process stepping on the concatenated batch: SyncBatchNorm statistics exchange,
+BatchNorm-backward sum exchange, gradient buckets and the SUM->MEAN fold must make the two runs the same training
+trajectory (reference: SyncBatchNorm + DistributedDataParallel, scripts/train.py:100-102)."""
+import os
+import socket
+
+import pytest
+import torch
+
+from oracle import fsnet_oracle as O
+
+pytestmark = pytest.mark.gpu
+B_RANK, H, W, STEPS = 2, 64, 128, 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _full_batch(it):
+    return O.synthetic_batch(2 * B_RANK, H, W, seed=300 + it)
+
+
+def _build(dev):
+    from fsnet_amd.configs import meta_arch_cfg, training_cfg
+    from fsnet_amd.engine.runtime import RT
+    from fsnet_amd.vision_base.networks.optimizers.optimizers import build_optimizer
+    from fsnet_amd.vision_base.utils.builder import build
+    RT.set_compute_dtype(torch.float32)
+    RT.tie_noise = False
+    m = build(**meta_arch_cfg(H, W, with_pose=True))
+    m.load_state_dict(O.init_state(seed=11, with_pose=True), strict=True)
+    m = m.to(dev).train()
+    tc = training_cfg()
+    return m, build_optimizer(m, **tc.optimizer), build(**tc.training_hook)
+
+
+def _rank_main(rank, world, port, out_path):
+    import torch.distributed as dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        m, opt, hook = _build(dev)
+        losses = []
+        for it in range(STEPS):
+            full = _full_batch(it)
+            mine = {k: (v[rank * B_RANK:(rank + 1) * B_RANK] if isinstance(v, torch.Tensor) else v) for k, v in full.items()}
+            out = hook(mine, m, opt)
+            losses.append(float(out["loss"].detach()))
+        torch.cuda.synchronize()
+        from fsnet_amd.engine.runtime import RT
+        assert RT.dp is not None and RT.dp.world == world and hook.graph_captures == 0
+        torch.save({"losses": losses,
+                    "params": torch.cat([p.detach().flatten() for p in m.parameters()]).cpu(),
+                    "running": torch.cat([b.detach().double().flatten() for n, b in m.named_buffers() if "running_" in n]).cpu()},
+                   out_path % rank)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_process_on_the_full_batch(dev, tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    out_path = str(tmp_path / "rank%d.pt")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, out_path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0, "rank process failed (exit code %r)" % p.exitcode
+    r0, r1 = torch.load(out_path % 0), torch.load(out_path % 1)
+    # both ranks hold the same model after every step
+    assert float((r0["params"] - r1["params"]).abs().max()) == 0.0
+    assert float((r0["running"] - r1["running"]).abs().max()) == 0.0
+
+    m, opt, hook = _build(dev)
+    losses = []
+    for it in range(STEPS):
+        out = hook(dict(_full_batch(it)), m, opt)
+        losses.append(float(out["loss"].detach()))
+    torch.cuda.synchronize()
+    params = torch.cat([p.detach().flatten() for p in m.parameters()]).cpu()
+    running = torch.cat([b.detach().double().flatten() for n, b in m.named_buffers() if "running_" in n]).cpu()
+    for it in range(STEPS):
+        dp_loss = 0.5 * (r0["losses"][it] + r1["losses"][it])       # mean over the global batch
+        assert abs(dp_loss - losses[it]) < 2e-5 * abs(losses[it]), (it, dp_loss, losses[it])
+    # same trajectory up to fp32 summation order (sign-noise parameters move by <= one Adam step, lr = 1e-4)
+    assert float((r0["params"] - params).abs().max()) < 2.5e-4
+    assert float(((r0["running"] - running).abs() / running.abs().clamp_min(1.0)).max()) < 1e-3
