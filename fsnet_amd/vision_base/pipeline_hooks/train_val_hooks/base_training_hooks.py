@@ -26,6 +26,9 @@ class BaseTrainingHook(object):
         if use_graph is None:
             use_graph = os.environ.get("FSNET_AMD_GRAPH", "1") != "0"
         self.use_graph = bool(use_graph)
+        # FSNET_AMD_GRAPH_DP=1: also capture data-parallel steps (SyncBN / gradient all-reduces become graph nodes).
+        # Off by default: it is only exercised at world size 1 so far (tests/test_dp_gpu.py).
+        self.graph_dp = os.environ.get("FSNET_AMD_GRAPH_DP", "0") != "0"
         self.graph_warmup = int(graph_warmup)   # eager steps before the capture (at least 2: see __call__)
         self.graph_captures = 0
         self._g = None            # dict(graph, sig, static, output, stream, ...) once captured
@@ -45,11 +48,10 @@ class BaseTrainingHook(object):
     def _graph_ok(self, meta_arch, optimizer, arena, fused):
         if not (self.use_graph and fused and arena is not None and torch.cuda.is_available()):
             return False
-        if RT.dp is not None:
-            return False
-        if torch.distributed.is_available() and torch.distributed.is_initialized() \
-                and torch.distributed.get_world_size() > 1:
-            return False
+        if not self.graph_dp and (RT.dp is not None or (
+                torch.distributed.is_available() and torch.distributed.is_initialized()
+                and torch.distributed.get_world_size() > 1)):
+            return False      # data-parallel steps replay RCCL collectives from the graph only on request
         if not next(meta_arch.parameters()).is_cuda:
             return False
         return True
@@ -95,7 +97,8 @@ class BaseTrainingHook(object):
             output = meta_arch(sdata, meta)
             loss = output['loss']
             (loss if loss.dim() == 0 else loss.mean()).backward()
-            optimizer.step(max_norm=self.clip_gradients, grad_scale=1.0)
+            grad_scale = RT.dp.finish() if RT.dp is not None else 1.0
+            optimizer.step(max_norm=self.clip_gradients, grad_scale=grad_scale)
         # capture records, it does not run: host bookkeeping happened once above, the first replay is that step
         assert optimizer._step_count_fused == steps_before + 1
         self._g = dict(graph=graph, sig=sig, static=static, output=output, arena=arena)

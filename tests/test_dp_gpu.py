@@ -43,7 +43,7 @@ def _run_steps(dev, use_dp):
     losses = []
     for it in range(2):
         out = hook(dict(O.synthetic_batch(2, 64, 128, seed=50 + it)), m, opt)
-        losses.append(float(out["loss"]))
+        losses.append(float(out["loss"].detach()))
     torch.cuda.synchronize()
     calls = None if RT.dp is None else RT.dp.world
     RT.dp = None
@@ -62,3 +62,38 @@ def test_dp_path_on_rccl_matches_single_process(dev):
     # two runs differ only by fp32 atomic ordering (depth-gradient scatter): ~1e-6 relative
     assert l_dp == pytest.approx(l_ref, rel=1e-5)
     assert float((p_dp - p_ref).abs().max()) < 2.5e-4   # <= one Adam step of lr=1e-4 on sign-noise parameters
+
+
+def test_dp_step_replayed_from_a_hipgraph_on_rccl(dev, monkeypatch):
+    """opt-in FSNET_AMD_GRAPH_DP=1: the data-parallel step (RCCL collectives included) captured and replayed"""
+    from fsnet_amd.configs import meta_arch_cfg, training_cfg
+    from fsnet_amd.engine.dataparallel import DataParallelContext
+    from fsnet_amd.engine.runtime import RT
+    from fsnet_amd.vision_base.networks.optimizers.optimizers import build_optimizer
+    from fsnet_amd.vision_base.utils.builder import build
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    monkeypatch.setenv("FSNET_AMD_GRAPH_DP", "1")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
+    try:
+        RT.set_compute_dtype(torch.float32)
+        RT.tie_noise = False
+        m = build(**meta_arch_cfg(64, 128, with_pose=True))
+        m.load_state_dict(O.init_state(seed=6, with_pose=True), strict=True)
+        m = m.to(dev).train()
+        tc = training_cfg()
+        opt = build_optimizer(m, **tc.optimizer)
+        hook = build(graph_warmup=2, **tc.training_hook)
+        m.ensure_arena()
+        RT.dp = DataParallelContext(m)
+        losses = []
+        for it in range(5):
+            out = hook(dict(O.synthetic_batch(2, 64, 128, seed=50 + it)), m, opt)
+            losses.append(float(out["loss"].detach()))
+        torch.cuda.synchronize()
+        assert hook.graph_captures == 1 and hook.graph_replays == 2 and hook.use_graph
+    finally:
+        RT.dp = None
+        dist.destroy_process_group()
+    l_ref, _, _ = _run_steps(dev, False)
+    assert losses[:2] == pytest.approx(l_ref, rel=1e-5)
+    assert all(l == l and l < 10 for l in losses)
