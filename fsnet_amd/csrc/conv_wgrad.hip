@@ -261,8 +261,38 @@ __global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const FsWgradArg
   }
 }
 
+// 3x3 slabs in tap-major column order (col = tap*Cs + ci), few splits: a block owns one co x 32 ci x 9 taps.  It
+// reads nine 128-byte column segments per slab, transposes through LDS and adds into dW[co][ci][3][3] as ONE
+// contiguous 288-float run (the flat kernel's lanes hit dW with a 36-byte stride: 9x the lines per wave).
+__global__ __launch_bounds__(320) void wgrad_reduce3x3_kernel(const FsWgradArgs p, int Cs) {
+  __shared__ float tmp[288];
+  const int co = blockIdx.y, ci0 = blockIdx.x * 32;
+  const int e = threadIdx.x;
+  if (e < 288) {
+    const int tap = e >> 5, j = e & 31;
+    const float* ws = p.workspace + (long)co * p.ws_cols + tap * Cs + ci0 + j;
+    const long slab = (long)p.ws_rows * p.ws_cols;
+    float acc = 0.f;
+    int z = 0;
+    for (; z + 3 < p.nsplit; z += 4) {
+      float a0 = ws[(long)z * slab], a1 = ws[(long)(z + 1) * slab], a2 = ws[(long)(z + 2) * slab], a3 = ws[(long)(z + 3) * slab];
+      acc += (a0 + a1) + (a2 + a3);
+    }
+    for (; z < p.nsplit; ++z) acc += ws[(long)z * slab];
+    tmp[j * 9 + tap] = acc;
+  }
+  __syncthreads();
+  if (e < 288) {
+    const int ci = ci0 + e / 9;
+    if (co < p.Co && ci < p.Ci) p.dw[((long)co * p.Ci + ci0) * 9 + e] += tmp[e];
+  }
+}
+
 void launch_reduce(const FsWgradArgs& b, int Co, int ncols, int eg, hipStream_t st) {
-  if (b.nsplit <= 8 && ncols >= 256)
+  const bool tapmajor3x3 = b.R == 3 && b.S == 3 && ncols % 9 == 0 && (ncols / 9) % 32 == 0;
+  if (tapmajor3x3 && b.nsplit <= 16 && ncols >= 9 * 64)
+    hipLaunchKernelGGL(wgrad_reduce3x3_kernel, dim3((unsigned)(ncols / 9 / 32), (unsigned)Co), dim3(320), 0, st, b, ncols / 9);
+  else if (b.nsplit <= 8 && ncols >= 256)
     hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)(Co * ((ncols + 255) / 256))), dim3(256), 0, st, b, eg);
   else
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(Co * ((ncols + 63) / 64))), dim3(256), 0, st, b, eg);
