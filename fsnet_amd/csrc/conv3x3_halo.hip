@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
   const int sgoff = p.stat_group_rows > 0 ? (int)((((long)n * p.Hd * p.Wd) / p.stat_group_rows) * p.Co) : 0;
   // per pixel tile b: element offsets into dst / addend / mask / bnb_x (32-bit: every activation tensor on this
   // path is far below 2^31 elements), -1 = lane holds no pixel.  Channel-only terms are hoisted per tile a.
-  int doff[TP], aoff[TP], moff[TP], xoff[TP];
+  int doff[TP], aoff[TP], moff[TP];
 #pragma unroll
   for (int b = 0; b < TP; ++b) {
     int pi = wp * WPIX + b * 16 + li;
@@ -201,7 +201,6 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
     doff[b] = mok ? n * (int)p.dN + y * (int)p.dH + x * (int)p.dW : -1;
     aoff[b] = n * (int)p.aN + y * (int)p.aH + x * (int)p.aW;
     moff[b] = n * (int)p.mN + y * (int)p.mH + x * (int)p.mW;
-    xoff[b] = ((n * p.Hd + y) * p.Wd + x) * p.Co;
   }
 #pragma unroll
   for (int a = 0; a < TC; ++a) {
@@ -234,7 +233,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
       }
       if (p.bnb_x) {   // BatchNorm-backward sums of the layer this gradient flows into: (sum g, sum g*xhat)
         float cv[4];
-        load4<T>(reinterpret_cast<const T*>(p.bnb_x) + xoff[b] + co, cv);
+        load4<T>(reinterpret_cast<const T*>(p.bnb_x) + doff[b] + co, cv);   // same layout as dst
         s1[a][0] += v[0]; s1[a][1] += v[1]; s1[a][2] += v[2]; s1[a][3] += v[3];
         s2[a][0] += v[0] * (cv[0] - mu.x) * is.x; s2[a][1] += v[1] * (cv[1] - mu.y) * is.y;
         s2[a][2] += v[2] * (cv[2] - mu.z) * is.z; s2[a][3] += v[3] * (cv[3] - mu.w) * is.w;

@@ -59,7 +59,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
   const int lane = t & 63, wave = t >> 6;
   const int wp = wave % WP, wc = wave / WP;
   const int li = lane & 15, lg = lane >> 4;
-  const int nch = p.nchunks;
+  // blockIdx.y = output-parity class of a stride-2 data gradient (conv.py): its own K slice of the operand, its own
+  // unit table, and the (y%2, x%2) = (cls>>1, cls&1) sub-lattice of dst / addend / mask / bnb_x (whose strides are
+  // the doubled ones of the sub-lattice)
+  const int cls = p.ncls > 1 ? blockIdx.y : 0;
+  const int nch = p.ncls > 1 ? p.cls_nch[cls] : p.nchunks;
 
   // XCD-aware tile mapping (block b runs on XCD b % 8, each XCD has a private 4 MB L2): all pixel tiles of one
   // channel tile go to the same XCD(s), so a weight tile is fetched from HBM/MALL once per XCD and then hit in L2.
@@ -73,12 +77,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
     if (px >= npix) return;
   }
 
-  for (int i = t; i < nch * UPR; i += 256) s_ktab[i] = reinterpret_cast<const int2*>(p.ktab)[i];
+  {
+    const int2* kt = reinterpret_cast<const int2*>(p.ktab) + (p.ncls > 1 ? p.cls_ktab_off[cls] : 0);
+    for (int i = t; i < nch * UPR; i += 256) s_ktab[i] = kt[i];
+  }
 
   const __amdgpu_buffer_rsrc_t rs_src =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, (int)p.src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wgt =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, (int)p.wgt_bytes, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(p.wgt)) +
+                                            (p.ncls > 1 ? p.cls_wgt_off[cls] : 0), 0, (int)p.wgt_bytes, 0x00020000);
 
   // ---- per-thread gather units (fixed over the K walk) ----
   int pvoff[LPU], phb[LPU], pwb[LPU];
@@ -99,6 +107,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
     }
   }
   const int stage_bytes = KG * 16;
+  const int wrow_bytes = p.wgt_row_bytes ? (int)p.wgt_row_bytes : nch * stage_bytes;
   const int co0 = cy * CO;
   const int OOB = 0x7fffffff;
   int wvoff[LCU];
@@ -106,7 +115,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
   for (int i = 0; i < LCU; ++i) {
     int idx = t + i * 256;
     int row = idx >> UPRS, qu = idx & (UPR - 1);
-    wvoff[i] = row < CO ? ((co0 + row) * nch * stage_bytes + qu * UG * 16) : OOB;
+    wvoff[i] = row < CO ? ((co0 + row) * wrow_bytes + qu * UG * 16) : OOB;
   }
   const int dmask = (1 << p.dshift) - 1;
 
@@ -229,6 +238,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
     long doff = (long)n * p.dN + (long)y * p.dH + (long)x * p.dW;
     long aoff = (long)n * p.aN + (long)y * p.aH + (long)x * p.aW;
     long moff = (long)n * p.mN + (long)y * p.mH + (long)x * p.mW;
+    if (cls) {
+      const int py = cls >> 1, px2 = cls & 1;
+      doff += py * (p.dH >> 1) + px2 * (p.dW >> 1);
+      aoff += py * (p.aH >> 1) + px2 * (p.aW >> 1);
+      moff += py * (p.mH >> 1) + px2 * (p.mW >> 1);
+    }
 #pragma unroll
     for (int a = 0; a < TC; ++a) {
       int co = co0 + wc * WCO + a * 16 + lg * 4;
@@ -255,7 +270,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
       }
       if (p.bnb_x) {   // BatchNorm-backward sums of the layer this gradient flows into: (sum g, sum g*xhat)
         float cv[4];
-        load4<T>(reinterpret_cast<const T*>(p.bnb_x) + (long)m * p.Co + co, cv);
+        load4<T>(reinterpret_cast<const T*>(p.bnb_x) + doff + co, cv);
         const float4 mu = *reinterpret_cast<const float4*>(p.bnb_mean + sgoff + co);
         const float4 is = *reinterpret_cast<const float4*>(p.bnb_invstd + sgoff + co);
         s1[a][0] += v[0]; s1[a][1] += v[1]; s1[a][2] += v[2]; s1[a][3] += v[3];
@@ -310,7 +325,7 @@ int launch_tile(const FsConvArgs& a, hipStream_t st) {
   const int npix = (a.M + PIX - 1) / PIX, nco = a.Co_p / CO;
   int blocks = npix * nco;
   if (nco % 8 != 0 && 8 % nco == 0) { const int g = 8 / nco; blocks = 8 * ((npix + g - 1) / g); }
-  hipLaunchKernelGGL((conv_igemm_kernel<T, PIX, CO, WP, KG>), dim3(blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, PIX, CO, WP, KG>), dim3(blocks, a.ncls > 1 ? a.ncls : 1), dim3(256), 0, st, a);
   return fs_launch_status();
 }
 

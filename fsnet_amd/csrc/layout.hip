@@ -7,6 +7,17 @@
 
 namespace {
 
+// K position -> tap of the OIHW tensor.  order 1 (3x3 only): the dgrad operand of a stride-2 convolution keeps the
+// taps of each output-parity class (y%2, x%2) contiguous, classes (0,0) (0,1) (1,0) (1,1): [4] [3,5] [1,7] [0,2,6,8],
+// so that each class is a plain K slice of the operand (conv.py: one stride-1 launch per class).
+__host__ __device__ inline int tap_at(int order, int pos, int RS) {
+  if (order == 1 && RS == 9) {
+    const int perm[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};
+    return perm[pos];
+  }
+  return pos;
+}
+
 template <typename T>
 __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ dst, int Co, int Ci, int R,
                                     int S, int rows, int cs, int cs_p, long ktot_p, long total, int transpose) {
@@ -16,6 +27,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
   int tap = k / cs_p, c = k % cs_p;
   float v = 0.f;
   if (row < rows && c < cs && tap < R * S) {
+    tap = tap_at(transpose == 2 ? 1 : 0, tap, R * S);
     int r = tap / S, s = tap % S;
     int co = transpose ? c : (int)row;
     int ci = transpose ? (int)row : c;
@@ -90,7 +102,8 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const FsPackDes
     T* dd = reinterpret_cast<T*>(d.dst_d);
     for (int i = threadIdx.x; i < nco * run; i += 256) {        // (ci, tap, co): co fastest
       int col = i % nco; int q = i / nco; int tap = q % RS; int cil = q / RS;
-      dd[(long)(ci0 + cil) * d.k_d + (long)tap * d.cs_d + co0 + col] = ElemTraits<T>::from_f(tile[col * PACK_ROW + cil * RS + tap]);
+      dd[(long)(ci0 + cil) * d.k_d + (long)tap * d.cs_d + co0 + col] =
+          ElemTraits<T>::from_f(tile[col * PACK_ROW + cil * RS + tap_at(d.tap_order_d, tap, RS)]);
     }
   }
 }

@@ -168,6 +168,7 @@ def pack_all(key, arena=None):
                 d.dst_d, d.rows_d, d.cs_d, d.k_d = op.w_d.data_ptr(), op.rows_d, op.Co_p, op.kd_p
             else:
                 d.dst_d, d.rows_d, d.cs_d, d.k_d = None, 0, 1, 1
+            d.tap_order_d = 1 if getattr(op, "s2_classes", False) else 0
             d.block_start = blocks
             blocks += int(lib.fs_pack_tile_blocks(op.Co, op.Ci, op.R, op.S))
         raw = bytes(arr)

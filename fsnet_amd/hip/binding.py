@@ -27,6 +27,8 @@ class FsConvArgs(C.Structure):
         ("M", C.c_int32), ("Co", C.c_int32), ("Co_p", C.c_int32), ("nchunks", C.c_int32), ("kg", C.c_int32),
         ("hb_mul", C.c_int32), ("hb_add", C.c_int32), ("sgn", C.c_int32), ("dshift", C.c_int32),
         ("relu", C.c_int32), ("out_f32", C.c_int32), ("N", C.c_int32), ("Cs", C.c_int32),
+        ("wgt_row_bytes", C.c_int64),
+        ("ncls", C.c_int32), ("cls_nch", C.c_int32 * 4), ("cls_ktab_off", C.c_int32 * 4), ("cls_wgt_off", C.c_int64 * 4),
         ("bnb_x", C.c_void_p), ("bnb_mean", C.c_void_p), ("bnb_invstd", C.c_void_p),
         ("stat_group_rows", C.c_int32),
     ]
@@ -51,6 +53,7 @@ class FsPackDesc(C.Structure):
         ("k_f", C.c_int64), ("k_d", C.c_int64), ("block_start", C.c_int64),
         ("Co", C.c_int32), ("Ci", C.c_int32), ("R", C.c_int32), ("S", C.c_int32),
         ("rows_f", C.c_int32), ("cs_f", C.c_int32), ("rows_d", C.c_int32), ("cs_d", C.c_int32),
+        ("tap_order_d", C.c_int32),
     ]
 
 

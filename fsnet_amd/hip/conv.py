@@ -135,6 +135,12 @@ class ConvOp:
             self.w_d = torch.zeros(self.rows_d, self.kd_p, dtype=dtype, device=device)
         self._tabs = {}
         eb = 2 if dtype == torch.bfloat16 else 4
+        # stride-2 3x3 dgrad by output parity: dx[2y'+py, 2x'+px] only receives the taps with r = py+1 (mod 2),
+        # s = px+1 (mod 2) -> four stride-1 problems with 1 / 2 / 2 / 4 taps whose weights are K slices of one
+        # operand packed in class order (layout.hip tap_at).  The parity-test formulation multiplies all 9 taps for
+        # every pixel and masks 3/4 of them.
+        self.s2_classes = bool(need_dgrad and stride == 2 and R == 3 and S == 3 and pad == 1
+                               and (self.Co_p * eb) % (self.kg_d * 16) == 0)
         halo_ok = (R == 3 and S == 3 and stride == 1)
         def chunks_ok(c):      # whole 64-byte chunks, or exactly half of one (16 bf16 channels)
             return (c * eb) % 64 == 0 or c * eb == 32
@@ -170,7 +176,8 @@ class ConvOp:
                                   self.Co_p, self.Ci_p, self.kf_p, 0, self.code, st), "pack_weights")
         if self.need_dgrad:
             check(lib.fs_pack_weights(weight.data_ptr(), self.w_d.data_ptr(), self.Co, self.Ci, self.R, self.S,
-                                      self.rows_d, self.Co_p, self.kd_p, 1, self.code, st), "pack_weights_t")
+                                      self.rows_d, self.Co_p, self.kd_p, 2 if self.s2_classes else 1, self.code, st),
+                  "pack_weights_t")
 
     def out_hw(self, H, W):
         Ho = (H + 2 * self.pad - self.R) // self.stride + 1
@@ -226,9 +233,85 @@ class ConvOp:
         """whether dgrad(..., bn_fuse=) may carry the BatchNorm-backward sums of a [N,H,W,Ci_p] gradient"""
         if self.Ci_p != self.Ci:
             return False
-        if groups > 1 and not (self.halo_d and USE_HALO) and ((N // groups) * H * W) % 256 != 0:
+        rows = (N // groups) * H * W
+        if self.s2_classes and H % 2 == 0 and W % 2 == 0:
+            rows //= 4                                  # one launch per output-parity class
+        if groups > 1 and not (self.halo_d and USE_HALO) and rows % 256 != 0:
             return False      # an implicit-GEMM tile could straddle two statistics groups
         return True
+
+    # (py, px) -> [(position in the class-ordered operand, dy row offset, dy column offset)]
+    _S2_CLASSES = (((0, 0), ((0, 0, 0),)),
+                   ((0, 1), ((1, 0, 1), (2, 0, 0))),
+                   ((1, 0), ((3, 1, 0), (4, 0, 0))),
+                   ((1, 1), ((5, 1, 1), (6, 1, 0), (7, 0, 1), (8, 0, 0))))
+
+    def _class_tables(self, sH, sW):
+        """unit tables of the four parity classes, concatenated; returns (table, [offset in units], [K stages])"""
+        key = ("c", sH, sW)
+        t = self._tabs.get(key)
+        if t is None:
+            eb = 2 if self.dtype == torch.bfloat16 else 4
+            ug = 4 if self.kg_d == 8 else 1
+            stage = self.kg_d * 16
+            tabs, offs, nchs = [], [], []
+            pos = 0
+            for _, taps in self._S2_CLASSES:
+                nunits = len(taps) * self.Co_p // (self.EG * ug)
+                tab = np.zeros((nunits, 2), dtype=np.int32)
+                k0 = np.arange(nunits, dtype=np.int64) * self.EG * ug
+                tl, c = k0 // self.Co_p, k0 % self.Co_p
+                dr = np.array([tp[1] for tp in taps], dtype=np.int64)[tl]
+                ds = np.array([tp[2] for tp in taps], dtype=np.int64)[tl]
+                tab[:, 0] = ((dr * sH + ds * sW + c) * eb).astype(np.int32)
+                tab[:, 1] = ((dr & 0xffff) | (ds << 16)).astype(np.int32)
+                tabs.append(tab); offs.append(pos); nchs.append(len(taps) * self.Co_p * eb // stage)
+                pos += nunits
+            t = self._tabs[key] = (torch.from_numpy(np.concatenate(tabs, 0)).to(self.device), offs, nchs)
+        return t
+
+    def _dgrad_s2_classes(self, dy, H, W, out, addend, mask, bn_fuse):
+        """all four parity classes in ONE launch (blockIdx.y = class)"""
+        N, Ho, Wo, Cd = dy.shape
+        eb = dy.element_size()
+        tab, offs, nchs = self._class_tables(*_nhwc_strides(dy)[1:])
+        o = out[:, 0::2, 0::2]                       # sub-lattice of class (0,0); the kernel shifts it per class
+        a = FsConvArgs()
+        a.src, a.dst, a.wgt = dy.data_ptr(), o.data_ptr(), self.w_d.data_ptr()
+        a.wgt_row_bytes = self.kd_p * eb
+        a.wgt_bytes = (self.rows_d - 1) * self.kd_p * eb + 4 * self.Co_p * eb      # longest class slice: 4 taps
+        a.sN, a.sH, a.sW = _nhwc_strides(dy)
+        a.ktab = tab.data_ptr()
+        a.src_bytes = _span_bytes(dy)
+        a.dN, a.dH, a.dW = _nhwc_strides(o)
+        if addend is not None:
+            ad = addend[:, 0::2, 0::2]
+            a.addend = ad.data_ptr()
+            a.aN, a.aH, a.aW = _nhwc_strides(ad)
+        if mask is not None:
+            mk = mask[:, 0::2, 0::2]
+            a.mask = mk.data_ptr()
+            a.mN, a.mH, a.mW = _nhwc_strides(mk)
+        a.Hs, a.Ws, a.Hd, a.Wd = Ho, Wo, H // 2, W // 2
+        a.M = N * (H // 2) * (W // 2)
+        a.Co, a.Co_p, a.nchunks, a.kg = out.shape[3], self.rows_d, max(nchs), self.kg_d
+        a.hb_mul, a.hb_add, a.sgn, a.dshift = 1, 0, 1, 0
+        a.N, a.Cs = N, self.Co_p
+        a.ncls = 4
+        for k, ((py, px), taps) in enumerate(self._S2_CLASSES):
+            assert k == 2 * py + px
+            a.cls_nch[k], a.cls_ktab_off[k] = nchs[k], offs[k]
+            a.cls_wgt_off[k] = taps[0][0] * self.Co_p * eb
+        if bn_fuse is not None:
+            c, st, sums = bn_fuse
+            a.bnb_x = c.data_ptr()                   # same layout as out: addressed through the dst offsets
+            a.bnb_mean, a.bnb_invstd = st.mean.data_ptr(), st.invstd.data_ptr()
+            a.stats = sums.data_ptr()
+            a.stat_group_rows = (N // st.groups) * (H // 2) * (W // 2) if st.groups > 1 else 0
+        flops = 2.0 * N * Ho * Wo * self.Co * self.R * self.S * self.Ci
+        _timed("conv_igemm", flops, lambda: check(lib.fs_conv_igemm(C.byref(a), self.code, stream_ptr()), "conv_dgrad_s2"),
+               tag=lambda: "dgrd %s dy[%d,%d,%d,%d]" % (self.describe(), N, Ho, Wo, Cd))
+        return out
 
     def dgrad(self, dy, H, W, out=None, addend=None, mask=None, bn_fuse=None):
         """dy: [N,Ho,Wo,Co_p] -> dx [N,H,W,Ci_p] (out may be a strided view; addend is summed in).
@@ -239,6 +322,14 @@ class ConvOp:
         assert Cd == self.Co_p and dy.dtype == self.dtype and self.need_dgrad
         if out is None:
             out = torch.empty(N, H, W, self.Ci_p, dtype=self.dtype, device=dy.device)
+        if bn_fuse is not None:
+            c, st, _ = bn_fuse
+            assert c.is_contiguous() and out.is_contiguous() and c.shape == out.shape and c.dtype == self.dtype
+            assert self.can_fuse_bn_bwd(N, H, W, st.groups)
+        if self.s2_classes:
+            if H % 2 or W % 2 or H != 2 * Ho or W != 2 * Wo:
+                raise NotImplementedError("stride-2 3x3 data gradient expects an even input size (%dx%d)" % (H, W))
+            return self._dgrad_s2_classes(dy, H, W, out, addend, mask, bn_fuse)
         a = FsConvArgs()
         a.src, a.wgt, a.dst = dy.data_ptr(), self.w_d.data_ptr(), out.data_ptr()
         a.bias, a.stats = None, None
@@ -260,8 +351,6 @@ class ConvOp:
         a.N, a.Cs = N, self.Co_p
         if bn_fuse is not None:
             c, st, sums = bn_fuse
-            assert c.is_contiguous() and c.shape == (N, H, W, out.shape[3]) and c.dtype == self.dtype
-            assert self.can_fuse_bn_bwd(N, H, W, st.groups)
             a.bnb_x, a.bnb_mean, a.bnb_invstd = c.data_ptr(), st.mean.data_ptr(), st.invstd.data_ptr()
             a.stats = sums.data_ptr()
             a.stat_group_rows = (N // st.groups) * H * W if st.groups > 1 else 0

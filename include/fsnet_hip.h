@@ -77,8 +77,18 @@ typedef struct FsConvArgs {
   int32_t out_f32;      /* store fp32 regardless of dtype */
   int32_t N;            /* batch size (fs_conv3x3_halo) */
   int32_t Cs;           /* source channels per tap (fs_conv3x3_halo) */
+  int64_t wgt_row_bytes; /* 0: packed weight rows are nchunks*kg*16 bytes apart.  Else the row stride in bytes: wgt
+                            then points at a K slice of a wider operand (one parity class of a stride-2 dgrad). */
+  int32_t ncls;          /* <= 1: one problem.  2..4 (fs_conv_igemm): blockIdx.y selects an output-parity class of a
+                            stride-2 data gradient: K stages cls_nch[c], unit table ktab + cls_ktab_off[c] (int2
+                            units), operand wgt + cls_wgt_off[c] bytes, and dst / addend / mask / bnb_x advanced by
+                            (c>>1)*H_stride/2 + (c&1)*W_stride/2 (their strides are those of the sub-lattice). */
+  int32_t cls_nch[4];
+  int32_t cls_ktab_off[4];
+  int64_t cls_wgt_off[4];
   const void* bnb_x;    /* NULL: stats = (sum v, sum v^2) of the outputs (BatchNorm forward statistics).
-                           Else: the raw conv output [M][Co] (dense, src dtype) of the BatchNorm whose input
+                           Else: the raw conv output (src dtype, addressed with the dst strides dN/dH/dW: same
+                           layout as dst) of the BatchNorm whose input
                            gradient this launch produces, and stats = (sum v, sum v*xhat), xhat =
                            (bnb_x - bnb_mean) * bnb_invstd: the first pass of BatchNorm backward
                            (fs_bn_bwd_reduce) fused into the data-gradient epilogue. */
@@ -141,6 +151,8 @@ typedef struct FsPackDesc {
   int32_t Co, Ci, R, S;
   int32_t rows_f, cs_f;   /* forward operand: padded rows (co), padded channels per tap (ci) */
   int32_t rows_d, cs_d;   /* dgrad operand:  padded rows (ci), padded channels per tap (co) */
+  int32_t tap_order_d;    /* 0: taps of the dgrad operand in (r,s) order; 1: 3x3 stride-2 parity-class order
+                             [4][3,5][1,7][0,2,6,8] (fs_pack_weights: transpose = 2) */
 } FsPackDesc;
 int fs_pack_weights_multi(const FsPackDesc* descs_dev, int n, int64_t total_blocks, int dtype, void* stream);
 /* blocks of fs_pack_weights_multi that one layer occupies (32 co x IB ci x R*S tiles): FsPackDesc.block_start is the
