@@ -9,9 +9,10 @@
 //   * the (TH+2) x (TW+2) input halo of the chunk is fetched ONCE (raw buffer loads, OOB = zero padding)
 //     and reused by all 9 taps straight from LDS (MFMA B fragments are read at shifted halo positions);
 //   * the 9 taps' weights of the chunk ([tap][co][64 B]) are staged together, so a wave issues
-//     9 * TP * TC MFMAs (72 for the 128x64 tile) between two barriers;
+//     9 * TP * TC MFMAs (36 for the 128x32 tile the dispatcher prefers, 72 for 128x64) between two barriers;
 //   * the next chunk's halo + weights are prefetched into registers while the current one is multiplied.
-// Arithmetic intensity of the 128x64 tile: 98 FLOP per fetched byte (3x the generic kernel).
+// Arithmetic intensity: 98 FLOP per fetched byte on a 128x64 tile, 67 on 128x32 (2-3x the generic kernel) — but see
+// dispatch(): occupancy, not reuse, decides the tile on the monodepth shapes.
 // Dgrad = same kernel on dY with Wt[ci][r][s][co] and the taps mirrored (sgn = -1).
 // The epilogue (bias / addend / ReLU / ReLU-mask / fp32 out / fused BN statistics) matches conv_igemm.hip.
 #include "common.h"
@@ -310,11 +311,16 @@ int dispatch(const FsConvArgs& a, hipStream_t st) {
     HaloGeom g = pick_geom(a.Hd, a.Wd, PIX, PIX == 256 ? 360 : (PIX == 128 ? 208 : 120));
     return g.TH == 0 ? 0L : (long)a.N * g.tiles_x * g.tiles_y * (cop / CO);
   };
-  if (cop % 64 == 0) {
-    if (blocks_for(128, 64) >= 256) return launch_halo<T, 128, 64, 2>(a, st);
-    return launch_halo<T, 64, 64, 2>(a, st);
+  if (cop % 32 == 0) {
+    // Occupancy decides here, not operand reuse: these launches are latency-bound (one wave of blocks, each a chain
+    // of load -> LDS -> MFMA -> store phases).  A 64-channel tile stages 36.8 KB of weights per chunk and only two
+    // blocks fit a CU; the 32-channel tile (18.4 KB, four blocks per CU, twice the blocks) is 5-15 % faster on every
+    // ResNet stage although each halo is then fetched twice, and the 16-channel tile wins when even that leaves the
+    // chip short of blocks (layer 4 at batch 12: 192 -> 384 blocks, 33 -> 25 us).  Measured the other way too:
+    // 256-pixel tiles, which halve the weight fill per pixel, are 20-30 % slower.
+    if (blocks_for(128, 32) < 256) return launch_halo<T, 128, 16, 4>(a, st);
+    return launch_halo<T, 128, 32, 4>(a, st);
   }
-  if (cop % 32 == 0) return launch_halo<T, 128, 32, 4>(a, st);
   if (cop % 16 == 0) {   // 16-channel decoder layers at 96x320 / 192x640: memory-bound, large pixel tiles
     if (blocks_for(256, 16) >= 1024) return launch_halo<T, 256, 16, 4>(a, st);
     return launch_halo<T, 128, 16, 4>(a, st);

@@ -3,7 +3,7 @@
 loss.backward() -> clip_grad_norm_ -> optimizer.step().  With the HIP FusedAdam the zero/clip/step
 collapse to one memset + two kernels over the flat arena, with no host synchronisation in the step.
 
-hipGraph replay: the step launches ~700 small kernels on two streams and the host needs ~10 ms to issue them,
+hipGraph replay: the step launches several hundred small kernels on two streams and the host needs 8-10 ms to issue them,
 about what the GPU needs to run them.  After `graph_warmup` eager steps the hook captures the whole step
 (zero-grad memset, weight re-pack, both forward/backward chains, clip + Adam) into one hipGraph on a private
 stream and replays it; the per-step scalars (Adam step count, learning rate, tie-break noise seed) live in
@@ -40,6 +40,10 @@ class BaseTrainingHook(object):
     # ------------------------------------------------------------------ graph path
     def _signature(self, data, meta_arch, optimizer):
         sig = [id(meta_arch), id(optimizer), self.clip_gradients]
+        # Adam's betas / eps / weight decay are baked into the captured launch (only lr and the step count live in
+        # device memory): changing them re-captures
+        for g in getattr(optimizer, "param_groups", []):
+            sig.append((tuple(g.get("betas", ())), g.get("eps"), g.get("weight_decay")))
         for k, v in data.items():
             if isinstance(v, torch.Tensor):
                 sig.append((k, tuple(v.shape), v.dtype))
