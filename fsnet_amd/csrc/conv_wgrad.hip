@@ -675,6 +675,7 @@ int launch_wgrad_halo(const FsWgradArgs& a, hipStream_t st) {
   b.ws_rows = a.Cd; b.ws_cols = 9 * Cs;
   const long slab = (long)b.ws_rows * b.ws_cols;
   // ~256-320 blocks: every extra split adds a Cd x 9Cs fp32 slab to write and re-read
+  // (re-measured with 512 / 768 / 1024 blocks after the reduce kernels got cheaper: 288 is still the fastest)
   long splits = std::max<long>(1, std::min<long>(npix / 2 > 0 ? npix / 2 : 1, (288 + out_tiles - 1) / out_tiles));
   if (!a.workspace) splits = 1;
   else splits = std::min<long>(splits, std::max<long>(1, a.workspace_elems / slab));
