@@ -21,7 +21,10 @@ class _Runtime:
         # 1 = the main (depth) chain hands them to a companion stream in batches of `wgrad_flush` layers,
         # 2 = every chain does.  Cross-stream edges are not free (host time eagerly, barrier packets in a
         # hipGraph), hence batches rather than one fork per layer.
-        self.wgrad_streams = int(os.environ.get("FSNET_AMD_WGRAD_STREAMS", "0"))
+        # Default 2 / batches of 8: +1.8 % on the reference workload (1618 vs 1589 samples/s, three runs each) once the
+        # conv kernels were light enough on LDS to co-reside with another stream's blocks; before that change every
+        # variant was slower than inline.  The gain is sensitive to the batch size (6: -4 %, 16: -3 %).
+        self.wgrad_streams = int(os.environ.get("FSNET_AMD_WGRAD_STREAMS", "2"))
         self.wgrad_flush = int(os.environ.get("FSNET_AMD_WGRAD_FLUSH", "8"))
         # 3 = the first `wgrad_side_budget` weight gradients of the main chain's backward (the decoder's, then
         # the encoder's deepest stages) run at the tail of the pose chain's stream, which finishes earlier
