@@ -63,6 +63,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
   // unit table, and the (y%2, x%2) = (cls>>1, cls&1) sub-lattice of dst / addend / mask / bnb_x (whose strides are
   // the doubled ones of the sub-lattice)
   const int cls = p.ncls > 1 ? blockIdx.y : 0;
+  // blockIdx.z = BatchNorm statistics group when its rows are not a multiple of the pixel tile (grp_imgs images per
+  // group, M = rows of ONE group): a tile then never straddles two groups
+  const int n0 = p.grp_imgs > 0 ? (int)blockIdx.z * p.grp_imgs : 0;
   const int nch = p.ncls > 1 ? p.cls_nch[cls] : p.nchunks;
 
   // XCD-aware tile mapping (block b runs on XCD b % 8, each XCD has a private 4 MB L2): all pixel tiles of one
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
     int row = idx >> UPRS;
     int m = pix0 + row;
     if (row < PIX && m < p.M) {
-      int x = m % p.Wd; int q = m / p.Wd; int y = q % p.Hd; int n = q / p.Hd;
+      int x = m % p.Wd; int q = m / p.Wd; int y = q % p.Hd; int n = q / p.Hd + n0;
       phb[i] = y * p.hb_mul + p.hb_add;
       pwb[i] = x * p.hb_mul + p.hb_add;
       pvoff[i] = (int)((n * p.sN + (long)phb[i] * sHe + (long)pwb[i] * sWe) * (long)sizeof(T));
@@ -227,14 +230,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
   for (int a = 0; a < TC; ++a)
 #pragma unroll
     for (int j = 0; j < 4; ++j) { s1[a][j] = 0.f; s2[a][j] = 0.f; }
-  const long sgoff = p.stat_group_rows > 0 ? (long)(pix0 / p.stat_group_rows) * p.Co : 0;
+  const long sgoff = p.grp_imgs > 0 ? (long)blockIdx.z * p.Co
+                                    : (p.stat_group_rows > 0 ? (long)(pix0 / p.stat_group_rows) * p.Co : 0);
 
 #pragma unroll
   for (int b = 0; b < TP; ++b) {
     int m = pix0 + wp * WPIX + b * 16 + li;
     bool mok = m < p.M;
     int x = 0, y = 0, n = 0;
-    if (mok) { x = m % p.Wd; int q = m / p.Wd; y = q % p.Hd; n = q / p.Hd; }
+    if (mok) { x = m % p.Wd; int q = m / p.Wd; y = q % p.Hd; n = q / p.Hd + n0; }
     long doff = (long)n * p.dN + (long)y * p.dH + (long)x * p.dW;
     long aoff = (long)n * p.aN + (long)y * p.aH + (long)x * p.aW;
     long moff = (long)n * p.mN + (long)y * p.mH + (long)x * p.mW;
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
       int co = co0 + t;
       if (co < p.Co) {
         // statistics group of this tile (groups are multiples of the tile height: fs_conv_igemm checks)
-        const long sg = p.stat_group_rows > 0 ? pix0 / p.stat_group_rows : 0;
+        const long sg = p.grp_imgs > 0 ? (long)blockIdx.z : (p.stat_group_rows > 0 ? pix0 / p.stat_group_rows : 0);
         double* sl = p.stats + (sg * FS_STAT_SLOTS + px % FS_STAT_SLOTS) * 2 * p.Co;
         atomicAdd(sl + co, (double)u);
         atomicAdd(sl + p.Co + co, (double)w);
@@ -325,7 +329,7 @@ int launch_tile(const FsConvArgs& a, hipStream_t st) {
   const int npix = (a.M + PIX - 1) / PIX, nco = a.Co_p / CO;
   int blocks = npix * nco;
   if (nco % 8 != 0 && 8 % nco == 0) { const int g = 8 / nco; blocks = 8 * ((npix + g - 1) / g); }
-  hipLaunchKernelGGL((conv_igemm_kernel<T, PIX, CO, WP, KG>), dim3(blocks, a.ncls > 1 ? a.ncls : 1), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, PIX, CO, WP, KG>), dim3(blocks, a.ncls > 1 ? a.ncls : 1, a.grp_imgs > 0 ? a.N / a.grp_imgs : 1), dim3(256), 0, st, a);
   return fs_launch_status();
 }
 

@@ -28,7 +28,7 @@ class FsConvArgs(C.Structure):
         ("hb_mul", C.c_int32), ("hb_add", C.c_int32), ("sgn", C.c_int32), ("dshift", C.c_int32),
         ("relu", C.c_int32), ("out_f32", C.c_int32), ("N", C.c_int32), ("Cs", C.c_int32),
         ("wgt_row_bytes", C.c_int64),
-        ("ncls", C.c_int32), ("cls_nch", C.c_int32 * 4), ("cls_ktab_off", C.c_int32 * 4), ("cls_wgt_off", C.c_int64 * 4),
+        ("grp_imgs", C.c_int32), ("ncls", C.c_int32), ("cls_nch", C.c_int32 * 4), ("cls_ktab_off", C.c_int32 * 4), ("cls_wgt_off", C.c_int64 * 4),
         ("bnb_x", C.c_void_p), ("bnb_mean", C.c_void_p), ("bnb_invstd", C.c_void_p),
         ("stat_group_rows", C.c_int32),
     ]

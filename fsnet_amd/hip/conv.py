@@ -194,17 +194,13 @@ class ConvOp:
             out = torch.empty(N, Ho, Wo, self.Co_p, dtype=torch.float32 if out_f32 else self.dtype,
                               device=x.device)
         halo = self.halo_f and USE_HALO
-        group_rows = 0
+        group_rows, grp_imgs = 0, 0
         if stats is not None and stat_groups > 1:
             assert N % stat_groups == 0 and addend is None
             n = N // stat_groups
             group_rows = n * Ho * Wo
             if not halo and group_rows % 256 != 0:
-                # a pixel tile of the implicit-GEMM kernel could straddle two groups: one launch per group
-                for g in range(stat_groups):
-                    self.forward(x[g * n:(g + 1) * n], out=out[g * n:(g + 1) * n], bias=bias, stats=stats[g],
-                                 relu=relu, out_f32=out_f32)
-                return out
+                grp_imgs = n       # a pixel tile could straddle two groups: one group per blockIdx.z instead
         a = FsConvArgs()
         a.src, a.wgt, a.dst = x.data_ptr(), self.w_f.data_ptr(), out.data_ptr()
         a.bias = bias.data_ptr() if bias is not None else None
@@ -224,6 +220,8 @@ class ConvOp:
         a.N, a.Cs = N, self.Ci_p
         a.stat_group_rows = group_rows
         flops = 2.0 * a.M * self.Co * self.R * self.S * self.Ci
+        if grp_imgs:
+            a.stat_group_rows, a.grp_imgs, a.M = 0, grp_imgs, grp_imgs * Ho * Wo
         fn = lib.fs_conv3x3_halo if halo else lib.fs_conv_igemm
         _timed("conv3x3_halo" if halo else "conv_igemm", flops, lambda: check(fn(C.byref(a), self.code, stream_ptr()), "conv_fwd"),
                tag=lambda: "fwd  %s x[%d,%d,%d,%d]" % (self.describe(), N, x.shape[1], x.shape[2], x.shape[3]))

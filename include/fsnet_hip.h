@@ -79,6 +79,9 @@ typedef struct FsConvArgs {
   int32_t Cs;           /* source channels per tap (fs_conv3x3_halo) */
   int64_t wgt_row_bytes; /* 0: packed weight rows are nchunks*kg*16 bytes apart.  Else the row stride in bytes: wgt
                             then points at a K slice of a wider operand (one parity class of a stride-2 dgrad). */
+  int32_t grp_imgs;      /* 0, or (fs_conv_igemm) images per BatchNorm statistics group when the launch carries one
+                            group per blockIdx.z: M is then the row count of ONE group and N the total batch.  Used
+                            instead of stat_group_rows when a group's rows are not a multiple of 256. */
   int32_t ncls;          /* <= 1: one problem.  2..4 (fs_conv_igemm): blockIdx.y selects an output-parity class of a
                             stride-2 data gradient: K stages cls_nch[c], unit table ktab + cls_ktab_off[c] (int2
                             units), operand wgt + cls_wgt_off[c] bytes, and dst / addend / mask / bnb_x advanced by
