@@ -493,10 +493,10 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const FsWgradArgs p,
 // accumulators through LDS once, after the last tile.  The generic kernel spends a 16x256 tile on 144 useful
 // columns and re-gathers the input per tap: 124 us for the 192x640 16->16 layer against ~15 us of HBM time.
 // ---------------------------------------------------------------------------------------------
-template <int CIT>
+template <int COT, int CIT>
 __global__ __launch_bounds__(256) void wgrad3x3_narrow_kernel(const FsWgradArgs p, const WGeom g) {
   typedef bf16 T;
-  constexpr int COT = 16;
+  constexpr int NWR = COT / 16, NWK = 4 / NWR, KS = 4 / NWK;   // waves along co / along pixels, K steps per wave
   constexpr int PIXT = 128, HMAX = 208, OOB = 0x7fffffff;
   constexpr int SA = COT + 8, SB = CIT + 8;
   constexpr int TB = CIT / 16;
@@ -504,13 +504,14 @@ __global__ __launch_bounds__(256) void wgrad3x3_narrow_kernel(const FsWgradArgs 
   constexpr int LA = (PIXT * UA + 255) / 256, LB = (HMAX * UB + 255) / 256;
   constexpr int NACC = 9 * TB * 4;                       // accumulator floats per lane
   // one arena: operand tiles during the walk, then (re-used) one wave's partial accumulators at a time
-  constexpr int OPER_BYTES = (PIXT * SA + HMAX * SB) * 2, RED_BYTES = NACC * 64 * 4;
+  constexpr int OPER_BYTES = (PIXT * SA + HMAX * SB) * 2, RED_BYTES = NWR * NACC * 64 * 4;
   __shared__ __attribute__((aligned(16))) char smem[OPER_BYTES > RED_BYTES ? OPER_BYTES : RED_BYTES];
   T* lds_a = reinterpret_cast<T*>(smem);
   T* lds_b = lds_a + PIXT * SA;
   float* lds_red = reinterpret_cast<float*>(smem);
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wr = wave % NWR, wk = wave / NWR;
   const int li = lane & 15, lg = lane >> 4;
   const int HW = g.TW + 2, nhalo = (g.TH + 2) * HW, ntile = g.TH * g.TW;
   const int ci0 = blockIdx.x * CIT;
@@ -567,14 +568,16 @@ __global__ __launch_bounds__(256) void wgrad3x3_narrow_kernel(const FsWgradArgs 
   };
 
   // this wave's K step: pixels wave*32 .. wave*32+31; lane (li, lg) supplies pixel lg*8 + (li>>2) (+4)
-  int arow[2], brow[2];
+  int arow[KS][2], brow[KS][2];
 #pragma unroll
-  for (int hf = 0; hf < 2; ++hf) {
-    int pk = wave * 32 + lg * 8 + (li >> 2) + hf * 4;
-    arow[hf] = pk * SA + (li & 3) * 4;
-    int pv = pk < ntile ? pk : 0;          // (pixels past the tile hold zero dY rows)
-    brow[hf] = ((pv / g.TW) * HW + (pv % g.TW)) * SB + (li & 3) * 4;
-  }
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      int pk = (wk * KS + ks) * 32 + lg * 8 + (li >> 2) + hf * 4;
+      arow[ks][hf] = pk * SA + wr * 16 + (li & 3) * 4;
+      int pv = pk < ntile ? pk : 0;          // (pixels past the tile hold zero dY rows)
+      brow[ks][hf] = ((pv / g.TW) * HW + (pv % g.TW)) * SB + (li & 3) * 4;
+    }
 
   f32x4 acc[9][TB];
 #pragma unroll
@@ -589,46 +592,49 @@ __global__ __launch_bounds__(256) void wgrad3x3_narrow_kernel(const FsWgradArgs 
     store_lds();
     __syncthreads();
     if (pt + g.nsplit < npix) load_regs(pt + g.nsplit);
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(&lds_a[arow[0]]));
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(&lds_a[arow[1]]));
-    uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-    const bf16x8 fa = __builtin_bit_cast(bf16x8, make_uint4(l2.x, l2.y, h2.x, h2.y));
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp) {
-      const int toff = ((tp / 3) * HW + (tp % 3)) * SB;
+    for (int ks = 0; ks < KS; ++ks) {
+      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(&lds_a[arow[ks][0]]));
+      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(&lds_a[arow[ks][1]]));
+      uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+      const bf16x8 fa = __builtin_bit_cast(bf16x8, make_uint4(l2.x, l2.y, h2.x, h2.y));
 #pragma unroll
-      for (int b = 0; b < TB; ++b) {
-        s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(&lds_b[brow[0] + toff + b * 16]));
-        s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(&lds_b[brow[1] + toff + b * 16]));
-        uint2 bl = __builtin_bit_cast(uint2, blo), bh = __builtin_bit_cast(uint2, bhi);
-        bf16x8 fb = __builtin_bit_cast(bf16x8, make_uint4(bl.x, bl.y, bh.x, bh.y));
-        acc[tp][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[tp][b], 0, 0, 0);
+      for (int tp = 0; tp < 9; ++tp) {
+        const int toff = ((tp / 3) * HW + (tp % 3)) * SB;
+#pragma unroll
+        for (int b = 0; b < TB; ++b) {
+          s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(&lds_b[brow[ks][0] + toff + b * 16]));
+          s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(&lds_b[brow[ks][1] + toff + b * 16]));
+          uint2 bl = __builtin_bit_cast(uint2, blo), bh = __builtin_bit_cast(uint2, bhi);
+          bf16x8 fb = __builtin_bit_cast(bf16x8, make_uint4(bl.x, bl.y, bh.x, bh.y));
+          acc[tp][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[tp][b], 0, 0, 0);
+        }
       }
     }
   }
 
   // ---- the four K partials -> wave 0, one wave at a time through the (now idle) operand arena ----
-  for (int w = 1; w < 4; ++w) {
+  for (int w = 1; w < NWK; ++w) {
     __syncthreads();
-    if (wave == w) {
+    if (wk == w) {
 #pragma unroll
       for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
         for (int b = 0; b < TB; ++b)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) lds_red[((tp * TB + b) * 4 + j) * 64 + lane] = acc[tp][b][j];
+          for (int j = 0; j < 4; ++j) lds_red[((wr * NACC + (tp * TB + b) * 4 + j)) * 64 + lane] = acc[tp][b][j];
     }
     __syncthreads();
-    if (wave == 0) {
+    if (wk == 0) {
 #pragma unroll
       for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
         for (int b = 0; b < TB; ++b)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[tp][b][j] += lds_red[((tp * TB + b) * 4 + j) * 64 + lane];
+          for (int j = 0; j < 4; ++j) acc[tp][b][j] += lds_red[((wr * NACC + (tp * TB + b) * 4 + j)) * 64 + lane];
     }
   }
-  if (wave > 0) return;
+  if (wk > 0) return;
   // ---- epilogue: D rows = co (lg*4 + j), cols = ci (li) ----
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp)
@@ -637,7 +643,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_narrow_kernel(const FsWgradArgs 
       int ci = ci0 + b * 16 + li;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        int co = lg * 4 + j;
+        int co = wr * 16 + lg * 4 + j;
         float v = acc[tp][b][j];
         if (g.nsplit > 1) {
           p.workspace[((long)blockIdx.z * p.ws_rows + co) * p.ws_cols + tp * g.Cs + ci] = v;
@@ -702,8 +708,9 @@ int launch_wgrad_narrow(const FsWgradArgs& a, hipStream_t st) {
   g.N = a.M / (a.Hd * a.Wd); g.Cs = Cs;
   const int CIT = Cs % 32 == 0 ? 32 : 16;
   const int out_tiles = Cs / CIT;
+  const int COT = a.Cd;                      // 16 or 32: the block owns all output channels
   const int npix = g.N * g.tiles_x * g.tiles_y;
-  b.ws_rows = 16; b.ws_cols = 9 * Cs;
+  b.ws_rows = COT; b.ws_cols = 9 * Cs;
   const long slab = (long)b.ws_rows * b.ws_cols;
   // every tile step waits one global-load latency: ~1024 short chains keep 4 blocks per CU in flight; the slabs
   // are tiny (16 x 9Cs floats)
@@ -712,8 +719,10 @@ int launch_wgrad_narrow(const FsWgradArgs& a, hipStream_t st) {
   else splits = std::min<long>(splits, std::max<long>(1, a.workspace_elems / slab));
   g.nsplit = (int)splits; b.nsplit = g.nsplit;
   dim3 grid(out_tiles, 1, g.nsplit);
-  if (CIT == 32) hipLaunchKernelGGL((wgrad3x3_narrow_kernel<32>), grid, dim3(256), 0, st, b, g);
-  else hipLaunchKernelGGL((wgrad3x3_narrow_kernel<16>), grid, dim3(256), 0, st, b, g);
+  if (COT == 32 && CIT == 32) hipLaunchKernelGGL((wgrad3x3_narrow_kernel<32, 32>), grid, dim3(256), 0, st, b, g);
+  else if (COT == 16 && CIT == 32) hipLaunchKernelGGL((wgrad3x3_narrow_kernel<16, 32>), grid, dim3(256), 0, st, b, g);
+  else if (COT == 16 && CIT == 16) hipLaunchKernelGGL((wgrad3x3_narrow_kernel<16, 16>), grid, dim3(256), 0, st, b, g);
+  else return FS_EINVAL;
   if (b.nsplit > 1) {
     const int ncols = 9 * Cs;
     launch_reduce(b, a.Co, ncols, 8, st);
@@ -729,7 +738,7 @@ int launch_wgrad(const FsWgradArgs& a, hipStream_t st) {
     if (a.use_halo && a.R == 3 && a.S == 3 && a.stride == 1 && a.Cd % 64 == 0 && Cs % 32 == 0 && a.x_bytes > 0 &&
         a.x_bytes <= 0x7fffffffLL && (long)a.M * a.Cd * 2 <= 0x7fffffffLL && a.M >= 1024)
       return launch_wgrad_halo(a, st);   // (tiny pixel counts: too few tiles to split, the generic kernel wins)
-    if (a.use_halo && a.R == 3 && a.S == 3 && a.stride == 1 && a.Cd == 16 && a.Co <= 16 && Cs % 16 == 0 &&
+    if (a.use_halo && a.R == 3 && a.S == 3 && a.stride == 1 && ((a.Cd == 16 && Cs % 16 == 0) || (a.Cd == 32 && Cs % 32 == 0)) &&
         a.x_bytes > 0 && a.x_bytes <= 0x7fffffffLL && (long)a.M * a.Cd * 2 <= 0x7fffffffLL && a.M >= 4096)
       return launch_wgrad_narrow(a, st);
   }

@@ -21,6 +21,7 @@ CASES = [
     (16, 16, 3, 1, 1, 2, 48, 64),     # 16-channel halo path (half-filled chunk) + narrow wgrad, CIT = 16
     (32, 16, 3, 1, 1, 2, 48, 96),     # narrow wgrad, CIT = 32
     (64, 16, 3, 1, 1, 3, 40, 56),     # narrow wgrad over two input-channel tiles, ragged tiles
+    (96, 32, 3, 1, 1, 2, 48, 96),     # narrow wgrad with 32 output channels (2 x 2 waves: channels x pixels)
     (512, 256, 1, 1, 0, 2, 6, 20),    # pose squeeze
     (256, 12, 1, 1, 0, 2, 6, 20),     # pose out (Co padded to 16)
     (64, 64, 3, 1, 1, 12, 48, 160),   # big M -> 128x64 tiles
