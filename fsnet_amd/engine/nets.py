@@ -197,16 +197,19 @@ class ConvLayer:
         self.need_dgrad = need_dgrad
         self._op = None
         self._key = None
+        self._owner = None
         self._packed = None
         self._bias = None
 
     def ready(self, dtype, device):
         key = (dtype, device)
-        if self._key != key:
+        if self._key != key or self._owner != id(self):
+            # (_owner: a copy.deepcopy of the module copies this object's state but is not in the pack registry —
+            # without the check the copy's MFMA operands would never follow its own weights)
             w = self.m.weight
             self._op = ConvOp(w.shape[1], w.shape[0], self.R, self.S, self.stride, self.pad, dtype, device,
                               need_dgrad=self.need_dgrad)
-            self._key, self._packed = key, None
+            self._key, self._packed, self._owner = key, None, id(self)
             _PACK_REGISTRY.setdefault(key, []).append(weakref.ref(self))
         if self._version() != self._packed:
             pack_all(key)          # one launch for every stale conv of the model

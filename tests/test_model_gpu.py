@@ -219,3 +219,28 @@ def test_resnet50_wpose_gradients_match_oracle(dev):
         worst = max(worst, rel)
         assert rel < 3e-2, (k, rel)
     print("R50 worst gradient rel-L2:", worst)
+
+
+@gpu
+def test_deepcopied_model_repacks_its_own_weights(dev):
+    """a copy.deepcopy made after the first forward must keep its MFMA operands in step with ITS weights"""
+    import copy
+    from fsnet_amd.engine.runtime import RT
+    from fsnet_amd.vision_base.networks.models.backbone.resnet import resnet
+    RT.set_compute_dtype(torch.float32)
+    torch.manual_seed(0)
+    a = resnet(18, pretrained=False, norm_eval=False).to(dev).train()
+    x = torch.rand(2, 3, 64, 128, device=dev)
+    with torch.no_grad():
+        a(x)                                   # builds and packs a's operands
+        b = copy.deepcopy(a)
+        for p in b.parameters():
+            p.mul_(0.5)                        # in-place: bumps the parameter version
+        fa = a(x)[-1].float()
+        state = {k: v.clone() for k, v in b.state_dict().items()}       # before b's forward moved its BN statistics
+        fb = b(x)[-1].float()
+        ref = resnet(18, pretrained=False, norm_eval=False).to(dev).train()   # never copied: packs from scratch
+        ref.load_state_dict(state)
+        fr = ref(x)[-1].float()
+    assert float((fb - fr).abs().max()) < 1e-4 * float(fr.abs().max())
+    assert float((fb - fa).abs().max()) > 1e-3 * float(fa.abs().max())
