@@ -14,6 +14,7 @@ import weakref
 import torch
 
 from ..hip import ops
+from ..hip.binding import raw_stream
 from ..hip.conv import ConvOp
 from .runtime import RT, grad_of
 
@@ -256,8 +257,16 @@ class ConvLayer:
 
 
 def bn_tensors(bn):
-    return {"weight": bn.weight.data, "bias": bn.bias.data, "running_mean": bn.running_mean,
-            "running_var": bn.running_var, "num_batches_tracked": bn.num_batches_tracked}
+    """the module's tensors as a dict, cached on the module while its storage stays where it is (five
+    nn.Module.__getattr__ lookups per BatchNorm call add up on the host side)"""
+    c = bn.__dict__.get("_fs_tensors")
+    w = bn.weight
+    if c is None or c[0] != w.data_ptr() or c[1] != bn.running_mean.data_ptr():
+        d = {"weight": w.data, "bias": bn.bias.data, "running_mean": bn.running_mean,
+             "running_var": bn.running_var, "num_batches_tracked": bn.num_batches_tracked}
+        c = (w.data_ptr(), bn.running_mean.data_ptr(), d)
+        bn.__dict__["_fs_tensors"] = c
+    return c[2]
 
 
 def _dp_stats(stats):
@@ -272,7 +281,7 @@ _BWD_POOLS = {}
 
 def bwd_pool_reset(device):
     """one memset per network backward for all its BatchNorm backward sums"""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, raw_stream(device.index))
     p = _BWD_POOLS.get(key)
     if p is None:
         p = _BWD_POOLS[key] = StatsPool(device)
@@ -282,7 +291,7 @@ def bwd_pool_reset(device):
 
 def _bwd_sums(c, st):
     """zeroed f64 [groups][SLOTS][2][C] from the current stream's backward pool"""
-    return _BWD_POOLS[(c.device, torch.cuda.current_stream(c.device).cuda_stream)].take(c.shape[-1], st.groups)
+    return _BWD_POOLS[(c.device, raw_stream(c.device.index))].take(c.shape[-1], st.groups)
 
 
 def _bn_bwd(dout, y, c, bn, st, H, W, relu=True, fold=False, g_out=None, sums=None):

@@ -107,9 +107,14 @@ class ParamArena:
     def owns(self, p):
         return id(p) in self._by_id
 
-    def intact(self):
-        """False if something (e.g. module.to(), load with assign) replaced the parameter storage."""
-        return all(p.data.data_ptr() == self.data.data_ptr() + 4 * o for p, o in zip(self.params, self.offsets))
+    def intact(self, full=False):
+        """False if something (e.g. module.to(), load with assign) replaced the parameter storage.  Per step only the
+        first and last parameter are looked at (whole-model moves: .to(), .float()); full=True checks every one."""
+        base = self.data.data_ptr()
+        if not full:
+            return (self.params[0].data.data_ptr() == base + 4 * self.offsets[0]
+                    and self.params[-1].data.data_ptr() == base + 4 * self.offsets[-1])
+        return all(p.data.data_ptr() == base + 4 * o for p, o in zip(self.params, self.offsets))
 
     def attach_grads(self, zero=True):
         if zero:

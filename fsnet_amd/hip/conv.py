@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from .binding import lib, check, stream_ptr, FsConvArgs, FsWgradArgs, FS_DTYPE_BF16, FS_DTYPE_F32
+from .binding import lib, check, stream_ptr, raw_stream, FsConvArgs, FsWgradArgs, FS_DTYPE_BF16, FS_DTYPE_F32
 
 
 class LaunchProfile:
@@ -97,7 +97,7 @@ _WGRAD_WS = {}
 
 def wgrad_workspace(device, elems=1 << 23):
     """per-device fp32 scratch for split-K partial slabs (32 MB; stream-ordered reuse)."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)   # one scratch per stream: no cross-stream reuse
+    key = (device, raw_stream(device.index))   # one scratch per stream: no cross-stream reuse
     ws = _WGRAD_WS.get(key)
     if ws is None or ws.numel() < elems:
         ws = _WGRAD_WS[key] = torch.empty(elems, dtype=torch.float32, device=device)
