@@ -45,6 +45,9 @@ class DataParallelContext:
         params = [p for p in module.parameters()]
         if not params:
             return
+        from .nets import flush_deferred, join_companions
+        flush_deferred()          # weight-gradient kernels handed to companion streams must have landed in the
+        join_companions()         # arena slice before it is reduced
         lo, hi = arena.slice_of(params)
         h = dist.all_reduce(arena.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.handles.append(h)

@@ -241,7 +241,7 @@ class ConvLayer:
         gw = grad_of(self.m.weight)
         gb = grad_of(self.m.bias) if self.m.bias is not None else None
         item = (op, dc, x, gw, gb, self.m.bias.numel() if gb is not None else 0)
-        mode = RT.wgrad_streams if (dc.is_cuda and RT.dp is None and RT.overlap) else 0
+        mode = RT.wgrad_streams if (dc.is_cuda and RT.overlap) else 0
         if mode:
             cur = torch.cuda.current_stream(dc.device)
             if mode == 3:
