@@ -1,0 +1,119 @@
+"""Properties that do not need an oracle, checked at the FULL benchmark size (BASELINE configs[1]: batch 12,
+192x640, ResNet-18 depth+pose, bf16) where the CPU oracle would take minutes per step:
+  * convolution forward is linear in its input, the weight gradient is additive over a split of the batch
+    (fp32 accumulation: exact up to summation order) — on the real layer shapes;
+  * one stacked pose pass == two separate calls (BatchNorm statistics groups) at full size;
+  * identical source and target frames under the identity pose reproject onto themselves: zero photometric loss
+    and zero pose gradient;
+  * a few full-size training steps stay finite, replay from the hipGraph, and keep every parameter finite."""
+import pytest
+import torch
+
+from oracle import fsnet_oracle as O
+
+pytestmark = pytest.mark.gpu
+B, H, W = 12, 192, 640
+
+
+@pytest.mark.parametrize("Ci,Co,h,w", [(64, 64, 48, 160), (512, 512, 6, 20), (16, 16, 192, 640)])
+def test_conv_linearity_and_wgrad_additivity_on_benchmark_shapes(dev, Ci, Co, h, w):
+    from fsnet_amd.hip.conv import ConvOp
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(Ci + h)
+    op = ConvOp(Ci, Co, 3, 3, 1, 1, dt, dev)
+    op.pack((torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)).to(dev))
+    # operands on a coarse binary grid: their sum is exactly representable in bf16, so linearity must hold to fp32
+    # accumulation order
+    x1 = (torch.randint(-8, 9, (B, h, w, op.Ci_p), generator=g).float() / 8).to(dev).to(dt)
+    x2 = (torch.randint(-8, 9, (B, h, w, op.Ci_p), generator=g).float() / 8).to(dev).to(dt)
+    y1 = op.forward(x1, out_f32=True)
+    y2 = op.forward(x2, out_f32=True)
+    y12 = op.forward(x1 + x2, out_f32=True)
+    scale = float(y12.abs().max())
+    assert float((y12 - (y1 + y2)).abs().max()) <= 2e-5 * scale
+    dy = (torch.randint(-4, 5, (B, h, w, op.Co_p), generator=g).float() / 4).to(dev).to(dt)
+    full = torch.zeros(Co, Ci, 3, 3, device=dev)
+    op.wgrad(dy, x1, full)
+    parts = torch.zeros(Co, Ci, 3, 3, device=dev)
+    for lo, hi in ((0, 5), (5, B)):
+        op.wgrad(dy[lo:hi].contiguous(), x1[lo:hi].contiguous(), parts)
+    torch.cuda.synchronize()
+    assert float((full - parts).abs().max()) <= 1e-4 * float(full.abs().max())
+    # data gradient: adjoint identity <conv(x), dy> == <x, dgrad(dy)>
+    lhs = float((y1.double() * dy.double()).sum())
+    dx = op.dgrad(dy, h, w)
+    rhs = float((x1.double() * dx.double()).sum())
+    assert abs(lhs - rhs) <= 2e-2 * (abs(lhs) + float(y1.abs().max()))      # dx is stored in bf16
+
+
+def test_stacked_pose_pairs_equal_separate_calls_at_full_size(dev):
+    import copy
+    from fsnet_amd.engine.runtime import RT
+    from fsnet_amd.vision_base.networks.models.backbone.resnet import resnet
+    RT.set_compute_dtype(torch.float32)
+    torch.manual_seed(1)
+    ma = resnet(18, pretrained=False, num_input_images=2, norm_eval=False).to(dev).train()
+    mb = copy.deepcopy(ma)
+    g = torch.Generator().manual_seed(2)
+    imgs = [torch.rand(B, 3, H, W, generator=g).to(dev) for _ in range(3)]
+    pairs = [(imgs[1], imgs[0]), (imgs[0], imgs[2])]
+    with torch.no_grad():
+        fa = [ma.forward_pair(*p) for p in pairs]
+        fb = mb.forward_pairs(pairs)
+    for k in range(2):
+        for i in range(5):
+            a, b = fa[k][i].float(), fb[i][k * B:(k + 1) * B].float()
+            assert float((a - b).norm() / a.norm()) < 2e-4, (k, i)
+    for (n, ba), (_, bb) in zip(ma.named_buffers(), mb.named_buffers()):
+        if "running" in n:
+            assert float((ba - bb).abs().max()) < 1e-4 * float(ba.abs().max().clamp_min(1.0)), n
+
+
+def test_identical_frames_reproject_onto_themselves(dev):
+    """reference monodepth2_decoder.py:68-128: sampling the source at its own pixel centres returns the source, so
+    with source == target and T = I the reprojection term vanishes for every depth"""
+    from fsnet_amd.hip import ops
+    S = 4
+    pl = ops.PhotometricLoss(B, H, W, [0, 1, 2, 3], dev, 0.5, 100.0)
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(B, 3, H, W, generator=g).to(dev)
+    P2 = torch.tensor([[0.58 * W, 0, 0.5 * W, 0], [0, 1.92 * H, 0.5 * H, 0], [0, 0, 1, 0]]).repeat(B, 1, 1).to(dev)
+    T = torch.eye(4).repeat(B, 1, 1).to(dev)
+    depths = [(torch.rand(B, 1, H >> s, W >> s, generator=g) * 20 + 2).to(dev) for s in range(S)]
+    disps = [1.0 / d for d in depths]
+    out = pl.forward(img, [img.clone(), img.clone()], P2, [T, T.clone()], None, depths, disps, noise_seed=-1)
+    torch.cuda.synchronize()
+    photo = out[:S].cpu()
+    smooth = out[S:2 * S].cpu()
+    # what is left per scale is the smoothness term only
+    assert float((photo - smooth).abs().max()) < 1e-6, (photo, smooth)
+    d_depth, d_disp, dT = pl.backward(None)
+    torch.cuda.synchronize()
+    assert float(dT[0].abs().max()) < 1e-6 and float(dT[1].abs().max()) < 1e-6
+
+
+def test_full_size_training_steps(dev):
+    from fsnet_amd.configs import meta_arch_cfg, training_cfg
+    from fsnet_amd.engine.runtime import RT
+    from fsnet_amd.vision_base.networks.optimizers.optimizers import build_optimizer
+    from fsnet_amd.vision_base.utils.builder import build
+    RT.set_compute_dtype(torch.bfloat16)
+    RT.tie_noise = True
+    torch.manual_seed(0)
+    m = build(**meta_arch_cfg(H, W, with_pose=True)).to(dev).train()
+    tc = training_cfg(clip_gradients=35.0, lr=1e-4)
+    opt = build_optimizer(m, **tc.optimizer)
+    hook = build(graph_warmup=2, **tc.training_hook)
+    batch = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in O.synthetic_batch(B, H, W, seed=1).items()}
+    losses = []
+    for it in range(8):                      # the same batch: the loss must go down
+        out = hook(dict(batch), m, opt)
+        losses.append(float(out["loss"].detach()))
+    torch.cuda.synchronize()
+    assert hook.graph_captures == 1 and hook.graph_replays == 5
+    assert all(l == l and 0 < l < 10 for l in losses), losses
+    assert losses[-1] < losses[0], losses
+    flat = torch.cat([p.detach().flatten() for p in m.parameters()])
+    assert bool(torch.isfinite(flat).all())
+    assert float(opt.grad_norm()) > 0
+    RT.tie_noise = False
