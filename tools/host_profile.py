@@ -20,6 +20,7 @@ torch.cuda.synchronize()
 import time
 t0 = time.perf_counter()
 N = 20
+torch.autograd.set_multithreading_enabled(False)   # backward on this thread: visible to cProfile
 pr = cProfile.Profile()
 pr.enable()
 for i in range(N):
