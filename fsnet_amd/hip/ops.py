@@ -375,3 +375,29 @@ def copy_multi(pairs):
 def counter_incr(buf):
     """device int32 counter += 1 on the current stream (replayable from a hipGraph)"""
     check(lib.fs_counter_incr(buf.data_ptr(), stream_ptr()), "counter_incr")
+
+
+# ---------------------------------------------------------------------------------------------
+# evaluation (SURVEY 8f rank 2)
+# ---------------------------------------------------------------------------------------------
+def resize_linear(src, H, W, invert=False):
+    """src: device fp32 [h, w] -> [H, W] with OpenCV's INTER_LINEAR rule (invert: 1 / resize(1 / src))."""
+    assert src.is_cuda and src.dtype == torch.float32 and src.dim() == 2
+    src = src.contiguous()
+    dst = torch.empty(H, W, dtype=torch.float32, device=src.device)
+    check(lib.fs_resize_linear(src.data_ptr(), dst.data_ptr(), src.shape[0], src.shape[1], H, W, int(invert),
+                               stream_ptr()), "resize_linear")
+    return dst
+
+
+def depth_eval(pred, gt):
+    """pred: device fp32 [B, h, w]; gt: device fp32 [B, H, W].  Returns f64 [B, 16] on the device:
+    ratio, err[7] (median-scaled), abs_err[7], n_valid  (kitti_unsupervised_eval.py:47-80)."""
+    assert pred.is_cuda and gt.is_cuda and pred.dtype == gt.dtype == torch.float32
+    assert pred.dim() == 3 and gt.dim() == 3 and pred.shape[0] == gt.shape[0]
+    pred, gt = pred.contiguous(), gt.contiguous()
+    out = torch.empty(pred.shape[0], 16, dtype=torch.float64, device=pred.device)
+    scratch = torch.empty(gt.numel() * 2, dtype=torch.float32, device=pred.device)
+    check(lib.fs_depth_eval(pred.data_ptr(), gt.data_ptr(), pred.shape[0], pred.shape[1], pred.shape[2], gt.shape[1],
+                            gt.shape[2], scratch.data_ptr(), out.data_ptr(), stream_ptr()), "depth_eval")
+    return out

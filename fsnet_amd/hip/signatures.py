@@ -15,6 +15,8 @@ SIGNATURES = {
     "fs_conv3x3_halo": (C.c_int, [P, I, P]),
     "fs_conv_wgrad": (C.c_int, [P, I, P]),
     "fs_pack_weights": (C.c_int, [P, P, I, I, I, I, I, I, L, I, I, P]),
+    "fs_resize_linear": (C.c_int, [P, P, I, I, I, I, I, P]),
+    "fs_depth_eval": (C.c_int, [P, P, I, I, I, I, I, P, P, P]),
     "fs_copy_multi": (C.c_int, [P, P, P, I, P]),
     "fs_pack_tile_blocks": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "fs_pack_weights_multi": (C.c_int, [P, I, L, I, P]),

@@ -1,0 +1,67 @@
+"""KittiEigenEvaluator with the reference's constructor and methods (monodepth/evaluation/
+kitti_unsupervised_eval.py:11-127).  `_single_loss` runs on the device: resize to the ground truth's size, valid mask
++ Garg crop, median scaling, clamp and the seven depth errors are one HIP launch per image (fs_depth_eval), so a
+validation pass does not copy depth maps to the host.  Ground-truth export from raw velodyne scans (`_precompute`,
+:27-45) is the data layer's job and is not part of this package: the evaluator loads the reference's `gt_saved_file`."""
+import os
+
+import numpy as np
+import torch
+
+from fsnet_amd.hip import ops
+
+
+class KittiEigenEvaluator(object):
+    def __init__(self, data_path=None, split_file=None, gt_saved_file=None, is_evaluate_absolute=False, gt_depths=None,
+                 device=None):
+        self.is_evaluate_absolute = is_evaluate_absolute
+        self.device = device
+        if gt_depths is not None:
+            self.gt_depths = gt_depths
+        elif gt_saved_file is not None and os.path.isfile(gt_saved_file):
+            self.gt_depths = np.load(gt_saved_file, fix_imports=True, encoding='latin1', allow_pickle=True)["data"]
+        else:
+            raise NotImplementedError(
+                "ground-truth export from raw KITTI velodyne scans is not part of fsnet_amd; run the reference's "
+                "KittiEigenEvaluator once to write %r and point gt_saved_file at it" % (gt_saved_file,))
+        self._gt_dev = {}
+
+    def _gt(self, index, device):
+        g = self._gt_dev.get(index)
+        if g is None or g.device != device:
+            g = torch.as_tensor(np.asarray(self.gt_depths[index], dtype=np.float32)).to(device)
+            if len(self._gt_dev) < 4096:
+                self._gt_dev[index] = g
+        return g
+
+    def _single_loss(self, depth_0, gt_depth):
+        """depth_0: predicted depth [h, w] (device tensor, or numpy as in the reference); gt_depth: [H, W]."""
+        dev = self.device
+        if isinstance(depth_0, torch.Tensor) and depth_0.is_cuda:
+            dev = depth_0.device
+        if dev is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        pred = torch.as_tensor(depth_0, dtype=torch.float32).to(dev)
+        gt = torch.as_tensor(gt_depth, dtype=torch.float32).to(dev)
+        out = ops.depth_eval(pred[None], gt[None])[0].cpu().numpy()
+        if out[15] == 0:
+            raise ValueError
+        return dict(ratio=np.float32(out[0]), error=tuple(out[1:8]), abs_error=tuple(out[8:15]))
+
+    def single_call(self, depth_0, index):
+        dev = depth_0.device if isinstance(depth_0, torch.Tensor) and depth_0.is_cuda else (
+            self.device or torch.device("cuda", torch.cuda.current_device()))
+        return self._single_loss(depth_0, self._gt(index, dev))
+
+    def log(self, writer, mean_errors, mean_abs_errors, global_step=0, epoch_num=0, is_print=True):
+        log_str = f"Epoch {epoch_num}"
+        log_str += "\n  " + ("{:>8} | " * 7).format("abs_rel", "sq_rel", "rmse", "rmse_log", "a1", "a2", "a3")
+        log_str += "\n" + ("&{: 8.3f}  " * 7).format(*np.asarray(mean_errors).tolist()) + "\\\\"
+        log_str += f"\nEpoch {epoch_num}| Abs Error without Scaled"
+        log_str += "\n  " + ("{:>8} | " * 7).format("abs_rel", "sq_rel", "rmse", "rmse_log", "a1", "a2", "a3")
+        log_str += "\n" + ("&{: 8.3f}  " * 7).format(*np.asarray(mean_abs_errors).tolist()) + "\\\\"
+        if writer is not None:
+            writer.add_text("evaluation logs", log_str.replace(' ', '&nbsp;').replace('\n', '  \n'), global_step=epoch_num)
+        if is_print:
+            print(log_str)
+        return log_str

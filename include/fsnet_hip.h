@@ -162,6 +162,17 @@ int fs_pack_weights_multi(const FsPackDesc* descs_dev, int n, int64_t total_bloc
  * running sum of this over the table, total_blocks the grand total.  -1 for unsupported shapes (R*S > 288). */
 int64_t fs_pack_tile_blocks(int Co, int Ci, int R, int S);
 
+/* Evaluation.  fs_resize_linear: single-channel fp32 [h][w] -> [H][W] with OpenCV's INTER_LINEAR
+ * rule; invert != 0 resizes the inverse: dst = 1 / resize(1 / src)  (base_evaluation_hooks.py:57).
+ * fs_depth_eval: per image b, pred [B][h][w] (resized on the fly to the ground truth's [H][W]) against gt [B][H][W]:
+ * mask 1e-3 < gt < 80 inside the Garg crop, ratio = median(gt) / median(pred), clamp to [1e-3, 80], the seven errors of
+ * compute_errors for the scaled and for the unscaled prediction (kitti_unsupervised_eval.py:47-80,
+ * monodepth_utils.py:271-289).  out16[b] = { ratio, err[7], abs_err[7], n_valid }; n_valid == 0 leaves zeros.
+ * scratch: B*H*W*8 bytes of device memory (the valid (gt, pred) pairs are compacted there once). */
+int fs_resize_linear(const float* src, float* dst, int h, int w, int H, int W, int invert, void* stream);
+int fs_depth_eval(const float* pred, const float* gt, int B, int h, int w, int H, int W, void* scratch,
+                  double* out16, void* stream);
+
 /* n <= FS_COPY_MAX device-to-device copies (16-byte aligned pointers, any byte counts) in one launch: the training
  * hook stages a batch into the static input buffers of its captured hipGraph with it
  * (base_training_hooks.py:28-31 does one .cuda() per tensor). */

@@ -110,3 +110,38 @@ def test_model_golden(tag, with_pose):
             ref = T(g["gradnorm_0"])
             big = ref > 1e-4 * ref.max()
             assert float(((gn - ref).abs() / ref)[big].max()) < 2e-2
+
+
+def test_eval_oracle_matches_reference_compute_errors():
+    """oracle/eval_oracle.compute_errors against the outputs of the real monodepth_utils.compute_errors"""
+    from oracle import eval_oracle as EO
+    g = np.load(os.path.join(GOLD, "eval.npz"))
+    for k in range(3):
+        mine = np.array(EO.compute_errors(g["gt_%d" % k], g["pred_%d" % k]), dtype=np.float64)
+        assert np.abs(mine - g["err_%d" % k]).max() <= 1e-7 * max(1.0, np.abs(g["err_%d" % k]).max())
+
+
+def test_eval_oracle_resize_and_single_loss_properties():
+    """the cv2.resize restatement (parity unpinned: cv2 is not in the image): identity at equal size, exact on
+    affine images away from the clamped borders, constant-preserving; single_loss: perfect prediction -> zero error,
+    a globally scaled prediction -> the same scaled errors and ratio = 1/scale, empty mask -> ValueError"""
+    from oracle import eval_oracle as EO
+    rng = np.random.RandomState(0)
+    img = rng.rand(24, 40).astype(np.float32)
+    assert np.array_equal(EO.cv2_resize_linear(img, 40, 24), img)
+    yy, xx = np.mgrid[0:24, 0:40].astype(np.float32)
+    ramp = 2 * xx + 3 * yy + 1
+    up = EO.cv2_resize_linear(ramp, 80, 48)
+    Y, X = np.mgrid[0:48, 0:80].astype(np.float32)
+    want = 2 * ((X + 0.5) / 2 - 0.5) + 3 * ((Y + 0.5) / 2 - 0.5) + 1
+    assert np.abs(up[2:-2, 2:-2] - want[2:-2, 2:-2]).max() < 1e-4
+    assert np.abs(EO.cv2_resize_linear(np.full((7, 9), 3.5, np.float32), 31, 17) - 3.5).max() < 1e-6
+    gt = np.zeros((100, 300), np.float32)
+    gt[45:95, 20:280] = rng.rand(50, 260).astype(np.float32) * 60 + 2
+    r = EO.single_loss(gt.copy() + (gt == 0), gt)
+    assert abs(r["ratio"] - 1) < 1e-6 and max(r["error"][:4]) < 1e-6 and min(r["error"][4:]) == 1.0
+    r2 = EO.single_loss((gt + (gt == 0)) * 0.5, gt)
+    assert abs(r2["ratio"] - 2) < 1e-5 and max(r2["error"][:4]) < 1e-5 and r2["abs_error"][0] > 0.4
+    import pytest
+    with pytest.raises(ValueError):
+        EO.single_loss(np.ones((100, 300), np.float32), np.zeros((100, 300), np.float32))

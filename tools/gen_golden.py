@@ -240,10 +240,26 @@ def gen_model(with_pose, tag, steps=3):
     np.savez_compressed(os.path.join(GOLD, "model_%s.npz" % tag), **out)
 
 
+def gen_eval():
+    """depth-error metrics of the REAL reference (monodepth_utils.compute_errors) on seeded inputs"""
+    from oracle import eval_oracle as EO
+    rng = np.random.RandomState(7)
+    out = {}
+    for k, n in enumerate((1, 7, 4096)):
+        gt = (rng.rand(n).astype(np.float32) * 79 + 0.5)
+        pred = (gt * np.exp(rng.randn(n).astype(np.float32) * 0.2)).astype(np.float32).clip(1e-3, 80.0)
+        ref = np.array(mu.compute_errors(gt, pred), dtype=np.float64)
+        mine = np.array(EO.compute_errors(gt, pred), dtype=np.float64)
+        print("compute_errors case %d: oracle - reference max abs %.3e" % (k, np.abs(ref - mine).max()))
+        out["gt_%d" % k], out["pred_%d" % k], out["err_%d" % k] = gt, pred, ref
+    np.savez_compressed(os.path.join(GOLD, "eval.npz"), **out)
+
+
 if __name__ == "__main__":
     gen_ops()
     gen_loss_chain()
     gen_model(True, "depthpose")
     gen_model(False, "wpose")
+    gen_eval()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")
