@@ -493,10 +493,13 @@ class DepthDecoderRunner:
             self.up1[i] = (ConvLayer(b1.sequence[0], valid_over_padded=True), b1.sequence[1])
         for s in module.scales:
             self.disp[s] = ConvLayer(module.convs[("dispconv", s)], valid_over_padded=True)
+        # MultiChannelDepthDecoderUncertain: one more 3x3 replicate conv per scale -> sigmoid (depth_encoder.py:163-186)
+        self.unc = {s: ConvLayer(module.convs[("uncertain_logz", s)], valid_over_padded=True)
+                    for s in module.scales if ("uncertain_logz", s) in module.convs}
         self.pool = None
 
     def forward(self, feats, train, depth_scale=None):
-        """feats: 5 NHWC dense tensors.  Returns ({scale: (logits, depth, disp)}, ctx)."""
+        """feats: 5 NHWC dense tensors.  Returns ({scale: (logits, depth, disp[, uncertain_z])}, ctx)."""
         m = self.m
         dev, dt = feats[-1].device, feats[-1].dtype
         if self.pool is None or self.pool.buf.device != dev:
@@ -539,12 +542,19 @@ class DepthDecoderRunner:
                 depth, disp = ops.depth_head_fwd(logits, m.depth_bins, K, m.min_depth, m.max_depth)
                 lv["logits"] = logits
                 outs[i] = (logits, depth, disp)
+                if i in self.unc:
+                    clu = self.unc[i]
+                    opu = clu.ready(dt, dev)
+                    u = ops.sigmoid_head_fwd(opu.forward(y1p, bias=clu.bias, out_f32=True))
+                    lv["unc"] = u
+                    outs[i] = (logits, depth, disp, u)
             ctx["lv"][i] = lv
             x = y1p[:, 1:-1, 1:-1]
         return outs, ctx
 
-    def backward(self, ctx, g_depth, g_disp):
-        """g_depth / g_disp: {scale: [N,1,H,W] fp32 or None}.  Returns the 5 feature gradients (NHWC)."""
+    def backward(self, ctx, g_depth, g_disp, g_unc=None):
+        """g_depth / g_disp / g_unc: {scale: [N,1,H,W] fp32 or None}.  Returns the 5 feature gradients (NHWC)."""
+        g_unc = g_unc or {}
         m = self.m
         feats = ctx["feats"]
         dev, dt = feats[-1].device, feats[-1].dtype
@@ -556,14 +566,21 @@ class DepthDecoderRunner:
             """padded-domain gradient of y1p_i from its dispconv (or zeros)."""
             lv = ctx["lv"][i]
             y1p = lv["y1p"]
+            G = None
             if i in m.scales and (g_depth.get(i) is not None or g_disp.get(i) is not None):
                 cld = self.disp[i]
                 opd = cld.ready(dt, dev)
                 dl = ops.depth_head_bwd(lv["logits"], m.depth_bins, g_depth.get(i), g_disp.get(i), K, m.min_depth,
                                         m.max_depth, dt)
                 cld.accumulate_param_grads(opd, dl, y1p)
-                return opd.dgrad(dl, y1p.shape[1], y1p.shape[2])
-            return torch.zeros_like(y1p)
+                G = opd.dgrad(dl, y1p.shape[1], y1p.shape[2])
+            if i in self.unc and g_unc.get(i) is not None:
+                clu = self.unc[i]
+                opu = clu.ready(dt, dev)
+                dlu = ops.sigmoid_head_bwd(lv["unc"], g_unc[i], opu.Co_p, dt)
+                clu.accumulate_param_grads(opu, dlu, y1p)
+                G = opu.dgrad(dlu, y1p.shape[1], y1p.shape[2], addend=G)
+            return G if G is not None else torch.zeros_like(y1p)
 
         Gp = disp_grad(0)
         for i in range(0, 5):

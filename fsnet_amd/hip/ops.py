@@ -401,3 +401,46 @@ def depth_eval(pred, gt):
     check(lib.fs_depth_eval(pred.data_ptr(), gt.data_ptr(), pred.shape[0], pred.shape[1], pred.shape[2], gt.shape[1],
                             gt.shape[2], scratch.data_ptr(), out.data_ptr(), stream_ptr()), "depth_eval")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# self-distillation
+# ---------------------------------------------------------------------------------------------
+def sigmoid_head_fwd(logits):
+    """logits: fp32 NHWC [N,H,W,Cp] whose channel 0 is the head output -> u [N,1,H,W] fp32"""
+    N, H, W, Cp = logits.shape
+    assert logits.dtype == torch.float32 and logits.is_contiguous()
+    u = torch.empty(N, 1, H, W, dtype=torch.float32, device=logits.device)
+    check(lib.fs_sigmoid_head_fwd(logits.data_ptr(), u.data_ptr(), N * H * W, Cp, stream_ptr()), "sigmoid_head_fwd")
+    return u
+
+
+def sigmoid_head_bwd(u, du, Cp, dtype):
+    """-> gradient w.r.t. the head's conv output, NHWC [N,H,W,Cp] in `dtype` (channels 1.. are zero)"""
+    N, _, H, W = u.shape
+    du = du.contiguous().float()
+    dl = torch.empty(N, H, W, Cp, dtype=dtype, device=u.device)
+    check(lib.fs_sigmoid_head_bwd(u.data_ptr(), du.data_ptr(), dl.data_ptr(), N * H * W, Cp, dtype_code(dtype),
+                                  stream_ptr()), "sigmoid_head_bwd")
+    return dl
+
+
+def distill_fwd(pred, teacher, uncertain=None):
+    """mean over all elements of |teacher - pred| (/ uncertain + log(uncertain + 1e-5)) as an f64 device scalar"""
+    assert pred.shape == teacher.shape and pred.dtype == teacher.dtype == torch.float32
+    pred, teacher = pred.contiguous(), teacher.contiguous()
+    if uncertain is not None:
+        assert uncertain.shape == pred.shape and uncertain.dtype == torch.float32
+        uncertain = uncertain.contiguous()
+    acc = torch.zeros((), dtype=torch.float64, device=pred.device)
+    check(lib.fs_distill_fwd(pred.data_ptr(), teacher.data_ptr(), _p(uncertain), pred.numel(), acc.data_ptr(),
+                             stream_ptr()), "distill_fwd")
+    return acc / pred.numel()
+
+
+def distill_bwd(pred, teacher, uncertain, gout):
+    d_pred = torch.empty_like(pred)
+    d_unc = torch.empty_like(uncertain) if uncertain is not None else None
+    check(lib.fs_distill_bwd(pred.data_ptr(), teacher.data_ptr(), _p(uncertain), pred.numel(), _p(gout), d_pred.data_ptr(),
+                             _p(d_unc), stream_ptr()), "distill_bwd")
+    return d_pred, d_unc

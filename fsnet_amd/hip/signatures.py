@@ -15,6 +15,10 @@ SIGNATURES = {
     "fs_conv3x3_halo": (C.c_int, [P, I, P]),
     "fs_conv_wgrad": (C.c_int, [P, I, P]),
     "fs_pack_weights": (C.c_int, [P, P, I, I, I, I, I, I, L, I, I, P]),
+    "fs_sigmoid_head_fwd": (C.c_int, [P, P, L, I, P]),
+    "fs_sigmoid_head_bwd": (C.c_int, [P, P, P, L, I, I, P]),
+    "fs_distill_fwd": (C.c_int, [P, P, P, L, P, P]),
+    "fs_distill_bwd": (C.c_int, [P, P, P, L, P, P, P, P]),
     "fs_resize_linear": (C.c_int, [P, P, I, I, I, I, I, P]),
     "fs_depth_eval": (C.c_int, [P, P, I, I, I, I, I, P, P, P]),
     "fs_copy_multi": (C.c_int, [P, P, P, I, P]),

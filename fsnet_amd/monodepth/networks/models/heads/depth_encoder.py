@@ -22,20 +22,25 @@ class _DepthDecoderFn(torch.autograd.Function):
         mod._pending += 1
         flat = []
         for s in mod.scales:
-            logits, depth, disp = outs[s]
+            logits, depth, disp = outs[s][:3]
             flat += [logits.permute(0, 3, 1, 2)[:, : mod.num_output_channels], depth, disp]
+            if mod._nout == 4:
+                flat.append(outs[s][3])
         return tuple(flat)
 
     @staticmethod
     def backward(ctx, *g):
         mod = ctx.mod
-        g_depth, g_disp = {}, {}
+        g_depth, g_disp, g_unc = {}, {}, {}
+        no = mod._nout
         for k, s in enumerate(mod.scales):
-            if g[3 * k] is not None:
+            if g[no * k] is not None:
                 raise NotImplementedError("gradient w.r.t. ('logits', s) is not supported by the HIP decoder")
-            g_depth[s] = None if g[3 * k + 1] is None else g[3 * k + 1].contiguous().float()
-            g_disp[s] = None if g[3 * k + 2] is None else g[3 * k + 2].contiguous().float()
-        gfeats = mod._runner.backward(ctx.c, g_depth, g_disp)
+            g_depth[s] = None if g[no * k + 1] is None else g[no * k + 1].contiguous().float()
+            g_disp[s] = None if g[no * k + 2] is None else g[no * k + 2].contiguous().float()
+            if no == 4:
+                g_unc[s] = None if g[no * k + 3] is None else g[no * k + 3].contiguous().float()
+        gfeats = mod._runner.backward(ctx.c, g_depth, g_disp, g_unc)
         ctx.c = None
         mod._pending -= 1
         if mod._pending == 0 and RT.dp is not None:
@@ -58,6 +63,7 @@ class DepthDecoder(nn.Module):
         self.min_depth, self.max_depth = min_depth, max_depth
         self._build_depth_bins(min_depth, max_depth, num_output_channels)
         self._init_layers()
+        self._nout = 4 if any(k[0] == "uncertain_logz" for k in self.convs) else 3   # tensors per scale
         self._runner = DepthDecoderRunner(self)
         self._pending = 0
         self._plist = None
@@ -100,13 +106,30 @@ class MultiChannelDepthDecoder(DepthDecoder):
             if self._plist is None:
                 self._plist = list(self.parameters())
             flat = _DepthDecoderFn.apply(self, len(feats), *feats, *self._plist)
+            no = self._nout
             for k, s in enumerate(self.scales):
-                outputs[('logits', s)], outputs[('depth', s, s)], outputs[('disp', s)] = flat[3 * k: 3 * k + 3]
+                outputs[('logits', s)], outputs[('depth', s, s)], outputs[('disp', s)] = flat[no * k: no * k + 3]
+                if no == 4:
+                    outputs[('uncertain_z', s)] = flat[no * k + 3]
             return outputs
         with torch.no_grad():
             outs, _ = self._runner.forward([nhwc_dense(f, f.dtype) for f in feats], train=self.decoder[0].sequence[1].training)
         for s in self.scales:
-            logits, depth, disp = outs[s]
+            logits, depth, disp = outs[s][:3]
             outputs[('logits', s)] = logits.permute(0, 3, 1, 2)[:, : self.num_output_channels]
             outputs[('depth', s, s)], outputs[('disp', s)] = depth, disp
+            if self._nout == 4:
+                outputs[('uncertain_z', s)] = outs[s][3]
         return outputs
+
+
+class MultiChannelDepthDecoderUncertain(MultiChannelDepthDecoder):
+    """MultiChannelDepthDecoder + a per-scale uncertainty head, sigmoid(3x3 replicate conv -> 1 channel)
+    (depth_encoder.py:142-194; the reference version does not emit ('logits', s), this one keeps them)."""
+
+    def _init_layers(self):
+        super()._init_layers()
+        for s in self.scales:
+            self.convs[("uncertain_logz", s)] = nn.Conv2d(int(self.num_ch_dec[s]), 1, kernel_size=3, padding=1,
+                                                          padding_mode='replicate')
+        self.decoder = nn.ModuleList(list(self.convs.values()))       # upconvs, dispconvs, then uncertain_logz

@@ -38,6 +38,21 @@ class _PhotoLossFn(torch.autograd.Function):
         return (None, None, None, None, None, None, None, dT[0], dT[1]) + tuple(d_depth) + tuple(d_disp)
 
 
+class _DistillFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, teacher, unc):
+        pred, teacher = pred.contiguous().float(), teacher.contiguous().float()
+        unc = None if unc is None else unc.contiguous().float()
+        ctx.save_for_backward(pred, teacher, unc)
+        return ops.distill_fwd(pred, teacher, unc)
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, teacher, unc = ctx.saved_tensors
+        d_pred, d_unc = ops.distill_bwd(pred, teacher, unc, g.detach().double().contiguous())
+        return d_pred, None, d_unc
+
+
 class MonoDepth2Decoder(nn.Module):
     def __init__(self, scales, height, width, frame_ids, depth_decoder_cfg, pose_decoder_cfg=None,
                  multiscale_head_cfg=None, **kwargs):
@@ -78,9 +93,11 @@ class MonoDepth2Decoder(nn.Module):
         for flag in _UNSUPPORTED_FLAGS:
             if getattr(self, flag, False):
                 raise NotImplementedError("MonoDepth2Decoder option %s is not implemented in the HIP loss chain" % flag)
-        for w in ("pose_loss_weight", "distillation_loss_weight", "residualflow_weight"):
+        for w in ("pose_loss_weight", "residualflow_weight"):
             if getattr(self, w, 0) > 0:
                 raise NotImplementedError("MonoDepth2Decoder term %s > 0 is not implemented in the HIP loss chain" % w)
+        if getattr(self, "distillation_loss_weight", 0) > 0 and getattr(self, "is_unscaled_distill", False):
+            raise NotImplementedError("is_unscaled_distill=True is not implemented (no shipped config enables it)")
         if not getattr(self, "overlapped_mask", False):
             raise NotImplementedError("overlapped_mask=False is not implemented (all shipped configs enable it)")
         if "motion_mask" in input_dict:
@@ -156,8 +173,21 @@ class MonoDepth2Decoder(nn.Module):
             hm["loss_mask_%d" % self.scales[0]] = dict(data=(self._pl.sel[0, 0:1] >= 2).unsqueeze(1))
         return losses, hm, total
 
+    def compute_distill_loss(self, output_dict, input_dict, scale):
+        """monodepth2_decoder.py:185-203: mean |teacher - pred| (/ uncertain_z + log(uncertain_z + 1e-5))"""
+        pred = output_dict[('depth', scale, scale)]
+        teacher = output_dict[('teacher_depth', scale, scale)].detach()
+        unc = output_dict[('uncertain_z', scale)] if getattr(self, 'is_uncertain_distill', False) else None
+        return _DistillFn.apply(pred, teacher, unc)
+
     def loss(self, output_dict, input_dict):
         losses, hm, total = self.compute_total_reprojection_loss(output_dict, input_dict)
+        distillation_weight = getattr(self, 'distillation_loss_weight', 0)
+        if distillation_weight > 0:                                   # reference :328-334
+            for scale in self.scales:
+                dl = self.compute_distill_loss(output_dict, input_dict, scale)
+                losses["distilation/{}".format(scale)] = dl.detach()
+                total = total + dl * distillation_weight
         losses["total_loss"] = total.detach()
         if not getattr(self, "is_log_image", True):
             hm = {}

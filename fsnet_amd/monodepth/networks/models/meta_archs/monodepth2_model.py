@@ -140,3 +140,41 @@ class MonoDepthWPose(_HipMetaArch):
         outputs = self.head.forward_depth(features, None if getattr(self.head.depth_decoder, "base_fx", None) is None
                                           else data['P2'])
         return self.head.get_prediction(data, outputs)
+
+
+class DistillWPoseMeta(_HipMetaArch):
+    """Second training stage (monodepth2_model.py:150-206): a frozen teacher network supplies
+    ('teacher_depth', s, s); the student (depth backbone + MultiChannelDepthDecoderUncertain head) is trained with
+    dataset poses, the photometric loss and the (uncertainty-weighted) L1 distillation term."""
+
+    def __init__(self, teacher_net_cfg, depth_backbone_cfg, teacher_net_path, head_cfg, train_cfg, test_cfg, **kwargs):
+        super().__init__()
+        self.teacher_net = build(**teacher_net_cfg)
+        if teacher_net_path is not None:
+            self.teacher_net.load_state_dict(torch.load(teacher_net_path, map_location='cpu'), strict=False)
+        for param in self.teacher_net.parameters():
+            param.requires_grad = False
+        self.depth_backbone = build(**depth_backbone_cfg)
+        self.head = build(frame_ids=train_cfg.frame_ids, **head_cfg)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self._post_init(kwargs)
+
+    def train(self, mode=True):
+        super().train(mode)
+        self.teacher_net.eval()
+        return self
+
+    def forward_train(self, data, meta):
+        self._begin_train()
+        image_0 = data[('image', 0)]
+        features = self.depth_backbone(image_0)
+        outputs = self.head.forward_depth(features, data['P2'])
+        outputs.update(self.teacher_net.compute_teacher_depth(image_0))
+        for f_i in self.train_cfg.frame_ids[1:]:
+            outputs[("cam_T_cam", f_i)] = data[('relative_pose', f_i)]
+        return self.head.loss(outputs, data)
+
+    def forward_test(self, data, meta):
+        features = self.depth_backbone(data[('image', 0)])
+        outputs = self.head.forward_depth(features, data['P2'])
+        return self.head.get_prediction(data, outputs)

@@ -162,6 +162,18 @@ int fs_pack_weights_multi(const FsPackDesc* descs_dev, int n, int64_t total_bloc
  * running sum of this over the table, total_blocks the grand total.  -1 for unsupported shapes (R*S > 288). */
 int64_t fs_pack_tile_blocks(int Co, int Ci, int R, int S);
 
+/* Self-distillation.  Uncertainty head: u = sigmoid(channel 0 of the fp32 NHWC conv output with Cp
+ * channels) (depth_encoder.py:186) and its backward into a Cp-channel gradient in the compute dtype (channels
+ * 1..Cp-1 zero).  Distillation loss (monodepth2_decoder.py:185-203, is_unscaled_distill = False): *sum_out +=
+ * sum |teacher - pred| / u + log(u + 1e-5)  (uncertain == NULL: sum |teacher - pred|); the caller divides by n.
+ * Backward for loss = sum / n with upstream gradient *gout (NULL = 1): d_pred, d_uncertain are overwritten. */
+int fs_sigmoid_head_fwd(const float* logits, float* u, int64_t M, int Cp, void* stream);
+int fs_sigmoid_head_bwd(const float* u, const float* du, void* dl, int64_t M, int Cp, int dtype, void* stream);
+int fs_distill_fwd(const float* pred, const float* teacher, const float* uncertain, int64_t n, double* sum_out,
+                   void* stream);
+int fs_distill_bwd(const float* pred, const float* teacher, const float* uncertain, int64_t n, const double* gout,
+                   float* d_pred, float* d_uncertain, void* stream);
+
 /* Evaluation.  fs_resize_linear: single-channel fp32 [h][w] -> [H][W] with OpenCV's INTER_LINEAR
  * rule; invert != 0 resizes the inverse: dst = 1 / resize(1 / src)  (base_evaluation_hooks.py:57).
  * fs_depth_eval: per image b, pred [B][h][w] (resized on the fly to the ground truth's [H][W]) against gt [B][H][W]:

@@ -145,3 +145,20 @@ def test_eval_oracle_resize_and_single_loss_properties():
     import pytest
     with pytest.raises(ValueError):
         EO.single_loss(np.ones((100, 300), np.float32), np.zeros((100, 300), np.float32))
+
+
+def test_distill_oracle_matches_reference_golden():
+    """oracle/distill_oracle.py against losses / gradient norms of the REAL DistillWPoseMeta (tests/golden/distill.npz)"""
+    from oracle import distill_oracle as D
+    g = np.load(os.path.join(GOLD, "distill.npz"))
+    sd = D.init_states(seed=int(g["seed"]), teacher_seed=int(g["teacher_seed"]))
+    names = [k for k in sd if D.is_student_param(k)]
+    for k in names:
+        sd[k].requires_grad_(True)
+    tot, losses, _ = D.forward_train(sd, O.synthetic_batch(int(g["B"]), int(g["H"]), int(g["W"]), seed=int(g["batch_seed"])))
+    tot.backward()
+    assert abs(float(tot.detach()) - float(g["loss"])) < 1e-6 * abs(float(g["loss"]))
+    for s in range(4):
+        assert abs(float(losses["distilation/%d" % s]) - float(g["ld_distilation_%d" % s])) < 1e-5 * float(g["ld_distilation_%d" % s])
+    assert float((sd["head.depth_decoder.decoder.14.weight"].grad - torch.from_numpy(g["unc_w_grad"])).abs().max()) \
+        < 1e-5 * float(np.abs(g["unc_w_grad"]).max())

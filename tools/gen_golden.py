@@ -255,11 +255,69 @@ def gen_eval():
     np.savez_compressed(os.path.join(GOLD, "eval.npz"), **out)
 
 
+def gen_distill():
+    """self-distillation stage through the REAL DistillWPoseMeta (monodepth2_model.py:150-206): loss terms and
+    parameter-gradient norms on a seeded batch; cross-checks oracle/distill_oracle.py"""
+    import tempfile
+    from oracle import distill_oracle as D
+    H, W, B = 64, 128, 2
+    enc = dict(name='vision_base.networks.models.backbone.resnet.resnet', depth=18, pretrained=False, frozen_stages=-1,
+               num_stages=4, out_indices=(-1, 0, 1, 2, 3), norm_eval=False, dilations=(1, 1, 1, 1))
+    dec = dict(num_ch_enc=np.array([64, 64, 128, 256, 512]), num_output_channels=16, use_skips=True, scales=[0, 1, 2, 3],
+               min_depth=0.5, max_depth=100)
+    sd = D.init_states(seed=21, teacher_seed=22)
+    with tempfile.TemporaryDirectory() as d:
+        tpath = os.path.join(d, "teacher.pth")
+        torch.save({k[len("teacher_net."):]: v.clone() for k, v in sd.items() if k.startswith("teacher_net.")}, tpath)
+        m = build(name='monodepth.networks.models.meta_archs.monodepth2_model.DistillWPoseMeta',
+                  teacher_net_cfg=EasyDict(name='monodepth.networks.models.meta_archs.teacher_model.MonoDepthInference',
+                                           backbone_cfg=EasyDict(**enc),
+                                           depth_head_cfg=EasyDict(name='monodepth.networks.models.heads.depth_encoder.MultiChannelDepthDecoder', **dec)),
+                  teacher_net_path=tpath,
+                  depth_backbone_cfg=EasyDict(**enc),
+                  head_cfg=EasyDict(name='monodepth.networks.models.heads.monodepth2_decoder.MonoDepth2Decoder',
+                                    scales=[0, 1, 2, 3], height=H, width=W, min_depth=0.5, max_depth=100.0,
+                                    overlapped_mask=True, is_log_image=False, distillation_loss_weight=0.3,
+                                    is_uncertain_distill=True,
+                                    depth_decoder_cfg=EasyDict(name='monodepth.networks.models.heads.depth_encoder.MultiChannelDepthDecoderUncertain', **dec)),
+                  train_cfg=EasyDict(frame_ids=[0, 1, -1]), test_cfg=EasyDict())
+    m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    m.train()
+    data = O.synthetic_batch(B, H, W, seed=400)
+    torch.manual_seed(0)
+    out = m(dict(data), dict(is_training=True, epoch_num=0, global_step=0))
+    out["loss"].backward()
+    names = [k for k, _ in m.named_parameters() if not k.startswith("teacher_net.")]
+    gn = np.array([float(p.grad.norm()) if p.grad is not None else 0.0 for k, p in m.named_parameters()
+                   if not k.startswith("teacher_net.")])
+    res = {"B": B, "H": H, "W": W, "seed": 21, "teacher_seed": 22, "batch_seed": 400,
+           "loss": float(out["loss"].detach()), "gradnorm": gn,
+           "unc_w_grad": npy(dict(m.named_parameters())["head.depth_decoder.decoder.14.weight"].grad),
+           "teacher_depth_0_mean": float(m.teacher_net.compute_teacher_depth(data[("image", 0)])[("teacher_depth", 0, 0)].mean())}
+    for k, v in out["loss_dict"].items():
+        res["ld_" + k.replace("/", "_")] = float(v)
+    # oracle against the reference
+    sdo = D.init_states(seed=21, teacher_seed=22)
+    for k in sdo:
+        if D.is_student_param(k):
+            sdo[k].requires_grad_(True)
+    tot, losses, _ = D.forward_train(sdo, O.synthetic_batch(B, H, W, seed=400))
+    tot.backward()
+    gno = np.array([float(sdo[k].grad.norm()) for k in names])
+    print("distill: loss ref %.8f oracle %.8f | gradnorm max rel dev %.3e" % (
+        res["loss"], float(tot), np.abs(gno - gn).max() / gn.max()))
+    for k in losses:
+        if k.startswith("distilation"):
+            print("   %s ref %.6f oracle %.6f" % (k, res["ld_" + k.replace("/", "_")], float(losses[k])))
+    np.savez_compressed(os.path.join(GOLD, "distill.npz"), **res)
+
+
 if __name__ == "__main__":
     gen_ops()
     gen_loss_chain()
     gen_model(True, "depthpose")
     gen_model(False, "wpose")
     gen_eval()
+    gen_distill()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")
