@@ -94,10 +94,15 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # FSNET_AMD_BENCH_SHARED_DEVICE=1 (test rigs with ONE GPU): every rank uses device 0 and the ranks talk over gloo,
+    # so that the multi-rank code path of this script can be exercised without a multi-GPU node.  Never set by the
+    # driver: its N-GPU runs use one device per rank and RCCL.
+    shared = os.environ.get("FSNET_AMD_BENCH_SHARED_DEVICE", "0") != "0"
+    dev_index = 0 if shared else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        torch.distributed.init_process_group(backend="nccl", init_method="env://")
+        torch.distributed.init_process_group(backend="gloo" if shared else "nccl", init_method="env://")
 
     from fsnet_amd.configs import meta_arch_cfg, training_cfg
     from fsnet_amd.engine.runtime import RT
