@@ -69,15 +69,44 @@ template <> __device__ inline void store4<bf16>(bf16* p, const float v[4]) {
   *reinterpret_cast<uint2*>(p) = t;
 }
 
-__device__ static inline float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Wave-wide sums without LDS traffic.  __shfl_xor lowers to ds_bpermute_b32 (an LDS-pipeline instruction plus its
+// address VALU op, six per sum); here four DPP adds fold each 16-lane row in the VALU — lane ^ 1, lane ^ 2 by
+// quad_perm, then row_half_mirror and row_mirror, which pair a lane with one holding the other half's partial — and
+// the four row totals are read through SGPRs.  Every lane returns the same value; call with all 64 lanes active.
+template <int CTRL>
+__device__ static inline float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ static inline double dpp_mov(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ static inline float read_lane(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ static inline double read_lane(double v, int lane) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)b, lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <typename F>
+__device__ static inline F row16_sum(F v) {      // every lane: the sum over its 16-lane DPP row
+  v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);    // row_half_mirror
+  v += dpp_mov<0x140>(v);    // row_mirror
   return v;
 }
+__device__ static inline float wave_sum(float v) {
+  v = row16_sum(v);
+  return (read_lane(v, 0) + read_lane(v, 16)) + (read_lane(v, 32) + read_lane(v, 48));
+}
 __device__ static inline double wave_sum_d(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v = row16_sum(v);
+  return (read_lane(v, 0) + read_lane(v, 16)) + (read_lane(v, 32) + read_lane(v, 48));
 }
 
 // block-wide sum (blockDim.x == 256): result valid in thread 0.  `sh` = 4 doubles of LDS.

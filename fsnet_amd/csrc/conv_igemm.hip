@@ -300,8 +300,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float u = s1[a][j], w = s2[a][j];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { u += __shfl_xor(u, o, 64); w += __shfl_xor(w, o, 64); }
+        u = row16_sum(u); w = row16_sum(w);     // over the 16 pixel lanes of this channel (DPP, no LDS)
         if (li == 0) {
           int cl = wc * WCO + a * 16 + lg * 4 + j;
           red[(wp * CO + cl) * 2] = u; red[(wp * CO + cl) * 2 + 1] = w;

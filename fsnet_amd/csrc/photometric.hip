@@ -504,8 +504,11 @@ __global__ __launch_bounds__(512) void photo_loss_bwd_kernel(const FsPhotoArgs p
   if (f == 1) s_dD[tid] = dD;
   __syncthreads();
   if (tid < 12) {
+    // per-block partial, reduced by photo_pose_grad_kernel: 23040 blocks adding into 24 cache lines cost ~90 us of
+    // serialised L2 atomics at the bench shape (and made dT depend on the block schedule)
     float v = s_red[f][tid][0] + s_red[f][tid][1] + s_red[f][tid][2] + s_red[f][tid][3];
-    if (v != 0.f) atomicAdd(p.dP + ((long)b * 2 + f) * 12 + tid, v);
+    const long blk = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    p.dP[(blk * 2 + f) * 12 + tid] = v;
   }
   // ---- transpose of the bilinear depth upsample: accumulate the tile's contributions in LDS first, then
   //      one global atomic per touched low-res pixel (scale-3 maps receive 256 full-res pixels each) ----
@@ -537,18 +540,37 @@ __global__ __launch_bounds__(512) void photo_loss_bwd_kernel(const FsPhotoArgs p
   }
 }
 
-// dT[f][b] (4x4, row 3 = 0) = K^T-contracted dP:  P = K3 * T[:3]  =>  dT[k][j] = sum_i K3[i][k] dP[i][j]
-__global__ void photo_pose_grad_kernel(const float* __restrict__ geo, const float* __restrict__ dP,
-                                       float* __restrict__ dT0, float* __restrict__ dT1, int B) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * 2) return;
-  int b = i >> 1, f = i & 1;
-  const float* K = geo + (long)b * GEO_STRIDE + 9;
-  const float* g = dP + ((long)b * 2 + f) * 12;
-  float* o = (f == 0 ? dT0 : dT1) + (long)b * 16;
-  for (int k = 0; k < 3; ++k)
-    for (int j = 0; j < 4; ++j) o[k * 4 + j] = K[0 * 3 + k] * g[0 * 4 + j] + K[1 * 3 + k] * g[1 * 4 + j] + K[2 * 3 + k] * g[2 * 4 + j];
-  for (int j = 0; j < 4; ++j) o[12 + j] = 0.f;
+// dT[f][b] (4x4, row 3 = 0) = K^T-contracted dP:  P = K3 * T[:3]  =>  dT[k][j] = sum_i K3[i][k] dP[i][j].
+// One block per (b, f): sums the per-tile partials dP[s][b][tile][f][12] of photo_loss_bwd_kernel in a fixed order
+// (21 groups of 12 lanes stride over the S * tiles partials, then the groups are added in f64).
+__global__ __launch_bounds__(256) void photo_pose_grad_kernel(const float* __restrict__ geo,
+                                                              const float* __restrict__ dP, float* __restrict__ dT0,
+                                                              float* __restrict__ dT1, int B, int S, int tiles) {
+  __shared__ double s_part[21][12];
+  __shared__ float s_g[12];
+  const int b = blockIdx.x >> 1, f = blockIdx.x & 1;
+  const int t = threadIdx.x, k = t % 12, grp = t / 12;
+  if (grp < 21) {
+    double acc = 0.0;
+    for (int j = grp; j < S * tiles; j += 21) {
+      int s = j / tiles, tl = j - s * tiles;
+      acc += (double)dP[((((long)s * B + b) * tiles + tl) * 2 + f) * 12 + k];
+    }
+    s_part[grp][k] = acc;
+  }
+  __syncthreads();
+  if (t < 12) {
+    double v = 0.0;
+    for (int g = 0; g < 21; ++g) v += s_part[g][t];
+    s_g[t] = (float)v;
+  }
+  __syncthreads();
+  if (t < 16) {
+    const float* K = geo + (long)b * GEO_STRIDE + 9;
+    float* o = (f == 0 ? dT0 : dT1) + (long)b * 16;
+    const int r = t >> 2, j = t & 3;
+    o[t] = r < 3 ? K[0 * 3 + r] * s_g[0 * 4 + j] + K[1 * 3 + r] * s_g[1 * 4 + j] + K[2 * 3 + r] * s_g[2 * 4 + j] : 0.f;
+  }
 }
 
 bool valid(const FsPhotoArgs* a) {
@@ -603,9 +625,15 @@ extern "C" int fs_photo_loss_bwd(const FsPhotoArgs* a, void* stream) {
   return fs_launch_status();
 }
 
-extern "C" int fs_photo_pose_grad(const float* geo, const float* dP, float* dT0, float* dT1, int B, void* stream) {
-  if (!geo || !dP || !dT0 || !dT1) return FS_EINVAL;
+extern "C" int64_t fs_photo_bwd_tiles(int H, int W) {
+  if (H < 2 || W < 2) return -1;
+  return (int64_t)((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+}
+
+extern "C" int fs_photo_pose_grad(const float* geo, const float* dP, float* dT0, float* dT1, int B, int S, int tiles,
+                                  void* stream) {
+  if (!geo || !dP || !dT0 || !dT1 || B < 1 || S < 1 || tiles < 1) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(photo_pose_grad_kernel, dim3((2 * B + 63) / 64), dim3(64), 0, st, geo, dP, dT0, dT1, B);
+  hipLaunchKernelGGL(photo_pose_grad_kernel, dim3(2 * B), dim3(256), 0, st, geo, dP, dT0, dT1, B, S, tiles);
   return fs_launch_status();
 }

@@ -234,7 +234,8 @@ class PhotometricLoss:
         self.out = torch.zeros(2 * S + 1, dtype=f64, device=device)
         self.hw = [(H >> s, W >> s) for s in self.scales]
         self.color = [None] * S
-        self.dP = torch.zeros(B, 2, 12, dtype=f32, device=device)
+        self.bwd_tiles = int(lib.fs_photo_bwd_tiles(H, W))
+        self.dP = torch.zeros(self.S * B * self.bwd_tiles, 2, 12, dtype=f32, device=device)   # per-tile partials
         self.d_depth = [torch.zeros(B, 1, h, w, dtype=f32, device=device) for (h, w) in self.hw]
         self.d_disp = [torch.empty(B, 1, h, w, dtype=f32, device=device) for (h, w) in self.hw]
         self.dT = [torch.zeros(B, 4, 4, dtype=f32, device=device) for _ in range(2)]
@@ -329,12 +330,11 @@ class PhotometricLoss:
         pa, sa = C.byref(self._pa), C.byref(self._sa)
         for d in self.d_depth:
             d.zero_()
-        self.dP.zero_()
         N_px = float(self.B * self.H * self.W)
         bwd_bytes = sum(40.0 * N_px + 8.0 * N_px / (4 ** s) for s in self.scales)
         _timed("photo_loss_bwd", bwd_bytes, lambda: check(lib.fs_photo_loss_bwd(pa, st), "photo_loss_bwd"))
         check(lib.fs_photo_pose_grad(self.geo.data_ptr(), self.dP.data_ptr(), self.dT[0].data_ptr(),
-                                     self.dT[1].data_ptr(), self.B, st), "photo_pose_grad")
+                                     self.dT[1].data_ptr(), self.B, self.S, self.bwd_tiles, st), "photo_pose_grad")
         check(lib.fs_smooth_bwd(sa, st), "smooth_bwd")
         return self.d_depth, self.d_disp, self.dT
 

@@ -301,8 +301,9 @@ int fs_pose_tail_bwd(const float* x, const float* dT, void* dx, int B, int hw, i
  *   fs_photo_identity  identity reprojection losses ident[B][2][H][W]; mask_sum[b] += sum(patched_mask[b])
  *   fs_photo_warp      pred[S][2][B][3][H][W], ov[S][2][B][H][W] (bilinear/border + nearest/zeros)
  *   fs_photo_loss_fwd  sel[S][B][H][W] (argmin: 0,1 identity; 2,3 reprojection), loss_sums[s][b] += masked sum
- *   fs_photo_loss_bwd  d_depth[s] += dL/d depth_s (low-res), dP[B][2][12] += dL/dP
- *   fs_photo_pose_grad dT_f[B][4][4] = K^T dP_f
+ *   fs_photo_loss_bwd  d_depth[s] += dL/d depth_s (low-res); dP[S][B][tiles][2][12] = per-tile partial sums of
+ *                      dL/dP (overwritten; tiles = fs_photo_bwd_tiles(H, W))
+ *   fs_photo_pose_grad dT_f[B][4][4] = K^T sum_{s,tile} dP  (fixed summation order: run-to-run reproducible)
  * noise_seed < 0 disables the tie-break noise (reference: randn*1e-5, :258-259).
  */
 typedef struct FsPhotoArgs {
@@ -330,7 +331,9 @@ int fs_photo_identity(const FsPhotoArgs* args, void* stream);
 int fs_photo_warp(const FsPhotoArgs* args, void* stream);
 int fs_photo_loss_fwd(const FsPhotoArgs* args, void* stream);
 int fs_photo_loss_bwd(const FsPhotoArgs* args, void* stream);
-int fs_photo_pose_grad(const float* geo, const float* dP, float* dT0, float* dT1, int B, void* stream);
+int64_t fs_photo_bwd_tiles(int H, int W);
+int fs_photo_pose_grad(const float* geo, const float* dP, float* dT0, float* dT1, int B, int S, int tiles,
+                       void* stream);
 
 /* Edge-aware smoothness (monodepth_utils.py:168-181; monodepth2_decoder.py:214-219,294-299) and
  * loss assembly (:292-304).  fs_color_pyramid = adaptive_avg_pool2d with an integer ratio.
