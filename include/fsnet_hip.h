@@ -174,6 +174,34 @@ int fs_distill_fwd(const float* pred, const float* teacher, const float* uncerta
 int fs_distill_bwd(const float* pred, const float* teacher, const float* uncertain, int64_t n, const double* gout,
                    float* d_pred, float* d_uncertain, void* stream);
 
+/* Training input pipeline: raw uint8 frames -> network / loss inputs in one launch.  Per sample b
+ * and frame f: cv2.warpAffine(INTER_LINEAR, BORDER_CONSTANT) with the inverted map minv[b] (f64, computed by the host
+ * exactly as OpenCV inverts the forward matrix), RandomMirror, the colour chain in the drawn order, Normalize and the
+ * HWC -> CHW transpose (vision_base/data/augmentations/augmentations.py:50-109, 200-226, 377-497, 527-591;
+ * configs/kitti_wpose_example:129-155).  Plans (host-drawn, one row per sample):
+ *   iplan[b] = { op0, op1, op2 (0 brightness, 1 contrast, 2 RGB->HSV->RGB round trip, 3 nothing; execution order),
+ *                bitmask (1 brightness drawn, 2 contrast drawn, 4 saturation drawn, 8 round trip present),
+ *                mirror, src_h, src_w, 0 }
+ *   fplan[b] = { brightness delta, contrast alpha, saturation ratio, 0 }
+ * src [B][F][Hs][Ws][3] uint8 (RGB, frames of sample b occupy the top-left src_h x src_w);
+ * image / original [F][B][3][H][W] fp32 (either may be NULL); mask [B][H][W] f64 = warped + mirrored patched_mask
+ * (NULL to skip).  mean / std apply to `image`; `original` is x / 255. */
+#define FS_AUG_IPLAN 8
+#define FS_AUG_FPLAN 4
+typedef struct FsAugArgs {
+  const uint8_t* src;
+  const double* minv;
+  const int32_t* iplan;
+  const float* fplan;
+  float* image;
+  float* original;
+  double* mask;
+  float mean[3];
+  float std[3];
+  int32_t B, F, Hs, Ws, H, W;
+} FsAugArgs;
+int fs_augment_frames(const FsAugArgs* args, void* stream);
+
 /* Evaluation.  fs_resize_linear: single-channel fp32 [h][w] -> [H][W] with OpenCV's INTER_LINEAR
  * rule; invert != 0 resizes the inverse: dst = 1 / resize(1 / src)  (base_evaluation_hooks.py:57).
  * fs_depth_eval: per image b, pred [B][h][w] (resized on the fly to the ground truth's [H][W]) against gt [B][H][W]:

@@ -1,0 +1,244 @@
+"""CPU restatement of the training input pipeline — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and tools/gen_golden.py may import this module; the product path
+(fsnet_amd/vision_base/data/augmentations + csrc/augment.hip) never does.
+
+Reference: vision_base/data/augmentations/augmentations.py
+    ConvertToFloat :50-59, Normalize :91-109, RandomSaturation :200-226, RandomMirror :377-433,
+    RandomWarpAffine :436-497, ConvertColor :527-542, RandomContrast :545-569, RandomBrightness :572-591,
+    ConvertToTensor :62-88; vision_base/utils/builder.py Shuffle :48-72;
+    vision_base/data/augmentations/utils.py flip_relative_pose :4-20; configs/kitti_wpose_example:129-155.
+
+Pinning status
+  * PINNED against the reference (tests/golden/augment.npz, made by tools/gen_golden.py::gen_augment from the real
+    classes): the random draws and their order, the P2 bookkeeping of RandomWarpAffine / RandomMirror,
+    flip_relative_pose, Normalize, RandomBrightness / RandomContrast / RandomSaturation arithmetic, the Shuffle order,
+    the mirror of images and masks.
+  * PARITY UNPINNED: cv2.warpAffine (INTER_LINEAR / INTER_NEAREST, BORDER_CONSTANT) and cv2.cvtColor
+    (RGB2HSV / HSV2RGB on float32).  OpenCV is a third-party dependency of the reference (requirement.txt:
+    opencv-python, unpinned version) and is not installed in this image, so the reference's own classes cannot execute
+    those two calls here.  They are restated from OpenCV 4.x: modules/imgproc/src/imgwarp.cpp (warpAffine: matrix
+    inversion in f64, AB_BITS = 10 fixed-point coordinates, INTER_BITS = 5 sub-pixel grid; remapBilinear / remapNearest
+    with BORDER_CONSTANT) and modules/imgproc/src/color_hsv.simd.hpp (RGB2HSV_f / HSV2RGB_f, hrange = 360).
+"""
+import numpy as np
+
+AB_BITS = 10
+AB_SCALE = 1 << AB_BITS
+INTER_BITS = 5
+INTER_TAB_SIZE = 1 << INTER_BITS
+FLT_EPSILON = np.float32(1.1920929e-07)
+
+
+# ------------------------------------------------------------------------------------------------
+# cv2.warpAffine (UNPINNED restatement)
+# ------------------------------------------------------------------------------------------------
+def invert_affine(M):
+    """imgwarp.cpp warpAffine: the 2x3 forward matrix (any float dtype) -> dst->src map, in float64."""
+    m = np.asarray(M, dtype=np.float64).reshape(6).copy()
+    D = m[0] * m[4] - m[1] * m[3]
+    D = 1.0 / D if D != 0 else 0.0
+    A11, A22 = m[4] * D, m[0] * D
+    m[0] = A11; m[1] *= -D
+    m[3] *= -D; m[4] = A22
+    b1 = -m[0] * m[2] - m[1] * m[5]
+    b2 = -m[3] * m[2] - m[4] * m[5]
+    m[2], m[5] = b1, b2
+    return m
+
+
+def _fixed_coords(minv, out_w, out_h, nearest):
+    round_delta = AB_SCALE // 2 if nearest else AB_SCALE // INTER_TAB_SIZE // 2
+    x = np.arange(out_w, dtype=np.float64)
+    y = np.arange(out_h, dtype=np.float64)
+    adelta = np.rint(minv[0] * x * AB_SCALE).astype(np.int64)
+    bdelta = np.rint(minv[3] * x * AB_SCALE).astype(np.int64)
+    X0 = np.rint((minv[1] * y + minv[2]) * AB_SCALE).astype(np.int64) + round_delta
+    Y0 = np.rint((minv[4] * y + minv[5]) * AB_SCALE).astype(np.int64) + round_delta
+    return X0[:, None] + adelta[None, :], Y0[:, None] + bdelta[None, :]
+
+
+def warp_affine_linear(src, M, out_w, out_h):
+    """src: float32 [H, W, C]; INTER_LINEAR, BORDER_CONSTANT (0)."""
+    src = np.asarray(src, dtype=np.float32)
+    H, W = src.shape[:2]
+    X, Y = _fixed_coords(invert_affine(M), out_w, out_h, nearest=False)
+    X >>= (AB_BITS - INTER_BITS)
+    Y >>= (AB_BITS - INTER_BITS)
+    sx, sy = X >> INTER_BITS, Y >> INTER_BITS
+    fx = (X & (INTER_TAB_SIZE - 1)).astype(np.float32) / np.float32(INTER_TAB_SIZE)
+    fy = (Y & (INTER_TAB_SIZE - 1)).astype(np.float32) / np.float32(INTER_TAB_SIZE)
+    one = np.float32(1.0)
+    w00, w01 = (one - fy) * (one - fx), (one - fy) * fx
+    w10, w11 = fy * (one - fx), fy * fx
+
+    def tap(yy, xx):
+        ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)
+        v = src[np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)]
+        return np.where(ok[..., None], v, np.float32(0.0))
+
+    out = tap(sy, sx) * w00[..., None]
+    out = out + tap(sy, sx + 1) * w01[..., None]
+    out = out + tap(sy + 1, sx) * w10[..., None]
+    out = out + tap(sy + 1, sx + 1) * w11[..., None]
+    return out.astype(np.float32)
+
+
+def warp_affine_nearest(src, M, out_w, out_h):
+    """src: [H, W] (any dtype, the patched mask is float64); INTER_NEAREST, BORDER_CONSTANT (0)."""
+    src = np.asarray(src)
+    H, W = src.shape[:2]
+    X, Y = _fixed_coords(invert_affine(M), out_w, out_h, nearest=True)
+    sx, sy = X >> AB_BITS, Y >> AB_BITS
+    ok = (sy >= 0) & (sy < H) & (sx >= 0) & (sx < W)
+    v = src[np.clip(sy, 0, H - 1), np.clip(sx, 0, W - 1)]
+    if v.ndim == 3:
+        ok = ok[..., None]
+    return np.where(ok, v, np.zeros((), dtype=src.dtype)).astype(src.dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+# cv2.cvtColor on float32 (UNPINNED restatement)
+# ------------------------------------------------------------------------------------------------
+def rgb2hsv(img):
+    img = np.asarray(img, dtype=np.float32)
+    r, g, b = img[..., 0], img[..., 1], img[..., 2]
+    v = np.maximum(np.maximum(r, g), b)
+    vmin = np.minimum(np.minimum(r, g), b)
+    diff = v - vmin
+    s = diff / (np.abs(v) + FLT_EPSILON)
+    d = np.float32(60.0) / (diff + FLT_EPSILON)
+    h = np.where(v == r, (g - b) * d, np.where(v == g, (b - r) * d + np.float32(120.0), (r - g) * d + np.float32(240.0)))
+    h = np.where(h < 0, h + np.float32(360.0), h).astype(np.float32)
+    return np.stack([h, s.astype(np.float32), v], axis=-1)
+
+
+_SECTOR = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])   # (b, g, r) <- tab index
+
+
+def hsv2rgb(img):
+    img = np.asarray(img, dtype=np.float32)
+    h, s, v = img[..., 0], img[..., 1], img[..., 2]
+    one = np.float32(1.0)
+    hh = h * (np.float32(6.0) / np.float32(360.0))
+    hh = np.where(hh < 0, hh + np.float32(6.0), hh)
+    hh = np.where(hh >= np.float32(6.0), hh - np.float32(6.0), hh).astype(np.float32)
+    sector = np.floor(hh).astype(np.int64)
+    f = (hh - sector.astype(np.float32)).astype(np.float32)
+    bad = (sector < 0) | (sector >= 6)
+    sector = np.where(bad, 0, sector)
+    f = np.where(bad, np.float32(0.0), f)
+    tab = np.stack([v, v * (one - s), v * (one - s * f), v * (one - s * (one - f))], axis=-1)
+    idx = _SECTOR[sector]                                    # [..., 3] = (b, g, r)
+    b = np.take_along_axis(tab, idx[..., 0:1], -1)[..., 0]
+    g = np.take_along_axis(tab, idx[..., 1:2], -1)[..., 0]
+    r = np.take_along_axis(tab, idx[..., 2:3], -1)[..., 0]
+    grey = s == 0
+    r, g, b = np.where(grey, v, r), np.where(grey, v, g), np.where(grey, v, b)
+    return np.stack([r, g, b], axis=-1).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------
+# the pipeline of configs/kitti_wpose_example:129-155 with explicit random draws ("plan")
+# ------------------------------------------------------------------------------------------------
+def draw_plan(warp_rng, bright_rng, contrast_rng, sat_rng, height, width, out_w, out_h, scale_lower=0.6,
+              scale_upper=1.4, shift_border=128, mirror_prob=0.5, delta=32, c_lower=0.6, c_upper=1.4, s_lower=0.6,
+              s_upper=1.4, distort_prob=1.0):
+    """The draws of one sample in the reference's order: RandomWarpAffine's Generator (:466-469), then the GLOBAL
+    np.random stream for RandomMirror (:410) and Shuffle (builder.py:61), then each colour op's own Generator in
+    the shuffled order (:222-223, :562-563, :587-588)."""
+    p = {}
+    s_original = max(height, width)
+    scale = s_original * warp_rng.uniform(scale_lower, scale_upper)
+    center_w = warp_rng.integers(low=shift_border, high=width - shift_border)
+    center_h = warp_rng.integers(low=shift_border, high=height - shift_border)
+    final_scale = max(out_w, out_h) / scale
+    p["M"] = np.array([[final_scale, 0, out_w / 2 - center_w * final_scale],
+                       [0, final_scale, out_h / 2 - center_h * final_scale]], dtype=np.float32)
+    p["final_scale"], p["shift_w"], p["shift_h"] = final_scale, out_w / 2 - center_w * final_scale, out_h / 2 - center_h * final_scale
+    p["mirror"] = bool(np.random.rand() <= mirror_prob)
+    order = np.random.permutation(3)        # children: 0 brightness, 1 contrast, 2 saturation (in HSV)
+    p["order"] = order
+    p["brightness"] = p["contrast"] = p["saturation"] = None
+    for k in order:
+        if k == 0 and bright_rng.random() <= distort_prob:
+            p["brightness"] = bright_rng.uniform(-delta, delta)
+        if k == 1 and contrast_rng.random() <= distort_prob:
+            p["contrast"] = contrast_rng.uniform(c_lower, c_upper)
+        if k == 2 and sat_rng.random() <= distort_prob:
+            p["saturation"] = sat_rng.uniform(s_lower, s_upper)
+    return p
+
+
+def warp_P2(P, final_scale, shift_w, shift_h):
+    """RandomWarpAffine calib update (:488-495), in P's dtype like the reference's in-place numpy ops."""
+    P = P.copy()
+    P[0:2, :] *= final_scale
+    P[0, 2] = P[0, 2] + shift_w
+    P[0, 3] = P[0, 3] + shift_w * P[2, 3]
+    P[1, 2] = P[1, 2] + shift_h
+    P[1, 3] = P[1, 3] + shift_h * P[2, 3]
+    return P
+
+
+def mirror_P2(P, width):
+    P = P.copy()
+    P[0, 3] = -P[0, 3]
+    P[0, 2] = width - P[0, 2] - 1
+    return P
+
+
+def flip_relative_pose(pose, axis_num=0):
+    """augmentations/utils.py:4-20 (scipy Rotation, as the reference)."""
+    from scipy.spatial.transform import Rotation as R
+    rot = R.from_matrix(pose[0:3, 0:3]).as_euler('xyz')
+    for i in range(3):
+        if i != axis_num:
+            rot[i] = rot[i] * -1
+    t = pose[0:3, 3:4].copy()
+    t[axis_num, :] *= -1
+    out = np.eye(4, dtype=np.float32)
+    out[0:3, 0:3] = R.from_euler('xyz', rot).as_matrix()
+    out[0:3, 3:4] = t
+    return out
+
+
+def colour_chain(img, plan):
+    """Shuffle[RandomBrightness, RandomContrast, HSV-RandomSaturation] on a float32 HWC image (0..255 scale)."""
+    img = np.asarray(img, dtype=np.float32)
+    for k in plan["order"]:
+        if k == 0 and plan["brightness"] is not None:
+            img = img + np.float32(plan["brightness"])
+        elif k == 1 and plan["contrast"] is not None:
+            img = img * np.float32(plan["contrast"])
+        elif k == 2:
+            hsv = rgb2hsv(img)
+            if plan["saturation"] is not None:
+                hsv[:, :, 1] *= np.float32(plan["saturation"])
+            img = hsv2rgb(hsv)
+    return img
+
+
+def normalize(img, mean, std):
+    """Normalize (:100-108): float32 in-place ops, true divisions."""
+    img = np.asarray(img, dtype=np.float32).copy()
+    img /= 255.0
+    img -= np.tile(np.asarray(mean, dtype=np.float32), int(img.shape[2] / 3))
+    img /= np.tile(np.asarray(std, dtype=np.float32), int(img.shape[2] / 3))
+    return img
+
+
+def run_sample(frames_u8, plan, out_w, out_h, mean, std):
+    """frames_u8: list of uint8 [H, W, 3].  Returns (images CHW list, original_images CHW list, patched_mask f64)."""
+    images, originals = [], []
+    for f in frames_u8:
+        w = warp_affine_linear(f.astype(np.float32), plan["M"], out_w, out_h)
+        if plan["mirror"]:
+            w = np.ascontiguousarray(w[:, ::-1])
+        originals.append(normalize(w, [0, 0, 0], [1, 1, 1]).transpose(2, 0, 1))
+        images.append(normalize(colour_chain(w, plan), mean, std).transpose(2, 0, 1))
+    H, W = frames_u8[0].shape[:2]
+    mask = warp_affine_nearest(np.ones([H, W]), plan["M"], out_w, out_h)
+    if plan["mirror"]:
+        mask = np.ascontiguousarray(mask[:, ::-1])
+    return images, originals, mask

@@ -1,0 +1,97 @@
+"""Input pipeline on the GPU (fs_augment_frames through DeviceAugment): bit-exact against the golden vectors made by
+the reference's own augmentation classes and, at KITTI size with ragged frame sizes, against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import augment_oracle as A
+from tests import helpers_augment as HA
+
+pytestmark = pytest.mark.gpu
+
+
+def _pipeline(g):
+    from fsnet_amd.vision_base.utils.builder import build
+    return build(**HA.pipeline_cfg(g))
+
+
+def test_device_pipeline_matches_reference_vectors(dev):
+    from fsnet_amd.vision_base.data.augmentations.augmentations import DeviceAugment
+    g = HA.golden()
+    transform = _pipeline(g)
+    np.random.seed(int(g["global_seed"]))
+    samples = [transform(HA.sample_dict(*HA.sample_inputs(g, n))) for n in range(int(g["n"]))]
+    batch = DeviceAugment(HA.FRAME_IDXS)(samples, dev)
+    torch.cuda.synchronize()
+    for n in range(int(g["n"])):
+        for j, i in enumerate(HA.FRAME_IDXS):
+            assert np.array_equal(batch[("image", i)][n].cpu().numpy(), g["s%d_image_%d" % (n, j)]), (n, i)
+            assert np.array_equal(batch[("original_image", i)][n].cpu().numpy(), g["s%d_orig_%d" % (n, j)]), (n, i)
+        assert np.array_equal(batch["patched_mask"][n].cpu().numpy(), g["s%d_mask" % n])
+        assert np.array_equal(batch["P2"][n].cpu().numpy(), g["s%d_P2" % n])
+    assert batch[("image", 0)].is_contiguous() and batch[("image", 0)].shape == (int(g["n"]), 3, int(g["out_h"]), int(g["out_w"]))
+    assert batch["patched_mask"].dtype == torch.float64 and batch["P2"].is_cuda
+
+
+def test_kitti_size_ragged_batch_matches_oracle(dev):
+    """192x640 crops of 370..376 x 1224..1242 frames (the sizes KITTI raw mixes), zoom-out borders included"""
+    from fsnet_amd.vision_base.data.augmentations.augmentations import DeviceAugment, PLAN
+    g = dict(HA.golden())
+    g["out_h"], g["out_w"] = np.int64(192), np.int64(640)
+    transform = _pipeline(g)
+    sizes = [(375, 1242), (370, 1224), (376, 1241), (374, 1238)]
+    rs = np.random.RandomState(17)
+    np.random.seed(5)
+    samples, raw = [], []
+    for h, w in sizes:
+        frames = [rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8) for _ in HA.FRAME_IDXS]
+        P2 = np.array([[721.5, 0, 609.5, 44.8], [0, 721.5, 172.8, 0.2], [0, 0, 1, 0.0027]])
+        poses = [np.eye(4, dtype=np.float32), np.eye(4, dtype=np.float32)]
+        samples.append(transform(HA.sample_dict(frames, P2, poses)))
+        raw.append(frames)
+    plans = [s[PLAN] for s in samples]
+    batch = DeviceAugment(HA.FRAME_IDXS)(samples, dev)
+    torch.cuda.synchronize()
+    borders = 0
+    for n, (frames, p) in enumerate(zip(raw, plans)):
+        oplan = dict(M=p["warp"]["M"], mirror=p["mirror"], order=[o for o, _ in p["ops"]],
+                     brightness=dict(p["ops"]).get(0), contrast=dict(p["ops"]).get(1), saturation=dict(p["ops"]).get(2))
+        imgs, origs, mask = A.run_sample(frames, oplan, 640, 192, g["mean"], g["std"])
+        for j, i in enumerate(HA.FRAME_IDXS):
+            assert np.array_equal(batch[("image", i)][n].cpu().numpy(), imgs[j]), (n, i)
+            assert np.array_equal(batch[("original_image", i)][n].cpu().numpy(), origs[j]), (n, i)
+        assert np.array_equal(batch["patched_mask"][n].cpu().numpy(), mask)
+        borders += int((mask == 0).any())
+    assert borders > 0            # at least one sample was zoomed out past the frame
+
+
+def test_identity_plan_returns_the_frame(dev):
+    """no warp scale, no mirror, no colour op: original_image = frame / 255 exactly, image = normalised frame"""
+    import ctypes as C
+    from fsnet_amd.hip.binding import lib, check, stream_ptr, FsAugArgs
+    rs = np.random.RandomState(1)
+    B, F, H, W = 2, 2, 37, 53
+    src = torch.from_numpy(rs.randint(0, 256, size=(B, F, H, W, 3)).astype(np.uint8)).to(dev)
+    minv = torch.tensor([[1, 0, 0, 0, 1, 0]] * B, dtype=torch.float64, device=dev)
+    iplan = torch.tensor([[3, 3, 3, 0, 0, H, W, 0]] * B, dtype=torch.int32, device=dev)
+    fplan = torch.zeros(B, 4, device=dev)
+    image = torch.empty(F, B, 3, H, W, device=dev)
+    orig = torch.empty(F, B, 3, H, W, device=dev)
+    mask = torch.empty(B, H, W, dtype=torch.float64, device=dev)
+    a = FsAugArgs()
+    a.src, a.minv, a.iplan, a.fplan = src.data_ptr(), minv.data_ptr(), iplan.data_ptr(), fplan.data_ptr()
+    a.image, a.original, a.mask = image.data_ptr(), orig.data_ptr(), mask.data_ptr()
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    for k in range(3):
+        a.mean[k], a.std[k] = mean[k], std[k]
+    a.B, a.F, a.Hs, a.Ws, a.H, a.W = B, F, H, W, H, W
+    check(lib.fs_augment_frames(C.byref(a), stream_ptr()), "augment")
+    torch.cuda.synchronize()
+    want = src.permute(1, 0, 4, 2, 3).cpu().numpy().astype(np.float32) / np.float32(255.0)   # true division
+    assert np.array_equal(orig.cpu().numpy(), want)
+    m = np.array(mean, dtype=np.float32).reshape(1, 1, 3, 1, 1)
+    s = np.array(std, dtype=np.float32).reshape(1, 1, 3, 1, 1)
+    assert np.array_equal(image.cpu().numpy(), (want - m) / s)
+    assert bool((mask == 1).all())
+    a.std[1] = 0.0
+    assert lib.fs_augment_frames(C.byref(a), stream_ptr()) == 1

@@ -312,12 +312,103 @@ def gen_distill():
     np.savez_compressed(os.path.join(GOLD, "distill.npz"), **res)
 
 
+def gen_augment():
+    """Training input pipeline (configs/kitti_wpose_example:129-155) through the REAL reference classes, built by
+    the reference's own builder.  cv2 is absent here: tools/ref_shims/cv2 routes warpAffine / cvtColor to the oracle's
+    restatement, so this pins draw order, P2 / pose bookkeeping, mirror, colour arithmetic and Normalize — not OpenCV."""
+    from oracle import augment_oracle as A
+    aug = 'vision_base.data.augmentations.augmentations'
+    frame_idxs = [0, 1, -1]
+    out_h, out_w, H, W = 24, 80, 300, 420
+    resize_keys = [('image', i) for i in frame_idxs] + [('original_image', i) for i in frame_idxs]
+    colour_keys = [('image', i) for i in frame_idxs]
+    mean, std = np.array([0.485, 0.456, 0.406]), np.array([0.229, 0.224, 0.225])
+    seeds = dict(warp=101, bright=102, contrast=103, sat=104)
+    E = EasyDict
+    cfg = E(name='vision_base.utils.builder.Sequential', cfg_list=[
+        E(name=aug + '.ConvertToFloat'),
+        E(name=aug + '.RandomWarpAffine', output_w=out_w, output_h=out_h, random_seed=seeds['warp']),
+        E(name=aug + '.RandomMirror', mirror_prob=0.5, pose_axis_pairs=[(("relative_pose", i), 0) for i in frame_idxs[1:]]),
+        E(name='vision_base.utils.builder.Shuffle', cfg_list=[
+            E(name=aug + '.RandomBrightness', distort_prob=1.0, random_seed=seeds['bright']),
+            E(name=aug + '.RandomContrast', distort_prob=1.0, lower=0.6, upper=1.4, random_seed=seeds['contrast']),
+            E(name='vision_base.utils.builder.Sequential', cfg_list=[
+                E(name=aug + '.ConvertColor', transform='HSV'),
+                E(name=aug + '.RandomSaturation', distort_prob=1.0, lower=0.6, upper=1.4, random_seed=seeds['sat']),
+                E(name=aug + '.ConvertColor', current='HSV', transform='RGB')])],
+          image_keys=colour_keys),
+        E(name=aug + '.Normalize', mean=mean, stds=std, image_keys=colour_keys),
+        E(name=aug + '.Normalize', mean=np.array([0, 0, 0]), stds=np.array([1, 1, 1]),
+          image_keys=[('original_image', i) for i in frame_idxs]),
+        E(name=aug + '.ConvertToTensor')],
+        image_keys=resize_keys, calib_keys=['P2'], gt_image_keys=['patched_mask'])
+    transform = build(**cfg)
+    # the oracle draws from generators seeded like the reference instances
+    rngs = {k: np.random.default_rng(v) for k, v in seeds.items()}
+    res = dict(H=H, W=W, out_h=out_h, out_w=out_w, mean=mean, std=std, n=4, frame_seed=900, global_seed=77,
+               **{"seed_" + k: v for k, v in seeds.items()})
+    np.random.seed(77)
+    gstate = np.random.get_state()
+    maxdev = 0.0
+    for n in range(4):
+        fr = np.random.RandomState(900 + n)
+        frames = [fr.randint(0, 256, size=(H, W, 3)).astype(np.uint8) for _ in frame_idxs]
+        P2 = np.array([[721.5, 0, 609.5, 44.8], [0, 721.5, 172.8, 0.2], [0, 0, 1, 0.0027]], dtype=np.float64)
+        poses = []
+        for j in range(2):
+            from scipy.spatial.transform import Rotation as R
+            T = np.eye(4, dtype=np.float32)
+            T[:3, :3] = R.from_euler('xyz', fr.uniform(-0.05, 0.05, 3)).as_matrix()
+            T[:3, 3] = fr.uniform(-1, 1, 3)
+            poses.append(T)
+        data = {}
+        for i, f in zip(frame_idxs, frames):
+            data[('image', i)] = f.copy()
+            data[('original_image', i)] = f.copy()
+        data['patched_mask'] = np.ones([H, W])
+        data['P2'] = P2.copy()
+        for i, T in zip(frame_idxs[1:], poses):
+            data[('relative_pose', i)] = T.copy()
+        np.random.set_state(gstate)
+        out = transform(data)
+        # the same sample through the oracle, with the global stream rewound to the same point
+        np.random.set_state(gstate)
+        plan = A.draw_plan(rngs['warp'], rngs['bright'], rngs['contrast'], rngs['sat'], H, W, out_w, out_h)
+        gstate = np.random.get_state()
+        imgs, origs, mask = A.run_sample(frames, plan, out_w, out_h, mean, std)
+        P = A.warp_P2(P2, plan["final_scale"], plan["shift_w"], plan["shift_h"])
+        if plan["mirror"]:
+            P = A.mirror_P2(P, out_w)
+        for j, i in enumerate(frame_idxs):
+            res["s%d_image_%d" % (n, j)] = npy(out[('image', i)])
+            res["s%d_orig_%d" % (n, j)] = npy(out[('original_image', i)])
+            maxdev = max(maxdev, float(np.abs(npy(out[('image', i)]) - imgs[j]).max()),
+                         float(np.abs(npy(out[('original_image', i)]) - origs[j]).max()))
+        res["s%d_mask" % n] = npy(out['patched_mask'])
+        res["s%d_P2" % n] = np.asarray(out['P2'])
+        res["s%d_mirror" % n] = plan["mirror"]
+        res["s%d_order" % n] = plan["order"]
+        for j, i in enumerate(frame_idxs[1:]):
+            res["s%d_pose_%d" % (n, j)] = np.asarray(out[('relative_pose', i)])
+            want = A.flip_relative_pose(poses[j].copy(), 0) if plan["mirror"] else poses[j]
+            maxdev = max(maxdev, float(np.abs(want - res["s%d_pose_%d" % (n, j)]).max()))
+            res["s%d_pose_in_%d" % (n, j)] = poses[j]
+        maxdev = max(maxdev, float(np.abs(mask - res["s%d_mask" % n]).max()), float(np.abs(P - res["s%d_P2" % n]).max()))
+        print("augment sample %d: mirror=%s order=%s" % (n, plan["mirror"], plan["order"]))
+    print("augment: oracle vs reference classes, max abs deviation over images/masks/P2/poses: %.3e" % maxdev)
+    np.savez_compressed(os.path.join(GOLD, "augment.npz"), **res)
+
+
 if __name__ == "__main__":
+    if "--only-augment" in sys.argv:
+        gen_augment()
+        sys.exit(0)
     gen_ops()
     gen_loss_chain()
     gen_model(True, "depthpose")
     gen_model(False, "wpose")
     gen_eval()
     gen_distill()
+    gen_augment()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")
