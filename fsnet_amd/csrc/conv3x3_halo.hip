@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
 HaloGeom pick_geom(int Hd, int Wd, int PIX, int hmax) {
   HaloGeom best{0, 0, 0, 0};
   double best_cost = 1e30;
-  for (int tw = 4; tw <= std::min(Wd, 64); ++tw) {
+  for (int tw = std::min(4, Wd); tw <= std::min(Wd, 64); ++tw) {
     int th = std::min(PIX / tw, Hd);
     if (th < 1 || (th + 2) * (tw + 2) > hmax) continue;
     int tx = (Wd + tw - 1) / tw, ty = (Hd + th - 1) / th;

@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_narrow_kernel(const FsWgradArgs 
 WGeom wgrad_pick_geom(int Hd, int Wd) {
   WGeom best{0, 0, 0, 0, 0, 0, 1};
   double best_cost = 1e30;
-  for (int tw = 4; tw <= std::min(Wd, 64); ++tw) {
+  for (int tw = std::min(4, Wd); tw <= std::min(Wd, 64); ++tw) {
     int th = std::min(128 / tw, Hd);
     if (th < 1 || (th + 2) * (tw + 2) > 208) continue;
     int tx = (Wd + tw - 1) / tw, ty = (Hd + th - 1) / th;

@@ -95,3 +95,57 @@ def test_identity_plan_returns_the_frame(dev):
     assert bool((mask == 1).all())
     a.std[1] = 0.0
     assert lib.fs_augment_frames(C.byref(a), stream_ptr()) == 1
+
+
+def test_pipeline_feeds_a_training_step(dev):
+    """DataLoader(collate_fn=DeviceAugment.collate) -> materialize -> BaseTrainingHook: the batch dict the device
+    pipeline produces is the one the reference's collate + .cuda() hands to the hook (keys, dtypes, layouts)."""
+    from torch.utils.data import DataLoader, Dataset
+    from fsnet_amd.configs import meta_arch_cfg, training_cfg
+    from fsnet_amd.engine.runtime import RT
+    from fsnet_amd.vision_base.data.augmentations.augmentations import DeviceAugment
+    from fsnet_amd.vision_base.networks.optimizers.optimizers import build_optimizer
+    from fsnet_amd.vision_base.utils.builder import build
+    H, W = 64, 96
+    g = dict(HA.golden())
+    g["out_h"], g["out_w"] = np.int64(H), np.int64(W)
+
+    class Frames(Dataset):                      # stands in for KittiDepthMonoDataset: decoded uint8 frames + calib
+        def __init__(self):
+            self.transform = _pipeline(g)
+
+        def __len__(self):
+            return 8
+
+        def __getitem__(self, n):
+            rs = np.random.RandomState(n)
+            base = rs.randint(0, 256, size=(300 // 20, 420 // 20, 3)).astype(np.uint8)
+            frame = np.kron(base, np.ones((20, 20, 1), dtype=np.uint8))              # blocky texture
+            frames = [np.roll(frame, 3 * i, axis=1) for i in HA.FRAME_IDXS]
+            P2 = np.array([[240.0, 0, 210.0, 10.0], [0, 240.0, 150.0, 0.1], [0, 0, 1, 0.003]])
+            poses = []
+            for i in HA.FRAME_IDXS[1:]:
+                T = np.eye(4, dtype=np.float32)
+                T[0, 3], T[2, 3] = 0.01, (-0.8 if i > 0 else 0.8)
+                poses.append(T)
+            return self.transform(HA.sample_dict(frames, P2, poses))
+
+    aug = DeviceAugment(HA.FRAME_IDXS)
+    loader = DataLoader(Frames(), batch_size=4, collate_fn=aug.collate, num_workers=0)
+    RT.set_compute_dtype(torch.float32)
+    torch.manual_seed(0)
+    m = build(**meta_arch_cfg(H, W, with_pose=False)).to(dev).train()
+    tc = training_cfg(clip_gradients=35.0, lr=1e-4)
+    opt = build_optimizer(m, **tc.optimizer)
+    hook = build(use_graph=False, **tc.training_hook)
+    losses = []
+    for batch in loader:
+        batch = aug.materialize(batch, dev)
+        assert batch[("image", 0)].shape == (4, 3, H, W) and batch[("image", 0)].dtype == torch.float32
+        assert batch["patched_mask"].dtype == torch.float64 and batch["P2"].shape == (4, 3, 4)
+        assert 0.0 <= float(batch[("original_image", 1)].min()) and float(batch[("original_image", 1)].max()) <= 1.0
+        out = hook(batch, m, opt)
+        losses.append(float(out["loss"].detach()))
+    torch.cuda.synchronize()
+    assert len(losses) == 2 and all(l == l and 0 < l < 10 for l in losses), losses
+    RT.set_compute_dtype(torch.bfloat16)

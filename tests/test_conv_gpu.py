@@ -26,6 +26,8 @@ CASES = [
     (256, 12, 1, 1, 0, 2, 6, 20),     # pose out (Co padded to 16)
     (64, 64, 3, 1, 1, 12, 48, 160),   # big M -> 128x64 tiles
     (128, 128, 3, 1, 1, 12, 48, 160), # big M -> 128x128 tiles
+    (512, 512, 3, 1, 1, 4, 2, 3),     # layer4 of a 64x96 input: feature map narrower than the smallest tile
+    (64, 64, 3, 1, 1, 3, 1, 2),
 ]
 
 
