@@ -122,7 +122,62 @@ __global__ __launch_bounds__(256) void augment_frames_kernel(const FsAugArgs p) 
   }
 }
 
+// Validation input (configs/kitti_wpose_example:156-166): Resize = cv2.resize(float image, INTER_LINEAR) to
+// rh x rw, zero-padded / cropped to H x W (augmentations.py:112-198), then Normalize and CHW.  OpenCV's float
+// path (resize.cpp resizeGeneric_ / HResizeLinear / VResizeLinear): source coordinate (d + 0.5) * scale - 0.5 in
+// f64, rounded to f32, floor + fraction; fraction 0 and index clamped at both borders; horizontal pass, then vertical.
+__device__ __forceinline__ void resize_coord(int d, double scale, int n, int& s0, float& f) {
+  float fx = (float)(((double)d + 0.5) * scale - 0.5);
+  int sx = (int)floorf(fx);
+  fx -= (float)sx;
+  if (sx < 0) { fx = 0.f; sx = 0; }
+  if (sx >= n - 1) { fx = 0.f; sx = n - 1; }
+  s0 = sx; f = fx;
+}
+
+__global__ __launch_bounds__(256) void resize_frames_kernel(const FsResizeArgs p) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.H * p.W) return;
+  const int y = i / p.W, x = i - y * p.W;
+  const int32_t* d = p.dims + b * 4;
+  const int sh = d[0], sw = d[1], rh = d[2], rw = d[3];
+  const bool inside = y < rh && x < rw;                    // outside: np.pad zeros (normalised below)
+  int x0 = 0, y0 = 0; float fx = 0.f, fy = 0.f;
+  if (inside) {
+    resize_coord(x, 1.0 / ((double)rw / (double)sw), sw, x0, fx);
+    resize_coord(y, 1.0 / ((double)rh / (double)sh), sh, y0, fy);
+  }
+  const int x1 = min(x0 + 1, sw - 1), y1 = min(y0 + 1, sh - 1);
+  const long HW = (long)p.H * p.W;
+  for (int f = 0; f < p.F; ++f) {
+    const uint8_t* src = p.src + ((long)b * p.F + f) * p.Hs * p.Ws * 3;
+    const long o = (((long)f * p.B + b) * 3) * HW + (long)y * p.W + x;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float v = 0.f;
+      if (inside) {
+        const float v00 = (float)src[((long)y0 * p.Ws + x0) * 3 + k], v01 = (float)src[((long)y0 * p.Ws + x1) * 3 + k];
+        const float v10 = (float)src[((long)y1 * p.Ws + x0) * 3 + k], v11 = (float)src[((long)y1 * p.Ws + x1) * 3 + k];
+        const float top = v00 * (1.f - fx) + v01 * fx, bot = v10 * (1.f - fx) + v11 * fx;
+        v = top * (1.f - fy) + bot * fy;
+      }
+      p.image[o + k * HW] = (v / 255.0f - p.mean[k]) / p.std[k];
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int fs_resize_frames(const FsResizeArgs* a, void* stream) {
+  if (!a || !a->src || !a->dims || !a->image) return FS_EINVAL;
+  if (a->B < 1 || a->F < 1 || a->H < 1 || a->W < 1 || a->Hs < 1 || a->Ws < 1) return FS_EINVAL;
+  if ((long)a->Hs * a->Ws * 3 > 0x7fffffffL) return FS_EINVAL;
+  for (int k = 0; k < 3; ++k) if (a->std[k] == 0.f) return FS_EINVAL;
+  dim3 grid((unsigned)(((long)a->H * a->W + 255) / 256), (unsigned)a->B);
+  hipLaunchKernelGGL(resize_frames_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a);
+  return fs_launch_status();
+}
 
 extern "C" int fs_augment_frames(const FsAugArgs* a, void* stream) {
   if (!a || !a->src || !a->minv || !a->iplan || !a->fplan || (!a->image && !a->original)) return FS_EINVAL;

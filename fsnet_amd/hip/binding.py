@@ -66,6 +66,14 @@ class FsAugArgs(C.Structure):
     ]
 
 
+class FsResizeArgs(C.Structure):
+    _fields_ = [
+        ("src", C.c_void_p), ("dims", C.c_void_p), ("image", C.c_void_p),
+        ("mean", C.c_float * 3), ("std", C.c_float * 3),
+        ("B", C.c_int32), ("F", C.c_int32), ("Hs", C.c_int32), ("Ws", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+    ]
+
+
 class FsBnApplyArgs(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("res", C.c_void_p), ("y", C.c_void_p),

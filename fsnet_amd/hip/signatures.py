@@ -45,6 +45,7 @@ SIGNATURES = {
     "fs_photo_pose_grad": (C.c_int, [P, P, P, P, I, I, I, P]),
     "fs_photo_bwd_tiles": (C.c_int64, [I, I]),
     "fs_augment_frames": (C.c_int, [P, P]),
+    "fs_resize_frames": (C.c_int, [P, P]),
     "fs_color_pyramid": (C.c_int, [P, P, I, I, I, I, I, P]),
     "fs_smooth_mean": (C.c_int, [P, P]),
     "fs_smooth_fwd": (C.c_int, [P, P]),

@@ -73,6 +73,49 @@ class ConvertToFloat(object):
         return data
 
 
+class Resize(object):
+    """reference :112-198 (validation input): cv2.resize to (h, w), then crop / zero-pad to `size`; P2 rows scale."""
+    def __init__(self, size, preserve_aspect_ratio=True, force_pad=True, image_keys=['image'], calib_keys=[],
+                 gt_image_keys=[], **kwargs):
+        if gt_image_keys:
+            raise NotImplementedError("nearest-neighbour resize of ground-truth images is not on the device path")
+        self.size, self.preserve_aspect_ratio, self.force_pad = size, preserve_aspect_ratio, force_pad
+        self.image_keys, self.calib_keys = image_keys, calib_keys
+
+    def __call__(self, data):
+        shape = _frame_shape(data, self.image_keys[0])
+        plan = _plan(data)
+        if plan["warp"] is not None or plan.get("resize") is not None or plan["ops"] or plan["mirror"]:
+            raise NotImplementedError("Resize is the only geometric stage of the validation pipeline")
+        data[('image_resize', 'original_shape')] = np.array([shape[0], shape[1]]).astype(int)
+        if self.preserve_aspect_ratio:
+            scale_factor_x = self.size[0] / shape[0]
+            scale_factor_y = self.size[1] / shape[1]
+            if self.force_pad:
+                scale_factor = min(scale_factor_x, scale_factor_y)
+                mode = 'pad_0' if scale_factor_x > scale_factor_y else 'pad_1'
+            else:
+                scale_factor = scale_factor_x
+                mode = 'crop_1' if scale_factor_x > scale_factor_y else 'pad_1'
+            h = int(np.round(shape[0] * scale_factor).astype(int))
+            w = int(np.round(shape[1] * scale_factor).astype(int))
+            scale_factor_yx = (scale_factor, scale_factor)
+        else:
+            scale_factor_yx = (self.size[0] / shape[0], self.size[1] / shape[1])
+            mode, h, w = 'none', self.size[0], self.size[1]
+        data[('image_resize', 'effective_size')] = np.array([h, w]).astype(int)
+        if len(self.size) <= 1:
+            raise NotImplementedError("Resize needs a (height, width) size on the device path")
+        plan["resize"] = dict(h=h, w=w, mode=mode, out_h=self.size[0], out_w=self.size[1], keys=list(self.image_keys),
+                              src_hw=(shape[0], shape[1]))
+        for key in self.calib_keys:
+            P = data[key]
+            P[0, :] = P[0, :] * scale_factor_yx[1]
+            P[1, :] = P[1, :] * scale_factor_yx[0]
+            data[key] = P
+        return data
+
+
 class RandomWarpAffine(object):
     """reference :436-497: random scale about a random centre, resized to (output_w, output_h); P2 follows."""
     def __init__(self, scale_lower=0.6, scale_upper=1.4, shift_border=128, output_w=1280, output_h=384,
@@ -277,9 +320,50 @@ class DeviceAugment(object):
         self.device = device
 
     # -- host side ---------------------------------------------------------------------------------
+    def _collate_resize(self, samples, plans):
+        B, F = len(samples), len(self.frame_idxs)
+        r0 = plans[0]["resize"]
+        Hs = max(p["resize"]["src_hw"][0] for p in plans)
+        Ws = max(p["resize"]["src_hw"][1] for p in plans)
+        src = torch.zeros(B, F, Hs, Ws, 3, dtype=torch.uint8)
+        src_np = src.numpy()
+        dims = np.zeros((B, 4), dtype=np.int32)
+        key0 = (self.image_family, self.frame_idxs[0])
+        mean, std = plans[0]["normalize"].get(key0, (np.zeros(3, np.float32), np.ones(3, np.float32)))
+        for b, (s, p) in enumerate(zip(samples, plans)):
+            r = p["resize"]
+            if p["warp"] is not None or p["ops"] or p["mirror"] or (r["out_h"], r["out_w"]) != (r0["out_h"], r0["out_w"]):
+                raise NotImplementedError("a validation batch is Resize + Normalize with one output size")
+            h, w = r["src_hw"]
+            for f, idx in enumerate(self.frame_idxs):
+                src_np[b, f, :h, :w] = s[(self.image_family, idx)]
+            # crop_1 keeps the left out_w columns of a wider resize; pads are zero rows / columns after it
+            dims[b] = (h, w, r["h"], r["w"])
+        batch = {PLAN: dict(src=src, dims=torch.from_numpy(dims), mean=mean, std=std, out_hw=(r0["out_h"], r0["out_w"]),
+                            kind="resize")}
+        self._collate_rest(samples, batch)
+        return batch
+
+    def _collate_rest(self, samples, batch):
+        skip = {PLAN, self.mask_key}
+        for idx in self.frame_idxs:
+            skip.add((self.image_family, idx)); skip.add((self.original_family, idx))
+        for key in samples[0]:
+            if key in skip:
+                continue
+            vals = [s[key] for s in samples]
+            if isinstance(vals[0], torch.Tensor):
+                batch[key] = torch.stack(vals)
+            elif isinstance(vals[0], np.ndarray):
+                batch[key] = torch.from_numpy(np.stack(vals))
+            else:
+                batch[key] = vals
+
     def collate(self, samples):
         B, F = len(samples), len(self.frame_idxs)
         plans = [s[PLAN] for s in samples]
+        if plans[0].get("resize") is not None:
+            return self._collate_resize(samples, plans)
         for p in plans:
             if p["warp"] is None:
                 raise NotImplementedError("DeviceAugment needs a RandomWarpAffine stage (it fixes the output size)")
@@ -336,30 +420,33 @@ class DeviceAugment(object):
             iplan[b, 4] = int(p["mirror"])
             iplan[b, 5], iplan[b, 6] = h, w
         batch = {PLAN: dict(src=src, minv=torch.from_numpy(minv), iplan=torch.from_numpy(iplan),
-                            fplan=torch.from_numpy(fplan), mean=mean, std=std, out_hw=(out_h, out_w))}
-        skip = {PLAN, self.mask_key}
-        for idx in self.frame_idxs:
-            skip.add((self.image_family, idx)); skip.add((self.original_family, idx))
-        for key in samples[0]:
-            if key in skip:
-                continue
-            vals = [s[key] for s in samples]
-            if isinstance(vals[0], torch.Tensor):
-                batch[key] = torch.stack(vals)
-            elif isinstance(vals[0], np.ndarray):
-                batch[key] = torch.from_numpy(np.stack(vals))
-            else:
-                batch[key] = vals
+                            fplan=torch.from_numpy(fplan), mean=mean, std=std, out_hw=(out_h, out_w), kind="warp")}
+        self._collate_rest(samples, batch)
         return batch
 
     # -- device side -------------------------------------------------------------------------------
     def materialize(self, batch, device=None):
-        from ....hip.binding import lib, check, stream_ptr, FsAugArgs
+        from ....hip.binding import lib, check, stream_ptr, FsAugArgs, FsResizeArgs
         device = torch.device(device or self.device or "cuda")
         plan = batch.pop(PLAN)
         src = plan["src"].to(device, non_blocking=True)
         B, F, Hs, Ws, _ = src.shape
         H, W = plan["out_hw"]
+        if plan["kind"] == "resize":
+            dims = plan["dims"].to(device, non_blocking=True)
+            image = torch.empty(F, B, 3, H, W, dtype=torch.float32, device=device)
+            r = FsResizeArgs()
+            r.src, r.dims, r.image = src.data_ptr(), dims.data_ptr(), image.data_ptr()
+            for k in range(3):
+                r.mean[k], r.std[k] = float(plan["mean"][k]), float(plan["std"][k])
+            r.B, r.F, r.Hs, r.Ws, r.H, r.W = B, F, Hs, Ws, H, W
+            check(lib.fs_resize_frames(C.byref(r), stream_ptr()), "resize_frames")
+            for f, idx in enumerate(self.frame_idxs):
+                batch[(self.image_family, idx)] = image[f]
+            for key, val in list(batch.items()):
+                if isinstance(val, torch.Tensor) and not val.is_cuda:
+                    batch[key] = val.to(device, non_blocking=True)
+            return batch
         minv = plan["minv"].to(device, non_blocking=True)
         iplan = plan["iplan"].to(device, non_blocking=True)
         fplan = plan["fplan"].to(device, non_blocking=True)

@@ -202,6 +202,19 @@ typedef struct FsAugArgs {
 } FsAugArgs;
 int fs_augment_frames(const FsAugArgs* args, void* stream);
 
+/* Validation input (configs/kitti_wpose_example:156-166): Resize (augmentations.py:112-198: cv2.resize INTER_LINEAR of
+ * the float image to rh x rw, then zero pad / crop to H x W) + Normalize + CHW.  dims[b] = { src_h, src_w, rh, rw };
+ * src as in FsAugArgs; image [F][B][3][H][W] fp32. */
+typedef struct FsResizeArgs {
+  const uint8_t* src;
+  const int32_t* dims;
+  float* image;
+  float mean[3];
+  float std[3];
+  int32_t B, F, Hs, Ws, H, W;
+} FsResizeArgs;
+int fs_resize_frames(const FsResizeArgs* args, void* stream);
+
 /* Evaluation.  fs_resize_linear: single-channel fp32 [h][w] -> [H][W] with OpenCV's INTER_LINEAR
  * rule; invert != 0 resizes the inverse: dst = 1 / resize(1 / src)  (base_evaluation_hooks.py:57).
  * fs_depth_eval: per image b, pred [B][h][w] (resized on the fly to the ground truth's [H][W]) against gt [B][H][W]:

@@ -14,10 +14,11 @@ Pinning status
     classes): the random draws and their order, the P2 bookkeeping of RandomWarpAffine / RandomMirror,
     flip_relative_pose, Normalize, RandomBrightness / RandomContrast / RandomSaturation arithmetic, the Shuffle order,
     the mirror of images and masks.
-  * PARITY UNPINNED: cv2.warpAffine (INTER_LINEAR / INTER_NEAREST, BORDER_CONSTANT) and cv2.cvtColor
-    (RGB2HSV / HSV2RGB on float32).  OpenCV is a third-party dependency of the reference (requirement.txt:
+  * PARITY UNPINNED: cv2.warpAffine (INTER_LINEAR / INTER_NEAREST, BORDER_CONSTANT), cv2.cvtColor
+    (RGB2HSV / HSV2RGB on float32) and cv2.resize (INTER_LINEAR on float32, the validation path's Resize :112-198;
+    restated from modules/imgproc/src/resize.cpp).  OpenCV is a third-party dependency of the reference (requirement.txt:
     opencv-python, unpinned version) and is not installed in this image, so the reference's own classes cannot execute
-    those two calls here.  They are restated from OpenCV 4.x: modules/imgproc/src/imgwarp.cpp (warpAffine: matrix
+    those calls here.  They are restated from OpenCV 4.x: modules/imgproc/src/imgwarp.cpp (warpAffine: matrix
     inversion in f64, AB_BITS = 10 fixed-point coordinates, INTER_BITS = 5 sub-pixel grid; remapBilinear / remapNearest
     with BORDER_CONSTANT) and modules/imgproc/src/color_hsv.simd.hpp (RGB2HSV_f / HSV2RGB_f, hrange = 360).
 """
@@ -242,3 +243,59 @@ def run_sample(frames_u8, plan, out_w, out_h, mean, std):
     if plan["mirror"]:
         mask = np.ascontiguousarray(mask[:, ::-1])
     return images, originals, mask
+
+
+# ------------------------------------------------------------------------------------------------
+# validation input: Resize (augmentations.py:112-198) + Normalize; cv2.resize is an UNPINNED restatement
+# ------------------------------------------------------------------------------------------------
+def _resize_coords(n_dst, n_src):
+    scale = 1.0 / (float(n_dst) / float(n_src))
+    f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    lo, hi = s < 0, s >= n_src - 1
+    f = np.where(lo | hi, np.float32(0.0), f)
+    s = np.where(lo, 0, np.where(hi, n_src - 1, s))
+    return s, f
+
+
+def resize_linear(src, w, h):
+    """cv2.resize(src, (w, h)) for float32 [H, W, C]: horizontal pass (1-fx, fx), then vertical (1-fy, fy)."""
+    src = np.asarray(src, dtype=np.float32)
+    H, W = src.shape[:2]
+    x0, fx = _resize_coords(w, W)
+    y0, fy = _resize_coords(h, H)
+    x1, y1 = np.minimum(x0 + 1, W - 1), np.minimum(y0 + 1, H - 1)
+    one = np.float32(1.0)
+    fxe, fye = fx[None, :, None], fy[:, None, None]
+    top = src[y0][:, x0] * (one - fxe) + src[y0][:, x1] * fxe
+    bot = src[y1][:, x0] * (one - fxe) + src[y1][:, x1] * fxe
+    return (top * (one - fye) + bot * fye).astype(np.float32)
+
+
+def resize_plan(shape, size, preserve_aspect_ratio=True, force_pad=True):
+    """the size logic of Resize.__call__ (:133-156): (h, w) of the cv2.resize, crop/pad mode, P2 scale (y, x)"""
+    if preserve_aspect_ratio:
+        sx, sy = size[0] / shape[0], size[1] / shape[1]
+        if force_pad:
+            sf = min(sx, sy)
+            mode = 'pad_0' if sx > sy else 'pad_1'
+        else:
+            sf = sx
+            mode = 'crop_1' if sx > sy else 'pad_1'
+        h = np.round(shape[0] * sf).astype(int)
+        w = np.round(shape[1] * sf).astype(int)
+        return int(h), int(w), mode, (sf, sf)
+    return size[0], size[1], 'none', (size[0] / shape[0], size[1] / shape[1])
+
+
+def run_val_sample(frame_u8, size, mean, std, preserve_aspect_ratio=False, force_pad=True):
+    h, w, mode, _ = resize_plan(frame_u8.shape, size, preserve_aspect_ratio, force_pad)
+    img = resize_linear(frame_u8.astype(np.float32), w, h)
+    if mode == 'crop_1':
+        img = img[:, 0:size[1]]
+    if mode == 'pad_1':
+        img = np.pad(img, [(0, 0), (0, size[1] - img.shape[1]), (0, 0)], 'constant')
+    if mode == 'pad_0':
+        img = np.pad(img, [(0, size[0] - img.shape[0]), (0, 0), (0, 0)], 'constant')
+    return normalize(img, mean, std).transpose(2, 0, 1)

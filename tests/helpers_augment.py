@@ -63,3 +63,26 @@ def pipeline_cfg(g, prefix='fsnet_amd.vision_base.data.augmentations.augmentatio
              image_keys=[('original_image', i) for i in FRAME_IDXS]),
         dict(name=prefix + '.ConvertToTensor')],
         image_keys=resize_keys, calib_keys=['P2'], gt_image_keys=['patched_mask'])
+
+
+VAL_CASES = (("stretch", dict(preserve_aspect_ratio=False)), ("pad1", dict(preserve_aspect_ratio=True, force_pad=True)),
+             ("pad0", dict(preserve_aspect_ratio=True, force_pad=True)), ("crop1", dict(preserve_aspect_ratio=True, force_pad=False)))
+
+
+def val_pipeline(g, kw, prefix='fsnet_amd.vision_base.data.augmentations.augmentations',
+                 builder='fsnet_amd.vision_base.utils.builder'):
+    """configs/kitti_wpose_example:156-166 at the golden's 48x160"""
+    from fsnet_amd.vision_base.utils.builder import build
+    return build(name=builder + '.Sequential', cfg_list=[
+        dict(name=prefix + '.ConvertToFloat'), dict(name=prefix + '.Resize', size=(48, 160), **kw),
+        dict(name=prefix + '.Normalize', mean=g['mean'], stds=g['std']), dict(name=prefix + '.ConvertToTensor')],
+        image_keys=[('image', 0)], calib_keys=['P2'])
+
+
+def val_frame(g, tag):
+    shp = tuple(int(v) for v in g['val_%s_shape' % tag])
+    fr = np.random.RandomState(int(g['val_%s_seed' % tag]))
+    return fr.randint(0, 256, size=shp + (3,)).astype(np.uint8)
+
+
+VAL_P2 = np.array([[721.5, 0, 609.5, 44.8], [0, 721.5, 172.8, 0.2], [0, 0, 1, 0.0027]], dtype=np.float64)

@@ -111,3 +111,28 @@ def test_hsv_known_answers():
     img = rs.uniform(-20, 300, size=(16, 16, 3)).astype(np.float32)       # brightness / contrast leave [0, 255]
     back = A.hsv2rgb(A.rgb2hsv(img))
     assert np.abs(back - img).max() < 2e-3 * 300
+
+
+def test_validation_resize_oracle_and_host_class_match_reference_vectors():
+    g = HA.golden()
+    for tag, kw in HA.VAL_CASES:
+        frame = HA.val_frame(g, tag)
+        assert np.array_equal(A.run_val_sample(frame, (48, 160), g["mean"], g["std"], **kw), g["val_%s_image" % tag]), tag
+        out = HA.val_pipeline(g, kw)({('image', 0): frame.copy(), 'P2': HA.VAL_P2.copy()})
+        assert np.array_equal(out['P2'].numpy(), g["val_%s_P2" % tag])
+        assert list(out[('image_resize', 'effective_size')]) == list(g["val_%s_effective" % tag])
+        assert list(out[('image_resize', 'original_shape')]) == list(g["val_%s_original" % tag])
+        assert out[('image', 0)].dtype == np.uint8
+
+
+def test_resize_known_answers():
+    rs = np.random.RandomState(2)
+    img = rs.randint(0, 256, size=(12, 20, 3)).astype(np.float32)
+    assert np.array_equal(A.resize_linear(img, 20, 12), img)                       # same size: identity
+    up = A.resize_linear(img, 40, 24)                                              # 2x: taps at +-0.25
+    assert np.array_equal(up[0, 0], img[0, 0]) and np.array_equal(up[-1, -1], img[-1, -1])   # clamped borders
+    want = img[0, 0] * np.float32(0.75) + img[0, 1] * np.float32(0.25)
+    assert np.array_equal(up[0, 1], want)
+    ramp = np.tile(np.arange(20, dtype=np.float32)[None, :, None], (12, 1, 3))
+    out = A.resize_linear(ramp, 10, 12)                                            # 2x down: mean of the pair
+    assert np.array_equal(out[:, :, 0], np.tile(np.arange(10, dtype=np.float32) * 2 + np.float32(0.5), (12, 1)))

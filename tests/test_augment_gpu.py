@@ -149,3 +149,24 @@ def test_pipeline_feeds_a_training_step(dev):
     torch.cuda.synchronize()
     assert len(losses) == 2 and all(l == l and 0 < l < 10 for l in losses), losses
     RT.set_compute_dtype(torch.bfloat16)
+
+
+def test_validation_resize_matches_reference_vectors(dev):
+    """Resize + Normalize of the validation path (stretch, both pads, crop) through fs_resize_frames"""
+    from fsnet_amd.vision_base.data.augmentations.augmentations import DeviceAugment
+    g = HA.golden()
+    aug = DeviceAugment([0], original_family=None, mask_key=None)
+    for tag, kw in HA.VAL_CASES:
+        frame = HA.val_frame(g, tag)
+        vt = HA.val_pipeline(g, kw)
+        samples = [vt({('image', 0): frame.copy(), 'P2': HA.VAL_P2.copy()}),
+                   vt({('image', 0): frame[:-3, :-5].copy(), 'P2': HA.VAL_P2.copy()})]      # ragged second sample
+        if kw.get("preserve_aspect_ratio"):
+            samples = samples[:1]       # a different aspect ratio changes the effective size, not a batch-mate
+        batch = aug(samples, dev)
+        torch.cuda.synchronize()
+        assert np.array_equal(batch[('image', 0)][0].cpu().numpy(), g["val_%s_image" % tag]), tag
+        assert np.array_equal(batch['P2'][0].cpu().numpy(), g["val_%s_P2" % tag])
+        if len(samples) == 2:
+            want = A.run_val_sample(frame[:-3, :-5], (48, 160), g["mean"], g["std"], **kw)
+            assert np.array_equal(batch[('image', 0)][1].cpu().numpy(), want)

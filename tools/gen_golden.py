@@ -396,6 +396,30 @@ def gen_augment():
         maxdev = max(maxdev, float(np.abs(mask - res["s%d_mask" % n]).max()), float(np.abs(P - res["s%d_P2" % n]).max()))
         print("augment sample %d: mirror=%s order=%s" % (n, plan["mirror"], plan["order"]))
     print("augment: oracle vs reference classes, max abs deviation over images/masks/P2/poses: %.3e" % maxdev)
+    # validation input: ConvertToFloat, Resize, Normalize, ConvertToTensor (configs/kitti_wpose_example:156-166)
+    if not hasattr(np, "int"):
+        np.int = int          # the reference's Resize uses the alias numpy removed in 1.24 (:134, :157)
+    vdev = 0.0
+    for tag, kw, shp in (("stretch", dict(preserve_aspect_ratio=False), (75, 250)),
+                         ("pad1", dict(preserve_aspect_ratio=True, force_pad=True), (120, 250)),
+                         ("pad0", dict(preserve_aspect_ratio=True, force_pad=True), (60, 400)),
+                         ("crop1", dict(preserve_aspect_ratio=True, force_pad=False), (60, 400))):
+        vt = build(**E(name='vision_base.utils.builder.Sequential', cfg_list=[
+            E(name=aug + '.ConvertToFloat'), E(name=aug + '.Resize', size=(48, 160), **kw),
+            E(name=aug + '.Normalize', mean=mean, stds=std), E(name=aug + '.ConvertToTensor')],
+            image_keys=[('image', 0)], calib_keys=['P2']))
+        fr = np.random.RandomState(950 + len(tag))
+        frame = fr.randint(0, 256, size=shp + (3,)).astype(np.uint8)
+        P2 = np.array([[721.5, 0, 609.5, 44.8], [0, 721.5, 172.8, 0.2], [0, 0, 1, 0.0027]], dtype=np.float64)
+        out = vt({('image', 0): frame.copy(), 'P2': P2.copy()})
+        res["val_%s_image" % tag] = npy(out[('image', 0)])
+        res["val_%s_P2" % tag] = np.asarray(out['P2'])
+        res["val_%s_shape" % tag] = np.array(shp)
+        res["val_%s_seed" % tag] = 950 + len(tag)
+        res["val_%s_effective" % tag] = np.asarray(out[('image_resize', 'effective_size')])
+        res["val_%s_original" % tag] = np.asarray(out[('image_resize', 'original_shape')])
+        vdev = max(vdev, float(np.abs(A.run_val_sample(frame, (48, 160), mean, std, **kw) - res["val_%s_image" % tag]).max()))
+    print("augment (validation Resize): oracle vs reference class, max abs deviation %.3e" % vdev)
     np.savez_compressed(os.path.join(GOLD, "augment.npz"), **res)
 
 

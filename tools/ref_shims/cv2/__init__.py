@@ -1,7 +1,7 @@
 """Import shim for tools/gen_golden.py ONLY (never on the product path, never on the GPU box).
 
 OpenCV is not installed in this image.  The reference's augmentation module imports cv2 at module level and calls
-exactly two of its functions on the training path (warpAffine, cvtColor).  This stand-in lets the module import and
+two of its functions on the training path (warpAffine, cvtColor) and resize on the validation path.  This stand-in lets the module import and
 routes those two calls to oracle/augment_oracle.py's restatement of OpenCV's algorithms — so golden vectors that
 pass through them pin the reference's OWN arithmetic around the calls (draw order, P2 bookkeeping, mirror, colour
 ops, Normalize) but NOT OpenCV itself: the oracle header and DESIGN.md mark warpAffine / cvtColor "parity unpinned".
@@ -29,5 +29,7 @@ def cvtColor(src, code):
     return A.hsv2rgb(src)
 
 
-def resize(*a, **k):
-    raise NotImplementedError("cv2.resize is not restated by this shim")
+def resize(src, dsize, interpolation=INTER_LINEAR):
+    from oracle import augment_oracle as A
+    assert interpolation == INTER_LINEAR and src.dtype.name == "float32"
+    return A.resize_linear(src, dsize[0], dsize[1])
