@@ -46,6 +46,11 @@ class DataParallelContext:
         if not params:
             return
         from .nets import flush_deferred, join_companions
+        if self.world > 1 and torch.cuda.is_current_stream_capturing():
+            # under capture join_companions() leaves the companion joins to the end of the step (ROCm 7.2 nested
+            # fork-join crash), so this all-reduce node would not depend on the weight-gradient kernels; harmless at
+            # world size 1 (the experiment FSNET_AMD_GRAPH_DP=1 covers), wrong beyond it -> the hook falls back to eager
+            raise RuntimeError("graph-captured data-parallel steps are not validated beyond world size 1")
         flush_deferred()          # weight-gradient kernels handed to companion streams must have landed in the
         join_companions()         # arena slice before it is reduced
         lo, hi = arena.slice_of(params)
