@@ -46,7 +46,7 @@ class DataParallelContext:
         if not params:
             return
         from .nets import flush_deferred, join_companions
-        if self.world > 1 and torch.cuda.is_current_stream_capturing():
+        if self.world > 1 and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
             # under capture join_companions() leaves the companion joins to the end of the step (ROCm 7.2 nested
             # fork-join crash), so this all-reduce node would not depend on the weight-gradient kernels; harmless at
             # world size 1 (the experiment FSNET_AMD_GRAPH_DP=1 covers), wrong beyond it -> the hook falls back to eager
