@@ -23,10 +23,15 @@ class DataParallelContext:
         self.meta = meta_arch
         self.bucket_of = {}
         self._synced = False
+        # the 100 small SyncBN exchanges per step go straight to the process group object: the checks and logging
+        # of the dist.all_reduce wrapper cost more host time than the exchange itself
+        self._pg = group if group is not None else dist.distributed_c10d._get_default_group()
+        self._sum = dist.AllreduceOptions()
+        self._sum.reduceOp = dist.ReduceOp.SUM
 
     # ---- small latency-bound exchanges (BN) ------------------------------------------------
     def allreduce_small(self, t):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        self._pg.allreduce([t], self._sum).wait()
 
     # ---- gradient buckets --------------------------------------------------------------------
     def begin_step(self, meta_arch):
