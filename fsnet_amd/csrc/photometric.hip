@@ -294,8 +294,12 @@ __global__ __launch_bounds__(256) void photo_loss_fwd_kernel(const FsPhotoArgs p
 }
 
 // ---------------------------------------------------------------------------------------------
-// loss backward, LDS tiled: tile 32x8 pixels q; coefficients of p in tile(+)1 from pred/target in tile(+)2.
-// 512 threads: the two source frames run concurrently (threads 0-255 frame 0, 256-511 frame 1).
+// loss backward, LDS tiled: tile 32x8 pixels q, one thread per pixel; coefficients of the window centres p in
+// tile(+)1 from pred/target in tile(+)2.  A window centre contributes to exactly one source frame — the one its
+// per-pixel minimum selected (sel == 2 + f) — so its nine coefficients are computed and stored once, with the frame
+// index beside them, and the gather at q sorts them into the two frames' accumulators.  (The first version ran the
+// two frames on separate thread halves with a coefficient plane each: twice the SSIM-derivative arithmetic and
+// twice the LDS gather traffic, half of it zeros by construction.)  Sums are formed in the same order as before.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int refl_mult(int pc, int qc, int n) {
   // how many taps delta in {-1,0,1} of window centre pc land (after reflection) on pixel qc
@@ -305,18 +309,18 @@ __device__ __forceinline__ int refl_mult(int pc, int qc, int n) {
   return m;
 }
 
-__global__ __launch_bounds__(512) void photo_loss_bwd_kernel(const FsPhotoArgs p) {
+__global__ __launch_bounds__(256) void photo_loss_bwd_kernel(const FsPhotoArgs p) {
   __shared__ float s_t[3][R2H][R2W];
   __shared__ float s_x[2][3][R2H][R2W];
-  __shared__ float s_coef[2][9][R1H][R1W];   // [frame][c*3 + {A,B,C}]
+  __shared__ float s_coef[9][R1H][R1W];      // c*3 + {A,B,C} of the frame selected at p
+  __shared__ int s_fr[R1H][R1W];             // that frame (0 / 1), -1: identity selected, masked out or outside
   __shared__ float s_red[2][12][4];
-  __shared__ float s_dD[TH * TW];
   __shared__ float s_dd[(TH + 2) * (TW + 2)];
   const int s = blockIdx.z / p.B, b = blockIdx.z % p.B;
   const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
   const int H = p.H, W = p.W;
   const long HW = (long)H * W;
-  const int f = threadIdx.x >> 8, tid = threadIdx.x & 255;
+  const int tid = threadIdx.x;
   const float* timg = p.img0 + (long)b * 3 * HW;
   const uint8_t* sel = p.sel + ((long)s * p.B + b) * HW;
   const float* ge = p.geo + (long)b * GEO_STRIDE;
@@ -324,7 +328,8 @@ __global__ __launch_bounds__(512) void photo_loss_bwd_kernel(const FsPhotoArgs p
   double msum = 0.0;
   for (int k = 0; k < p.B; ++k) msum += p.mask_sum[k];
   const float gscale = (float)(gout / ((double)p.S * (msum + 1e-6)));
-  const float* pred = p.pred + (((long)s * 2 + f) * p.B + b) * 3 * HW;
+  const float* pred0 = p.pred + (((long)s * 2 + 0) * p.B + b) * 3 * HW;
+  const float* pred1 = p.pred + (((long)s * 2 + 1) * p.B + b) * 3 * HW;
   // tiles whose 2-pixel halo lies inside the image need no reflection bookkeeping (the common case)
   const bool interior = ty0 >= 2 && tx0 >= 2 && ty0 + TH + 2 <= H && tx0 + TW + 2 <= W;
 
@@ -335,28 +340,31 @@ __global__ __launch_bounds__(512) void photo_loss_bwd_kernel(const FsPhotoArgs p
     long o = (long)y * W + x;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      if (f == 0) s_t[c][ry][rx] = in ? timg[c * HW + o] : 0.f;
-      s_x[f][c][ry][rx] = in ? pred[c * HW + o] : 0.f;
+      s_t[c][ry][rx] = in ? timg[c * HW + o] : 0.f;
+      s_x[0][c][ry][rx] = in ? pred0[c * HW + o] : 0.f;
+      s_x[1][c][ry][rx] = in ? pred1[c * HW + o] : 0.f;
     }
   }
-  for (int i = threadIdx.x; i < (TH + 2) * (TW + 2); i += 512) s_dd[i] = 0.f;
+  for (int i = tid; i < (TH + 2) * (TW + 2); i += 256) s_dd[i] = 0.f;
   __syncthreads();
 
-  // ---- coefficients at p in tile(+)1 ----
+  // ---- coefficients at p in tile(+)1, for the frame p selected ----
   for (int i = tid; i < R1H * R1W; i += 256) {
     int ry = i / R1W, rx = i - ry * R1W;
     int y = ty0 - 1 + ry, x = tx0 - 1 + rx;
     float wgt = 0.f;
+    int f = -1;
     bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-    if (in && sel[(long)y * W + x] == 2 + f) {
-      float pm = p.patched_mask ? (float)p.patched_mask[(long)b * HW + (long)y * W + x] : 1.f;
-      wgt = pm * gscale * (0.85f / 3.f);
+    if (in) {
+      int sv = sel[(long)y * W + x];
+      if (sv >= 2) {
+        float pm = p.patched_mask ? (float)p.patched_mask[(long)b * HW + (long)y * W + x] : 1.f;
+        wgt = pm * gscale * (0.85f / 3.f);
+        f = sv - 2;
+      }
     }
-    if (wgt == 0.f) {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) s_coef[f][k][ry][rx] = 0.f;
-      continue;
-    }
+    if (wgt == 0.f) { s_fr[ry][rx] = -1; continue; }
+    s_fr[ry][rx] = f;
     int ys[3] = {ry, ry + 1, ry + 2}, xs[3] = {rx, rx + 1, rx + 2};   // interior: window = R2 rows ry..ry+2
     if (!interior) {
       ys[0] = refl(y - 1, H) - (ty0 - 2); ys[2] = refl(y + 1, H) - (ty0 - 2);
@@ -401,39 +409,43 @@ __global__ __launch_bounds__(512) void photo_loss_bwd_kernel(const FsPhotoArgs p
         Bc = -h * n * b2;
         Cc = h * a2 * d;
       }
-      s_coef[f][c * 3 + 0][ry][rx] = wgt * A;
-      s_coef[f][c * 3 + 1][ry][rx] = wgt * Bc;
-      s_coef[f][c * 3 + 2][ry][rx] = wgt * Cc;
+      s_coef[c * 3 + 0][ry][rx] = wgt * A;
+      s_coef[c * 3 + 1][ry][rx] = wgt * Bc;
+      s_coef[c * 3 + 2][ry][rx] = wgt * Cc;
     }
   }
   __syncthreads();
 
-  // ---- gather d loss / d pred(q), chain through the sampler and the projection ----
+  // ---- gather d loss / d pred_f(q) for both frames, chain through the sampler and the projection ----
   const int qx = tx0 + (tid % TW), qy = ty0 + (tid / TW);
   const bool qin = qx < W && qy < H;
-  float dD = 0.f;
-  float dP[12];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) dP[k] = 0.f;
+  const int ly = tid / TW + 2, lx = tid % TW + 2;  // q inside the R2 arrays
+  float dpred[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
   if (qin) {
-    const int ly = tid / TW + 2, lx = tid % TW + 2;  // q inside the R2 arrays
-    float dpred[3] = {0.f, 0.f, 0.f};
     if (interior) {
       // every window centre in [q-1, q+1]^2 contributes exactly once
       const int cy = tid / TW, cx = tid % TW;     // coefficient-region row/col of (qy-1, qx-1)
+      float acc[2][9];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float sa = 0.f, sb = 0.f, sc = 0.f;
+      for (int k = 0; k < 9; ++k) { acc[0][k] = 0.f; acc[1][k] = 0.f; }
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+      for (int a = 0; a < 3; ++a)
 #pragma unroll
-          for (int bb = 0; bb < 3; ++bb) {
-            sa += s_coef[f][c * 3][cy + a][cx + bb];
-            sb += s_coef[f][c * 3 + 1][cy + a][cx + bb];
-            sc += s_coef[f][c * 3 + 2][cy + a][cx + bb];
+        for (int bb = 0; bb < 3; ++bb) {
+          const int fr = s_fr[cy + a][cx + bb];
+          if (fr < 0) continue;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) {
+            const float cv = s_coef[k][cy + a][cx + bb];
+            acc[0][k] += fr == 0 ? cv : 0.f;
+            acc[1][k] += fr == 1 ? cv : 0.f;
           }
-        dpred[c] = sa + sb * s_x[f][c][ly][lx] + sc * s_t[c][ly][lx];
-      }
+        }
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          dpred[f][c] = acc[f][c * 3] + acc[f][c * 3 + 1] * s_x[f][c][ly][lx] + acc[f][c * 3 + 2] * s_t[c][ly][lx];
     } else {
       for (int py = qy - 1; py <= qy + 1; ++py) {
         if ((unsigned)py >= (unsigned)H) continue;
@@ -445,23 +457,40 @@ __global__ __launch_bounds__(512) void photo_loss_bwd_kernel(const FsPhotoArgs p
           if (!mx) continue;
           float mult = (float)(my * mx);
           int ry = py - (ty0 - 1), rx = px - (tx0 - 1);
+          const int fr = s_fr[ry][rx];
+          if (fr < 0) continue;
 #pragma unroll
-          for (int c = 0; c < 3; ++c)
-            dpred[c] += mult * (s_coef[f][c * 3][ry][rx] + s_coef[f][c * 3 + 1][ry][rx] * s_x[f][c][ly][lx] +
-                                s_coef[f][c * 3 + 2][ry][rx] * s_t[c][ly][lx]);
+          for (int c = 0; c < 3; ++c) {
+            const float v = mult * (s_coef[c * 3][ry][rx] + s_coef[c * 3 + 1][ry][rx] * s_x[fr][c][ly][lx] +
+                                    s_coef[c * 3 + 2][ry][rx] * s_t[c][ly][lx]);
+            dpred[0][c] += fr == 0 ? v : 0.f;
+            dpred[1][c] += fr == 1 ? v : 0.f;
+          }
         }
       }
     }
-    if (sel[(long)qy * W + qx] == 2 + f) {
+    const int sq = sel[(long)qy * W + qx];
+    if (sq >= 2) {
+      const int f = sq - 2;
       float pm = p.patched_mask ? (float)p.patched_mask[(long)b * HW + (long)qy * W + qx] : 1.f;
       float wl1 = pm * gscale * (0.15f / 3.f);
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         float df = s_x[f][c][ly][lx] - s_t[c][ly][lx];
-        dpred[c] += wl1 * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
+        float g1 = wl1 * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
+        dpred[0][c] += f == 0 ? g1 : 0.f;
+        dpred[1][c] += f == 1 ? g1 : 0.f;
       }
     }
-    if (dpred[0] != 0.f || dpred[1] != 0.f || dpred[2] != 0.f) {
+  }
+  float dDf[2] = {0.f, 0.f};
+  const long blk = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    float dP[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) dP[k] = 0.f;
+    if (qin && (dpred[f][0] != 0.f || dpred[f][1] != 0.f || dpred[f][2] != 0.f)) {
       Geo gq;
       project_pixel(p.depth[s], b, qy, qx, H, W, p.dh[s], p.dw[s], ge, f, gq);
       Taps t;
@@ -473,8 +502,8 @@ __global__ __launch_bounds__(512) void photo_loss_bwd_kernel(const FsPhotoArgs p
         const float* sc = src + c * HW;
         float v00 = sc[(long)t.y0 * W + t.x0], v01 = sc[(long)t.y0 * W + t.x1];
         float v10 = sc[(long)t.y1 * W + t.x0], v11 = sc[(long)t.y1 * W + t.x1];
-        gix += dpred[c] * ((v01 - v00) * (1.f - t.wy) + (v11 - v10) * t.wy);
-        giy += dpred[c] * ((v10 - v00) * (1.f - t.wx) + (v11 - v01) * t.wx);
+        gix += dpred[f][c] * ((v01 - v00) * (1.f - t.wy) + (v11 - v10) * t.wy);
+        giy += dpred[f][c] * ((v10 - v00) * (1.f - t.wx) + (v11 - v01) * t.wx);
       }
       float du = gix * t.mx, dv = giy * t.my;   // (W-1)/2 of the sampler cancels 2/(W-1) of Project3D
       float iz = 1.f / gq.Zp;
@@ -484,7 +513,7 @@ __global__ __launch_bounds__(512) void photo_loss_bwd_kernel(const FsPhotoArgs p
       float pr0 = P[0] * gq.r[0] + P[1] * gq.r[1] + P[2] * gq.r[2];
       float pr1 = P[4] * gq.r[0] + P[5] * gq.r[1] + P[6] * gq.r[2];
       float pr2 = P[8] * gq.r[0] + P[9] * gq.r[1] + P[10] * gq.r[2];
-      dD = dX * pr0 + dY * pr1 + dZ * pr2;
+      dDf[f] = dX * pr0 + dY * pr1 + dZ * pr2;
       float cam[3] = {gq.D * gq.r[0], gq.D * gq.r[1], gq.D * gq.r[2]};
       float dxyz[3] = {dX, dY, dZ};
 #pragma unroll
@@ -494,21 +523,19 @@ __global__ __launch_bounds__(512) void photo_loss_bwd_kernel(const FsPhotoArgs p
         dP[i * 4 + 3] = dxyz[i];
       }
     }
-  }
-  // reduce the 12 projection-matrix partials per frame -> one atomic each
+    // the 12 projection-matrix partials of this frame: wave sums -> LDS
 #pragma unroll
-  for (int k = 0; k < 12; ++k) {
-    float v = wave_sum(dP[k]);
-    if ((tid & 63) == 0) s_red[f][k][tid >> 6] = v;
+    for (int k = 0; k < 12; ++k) {
+      float v = wave_sum(dP[k]);
+      if ((tid & 63) == 0) s_red[f][k][tid >> 6] = v;
+    }
   }
-  if (f == 1) s_dD[tid] = dD;
   __syncthreads();
-  if (tid < 12) {
+  if (tid < 24) {
     // per-block partial, reduced by photo_pose_grad_kernel: 23040 blocks adding into 24 cache lines cost ~90 us of
     // serialised L2 atomics at the bench shape (and made dT depend on the block schedule)
-    float v = s_red[f][tid][0] + s_red[f][tid][1] + s_red[f][tid][2] + s_red[f][tid][3];
-    const long blk = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    p.dP[(blk * 2 + f) * 12 + tid] = v;
+    const int f = tid / 12, k = tid % 12;
+    p.dP[(blk * 2 + f) * 12 + k] = s_red[f][k][0] + s_red[f][k][1] + s_red[f][k][2] + s_red[f][k][3];
   }
   // ---- transpose of the bilinear depth upsample: accumulate the tile's contributions in LDS first, then
   //      one global atomic per touched low-res pixel (scale-3 maps receive 256 full-res pixels each) ----
@@ -516,8 +543,8 @@ __global__ __launch_bounds__(512) void photo_loss_bwd_kernel(const FsPhotoArgs p
   Geo g0;
   upsample_taps(ty0, tx0, H, W, h, w, g0);
   const int by = g0.y0, bx = g0.x0;
-  if (f == 0) {
-    float dD_total = dD + s_dD[tid];
+  {
+    float dD_total = dDf[0] + dDf[1];
     if (qin && dD_total != 0.f) {
       Geo g;
       upsample_taps(qy, qx, H, W, h, w, g);
@@ -531,7 +558,7 @@ __global__ __launch_bounds__(512) void photo_loss_bwd_kernel(const FsPhotoArgs p
   }
   __syncthreads();
   float* dd = p.d_depth[s] + (long)b * h * w;
-  for (int i = threadIdx.x; i < (TH + 2) * (TW + 2); i += 512) {
+  for (int i = tid; i < (TH + 2) * (TW + 2); i += 256) {
     float v = s_dd[i];
     if (v != 0.f) {
       int yy = by + i / (TW + 2), xx = bx + i % (TW + 2);
@@ -621,7 +648,7 @@ extern "C" int fs_photo_loss_bwd(const FsPhotoArgs* a, void* stream) {
   for (int s = 0; s < a->S; ++s) if (!a->depth[s] || !a->d_depth[s]) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((a->W + TW - 1) / TW, (a->H + TH - 1) / TH, a->S * a->B);
-  hipLaunchKernelGGL(photo_loss_bwd_kernel, grid, dim3(512), 0, st, *a);
+  hipLaunchKernelGGL(photo_loss_bwd_kernel, grid, dim3(256), 0, st, *a);
   return fs_launch_status();
 }
 
