@@ -215,28 +215,47 @@ constexpr int TW = 32, TH = 8;
 constexpr int R2W = TW + 4, R2H = TH + 4;   // pred / target region of the backward
 constexpr int R1W = TW + 2, R1H = TH + 2;   // coefficient region (= stencil region of the forward)
 
-// SSIM + L1 of one pixel from LDS planes [3][R1H][R1W]; (ly, lx) = position inside the region
-__device__ __forceinline__ float reproj_lds(const float (*xs)[R1H][R1W], const float (*ts)[R1H][R1W], int ly, int lx) {
-  float ssim_sum = 0.f, l1 = 0.f;
+// SSIM + L1 of one pixel against both warped frames from LDS planes [3][R1H][R1W]; (ly, lx) = position inside the
+// region.  The nine target taps of a channel are read once and serve both frames (sums in the same order as the
+// one-frame form: results are bit-identical); a frame whose sample fell outside the image (want[f] false) is skipped.
+__device__ __forceinline__ void reproj_lds2(const float (*xs)[3][R1H][R1W], const float (*ts)[R1H][R1W], int ly, int lx,
+                                            const bool (&want)[2], float (&out)[2]) {
+  float ssim_sum[2] = {0.f, 0.f}, l1[2] = {0.f, 0.f};
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    float sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+    float tv[9];
+    float sy = 0, syy = 0;
 #pragma unroll
-    for (int a = -1; a <= 1; ++a)
+    for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int bb = -1; bb <= 1; ++bb) {
-        float xv = xs[c][ly + a][lx + bb], tv = ts[c][ly + a][lx + bb];
-        sx += xv; sy += tv; sxx += xv * xv; syy += tv * tv; sxy += xv * tv;
+      for (int bb = 0; bb < 3; ++bb) {
+        float v = ts[c][ly - 1 + a][lx - 1 + bb];
+        tv[a * 3 + bb] = v; sy += v; syy += v * v;
       }
     const float k = 1.f / 9.f;
-    float mux = sx * k, muy = sy * k;
-    float sgx = sxx * k - mux * mux, sgy = syy * k - muy * muy, sgxy = sxy * k - mux * muy;
-    float n = (2.f * mux * muy + C1) * (2.f * sgxy + C2);
-    float d = (mux * mux + muy * muy + C1) * (sgx + sgy + C2);
-    ssim_sum += fminf(fmaxf((1.f - n / d) * 0.5f, 0.f), 1.f);
-    l1 += fabsf(ts[c][ly][lx] - xs[c][ly][lx]);
+    const float muy = sy * k;
+    const float sgy = syy * k - muy * muy;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      if (!want[f]) continue;
+      float sx = 0, sxx = 0, sxy = 0;
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) {
+          float xv = xs[f][c][ly - 1 + a][lx - 1 + bb];
+          sx += xv; sxx += xv * xv; sxy += xv * tv[a * 3 + bb];
+        }
+      float mux = sx * k;
+      float sgx = sxx * k - mux * mux, sgxy = sxy * k - mux * muy;
+      float n = (2.f * mux * muy + C1) * (2.f * sgxy + C2);
+      float d = (mux * mux + muy * muy + C1) * (sgx + sgy + C2);
+      ssim_sum[f] += fminf(fmaxf((1.f - n / d) * 0.5f, 0.f), 1.f);
+      l1[f] += fabsf(tv[4] - xs[f][c][ly][lx]);
+    }
   }
-  return 0.85f * (ssim_sum / 3.f) + 0.15f * (l1 / 3.f);
+#pragma unroll
+  for (int f = 0; f < 2; ++f) out[f] = 0.85f * (ssim_sum[f] / 3.f) + 0.15f * (l1[f] / 3.f);
 }
 
 // LDS-tiled: a block owns 32x8 pixels of one (scale, batch) plane; target and both warped images of the
@@ -278,11 +297,14 @@ __global__ __launch_bounds__(256) void photo_loss_fwd_kernel(const FsPhotoArgs p
       float v = p.ident[((long)b * 2 + f) * HW + i] + tie_noise(seed, key);
       if (f == 0 || v < best) { best = v; bi = f; }
     }
+    bool want[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) want[f] = p.ov[(((long)s * 2 + f) * p.B + b) * HW + i] != 0;
+    float rv[2];
+    reproj_lds2(s_x, s_t, ly + 1, lx + 1, want, rv);
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
-      long o = (((long)s * 2 + f) * p.B + b);
-      float v = 100.f;
-      if (p.ov[o * HW + i]) v = reproj_lds(s_x[f], s_t, ly + 1, lx + 1);
+      float v = want[f] ? rv[f] : 100.f;
       if (v < best) { best = v; bi = 2 + f; }
     }
     p.sel[((long)s * p.B + b) * HW + i] = (uint8_t)bi;
