@@ -92,6 +92,7 @@ def _nhwc_strides(t):
 import os
 
 USE_HALO = os.environ.get("FSNET_AMD_HALO", "1") != "0"   # 3x3/s1 LDS-halo kernel (conv3x3_halo.hip)
+USE_STEM_LDS = os.environ.get("FSNET_AMD_STEM_LDS", "1") != "0"   # 7x7/s2 stem kernel (conv_stem.hip)
 _WGRAD_WS = {}
 
 
@@ -144,6 +145,9 @@ class ConvOp:
         halo_ok = (R == 3 and S == 3 and stride == 1)
         def chunks_ok(c):      # whole 64-byte chunks, or exactly half of one (16 bf16 channels)
             return (c * eb) % 64 == 0 or c * eb == 32
+        # 7x7/s2 stem over 16-byte pixels: LDS-resident weights + im2col from an LDS patch (conv_stem.hip)
+        self.stem_lds = (R == 7 and S == 7 and stride == 2 and pad == 3 and dtype == torch.bfloat16 and self.Ci_p == 8
+                         and Co == 64 and USE_STEM_LDS)
         self.halo_f = halo_ok and chunks_ok(self.Ci_p) and self.Co_p % 16 == 0
         self.halo_d = halo_ok and need_dgrad and chunks_ok(self.Co_p) and roundup(self.Ci_p, 16) % 16 == 0
         # wgrad columns (r, s, ci): same grouping as the forward K walk without chunk padding
@@ -194,12 +198,14 @@ class ConvOp:
             out = torch.empty(N, Ho, Wo, self.Co_p, dtype=torch.float32 if out_f32 else self.dtype,
                               device=x.device)
         halo = self.halo_f and USE_HALO
+        stem = (self.stem_lds and bias is None and addend is None and not relu and not out_f32
+                and out.shape[3] == 64 and out.dtype == self.dtype)
         group_rows, grp_imgs = 0, 0
         if stats is not None and stat_groups > 1:
             assert N % stat_groups == 0 and addend is None
             n = N // stat_groups
             group_rows = n * Ho * Wo
-            if not halo and group_rows % 256 != 0:
+            if not halo and not stem and group_rows % 256 != 0:
                 grp_imgs = n       # a pixel tile could straddle two groups: one group per blockIdx.z instead
         a = FsConvArgs()
         a.src, a.wgt, a.dst = x.data_ptr(), self.w_f.data_ptr(), out.data_ptr()
@@ -223,6 +229,10 @@ class ConvOp:
         if grp_imgs:
             a.stat_group_rows, a.grp_imgs, a.M = 0, grp_imgs, grp_imgs * Ho * Wo
         fn = lib.fs_conv3x3_halo if halo else lib.fs_conv_igemm
+        if stem:
+            _timed("conv_stem", flops, lambda: check(lib.fs_conv_stem(C.byref(a), self.code, stream_ptr()), "conv_stem"),
+                   tag=lambda: "fwd  %s x[%d,%d,%d,%d]" % (self.describe(), N, x.shape[1], x.shape[2], x.shape[3]))
+            return out
         _timed("conv3x3_halo" if halo else "conv_igemm", flops, lambda: check(fn(C.byref(a), self.code, stream_ptr()), "conv_fwd"),
                tag=lambda: "fwd  %s x[%d,%d,%d,%d]" % (self.describe(), N, x.shape[1], x.shape[2], x.shape[3]))
         return out

@@ -13,6 +13,7 @@ SIGNATURES = {
     "fs_target_arch": (C.c_char_p, []),
     "fs_conv_igemm": (C.c_int, [P, I, P]),
     "fs_conv3x3_halo": (C.c_int, [P, I, P]),
+    "fs_conv_stem": (C.c_int, [P, I, P]),
     "fs_conv_wgrad": (C.c_int, [P, I, P]),
     "fs_pack_weights": (C.c_int, [P, P, I, I, I, I, I, I, L, I, I, P]),
     "fs_sigmoid_head_fwd": (C.c_int, [P, P, L, I, P]),

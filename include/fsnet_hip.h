@@ -108,6 +108,12 @@ int fs_conv_igemm(const FsConvArgs* args, int dtype, void* stream);
  */
 int fs_conv3x3_halo(const FsConvArgs* args, int dtype, void* stream);
 
+/* 7x7 / stride-2 / pad-3 stem (resnet.py:118-121: conv1 of both encoders) over 8-channel bf16 pixels, forward only:
+ * weights resident in LDS, im2col from an LDS input patch, persistent blocks.  Same arguments and packed forward
+ * operand as fs_conv_igemm (ktab unused); requires Cs == 8, Co == Co_p == 64, bf16 output, no bias / addend / mask /
+ * relu; stats and stat_group_rows as in fs_conv_igemm. */
+int fs_conv_stem(const FsConvArgs* args, int dtype, void* stream);
+
 /* Convolution weight gradient.  Replaces convolution_backward(weight) at the same call sites.
  * dy is dense [M][Cd]; x is the forward input (strided NHWC); dw is the fp32 OIHW gradient
  * [Co][Ci][R][S] and is accumulated into (+=, deterministic).  ktab as above, one entry

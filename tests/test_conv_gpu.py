@@ -166,3 +166,42 @@ def test_dgrad_epilogue_carries_bn_backward_sums(dev, case, dtype):
     tol = 1e-5 if dtype == torch.float32 else 2e-2
     assert float((a - b).abs().max()) <= tol * float(b.abs().max()), float((a - b).abs().max() / b.abs().max())
     assert float((dx2.float() - dx.float()).abs().max()) <= (1e-4 if dtype == torch.float32 else 5e-2) * float(dx.float().abs().max())
+
+
+@pytest.mark.parametrize("Ci,N,H,W,groups", [(3, 2, 32, 64, 1), (6, 4, 64, 96, 2), (3, 3, 38, 70, 1), (6, 12, 192, 640, 2)])
+def test_stem_lds_kernel(dev, Ci, N, H, W, groups):
+    """7x7/s2 stem through conv_stem.hip (LDS-resident weights, LDS im2col, persistent blocks): output and the
+    per-group BatchNorm statistics against torch's conv2d on the same bf16 operands; ragged tiles and a batch that
+    spans several persistent blocks included."""
+    from fsnet_amd.hip.conv import ConvOp
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(31 + Ci + H)
+    x = torch.randn(N, Ci, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(64, Ci, 7, 7, generator=g) / (Ci * 49) ** 0.5).bfloat16().float()
+    op = ConvOp(Ci, 64, 7, 7, 2, 3, dtype, dev, need_dgrad=False)
+    assert op.stem_lds
+    op.pack(w.to(dev).contiguous())
+    xd = to_nhwc(x.to(dev), op.Ci_p, dtype)
+    stats = torch.zeros(groups, 8, 2, 64, dtype=torch.float64, device=dev)
+    y = op.forward(xd, stats=stats, stat_groups=groups)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.to(dev), w.to(dev), None, stride=2, padding=3)            # fp32 on the same operands
+    got = y.float().permute(0, 3, 1, 2)
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 6e-3 * scale                      # bf16 output rounding
+    n = N // groups
+    for gi in range(groups):
+        r = ref[gi * n:(gi + 1) * n].double()
+        yb = got[gi * n:(gi + 1) * n].double()        # statistics are taken from the fp32 accumulators
+        s = stats[gi].sum(0).cpu()
+        assert torch.allclose(s[0], r.sum(dim=(0, 2, 3)).cpu(), rtol=2e-3, atol=2e-3 * (r ** 2).sum(dim=(0, 2, 3)).max().sqrt().item())
+        assert torch.allclose(s[1], (r ** 2).sum(dim=(0, 2, 3)).cpu(), rtol=3e-3)
+        assert yb.shape == r.shape
+    # the generic path on the same inputs agrees to bf16 rounding
+    import fsnet_amd.hip.conv as CV
+    op2 = ConvOp(Ci, 64, 7, 7, 2, 3, dtype, dev, need_dgrad=False)
+    op2.stem_lds = False
+    op2.pack(w.to(dev).contiguous())
+    y2 = op2.forward(xd)
+    torch.cuda.synchronize()
+    assert (y2.float() - y.float()).abs().max().item() <= 1.6e-2 * scale
