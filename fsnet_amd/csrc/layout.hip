@@ -70,6 +70,72 @@ __host__ __device__ inline int pack_ib(int RS, int Ci) {
   return p2;
 }
 
+// tile body; RS_C / NCI_C / NCO_C > 0 fix the tap count and the tile extent at compile time (the full 32 x 32 x 9
+// tiles of the 3x3 layers are 97 % of the work: with run-time divisors the index arithmetic — three div/mod chains per
+// element and pass — cost more than the 176 MB the kernel moves: 139 us against ~50)
+template <typename T, int RS_C, int NCI_C, int NCO_C>
+__device__ __forceinline__ void pack_tile(const FsPackDesc& d, float* tile, int co0, int ci0, int nco_r, int nci_r) {
+  const int RS = RS_C > 0 ? RS_C : d.R * d.S;
+  const int nci = NCI_C > 0 ? NCI_C : nci_r;
+  const int nco = NCO_C > 0 ? NCO_C : nco_r;
+  const int run = nci * RS;                         // contiguous floats per co in the master tensor
+  if (RS_C > 0 && NCI_C > 0 && (NCI_C * RS_C) % 4 == 0 && (d.Ci * RS) % 4 == 0 && (ci0 * RS) % 4 == 0) {
+    constexpr int RUN4 = NCI_C * RS_C / 4 > 0 ? NCI_C * RS_C / 4 : 1;       // 16-byte loads of the master rows
+    for (int i = threadIdx.x; i < nco * RUN4; i += 256) {
+      const int col = i / RUN4, r4 = i - col * RUN4;
+      const float4 v = *reinterpret_cast<const float4*>(d.w + ((long)(co0 + col) * d.Ci + ci0) * RS + r4 * 4);
+      float* o = tile + col * PACK_ROW + r4 * 4;
+      o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
+  } else {
+    for (int i = threadIdx.x; i < nco * run; i += 256) {
+      int col = i / run, rem = i - col * run;
+      tile[col * PACK_ROW + rem] = d.w[((long)(co0 + col) * d.Ci + ci0) * RS + rem];
+    }
+  }
+  __syncthreads();
+  T* df = reinterpret_cast<T*>(d.dst_f);
+  T* dd = reinterpret_cast<T*>(d.dst_d);
+  if constexpr (RS_C > 0 && NCI_C % 8 == 0 && NCI_C > 0 && NCO_C % 8 == 0 && NCO_C > 0) {
+    // full tile: one thread gathers 8 consecutive channels from LDS and stores them as 16-byte lanes (a 2-byte
+    // store per element kept the kernel at the store-issue rate)
+    constexpr int VN = VecN<T>::N;
+    for (int i = threadIdx.x; i < NCO_C * RS_C * (NCI_C / 8); i += 256) {     // (co, tap, 8 ci)
+      const int cig = i % (NCI_C / 8); const int q = i / (NCI_C / 8); const int tap = q % RS_C; const int col = q / RS_C;
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = tile[col * PACK_ROW + (cig * 8 + k) * RS_C + tap];
+      T* o = df + (long)(co0 + col) * d.k_f + (long)tap * d.cs_f + ci0 + cig * 8;
+#pragma unroll
+      for (int h = 0; h < 8 / VN; ++h) storev<T>(o + h * VN, v + h * VN);
+    }
+    if (dd) {
+      for (int i = threadIdx.x; i < NCI_C * RS_C * (NCO_C / 8); i += 256) {   // (ci, tap, 8 co)
+        const int cog = i % (NCO_C / 8); const int q = i / (NCO_C / 8); const int tap = q % RS_C; const int cil = q / RS_C;
+        const int st = tap_at(d.tap_order_d, tap, RS_C);
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = tile[(cog * 8 + k) * PACK_ROW + cil * RS_C + st];
+        T* o = dd + (long)(ci0 + cil) * d.k_d + (long)tap * d.cs_d + co0 + cog * 8;
+#pragma unroll
+        for (int h = 0; h < 8 / VN; ++h) storev<T>(o + h * VN, v + h * VN);
+      }
+    }
+    return;
+  }
+  for (int i = threadIdx.x; i < nco * run; i += 256) {          // (co, tap, ci): ci fastest
+    int cil = i % nci; int q = i / nci; int tap = q % RS; int col = q / RS;
+    df[(long)(co0 + col) * d.k_f + (long)tap * d.cs_f + ci0 + cil] = ElemTraits<T>::from_f(tile[col * PACK_ROW + cil * RS + tap]);
+  }
+  if (dd) {
+    for (int i = threadIdx.x; i < nco * run; i += 256) {        // (ci, tap, co): co fastest
+      int col = i % nco; int q = i / nco; int tap = q % RS; int cil = q / RS;
+      dd[(long)(ci0 + cil) * d.k_d + (long)tap * d.cs_d + co0 + col] =
+          ElemTraits<T>::from_f(tile[col * PACK_ROW + cil * RS + tap_at(d.tap_order_d, tap, RS)]);
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const FsPackDesc* __restrict__ descs, int n) {
   __shared__ float tile[PACK_CB * PACK_ROW];
@@ -87,25 +153,10 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const FsPackDes
   const int co0 = (local / nci_t) * PACK_CB, ci0 = (local % nci_t) * IB;
   const int nco = min(PACK_CB, d.Co - co0), nci = min(IB, d.Ci - ci0);
   if (nco <= 0 || nci <= 0) return;
-  const int run = nci * RS;                         // contiguous floats per co in the master tensor
-  for (int i = threadIdx.x; i < nco * run; i += 256) {
-    int col = i / run, rem = i - col * run;
-    tile[col * PACK_ROW + rem] = d.w[((long)(co0 + col) * d.Ci + ci0) * RS + rem];
-  }
-  __syncthreads();
-  T* df = reinterpret_cast<T*>(d.dst_f);
-  for (int i = threadIdx.x; i < nco * run; i += 256) {          // (co, tap, ci): ci fastest
-    int cil = i % nci; int q = i / nci; int tap = q % RS; int col = q / RS;
-    df[(long)(co0 + col) * d.k_f + (long)tap * d.cs_f + ci0 + cil] = ElemTraits<T>::from_f(tile[col * PACK_ROW + cil * RS + tap]);
-  }
-  if (d.dst_d) {
-    T* dd = reinterpret_cast<T*>(d.dst_d);
-    for (int i = threadIdx.x; i < nco * run; i += 256) {        // (ci, tap, co): co fastest
-      int col = i % nco; int q = i / nco; int tap = q % RS; int cil = q / RS;
-      dd[(long)(ci0 + cil) * d.k_d + (long)tap * d.cs_d + co0 + col] =
-          ElemTraits<T>::from_f(tile[col * PACK_ROW + cil * RS + tap_at(d.tap_order_d, tap, RS)]);
-    }
-  }
+  if (RS == 9 && nci == 32 && nco == PACK_CB) pack_tile<T, 9, 32, PACK_CB>(d, tile, co0, ci0, nco, nci);
+  else if (RS == 9) pack_tile<T, 9, 0, 0>(d, tile, co0, ci0, nco, nci);
+  else if (RS == 1 && nci == IB && nco == PACK_CB && IB == 128) pack_tile<T, 1, 128, PACK_CB>(d, tile, co0, ci0, nco, nci);
+  else pack_tile<T, 0, 0, 0>(d, tile, co0, ci0, nco, nci);
 }
 
 }  // namespace
