@@ -654,6 +654,126 @@ __global__ __launch_bounds__(256) void wgrad3x3_narrow_kernel(const FsWgradArgs 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 7x7 / stride-2 / pad-3 stem (8-channel bf16 input, 64 output channels): dW[co][(r,s,ci)] = sum over pixels of
+// dY[pix][co] * X[2y+r-3][2x+s-3][ci].  The generic kernel gathers the im2col operand from global memory, 49 x 16 B
+// per output pixel (578 MB for the stacked pose batch: 145 us at the tail of the step, where nothing overlaps it).
+// Here a persistent block stages an 8 x 16-pixel tile of dY and the 21 x 37-pixel input patch in LDS once; an MFMA
+// column tile is TWO horizontally adjacent taps x 8 channels = 32 contiguous bytes of the patch, so the transposing
+// LDS read that serves the 3x3 kernel's B operand works unchanged (rows = pixels at patch stride 2).  Each wave owns
+// 7 of the 28 column tiles (7 kernel rows x 4 tap pairs; the 8th tap of a row does not exist and is not written) for
+// all 64 output channels and keeps them in accumulators over the block's tiles; one fp32 slab per block at the end.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wgrad_stem_kernel(const FsWgradArgs p, int tiles_x, int tiles_y, int ntiles,
+                                                         int tiles_per_block) {
+  typedef bf16 T;
+  constexpr int TY = 8, TX = 16, PIXT = TY * TX, PH = 2 * TY + 5, PW = 2 * TX + 6;
+  constexpr int SA = 64 + 8, OOB = 0x7fffffff;
+  constexpr int LA = PIXT * 8 / 256, LB = (PH * PW + 255) / 256;
+  __shared__ __attribute__((aligned(16))) T lds_a[PIXT * SA];
+  __shared__ __attribute__((aligned(16))) T lds_b[PH * PW * 8];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.dy), 0, (int)((long)p.M * p.Cd * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+
+  uint4 ra[LA], rb[LB];
+  auto load_regs = [&](int tile) {
+    const int tx_i = tile % tiles_x; const int q = tile / tiles_x; const int ty_i = q % tiles_y; const int n = q / tiles_y;
+    const int y0 = ty_i * TY, x0 = tx_i * TX;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      const int idx = t + i * 256, pix = idx >> 3, u = idx & 7;
+      const int y = y0 + (pix >> 4), x = x0 + (pix & 15);
+      const bool ok = y < p.Hd && x < p.Wd;
+      ra[i] = wg_buf_load16(rs_dy, ok ? (int)((((long)n * p.Hd + y) * p.Wd + x) * p.Cd + u * 8) * 2 : OOB);
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+      const int idx = t + i * 256, py = idx / PW, px = idx - py * PW;
+      const int sy = 2 * y0 - 3 + py, sx = 2 * x0 - 3 + px;
+      const bool ok = idx < PH * PW && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
+      rb[i] = wg_buf_load16(rs_x, ok ? (int)(((long)n * p.sN + (long)sy * p.sH + (long)sx * p.sW) * 2) : OOB);
+    }
+  };
+  auto store_lds = [&]() {
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      const int idx = t + i * 256, pix = idx >> 3, u = idx & 7;
+      *reinterpret_cast<uint4*>(&lds_a[pix * SA + u * 8]) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+      const int idx = t + i * 256;
+      if (idx < PH * PW) *reinterpret_cast<uint4*>(&lds_b[idx * 8]) = rb[i];
+    }
+  };
+
+  // transposed-fragment row offsets (see wgrad3x3_halo_kernel): lane (li, lg) supplies pixel
+  // k = ks*32 + lg*8 + (li>>2) (+4), i.e. tile row ks*2 + (lg>>1), column (lg&1)*8 + (li>>2) (+4)
+  int arow[4][2], brow[4][2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int ty = ks * 2 + (lg >> 1), tx = (lg & 1) * 8 + (li >> 2) + hf * 4;
+      arow[ks][hf] = (ty * TX + tx) * SA + (li & 3) * 4;
+      brow[ks][hf] = ((2 * ty) * PW + 2 * tx) * 8 + (li & 3) * 4;
+    }
+
+  f32x4 acc[4][7];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 7; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int tile0 = blockIdx.x * tiles_per_block, tile1 = min(tile0 + tiles_per_block, ntiles);
+  if (tile0 < tile1) load_regs(tile0);
+  for (int tile = tile0; tile < tile1; ++tile) {
+    __syncthreads();
+    store_lds();
+    __syncthreads();
+    if (tile + 1 < tile1) load_regs(tile + 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 fa[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(&lds_a[arow[ks][0] + a * 16]));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(&lds_a[arow[ks][1] + a * 16]));
+        uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+        fa[a] = __builtin_bit_cast(bf16x8, make_uint4(l2.x, l2.y, h2.x, h2.y));
+      }
+#pragma unroll
+      for (int c = 0; c < 7; ++c) {
+        const int ct = wave * 7 + c;                         // column tile: kernel row ct / 4, tap pair ct % 4
+        const int toff = ((ct >> 2) * PW + 2 * (ct & 3)) * 8;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(&lds_b[brow[ks][0] + toff]));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(&lds_b[brow[ks][1] + toff]));
+        uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+        const bf16x8 fb = __builtin_bit_cast(bf16x8, make_uint4(l2.x, l2.y, h2.x, h2.y));
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb, acc[a][c], 0, 0, 0);
+      }
+    }
+  }
+
+  // D rows = co (a*16 + lg*4 + j), cols = li: tap 2*pair + (li >> 3), channel li & 7
+  float* ws = p.workspace + (long)blockIdx.x * p.ws_rows * p.ws_cols;
+#pragma unroll
+  for (int c = 0; c < 7; ++c) {
+    const int ct = wave * 7 + c, r = ct >> 2, s = 2 * (ct & 3) + (li >> 3);
+    if (s >= 7) continue;
+    const int col = (r * 7 + s) * 8 + (li & 7);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ws[(long)(a * 16 + lg * 4 + j) * p.ws_cols + col] = acc[a][c][j];
+  }
+}
+
 WGeom wgrad_pick_geom(int Hd, int Wd) {
   WGeom best{0, 0, 0, 0, 0, 0, 1};
   double best_cost = 1e30;
@@ -730,11 +850,33 @@ int launch_wgrad_narrow(const FsWgradArgs& a, hipStream_t st) {
   return fs_launch_status();
 }
 
+int launch_wgrad_stem(const FsWgradArgs& a, hipStream_t st) {
+  FsWgradArgs b = a;
+  const int tiles_x = (a.Wd + 15) / 16, tiles_y = (a.Hd + 7) / 8;
+  const long ntiles = (long)(a.M / (a.Hd * a.Wd)) * tiles_x * tiles_y;
+  b.ws_rows = 64; b.ws_cols = 49 * 8;
+  const long slab = (long)b.ws_rows * b.ws_cols;
+  // one slab per persistent block: ~1.25 blocks per CU keeps the slab traffic (100 KB each, written and re-read)
+  // well below the operand traffic
+  const long max_blocks = std::min<long>(320, a.workspace_elems / slab);
+  if (max_blocks < 1 || ntiles < 1) return FS_EINVAL;
+  const int per = (int)((ntiles + max_blocks - 1) / max_blocks);
+  const int blocks = (int)((ntiles + per - 1) / per);
+  b.nsplit = blocks;
+  hipLaunchKernelGGL(wgrad_stem_kernel, dim3(blocks), dim3(256), 0, st, b, tiles_x, tiles_y, (int)ntiles, per);
+  launch_reduce(b, a.Co, 49 * 8, 8, st);
+  return fs_launch_status();
+}
+
 template <typename T>
 int launch_wgrad(const FsWgradArgs& a, hipStream_t st) {
   constexpr bool kBf16 = sizeof(T) == 2;  // f32 tiles are capped by the 64 KB static LDS limit
   if constexpr (kBf16) {
     const int Cs = a.ncolgroups * 8 / (a.R * a.S);
+    if (a.use_halo && a.R == 7 && a.S == 7 && a.stride == 2 && a.pad == 3 && Cs == 8 && a.Cd == 64 && a.Co == 64 &&
+        a.workspace && a.x_bytes > 0 && a.x_bytes <= 0x7fffffffLL && (long)a.M * a.Cd * 2 <= 0x7fffffffLL &&
+        a.M >= 4096 && a.M % (a.Hd * a.Wd) == 0)
+      return launch_wgrad_stem(a, st);
     if (a.use_halo && a.R == 3 && a.S == 3 && a.stride == 1 && a.Cd % 64 == 0 && Cs % 32 == 0 && a.x_bytes > 0 &&
         a.x_bytes <= 0x7fffffffLL && (long)a.M * a.Cd * 2 <= 0x7fffffffLL && a.M >= 1024)
       return launch_wgrad_halo(a, st);   // (tiny pixel counts: too few tiles to split, the generic kernel wins)

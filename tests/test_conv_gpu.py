@@ -197,6 +197,17 @@ def test_stem_lds_kernel(dev, Ci, N, H, W, groups):
         assert torch.allclose(s[0], r.sum(dim=(0, 2, 3)).cpu(), rtol=2e-3, atol=2e-3 * (r ** 2).sum(dim=(0, 2, 3)).max().sqrt().item())
         assert torch.allclose(s[1], (r ** 2).sum(dim=(0, 2, 3)).cpu(), rtol=3e-3)
         assert yb.shape == r.shape
+    # weight gradient (wgrad_stem_kernel from 4096 output pixels on, the generic kernel below) against autograd
+    gy = torch.randn(ref.shape, generator=torch.Generator().manual_seed(5)).bfloat16().float()
+    xr, wr = x.clone().to(dev), w.clone().to(dev).requires_grad_(True)
+    F.conv2d(xr, wr, None, stride=2, padding=3).backward(gy.to(dev))
+    dw = torch.zeros(64, Ci, 7, 7, device=dev)
+    op.wgrad(to_nhwc(gy.to(dev), 64, dtype), xd, dw)
+    torch.cuda.synchronize()
+    assert (dw - wr.grad).abs().max().item() <= 2e-3 * wr.grad.abs().max().item()
+    op.wgrad(to_nhwc(gy.to(dev), 64, dtype), xd, dw)           # accumulates into dw
+    torch.cuda.synchronize()
+    assert (dw - 2 * wr.grad).abs().max().item() <= 4e-3 * wr.grad.abs().max().item()
     # the generic path on the same inputs agrees to bf16 rounding
     import fsnet_amd.hip.conv as CV
     op2 = ConvOp(Ci, 64, 7, 7, 2, 3, dtype, dev, need_dgrad=False)
