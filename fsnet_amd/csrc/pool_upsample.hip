@@ -48,13 +48,16 @@ template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx,
                                                           const T* __restrict__ addend, T* __restrict__ dx, int N,
                                                           int H, int W, int C, int Ho, int Wo) {
-  const int CG = C / 4;
+  constexpr int VN = VecN<T>::N;           // one 16-byte lane per thread: 8 bf16 / 4 f32 channels
+  const int CG = C / VN;
   const long total = (long)N * H * W * CG;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     int cg = (int)(i % CG); long m = i / CG;
     int w = (int)(m % W); long q = m / W; int h = (int)(q % H); long n = q / H;
-    float acc[4] = {0, 0, 0, 0};
-    if (addend) load4<T>(addend + m * C + cg * 4, acc);
+    float acc[VN];
+#pragma unroll
+    for (int j = 0; j < VN; ++j) acc[j] = 0.f;
+    if (addend) loadv<T>(addend + m * C + cg * VN, acc);
     for (int ho = (h - 1 + 1) / 2; ho <= (h + 1) / 2; ++ho) {   // windows with |h - 2ho| <= 1
       if (ho < 0 || ho >= Ho) continue;
       int r = h - (ho * 2 - 1);
@@ -64,16 +67,18 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
         int s = w - (wo * 2 - 1);
         if (s < 0 || s > 2) continue;
         long mo = (n * Ho + ho) * Wo + wo;
-        uint32_t packed = *reinterpret_cast<const uint32_t*>(idx + mo * C + cg * 4);
-        float g[4];
-        load4<T>(dy + mo * C + cg * 4, g);
+        uint32_t packed[VN / 4];
+#pragma unroll
+        for (int k = 0; k < VN / 4; ++k) packed[k] = reinterpret_cast<const uint32_t*>(idx + mo * C + cg * VN)[k];
+        float g[VN];
+        loadv<T>(dy + mo * C + cg * VN, g);
         int code = r * 3 + s;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if ((int)((packed >> (8 * j)) & 0xff) == code) acc[j] += g[j];
+        for (int j = 0; j < VN; ++j)
+          if ((int)((packed[j >> 2] >> (8 * (j & 3))) & 0xff) == code) acc[j] += g[j];
       }
     }
-    store4<T>(dx + m * C + cg * 4, acc);
+    storev<T>(dx + m * C + cg * VN, acc);
   }
 }
 
@@ -217,10 +222,10 @@ extern "C" int fs_maxpool_fwd(const void* x, void* y, uint8_t* idx, int N, int H
 
 extern "C" int fs_maxpool_bwd(const void* dy, const uint8_t* idx, const void* addend, void* dx, int N, int H, int W,
                               int C, int dtype, void* stream) {
-  if (!dy || !dx || !idx || C % 4 != 0) return FS_EINVAL;
+  if (!dy || !dx || !idx || C % (dtype == FS_DTYPE_BF16 ? 8 : 4) != 0) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  dim3 grid(grid_for((long)N * H * W * (C / 4)));
+  dim3 grid(grid_for((long)N * H * W * (C / (dtype == FS_DTYPE_BF16 ? 8 : 4))));
   if (dtype == FS_DTYPE_BF16)
     hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)dy, idx, (const bf16*)addend, (bf16*)dx, N, H, W, C, Ho, Wo);
   else if (dtype == FS_DTYPE_F32)
