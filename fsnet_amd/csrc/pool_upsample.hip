@@ -82,68 +82,81 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
   }
 }
 
+// V consecutive channels per thread: 4 (8 bytes of bf16, any C % 4 == 0) or 8 (a full 16-byte bf16 lane)
+template <typename T, int V> __device__ inline void ldc(const T* p, float* v) {
+  if constexpr (V == 8) loadv<T>(p, v); else load4<T>(p, v);
+}
+template <typename T, int V> __device__ inline void stc(T* p, const float* v) {
+  if constexpr (V == 8) storev<T>(p, v); else store4<T>(p, v);
+}
+
 // out[n, hp, wp, :] for the padded (2h+2)x(2w+2) grid = cat(up2(a), b) at the replicate-clamped pixel
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(256) void upcat_pad_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b,
                                                             T* __restrict__ out, int N, int h, int w, int Ca,
                                                             int Cb) {
-  const int H = 2 * h, W = 2 * w, Hp = H + 2, Wp = W + 2, C = Ca + Cb, CG = C / 4;
+  const int H = 2 * h, W = 2 * w, Hp = H + 2, Wp = W + 2, C = Ca + Cb, CG = C / V;
   const long total = (long)N * Hp * Wp * CG;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     int cg = (int)(i % CG); long m = i / CG;
     int wp = (int)(m % Wp); long q = m / Wp; int hp = (int)(q % Hp); long n = q / Hp;
     int hi = min(max(hp - 1, 0), H - 1), wi = min(max(wp - 1, 0), W - 1);
-    int c = cg * 4;
-    float v[4];
-    if (c < Ca) load4<T>(a + ((n * h + (hi >> 1)) * w + (wi >> 1)) * Ca + c, v);
-    else load4<T>(b + ((n * H + hi) * W + wi) * Cb + (c - Ca), v);
-    store4<T>(out + m * C + c, v);
+    int c = cg * V;
+    float v[V];
+    if (c < Ca) ldc<T, V>(a + ((n * h + (hi >> 1)) * w + (wi >> 1)) * Ca + c, v);
+    else ldc<T, V>(b + ((n * H + hi) * W + wi) * Cb + (c - Ca), v);
+    stc<T, V>(out + m * C + c, v);
   }
 }
 
 // folded value of the padded gradient at interior pixel (hi, wi)
-template <typename T>
-__device__ inline void fold_load(const T* dpad, long n, int hi, int wi, int H, int W, int C, int c, float g[4]) {
+template <typename T, int V>
+__device__ inline void fold_load(const T* dpad, long n, int hi, int wi, int H, int W, int C, int c, float* g) {
   const int Hp = H + 2, Wp = W + 2;
   int hs[2] = {hi + 1, 0}, ws[2] = {wi + 1, 0};
   int nh = 1, nw = 1;
   if (hi == 0) { hs[1] = 0; nh = 2; } else if (hi == H - 1) { hs[1] = H + 1; nh = 2; }
   if (wi == 0) { ws[1] = 0; nw = 2; } else if (wi == W - 1) { ws[1] = W + 1; nw = 2; }
-  g[0] = g[1] = g[2] = g[3] = 0.f;
+#pragma unroll
+  for (int j = 0; j < V; ++j) g[j] = 0.f;
   for (int x = 0; x < nh; ++x)
     for (int y = 0; y < nw; ++y) {
-      float t[4];
-      load4<T>(dpad + ((n * Hp + hs[x]) * Wp + ws[y]) * C + c, t);
-      g[0] += t[0]; g[1] += t[1]; g[2] += t[2]; g[3] += t[3];
+      float t[V];
+      ldc<T, V>(dpad + ((n * Hp + hs[x]) * Wp + ws[y]) * C + c, t);
+#pragma unroll
+      for (int j = 0; j < V; ++j) g[j] += t[j];
     }
 }
 
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(256) void upcat_pad_bwd_kernel(const T* __restrict__ dpad, T* __restrict__ da,
                                                             T* __restrict__ db, int N, int h, int w, int Ca,
                                                             int Cb) {
   const int H = 2 * h, W = 2 * w, C = Ca + Cb;
-  const int CGa = Ca / 4, CGb = Cb / 4;
+  const int CGa = Ca / V, CGb = Cb / V;
   const long ta = (long)N * h * w * CGa, tb = (long)N * H * W * CGb;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < ta + tb; i += (long)gridDim.x * 256) {
     if (i < ta) {
       int cg = (int)(i % CGa); long m = i / CGa;
       int x = (int)(m % w); long q = m / w; int y = (int)(q % h); long n = q / h;
-      float acc[4] = {0, 0, 0, 0};
+      float acc[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[j] = 0.f;
       for (int dy = 0; dy < 2; ++dy)
         for (int dx = 0; dx < 2; ++dx) {
-          float g[4];
-          fold_load<T>(dpad, n, 2 * y + dy, 2 * x + dx, H, W, C, cg * 4, g);
-          acc[0] += g[0]; acc[1] += g[1]; acc[2] += g[2]; acc[3] += g[3];
+          float g[V];
+          fold_load<T, V>(dpad, n, 2 * y + dy, 2 * x + dx, H, W, C, cg * V, g);
+#pragma unroll
+          for (int j = 0; j < V; ++j) acc[j] += g[j];
         }
-      store4<T>(da + m * Ca + cg * 4, acc);
+      stc<T, V>(da + m * Ca + cg * V, acc);
     } else {
       long k = i - ta;
       int cg = (int)(k % CGb); long m = k / CGb;
       int x = (int)(m % W); long q = m / W; int y = (int)(q % H); long n = q / H;
-      float g[4];
-      fold_load<T>(dpad, n, y, x, H, W, C, Ca + cg * 4, g);
-      store4<T>(db + m * Cb + cg * 4, g);
+      float g[V];
+      fold_load<T, V>(dpad, n, y, x, H, W, C, Ca + cg * V, g);
+      stc<T, V>(db + m * Cb + cg * V, g);
     }
   }
 }
@@ -238,11 +251,14 @@ extern "C" int fs_upcat_pad_fwd(const void* a, const void* b, void* out, int N, 
                                 int dtype, void* stream) {
   if (!a || !out || (Cb > 0 && !b) || Ca % 4 != 0 || Cb % 4 != 0) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  dim3 grid(grid_for((long)N * (2 * h + 2) * (2 * w + 2) * ((Ca + Cb) / 4)));
-  if (dtype == FS_DTYPE_BF16)
-    hipLaunchKernelGGL(upcat_pad_fwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)a, (const bf16*)b, (bf16*)out, N, h, w, Ca, Cb);
+  const bool wide = dtype == FS_DTYPE_BF16 && Ca % 8 == 0 && Cb % 8 == 0;     // 16-byte lanes
+  dim3 grid(grid_for((long)N * (2 * h + 2) * (2 * w + 2) * ((Ca + Cb) / (wide ? 8 : 4))));
+  if (wide)
+    hipLaunchKernelGGL((upcat_pad_fwd_kernel<bf16, 8>), grid, dim3(256), 0, st, (const bf16*)a, (const bf16*)b, (bf16*)out, N, h, w, Ca, Cb);
+  else if (dtype == FS_DTYPE_BF16)
+    hipLaunchKernelGGL((upcat_pad_fwd_kernel<bf16, 4>), grid, dim3(256), 0, st, (const bf16*)a, (const bf16*)b, (bf16*)out, N, h, w, Ca, Cb);
   else if (dtype == FS_DTYPE_F32)
-    hipLaunchKernelGGL(upcat_pad_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, N, h, w, Ca, Cb);
+    hipLaunchKernelGGL((upcat_pad_fwd_kernel<float, 4>), grid, dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, N, h, w, Ca, Cb);
   else return FS_EINVAL;
   return fs_launch_status();
 }
@@ -251,11 +267,15 @@ extern "C" int fs_upcat_pad_bwd(const void* dpad, void* da, void* db, int N, int
                                 void* stream) {
   if (!dpad || !da || (Cb > 0 && !db) || Ca % 4 != 0 || Cb % 4 != 0) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  dim3 grid(grid_for((long)N * h * w * (Ca / 4) + (long)N * 4 * h * w * (Cb / 4)));
-  if (dtype == FS_DTYPE_BF16)
-    hipLaunchKernelGGL(upcat_pad_bwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)dpad, (bf16*)da, (bf16*)db, N, h, w, Ca, Cb);
+  const bool wide = dtype == FS_DTYPE_BF16 && Ca % 8 == 0 && Cb % 8 == 0;
+  const int V = wide ? 8 : 4;
+  dim3 grid(grid_for((long)N * h * w * (Ca / V) + (long)N * 4 * h * w * (Cb / V)));
+  if (wide)
+    hipLaunchKernelGGL((upcat_pad_bwd_kernel<bf16, 8>), grid, dim3(256), 0, st, (const bf16*)dpad, (bf16*)da, (bf16*)db, N, h, w, Ca, Cb);
+  else if (dtype == FS_DTYPE_BF16)
+    hipLaunchKernelGGL((upcat_pad_bwd_kernel<bf16, 4>), grid, dim3(256), 0, st, (const bf16*)dpad, (bf16*)da, (bf16*)db, N, h, w, Ca, Cb);
   else if (dtype == FS_DTYPE_F32)
-    hipLaunchKernelGGL(upcat_pad_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)dpad, (float*)da, (float*)db, N, h, w, Ca, Cb);
+    hipLaunchKernelGGL((upcat_pad_bwd_kernel<float, 4>), grid, dim3(256), 0, st, (const float*)dpad, (float*)da, (float*)db, N, h, w, Ca, Cb);
   else return FS_EINVAL;
   return fs_launch_status();
 }
