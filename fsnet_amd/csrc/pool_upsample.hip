@@ -15,13 +15,16 @@ template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                           uint8_t* __restrict__ idx, int N, int H, int W, int C,
                                                           int Ho, int Wo) {
-  const int CG = C / 4;
+  constexpr int VN = VecN<T>::N;           // one 16-byte lane per thread: 8 bf16 / 4 f32 channels
+  const int CG = C / VN;
   const long total = (long)N * Ho * Wo * CG;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     int cg = (int)(i % CG); long m = i / CG;
     int wo = (int)(m % Wo); long q = m / Wo; int ho = (int)(q % Ho); long n = q / Ho;
-    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    int bi[4] = {0, 0, 0, 0};
+    float best[VN];
+    int bi[VN];
+#pragma unroll
+    for (int j = 0; j < VN; ++j) { best[j] = -INFINITY; bi[j] = 0; }
     bool first = true;
     for (int r = 0; r < 3; ++r) {
       int h = ho * 2 - 1 + r;
@@ -29,17 +32,21 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
       for (int s = 0; s < 3; ++s) {
         int w = wo * 2 - 1 + s;
         if ((unsigned)w >= (unsigned)W) continue;
-        float v[4];
-        load4<T>(x + ((n * H + h) * W + w) * C + cg * 4, v);
+        float v[VN];
+        loadv<T>(x + ((n * H + h) * W + w) * C + cg * VN, v);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < VN; ++j)
           if (first || v[j] > best[j]) { best[j] = v[j]; bi[j] = r * 3 + s; }  // first max wins (ATen)
         first = false;
       }
     }
-    store4<T>(y + m * C + cg * 4, best);
-    uint32_t packed = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
-    *reinterpret_cast<uint32_t*>(idx + m * C + cg * 4) = packed;
+    storev<T>(y + m * C + cg * VN, best);
+#pragma unroll
+    for (int k = 0; k < VN / 4; ++k) {
+      uint32_t packed = (uint32_t)bi[4 * k] | ((uint32_t)bi[4 * k + 1] << 8) | ((uint32_t)bi[4 * k + 2] << 16) |
+                        ((uint32_t)bi[4 * k + 3] << 24);
+      reinterpret_cast<uint32_t*>(idx + m * C + cg * VN)[k] = packed;
+    }
   }
 }
 
@@ -221,10 +228,11 @@ int grid_for(long items) {
 
 extern "C" int fs_maxpool_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int dtype,
                               void* stream) {
-  if (!x || !y || !idx || C % 4 != 0) return FS_EINVAL;
+  const int vn = dtype == FS_DTYPE_BF16 ? 8 : 4;
+  if (!x || !y || !idx || C % vn != 0) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  dim3 grid(grid_for((long)N * Ho * Wo * (C / 4)));
+  dim3 grid(grid_for((long)N * Ho * Wo * (C / vn)));
   if (dtype == FS_DTYPE_BF16)
     hipLaunchKernelGGL(maxpool_fwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, (bf16*)y, idx, N, H, W, C, Ho, Wo);
   else if (dtype == FS_DTYPE_F32)
