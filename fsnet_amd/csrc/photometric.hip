@@ -25,8 +25,10 @@ __device__ __forceinline__ int refl(int i, int n) { return i < 0 ? -i : (i >= n 
 // setup: K, K^-1 (f64 adjugate == pinv for a regular K), P_f = (K T_f)[:3]; zero the accumulators
 // ---------------------------------------------------------------------------------------------
 __global__ void photo_setup_kernel(const float* __restrict__ P2, const float* __restrict__ T0,
-                                   const float* __restrict__ T1, float* __restrict__ geo, int B) {
+                                   const float* __restrict__ T1, float* __restrict__ geo, int B,
+                                   int* __restrict__ seed_counter) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (seed_counter && b == 0) *seed_counter += 1;      // tie-break noise seed of this step (read by the loss forward)
   if (b >= B) return;
   double k[3][3];
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) k[i][j] = (double)P2[b * 12 + i * 4 + j];
@@ -630,10 +632,11 @@ bool valid(const FsPhotoArgs* a) {
 
 }  // namespace
 
-extern "C" int fs_photo_setup(const float* P2, const float* T0, const float* T1, float* geo, int B, void* stream) {
+extern "C" int fs_photo_setup(const float* P2, const float* T0, const float* T1, float* geo, int B, int* seed_counter,
+                              void* stream) {
   if (!P2 || !T0 || !T1 || !geo) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(photo_setup_kernel, dim3((B + 63) / 64), dim3(64), 0, st, P2, T0, T1, geo, B);
+  hipLaunchKernelGGL(photo_setup_kernel, dim3((B + 63) / 64), dim3(64), 0, st, P2, T0, T1, geo, B, seed_counter);
   return fs_launch_status();
 }
 

@@ -139,7 +139,11 @@ __global__ void loss_finalize_kernel(const double* __restrict__ loss_sums, const
 // ---------------------------------------------------------------------------------------------
 // optimizer
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, double* __restrict__ out,
+                                                     int* __restrict__ step_counter) {
+  // the optimizer's device-resident step count is bumped here (nothing in this kernel reads it; the Adam launch that
+  // follows does): one serial 5-us node less at the tail of every step
+  if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1;
   double acc = 0.0;
   long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   const long stride = (long)gridDim.x * 256 * 4;
@@ -232,10 +236,10 @@ extern "C" int fs_loss_finalize(const double* loss_sums, const double* mask_sum,
   return fs_launch_status();
 }
 
-extern "C" int fs_sumsq(const float* g, int64_t n, double* out, void* stream) {
+extern "C" int fs_sumsq(const float* g, int64_t n, double* out, int* step_counter, void* stream) {
   if (!g || !out || n <= 0) return FS_EINVAL;
   long blocks = std::min<long>((n / 4 + 255) / 256 + 1, 1024);
-  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g, (long)n, out);
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g, (long)n, out, step_counter);
   return fs_launch_status();
 }
 

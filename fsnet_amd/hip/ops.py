@@ -236,7 +236,13 @@ class PhotometricLoss:
         self.color = [None] * S
         self.bwd_tiles = int(lib.fs_photo_bwd_tiles(H, W))
         self.dP = torch.zeros(self.S * B * self.bwd_tiles, 2, 12, dtype=f32, device=device)   # per-tile partials
-        self.d_depth = [torch.zeros(B, 1, h, w, dtype=f32, device=device) for (h, w) in self.hw]
+        # one flat buffer behind the per-scale depth gradients: a single memset per backward instead of one per scale
+        sizes = [B * h * w for (h, w) in self.hw]
+        self._dd_flat = torch.zeros(sum(sizes), dtype=f32, device=device)
+        self.d_depth, o = [], 0
+        for n_el, (h, w) in zip(sizes, self.hw):
+            self.d_depth.append(self._dd_flat[o:o + n_el].view(B, 1, h, w))
+            o += n_el
         self.d_disp = [torch.empty(B, 1, h, w, dtype=f32, device=device) for (h, w) in self.hw]
         self.dT = [torch.zeros(B, 4, 4, dtype=f32, device=device) for _ in range(2)]
         self.pyr = [None if s == 0 else torch.empty(B, 3, H >> s, W >> s, dtype=f32, device=device)
@@ -304,10 +310,10 @@ class PhotometricLoss:
         self._fill(img0, srcs, patched_mask, depths, disps, noise_seed, None)
         pre, self._prefetched = self._prefetched, None
         have_inputs = pre == (img0.data_ptr(), srcs[0].data_ptr(), srcs[1].data_ptr(), _p(patched_mask))
-        if noise_seed is None:
-            counter_incr(self.seed_buf)       # fresh noise every step, also when the step is a graph replay
         pa, sa = C.byref(self._pa), C.byref(self._sa)
-        check(lib.fs_photo_setup(P2.data_ptr(), Ts[0].data_ptr(), Ts[1].data_ptr(), self.geo.data_ptr(), self.B, st),
+        # (noise_seed None: the setup kernel bumps the device seed — fresh noise every step, also on a graph replay)
+        check(lib.fs_photo_setup(P2.data_ptr(), Ts[0].data_ptr(), Ts[1].data_ptr(), self.geo.data_ptr(), self.B,
+                                 self.seed_buf.data_ptr() if noise_seed is None else None, st),
               "photo_setup")
         if not have_inputs:
             self._input_only(img0, pa, st)
@@ -328,8 +334,7 @@ class PhotometricLoss:
         img0, srcs, patched_mask, depths, disps, noise_seed = self._keep
         self._fill(img0, srcs, patched_mask, depths, disps, noise_seed, gout)
         pa, sa = C.byref(self._pa), C.byref(self._sa)
-        for d in self.d_depth:
-            d.zero_()
+        self._dd_flat.zero_()
         N_px = float(self.B * self.H * self.W)
         bwd_bytes = sum(40.0 * N_px + 8.0 * N_px / (4 ** s) for s in self.scales)
         _timed("photo_loss_bwd", bwd_bytes, lambda: check(lib.fs_photo_loss_bwd(pa, st), "photo_loss_bwd"))
@@ -339,8 +344,9 @@ class PhotometricLoss:
         return self.d_depth, self.d_disp, self.dT
 
 
-def sumsq(g, out):
-    check(lib.fs_sumsq(g.data_ptr(), g.numel(), out.data_ptr(), stream_ptr()), "sumsq")
+def sumsq(g, out, step_counter=None):
+    """out += sum(g^2); step_counter: device int32 bumped by one in the same launch"""
+    check(lib.fs_sumsq(g.data_ptr(), g.numel(), out.data_ptr(), _p(step_counter), stream_ptr()), "sumsq")
 
 
 def adam_step(p, g, m, v, lr, b1, b2, eps, wd, step, max_norm=0.0, sumsq_buf=None, grad_scale=1.0, step_buf=None,

@@ -38,7 +38,7 @@ SIGNATURES = {
     "fs_depth_head_bwd": (C.c_int, [P, P, P, P, P, L, I, I, F, F, I, P]),
     "fs_pose_tail_fwd": (C.c_int, [P, P, P, P, I, I, I, I, I, F, P]),
     "fs_pose_tail_bwd": (C.c_int, [P, P, P, I, I, I, I, I, F, I, P]),
-    "fs_photo_setup": (C.c_int, [P, P, P, P, I, P]),
+    "fs_photo_setup": (C.c_int, [P, P, P, P, I, P, P]),
     "fs_photo_identity": (C.c_int, [P, P]),
     "fs_photo_warp": (C.c_int, [P, P]),
     "fs_photo_loss_fwd": (C.c_int, [P, P]),
@@ -52,7 +52,7 @@ SIGNATURES = {
     "fs_smooth_fwd": (C.c_int, [P, P]),
     "fs_smooth_bwd": (C.c_int, [P, P]),
     "fs_loss_finalize": (C.c_int, [P, P, P, P, P, P]),
-    "fs_sumsq": (C.c_int, [P, L, P, P]),
+    "fs_sumsq": (C.c_int, [P, L, P, P, P]),
     "fs_counter_incr": (C.c_int, [P, P]),
     "fs_adam_step": (C.c_int, [P, P, P, P, L, F, F, F, F, F, I, F, P, F, P, P, P]),
 }

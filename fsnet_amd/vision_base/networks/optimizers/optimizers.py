@@ -72,19 +72,20 @@ class FusedAdam(optim.Optimizer):
         if arena is not None:
             m, v = self._flat_state(arena)
             dev = arena.data.device
-            sq = None
-            if max_norm is not None and max_norm > 0:
-                if self._sumsq is None or self._sumsq.device != dev:
-                    self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
-                self._sumsq.zero_()
-                ops.sumsq(arena.grad, self._sumsq)
-                sq = self._sumsq
             if self._step_buf is None or self._step_buf.device != dev:
                 self._step_buf = torch.full((1,), self._step_count_fused, dtype=torch.int32, device=dev)
                 self._lr_buf = torch.full((1,), float(g0["lr"]), dtype=torch.float32, device=dev)
                 self._lr_host = float(g0["lr"])
             self.sync_lr()
-            ops.counter_incr(self._step_buf)
+            sq = None
+            if max_norm is not None and max_norm > 0:
+                if self._sumsq is None or self._sumsq.device != dev:
+                    self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+                self._sumsq.zero_()
+                ops.sumsq(arena.grad, self._sumsq, step_counter=self._step_buf)   # also bumps the device step count
+                sq = self._sumsq
+            else:
+                ops.counter_incr(self._step_buf)
             ops.adam_step(arena.data, arena.grad, m, v, g0["lr"], g0["betas"][0], g0["betas"][1], g0["eps"],
                           g0["weight_decay"], 1, max_norm=max_norm or 0.0, sumsq_buf=sq,
                           grad_scale=grad_scale, step_buf=self._step_buf, lr_buf=self._lr_buf)

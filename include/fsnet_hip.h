@@ -373,7 +373,8 @@ typedef struct FsPhotoArgs {
   int32_t noise_seed;
   const int32_t* noise_seed_ptr;  /* device-resident seed (overrides noise_seed when non-NULL; hipGraph replay) */
 } FsPhotoArgs;
-int fs_photo_setup(const float* P2, const float* T0, const float* T1, float* geo, int B, void* stream);
+int fs_photo_setup(const float* P2, const float* T0, const float* T1, float* geo, int B, int* seed_counter,
+                   void* stream);   /* seed_counter (or NULL): device int bumped by one — the noise seed of this step */
 int fs_photo_identity(const FsPhotoArgs* args, void* stream);
 int fs_photo_warp(const FsPhotoArgs* args, void* stream);
 int fs_photo_loss_fwd(const FsPhotoArgs* args, void* stream);
@@ -411,7 +412,7 @@ int fs_loss_finalize(const double* loss_sums, const double* mask_sum, const doub
  * step_ptr / lr_ptr: optional device-resident step count / learning rate (override the scalars) so that the
  * launch can be replayed from a hipGraph; fs_counter_incr bumps such a counter on the stream.
  */
-int fs_sumsq(const float* g, int64_t n, double* out, void* stream);
+int fs_sumsq(const float* g, int64_t n, double* out, int* step_counter, void* stream);   /* step_counter (or NULL): +1 */
 int fs_counter_incr(int32_t* counter, void* stream);
 int fs_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                  float eps, float weight_decay, int step, float max_norm, const double* sumsq, float grad_scale,
