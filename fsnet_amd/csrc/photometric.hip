@@ -592,35 +592,41 @@ __global__ __launch_bounds__(256) void photo_loss_bwd_kernel(const FsPhotoArgs p
 }
 
 // dT[f][b] (4x4, row 3 = 0) = K^T-contracted dP:  P = K3 * T[:3]  =>  dT[k][j] = sum_i K3[i][k] dP[i][j].
-// One block per (b, f): sums the per-tile partials dP[s][b][tile][f][12] of photo_loss_bwd_kernel in a fixed order
-// (21 groups of 12 lanes stride over the S * tiles partials, then the groups are added in f64).
+// One block per (b, f): sums the per-tile partials dP[s][b][tile][f][12] of photo_loss_bwd_kernel in a fixed order.
+// A partial is three 16-byte lanes; thread (row lane r of 85, quarter q of 3) strides over the S * tiles rows, the
+// 85 lanes are then added in f64 (first version: 4-byte loads, 366 dependent-latency iterations per thread — 33 us on
+// the critical path between the loss backward and the pose chain's backward).
 __global__ __launch_bounds__(256) void photo_pose_grad_kernel(const float* __restrict__ geo,
                                                               const float* __restrict__ dP, float* __restrict__ dT0,
                                                               float* __restrict__ dT1, int B, int S, int tiles) {
-  __shared__ double s_part[21][12];
+  constexpr int RL = 85;
+  __shared__ double s_part[RL][12];
   __shared__ float s_g[12];
   const int b = blockIdx.x >> 1, f = blockIdx.x & 1;
-  const int t = threadIdx.x, k = t % 12, grp = t / 12;
-  if (grp < 21) {
-    double acc = 0.0;
-    for (int j = grp; j < S * tiles; j += 21) {
-      int s = j / tiles, tl = j - s * tiles;
-      acc += (double)dP[((((long)s * B + b) * tiles + tl) * 2 + f) * 12 + k];
+  const int t = threadIdx.x, q = t % 3, r = t / 3;
+  if (r < RL) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    const int rows = S * tiles;
+#pragma unroll 4
+    for (int j = r; j < rows; j += RL) {
+      const int s = j / tiles, tl = j - s * tiles;
+      const float4 v = *reinterpret_cast<const float4*>(dP + ((((long)s * B + b) * tiles + tl) * 2 + f) * 12 + q * 4);
+      a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
     }
-    s_part[grp][k] = acc;
+    s_part[r][q * 4 + 0] = a0; s_part[r][q * 4 + 1] = a1; s_part[r][q * 4 + 2] = a2; s_part[r][q * 4 + 3] = a3;
   }
   __syncthreads();
   if (t < 12) {
     double v = 0.0;
-    for (int g = 0; g < 21; ++g) v += s_part[g][t];
+    for (int g = 0; g < RL; ++g) v += s_part[g][t];
     s_g[t] = (float)v;
   }
   __syncthreads();
   if (t < 16) {
     const float* K = geo + (long)b * GEO_STRIDE + 9;
     float* o = (f == 0 ? dT0 : dT1) + (long)b * 16;
-    const int r = t >> 2, j = t & 3;
-    o[t] = r < 3 ? K[0 * 3 + r] * s_g[0 * 4 + j] + K[1 * 3 + r] * s_g[1 * 4 + j] + K[2 * 3 + r] * s_g[2 * 4 + j] : 0.f;
+    const int rr = t >> 2, j = t & 3;
+    o[t] = rr < 3 ? K[0 * 3 + rr] * s_g[0 * 4 + j] + K[1 * 3 + rr] * s_g[1 * 4 + j] + K[2 * 3 + rr] * s_g[2 * 4 + j] : 0.f;
   }
 }
 
