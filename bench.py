@@ -197,6 +197,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
     if world > 1:
+        if RT.dp is not None:
+            RT.dp.close()
         torch.distributed.destroy_process_group()
 
 

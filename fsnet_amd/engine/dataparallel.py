@@ -28,10 +28,16 @@ class DataParallelContext:
         self._pg = group if group is not None else dist.distributed_c10d._get_default_group()
         self._sum = dist.AllreduceOptions()
         self._sum.reduceOp = dist.ReduceOp.SUM
+        # ... and, over RCCL, straight to ncclAllReduce on the current stream (rccl_direct.py; None: torch.distributed)
+        from .rccl_direct import DirectComm
+        self._direct = DirectComm.create(group)
 
     # ---- small latency-bound exchanges (BN) ------------------------------------------------
     def allreduce_small(self, t):
-        self._pg.allreduce([t], self._sum).wait()
+        if self._direct is not None and not torch.cuda.is_current_stream_capturing():
+            self._direct.all_reduce_sum(t)
+        else:
+            self._pg.allreduce([t], self._sum).wait()
 
     # ---- gradient buckets --------------------------------------------------------------------
     def begin_step(self, meta_arch):
@@ -61,6 +67,12 @@ class DataParallelContext:
         lo, hi = arena.slice_of(params)
         h = dist.all_reduce(arena.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.handles.append(h)
+
+    def close(self):
+        """release the direct RCCL communicator (before the process group is destroyed)"""
+        if self._direct is not None:
+            self._direct.close()
+            self._direct = None
 
     def finish(self):
         """wait for the outstanding gradient all-reduces; returns the scale that turns SUM into MEAN."""

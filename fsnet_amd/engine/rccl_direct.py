@@ -1,0 +1,116 @@
+"""Direct RCCL calls for the small, latency-bound SyncBatchNorm exchanges.
+
+A data-parallel step issues 100 all-reduces of a few hundred bytes.  Through torch.distributed each
+costs ~30 us of host time — tensor checks, the event hand-shake with the process group's internal stream, the work
+object and its watchdog bookkeeping — which makes the eager N > 1 step host-bound.  The exchange itself is one
+ncclAllReduce on the stream the producing and consuming kernels already run on, so this module opens a second RCCL
+communicator over the same ranks (unique id from rank 0, distributed with torch.distributed) and calls
+ncclAllReduce through ctypes on the current HIP stream: stream order does the rest, nothing else is launched.
+
+Gradient buckets stay on torch.distributed (large, asynchronous, overlapped on the process group's stream).
+Everything here fails soft: any error while loading the library, creating the communicator or in the start-up
+self-test (a known f64 vector reduced both ways must agree) leaves `DirectComm.create` returning None and the
+torch.distributed path in use.
+"""
+import ctypes as C
+import os
+
+import torch
+import torch.distributed as dist
+
+NCCL_SUM = 0
+NCCL_DTYPE = {torch.float64: 8, torch.float32: 7, torch.int32: 2, torch.int64: 4}
+
+
+class _UniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+def _load():
+    path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    lib = C.CDLL(path)          # the copy torch already mapped: same RCCL for both communicators
+    lib.ncclGetUniqueId.restype = C.c_int
+    lib.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
+    lib.ncclCommInitRank.restype = C.c_int
+    lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
+    lib.ncclAllReduce.restype = C.c_int
+    lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.ncclCommDestroy.restype = C.c_int
+    lib.ncclCommDestroy.argtypes = [C.c_void_p]
+    lib.ncclGetErrorString.restype = C.c_char_p
+    lib.ncclGetErrorString.argtypes = [C.c_int]
+    return lib
+
+
+class DirectComm(object):
+    def __init__(self, lib, comm, world, rank, device):
+        self.lib, self.comm, self.world, self.rank, self.device = lib, comm, world, rank, device
+
+    @classmethod
+    def create(cls, group=None, device=None):
+        """Collective over `group`; returns None when the direct path is unavailable or fails its self-test."""
+        if os.environ.get("FSNET_AMD_RCCL_DIRECT", "1") == "0" or not torch.cuda.is_available():
+            return None
+        try:
+            if dist.get_backend(group) != "nccl":
+                return None
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+            device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+            # stage 1 (local): library + unique id.  The ranks agree on its outcome BEFORE anyone enters the blocking
+            # ncclCommInitRank, so a rank that cannot load the library does not strand the others there.
+            lib, uid, err = None, _UniqueId(), None
+            try:
+                lib = _load()
+                if rank == 0:
+                    cls._check(lib, lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+            except Exception as e:      # noqa: BLE001
+                err = e
+            ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok) != 1:
+                raise RuntimeError("a rank could not prepare the RCCL communicator (%s)" % (err,))
+            blob = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).to(device)
+            dist.broadcast(blob, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            C.memmove(C.byref(uid), bytes(blob.cpu().numpy().tobytes()), 128)
+            comm = C.c_void_p()
+            with torch.cuda.device(device):
+                cls._check(lib, lib.ncclCommInitRank(C.byref(comm), world, uid, rank), "ncclCommInitRank")
+            self = cls(lib, comm, world, rank, device)
+            if not self._self_test(group):
+                self.close()
+                return None
+            return self
+        except Exception as e:      # noqa: BLE001 — any failure means "use torch.distributed"
+            import warnings
+            warnings.warn("fsnet_amd: direct RCCL path unavailable (%s: %s); SyncBN exchanges use torch.distributed" % (
+                type(e).__name__, e))
+            return None
+
+    def close(self):
+        if self.comm is not None and self.comm.value:
+            torch.cuda.synchronize(self.device)
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = None
+
+    @staticmethod
+    def _check(lib, status, what):
+        if status != 0:
+            raise RuntimeError("%s failed: %s" % (what, lib.ncclGetErrorString(status).decode()))
+
+    def all_reduce_sum(self, t):
+        """in-place SUM over the ranks, enqueued on the current HIP stream"""
+        from ..hip.binding import raw_stream
+        assert t.is_cuda and t.is_contiguous()
+        self._check(self.lib, self.lib.ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), NCCL_DTYPE[t.dtype], NCCL_SUM,
+                                                     self.comm, C.c_void_p(raw_stream(t.device.index))), "ncclAllReduce")
+
+    def _self_test(self, group):
+        # integer-valued f64: the sum is exact whatever order the two communicators add in
+        a = (torch.arange(37, dtype=torch.float64, device=self.device) + 1.0) * (self.rank + 1)
+        b = a.clone()
+        self.all_reduce_sum(a)
+        dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
+        torch.cuda.synchronize(self.device)
+        ok = torch.tensor([1 if torch.equal(a, b) else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)      # every rank takes the same decision
+        return bool(int(ok) == 1)

@@ -45,7 +45,7 @@ def _run_steps(dev, use_dp):
         out = hook(dict(O.synthetic_batch(2, 64, 128, seed=50 + it)), m, opt)
         losses.append(float(out["loss"].detach()))
     torch.cuda.synchronize()
-    calls = None if RT.dp is None else RT.dp.world
+    calls = None if RT.dp is None else (RT.dp.world, RT.dp._direct is not None)
     RT.dp = None
     return losses, torch.cat([p.detach().flatten() for p in m.parameters()]).cpu(), calls
 
@@ -58,10 +58,37 @@ def test_dp_path_on_rccl_matches_single_process(dev):
     finally:
         dist.destroy_process_group()
     l_ref, p_ref, _ = _run_steps(dev, False)
-    assert world == 1
+    assert world == (1, True)          # RCCL backend: the SyncBN exchanges went through the direct communicator
     # two runs differ only by fp32 atomic ordering (depth-gradient scatter): ~1e-6 relative
     assert l_dp == pytest.approx(l_ref, rel=2e-4)
     assert float((p_dp - p_ref).abs().max()) < 2.5e-4   # <= one Adam step of lr=1e-4 on sign-noise parameters
+
+
+def test_direct_rccl_communicator(dev):
+    """rccl_direct.DirectComm at world size 1: created from the process group, passes its self-test, reduces in place
+    on the current stream (a 1-rank SUM is the identity) for every dtype the engine exchanges; switched off by env"""
+    from fsnet_amd.engine.rccl_direct import DirectComm
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
+    try:
+        comm = DirectComm.create()
+        assert comm is not None and comm.world == 1
+        side = torch.cuda.Stream()
+        for dt in (torch.float64, torch.float32):
+            t = torch.randn(8, 2, 64, device=dev).to(dt)
+            want = t.clone()
+            with torch.cuda.stream(side):
+                t.mul_(2.0)
+                comm.all_reduce_sum(t)            # ordered after the mul on the same stream
+            side.synchronize()
+            assert torch.equal(t, want * 2.0)
+        os.environ["FSNET_AMD_RCCL_DIRECT"] = "0"
+        try:
+            assert DirectComm.create() is None
+        finally:
+            del os.environ["FSNET_AMD_RCCL_DIRECT"]
+    finally:
+        dist.destroy_process_group()
 
 
 @pytest.mark.skipif(os.environ.get("FSNET_AMD_TEST_GRAPH_DP", "0") == "0",
