@@ -53,6 +53,20 @@ _DEFERRED = {}          # chain stream id -> (chain stream, [weight-gradient wor
 _CALLBACK_QUEUED = [False]
 
 
+_STREAM_OBJS = {}
+
+
+def _current_stream(device=None):
+    """torch's current Stream object, cached by raw handle (building one costs ~6 us; 60+ lookups per step)"""
+    from ..hip.binding import raw_stream
+    idx = torch.cuda.current_device() if device is None or device.index is None else device.index
+    key = (idx, raw_stream(idx))
+    s = _STREAM_OBJS.get(key)
+    if s is None:
+        s = _STREAM_OBJS[key] = torch.cuda.current_stream(idx)
+    return s
+
+
 def _run_param_grads(op, dc, x, gw, gb, nb):
     op.wgrad(dc, x, gw)
     if gb is not None:
@@ -243,7 +257,7 @@ class ConvLayer:
         item = (op, dc, x, gw, gb, self.m.bias.numel() if gb is not None else 0)
         mode = RT.wgrad_streams if (dc.is_cuda and RT.overlap) else 0
         if mode:
-            cur = torch.cuda.current_stream(dc.device)
+            cur = _current_stream(dc.device)
             if mode == 3:
                 # only while the budget lasts: hand over about as much as balances the two chains
                 ent = _DEFERRED.get(cur.cuda_stream)
@@ -476,7 +490,7 @@ class ResNetRunner:
         op = self.stem.ready(y0.dtype, y0.device)
         self.stem.accumulate_param_grads(op, dc0, ctx["x"])
         if RT.wgrad_streams != 3:
-            flush_deferred(torch.cuda.current_stream())
+            flush_deferred(_current_stream())
 
 
 # ==============================================================================================
@@ -607,7 +621,7 @@ class DepthDecoderRunner:
             else:
                 gfeats[4] = op0.dgrad(dc0, h, w)
         if RT.wgrad_streams != 3:
-            flush_deferred(torch.cuda.current_stream())
+            flush_deferred(_current_stream())
         return gfeats
 
 
@@ -661,5 +675,5 @@ class PoseDecoderRunner:
             # gradient w.r.t. the input activation, masked by the producing ReLU (none for the encoder feature)
             d = op.dgrad(d, xin.shape[1], xin.shape[2], mask=(xin if j > 0 else None))
         if RT.wgrad_streams != 3:
-            flush_deferred(torch.cuda.current_stream())
+            flush_deferred(_current_stream())
         return d

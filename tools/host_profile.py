@@ -32,3 +32,6 @@ print("host time per step (issue only, profiler on): %.2f ms" % ((t1 - t0) / N *
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28)
 print(s.getvalue()[:6000])
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45)
+print(s.getvalue()[:9000])
