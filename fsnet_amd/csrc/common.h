@@ -69,6 +69,11 @@ template <> __device__ inline void store4<bf16>(bf16* p, const float v[4]) {
   *reinterpret_cast<uint2*>(p) = t;
 }
 
+// x / d for 0 <= x < 4096, 1 <= d <= 255 with a host-computed magic: the tile kernels decode (row, column) of ~10
+// tile-relative indices per thread by run-time tile widths, and an integer division is ~35 VALU instructions on CDNA
+__host__ __device__ static inline unsigned fs_div_magic(int d) { return (1u << 20) / (unsigned)d + 1u; }
+__device__ static inline int fs_fastdiv(int x, unsigned magic) { return (int)(((unsigned)x * magic) >> 20); }
+
 // Wave-wide sums without LDS traffic.  __shfl_xor lowers to ds_bpermute_b32 (an LDS-pipeline instruction plus its
 // address VALU op, six per sum); here four DPP adds fold each 16-lane row in the VALU — lane ^ 1, lane ^ 2 by
 // quad_perm, then row_half_mirror and row_mirror, which pair a lane with one holding the other half's partial — and

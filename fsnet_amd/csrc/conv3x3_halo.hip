@@ -30,6 +30,7 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, int vof
 struct HaloGeom {
   int TH, TW;        // pixel tile
   int tiles_x, tiles_y;
+  unsigned mTW, mHW; // fs_div_magic(TW), fs_div_magic(TW + 2)
 };
 
 template <typename T, int PIX, int CO, int WP>
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
   for (int i = 0; i < LH; ++i) {
     int idx = t + i * 256;
     int hp = idx >> 2, q = idx & 3;
-    int hy = hp / HW, hx = hp - hy * HW;
+    int hy = fs_fastdiv(hp, g.mHW), hx = hp - hy * HW;
     int sy = oy + hy, sx = ox + hx;
     // (a 16-channel bf16 layer fills half a 64-byte chunk: the upper units stay zero, as do their weights)
     bool ok = hp < nhalo && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws && q * 16 < row_bytes;
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
   for (int b = 0; b < TP; ++b) {
     int pi = wp * WPIX + b * 16 + li;
     if (pi >= ntile) pi = 0;                       // padding lanes read a valid halo row; results are discarded
-    int ty = pi / g.TW, tx = pi - ty * g.TW;
+    int ty = fs_fastdiv(pi, g.mTW), tx = pi - ty * g.TW;
     hbase[b] = (ty * HW + tx) * HS + lg;
   }
 
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
 #pragma unroll
   for (int b = 0; b < TP; ++b) {
     int pi = wp * WPIX + b * 16 + li;
-    int ty = pi / g.TW, tx = pi - ty * g.TW;
+    int ty = fs_fastdiv(pi, g.mTW), tx = pi - ty * g.TW;
     int y = y0 + ty, x = x0 + tx;
     bool mok = pi < ntile && y < p.Hd && x < p.Wd;
     doff[b] = mok ? n * (int)p.dN + y * (int)p.dH + x * (int)p.dW : -1;
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
 
 // pick the pixel tile (TH x TW <= PIX, halo <= hmax) that wastes the fewest lanes, preferring wide tiles
 HaloGeom pick_geom(int Hd, int Wd, int PIX, int hmax) {
-  HaloGeom best{0, 0, 0, 0};
+  HaloGeom best{0, 0, 0, 0, 0u, 0u};
   double best_cost = 1e30;
   for (int tw = std::min(4, Wd); tw <= std::min(Wd, 64); ++tw) {
     int th = std::min(PIX / tw, Hd);
@@ -289,6 +290,7 @@ HaloGeom pick_geom(int Hd, int Wd, int PIX, int hmax) {
     double cost = waste * (1.0 + 0.15 * halo);
     if (cost < best_cost - 1e-9) { best_cost = cost; best = HaloGeom{th, tw, tx, ty}; }
   }
+  if (best.TW > 0) { best.mTW = fs_div_magic(best.TW); best.mHW = fs_div_magic(best.TW + 2); }
   return best;
 }
 

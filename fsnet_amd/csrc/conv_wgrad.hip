@@ -336,7 +336,7 @@ int launch_tile(const FsWgradArgs& a, hipStream_t st) {
 // reads at shifted halo rows), i.e. 9x fewer input fetches and 72 MFMAs per wave between barriers; the
 // generic kernel above re-gathers the input per tap and synchronises every 4 MFMAs.
 // ---------------------------------------------------------------------------------------------
-struct WGeom { int TH, TW, tiles_x, tiles_y, N, Cs, nsplit; };
+struct WGeom { int TH, TW, tiles_x, tiles_y, N, Cs, nsplit; unsigned mTW, mHW; };
 
 __device__ __forceinline__ uint4 wg_buf_load16(__amdgpu_buffer_rsrc_t rsrc, int voff) {
   return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
@@ -370,12 +370,14 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const FsWgradArgs p,
 #pragma unroll
   for (int i = 0; i < LA; ++i) {
     int pix = (t + i * 256) / UA;
-    aty[i] = pix < ntile ? pix / g.TW : -1; atx[i] = pix < ntile ? pix % g.TW : 0;
+    const int aq = fs_fastdiv(min(pix, 4095), g.mTW);
+    aty[i] = pix < ntile ? aq : -1; atx[i] = pix < ntile ? pix - aq * g.TW : 0;
   }
 #pragma unroll
   for (int i = 0; i < LB; ++i) {
     int hp = (t + i * 256) / UB;
-    bhy[i] = hp < nhalo ? hp / HW : -1; bhx[i] = hp < nhalo ? hp % HW : 0;
+    const int bq = fs_fastdiv(min(hp, 4095), g.mHW);
+    bhy[i] = hp < nhalo ? bq : -1; bhx[i] = hp < nhalo ? hp - bq * HW : 0;
   }
   uint4 ra[LA], rb[LB];
   auto load_regs = [&](int pt) {
@@ -420,7 +422,8 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const FsWgradArgs p,
       int pk = ks * 32 + lg * 8 + (li >> 2) + hf * 4;
       arow[ks][hf] = pk * SA + wr * (COT / 2) + (li & 3) * 4;
       int pv = pk < ntile ? pk : 0;
-      brow[ks][hf] = ((pv / g.TW) * HW + (pv % g.TW)) * SB + wcn * (CIT / 2) + (li & 3) * 4;
+      const int pq = fs_fastdiv(pv, g.mTW);
+      brow[ks][hf] = (pq * HW + (pv - pq * g.TW)) * SB + wcn * (CIT / 2) + (li & 3) * 4;
     }
 
   f32x4 acc[9][TA][TB];
@@ -526,12 +529,14 @@ __global__ __launch_bounds__(256) void wgrad3x3_narrow_kernel(const FsWgradArgs 
 #pragma unroll
   for (int i = 0; i < LA; ++i) {
     int pix = (t + i * 256) / UA;
-    aty[i] = pix < ntile ? pix / g.TW : -1; atx[i] = pix < ntile ? pix % g.TW : 0;
+    const int aq = fs_fastdiv(min(pix, 4095), g.mTW);
+    aty[i] = pix < ntile ? aq : -1; atx[i] = pix < ntile ? pix - aq * g.TW : 0;
   }
 #pragma unroll
   for (int i = 0; i < LB; ++i) {
     int hp = (t + i * 256) / UB;
-    bhy[i] = hp < nhalo ? hp / HW : -1; bhx[i] = hp < nhalo ? hp % HW : 0;
+    const int bq = fs_fastdiv(min(hp, 4095), g.mHW);
+    bhy[i] = hp < nhalo ? bq : -1; bhx[i] = hp < nhalo ? hp - bq * HW : 0;
   }
   uint4 ra[LA], rb[LB];
   auto load_regs = [&](int pt) {
@@ -576,7 +581,8 @@ __global__ __launch_bounds__(256) void wgrad3x3_narrow_kernel(const FsWgradArgs 
       int pk = (wk * KS + ks) * 32 + lg * 8 + (li >> 2) + hf * 4;
       arow[ks][hf] = pk * SA + wr * 16 + (li & 3) * 4;
       int pv = pk < ntile ? pk : 0;          // (pixels past the tile hold zero dY rows)
-      brow[ks][hf] = ((pv / g.TW) * HW + (pv % g.TW)) * SB + (li & 3) * 4;
+      const int pq = fs_fastdiv(pv, g.mTW);
+      brow[ks][hf] = (pq * HW + (pv - pq * g.TW)) * SB + (li & 3) * 4;
     }
 
   f32x4 acc[9][TB];
@@ -775,7 +781,7 @@ __global__ __launch_bounds__(256) void wgrad_stem_kernel(const FsWgradArgs p, in
 }
 
 WGeom wgrad_pick_geom(int Hd, int Wd) {
-  WGeom best{0, 0, 0, 0, 0, 0, 1};
+  WGeom best{0, 0, 0, 0, 0, 0, 1, 0u, 0u};
   double best_cost = 1e30;
   for (int tw = std::min(4, Wd); tw <= std::min(Wd, 64); ++tw) {
     int th = std::min(128 / tw, Hd);
@@ -786,6 +792,7 @@ WGeom wgrad_pick_geom(int Hd, int Wd) {
     double cost = waste * (1.0 + 0.15 * halo);
     if (cost < best_cost - 1e-9) { best_cost = cost; best.TH = th; best.TW = tw; best.tiles_x = tx; best.tiles_y = ty; }
   }
+  if (best.TW > 0) { best.mTW = fs_div_magic(best.TW); best.mHW = fs_div_magic(best.TW + 2); }
   return best;
 }
 
