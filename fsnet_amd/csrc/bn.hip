@@ -11,6 +11,27 @@
 
 namespace {
 
+// Index decoding of the element-wise passes.  These kernels move 16 bytes per thread, so the address arithmetic is
+// most of their instruction count: a 64-bit division by a run-time value is >100 VALU instructions on CDNA and the
+// first version did six per vector (vector -> (row, channel group), row -> (n, h, w) twice).  Channel-group counts
+// are powers of two for every ResNet / decoder width (shift + mask), rows fit 32 bits, and dense tensors need no
+// (n, h, w) at all.
+__device__ __forceinline__ int pow2_shift(int v) { return (v & (v - 1)) == 0 ? __ffs(v) - 1 : -1; }
+__device__ __forceinline__ void split_vec(long i, int CG, int sh, int& cg, long& m) {
+  if (sh >= 0) { cg = (int)(i & (CG - 1)); m = i >> sh; }
+  else if (i < (1L << 31)) { const unsigned u = (unsigned)i, q = u / (unsigned)CG; cg = (int)(u - q * CG); m = q; }
+  else { cg = (int)(i % CG); m = i / CG; }
+}
+__device__ __forceinline__ void split_row(long m, int H, int W, long& n, int& h, int& w) {
+  if (m < (1L << 31)) {
+    const unsigned u = (unsigned)m, q = u / (unsigned)W, nn = q / (unsigned)H;
+    w = (int)(u - q * W); h = (int)(q - nn * H); n = nn;
+  } else {
+    w = (int)(m % W); const long q = m / W; h = (int)(q % H); n = q / H;
+  }
+}
+
+
 constexpr int MAXC = 2048;
 
 // ---------------------------------------------------------------------------------------------
@@ -97,10 +118,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const FsBnApplyArgs p) {
   const T* __restrict__ res = reinterpret_cast<const T*>(p.res);
   T* __restrict__ y = reinterpret_cast<T*>(p.y);
   constexpr int V = VecN<T>::N;
-  const int CG = C / V;
+  const int CG = C / V, cg_sh = pow2_shift(CG);
   const long total = (long)Mg * CG;
+  const bool dense_y = !p.pad_out && p.yW == C && p.yH == (long)p.W * C && p.yN == (long)p.H * p.W * C;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    int cg = (int)(i % CG); long m = (long)z * Mg + i / CG;
+    int cg; long m;
+    split_vec(i, CG, cg_sh, cg, m);
+    m += (long)z * Mg;
     int c = cg * V;
     float v[V];
     loadv<T>(x + m * C + c, v);
@@ -120,7 +144,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const FsBnApplyArgs p) {
 #pragma unroll
       for (int j = 0; j < V; ++j) v[j] = fmaxf(v[j], 0.f);
     }
-    int w = (int)(m % p.W); long q = m / p.W; int h = (int)(q % p.H); long n = q / p.H;
+    if (dense_y) { storev<T>(y + m * C + c, v); continue; }
+    int w, h; long n;
+    split_row(m, p.H, p.W, n, h, w);
     if (!p.pad_out) {
       storev<T>(y + n * p.yN + (long)h * p.yH + (long)w * p.yW + c, v);
     } else {
@@ -167,7 +193,20 @@ __device__ inline void load_dout(const FsBnBwdArgs& p, const T* dout, long n, in
 template <typename T>
 __device__ inline void masked_grad(const FsBnBwdArgs& p, const T* dout, const T* yv, long m, int c, float* g) {
   constexpr int V = VecN<T>::N;
-  int w = (int)(m % p.W); long q = m / p.W; int h = (int)(q % p.H); long n = q / p.H;
+  const long hw = (long)p.H * p.W;
+  if (!p.fold && p.gW == p.C && p.gH == (long)p.W * p.C && p.gN == hw * p.C &&
+      (!p.relu || (p.yW == p.C && p.yH == (long)p.W * p.C && p.yN == hw * p.C))) {      // dense: no (n, h, w)
+    loadv<T>(dout + m * p.C + c, g);
+    if (p.relu) {
+      float yy[V];
+      loadv<T>(yv + m * p.C + c, yy);
+#pragma unroll
+      for (int j = 0; j < V; ++j) g[j] = yy[j] > 0.f ? g[j] : 0.f;
+    }
+    return;
+  }
+  int w, h; long n;
+  split_row(m, p.H, p.W, n, h, w);
   load_dout<T>(p, dout, n, h, w, c, g);
   if (p.relu) {
     float yy[V];
@@ -278,10 +317,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const FsBnBwdArgs p) 
   T* __restrict__ dx = reinterpret_cast<T*>(p.dx);
   T* __restrict__ gout = reinterpret_cast<T*>(p.g_out);
   constexpr int V = VecN<T>::N;
-  const int CG = C / V;
+  const int CG = C / V, cg_sh = pow2_shift(CG);
   const long total = (long)Mg * CG;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    int cg = (int)(i % CG); long m = (long)z * Mg + i / CG;
+    int cg; long m;
+    split_vec(i, CG, cg_sh, cg, m);
+    m += (long)z * Mg;
     int c = cg * V;
     float g[V], xr[V], o[V];
     masked_grad<T>(p, dout, yv, m, c, g);
