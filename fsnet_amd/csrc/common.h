@@ -74,6 +74,22 @@ template <> __device__ inline void store4<bf16>(bf16* p, const float v[4]) {
 __host__ __device__ static inline unsigned fs_div_magic(int d) { return (1u << 20) / (unsigned)d + 1u; }
 __device__ static inline int fs_fastdiv(int x, unsigned magic) { return (int)(((unsigned)x * magic) >> 20); }
 
+// x / d for 0 <= x < 2^31 and 1 <= d < 2^31: m = floor(2^(31+l) / d) + 1 with l = ceil(log2 d) (m < 2^32), quotient
+// (x * m) >> (31 + l) — exact because m*d - 2^(31+l) <= d and x*d < 2^(31+l).  Two multiplies and a shift instead of
+// the ~35-instruction division sequence.
+struct FsDiv { unsigned m; unsigned sh; };
+__host__ static inline FsDiv fs_make_div(int d) {
+  int l = 0;
+  while ((1LL << l) < (long long)d) ++l;
+  FsDiv r;
+  r.m = (unsigned)(((1ULL << (31 + l)) / (unsigned long long)d) + 1ULL);
+  r.sh = (unsigned)(31 + l);
+  return r;
+}
+__device__ static inline int fs_div(int x, FsDiv d) {
+  return (int)(((unsigned long long)(unsigned)x * d.m) >> d.sh);
+}
+
 // Wave-wide sums without LDS traffic.  __shfl_xor lowers to ds_bpermute_b32 (an LDS-pipeline instruction plus its
 // address VALU op, six per sum); here four DPP adds fold each 16-lane row in the VALU — lane ^ 1, lane ^ 2 by
 // quad_perm, then row_half_mirror and row_mirror, which pair a lane with one holding the other half's partial — and

@@ -39,7 +39,7 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, int vof
 }
 
 template <typename T, int PIX, int CO, int WP, int KG>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p, const FsDiv dW, const FsDiv dH) {
   using TR = ElemTraits<T>;
   constexpr int WC = 4 / WP;
   constexpr int WPIX = PIX / WP, WCO = CO / WC;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
     int row = idx >> UPRS;
     int m = pix0 + row;
     if (row < PIX && m < p.M) {
-      int x = m % p.Wd; int q = m / p.Wd; int y = q % p.Hd; int n = q / p.Hd + n0;
+      int q = fs_div(m, dW); int x = m - q * p.Wd; int n = fs_div(q, dH); int y = q - n * p.Hd; n += n0;
       phb[i] = y * p.hb_mul + p.hb_add;
       pwb[i] = x * p.hb_mul + p.hb_add;
       pvoff[i] = (int)((n * p.sN + (long)phb[i] * sHe + (long)pwb[i] * sWe) * (long)sizeof(T));
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p) {
     int m = pix0 + wp * WPIX + b * 16 + li;
     bool mok = m < p.M;
     int x = 0, y = 0, n = 0;
-    if (mok) { x = m % p.Wd; int q = m / p.Wd; y = q % p.Hd; n = q / p.Hd + n0; }
+    if (mok) { int q = fs_div(m, dW); x = m - q * p.Wd; n = fs_div(q, dH); y = q - n * p.Hd; n += n0; }
     long doff = (long)n * p.dN + (long)y * p.dH + (long)x * p.dW;
     long aoff = (long)n * p.aN + (long)y * p.aH + (long)x * p.aW;
     long moff = (long)n * p.mN + (long)y * p.mH + (long)x * p.mW;
@@ -328,7 +328,8 @@ int launch_tile(const FsConvArgs& a, hipStream_t st) {
   const int npix = (a.M + PIX - 1) / PIX, nco = a.Co_p / CO;
   int blocks = npix * nco;
   if (nco % 8 != 0 && 8 % nco == 0) { const int g = 8 / nco; blocks = 8 * ((npix + g - 1) / g); }
-  hipLaunchKernelGGL((conv_igemm_kernel<T, PIX, CO, WP, KG>), dim3(blocks, a.ncls > 1 ? a.ncls : 1, a.grp_imgs > 0 ? a.N / a.grp_imgs : 1), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, PIX, CO, WP, KG>), dim3(blocks, a.ncls > 1 ? a.ncls : 1, a.grp_imgs > 0 ? a.N / a.grp_imgs : 1), dim3(256), 0, st, a,
+                     fs_make_div(a.Wd), fs_make_div(a.Hd));
   return fs_launch_status();
 }
 
