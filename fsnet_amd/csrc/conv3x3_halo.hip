@@ -31,6 +31,8 @@ struct HaloGeom {
   int TH, TW;        // pixel tile
   int tiles_x, tiles_y;
   unsigned mTW, mHW; // fs_div_magic(TW), fs_div_magic(TW + 2)
+  FsDiv dTX, dTY;    // tiles_x, tiles_y
+  FsDiv dIPG;        // images per BatchNorm statistics group (stat_group_rows / (Hd*Wd)); unused when 0 groups
 };
 
 template <typename T, int PIX, int CO, int WP>
@@ -70,8 +72,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
     else { cy = id % nco; px = id / nco; }
     if (px >= npix) return;
   }
-  const int tx_i = px % g.tiles_x; const int tq = px / g.tiles_x;
-  const int ty_i = tq % g.tiles_y; const int n = tq / g.tiles_y;
+  const int tq = fs_div(px, g.dTX); const int tx_i = px - tq * g.tiles_x;
+  const int n = fs_div(tq, g.dTY); const int ty_i = tq - n * g.tiles_y;
   const int y0 = ty_i * g.TH, x0 = tx_i * g.TW;
   const int co0 = cy * CO;
   const int fwd = p.sgn > 0;
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
   for (int a = 0; a < TC; ++a)
 #pragma unroll
     for (int j = 0; j < 4; ++j) { s1[a][j] = 0.f; s2[a][j] = 0.f; }
-  const int sgoff = p.stat_group_rows > 0 ? (int)((((long)n * p.Hd * p.Wd) / p.stat_group_rows) * p.Co) : 0;
+  const int sgoff = p.stat_group_rows > 0 ? fs_div(n, g.dIPG) * p.Co : 0;
   // per pixel tile b: element offsets into dst / addend / mask / bnb_x (32-bit: every activation tensor on this
   // path is far below 2^31 elements), -1 = lane holds no pixel.  Channel-only terms are hoisted per tile a.
   int doff[TP], aoff[TP], moff[TP];
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
       for (int k = 0; k < WP; ++k) { u += red[(k * CO + t) * 2]; w += red[(k * CO + t) * 2 + 1]; }
       int co = co0 + t;
       if (co < p.Co) {
-        const long sg = p.stat_group_rows > 0 ? ((long)n * p.Hd * p.Wd) / p.stat_group_rows : 0;   // whole images
+        const long sg = p.stat_group_rows > 0 ? fs_div(n, g.dIPG) : 0;   // whole images
         double* sl = p.stats + (sg * FS_STAT_SLOTS + px % FS_STAT_SLOTS) * 2 * p.Co;
         atomicAdd(sl + co, (double)u);
         atomicAdd(sl + p.Co + co, (double)w);
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
 
 // pick the pixel tile (TH x TW <= PIX, halo <= hmax) that wastes the fewest lanes, preferring wide tiles
 HaloGeom pick_geom(int Hd, int Wd, int PIX, int hmax) {
-  HaloGeom best{0, 0, 0, 0, 0u, 0u};
+  HaloGeom best{0, 0, 0, 0, 0u, 0u, FsDiv{0u, 0u}, FsDiv{0u, 0u}, FsDiv{0u, 0u}};
   double best_cost = 1e30;
   for (int tw = std::min(4, Wd); tw <= std::min(Wd, 64); ++tw) {
     int th = std::min(PIX / tw, Hd);
@@ -290,7 +292,10 @@ HaloGeom pick_geom(int Hd, int Wd, int PIX, int hmax) {
     double cost = waste * (1.0 + 0.15 * halo);
     if (cost < best_cost - 1e-9) { best_cost = cost; best = HaloGeom{th, tw, tx, ty}; }
   }
-  if (best.TW > 0) { best.mTW = fs_div_magic(best.TW); best.mHW = fs_div_magic(best.TW + 2); }
+  if (best.TW > 0) {
+    best.mTW = fs_div_magic(best.TW); best.mHW = fs_div_magic(best.TW + 2);
+    best.dTX = fs_make_div(best.tiles_x); best.dTY = fs_make_div(best.tiles_y);
+  }
   return best;
 }
 
@@ -298,6 +303,11 @@ template <typename T, int PIX, int CO, int WP>
 int launch_halo(const FsConvArgs& a, hipStream_t st) {
   HaloGeom g = pick_geom(a.Hd, a.Wd, PIX, PIX == 256 ? 360 : (PIX == 128 ? 208 : 120));
   if (g.TH == 0) return FS_EINVAL;
+  if (a.stat_group_rows > 0) {
+    const long hw = (long)a.Hd * a.Wd;
+    if (a.stat_group_rows % hw != 0) return FS_EINVAL;          // statistics groups are whole images
+    g.dIPG = fs_make_div((int)(a.stat_group_rows / hw));
+  }
   const int npix = a.N * g.tiles_x * g.tiles_y, nco = a.Co_p / CO;
   int blocks = npix * nco;
   if (nco % 8 != 0 && 8 % nco == 0) { const int q = 8 / nco; blocks = 8 * ((npix + q - 1) / q); }

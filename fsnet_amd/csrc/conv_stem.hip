@@ -27,7 +27,8 @@ __device__ __forceinline__ uint4 stem_load16(__amdgpu_buffer_rsrc_t rsrc, int vo
 }
 
 __global__ __launch_bounds__(256) void conv_stem_kernel(const FsConvArgs p, int tiles_x, int tiles_y, int ntiles,
-                                                        int tiles_per_block) {
+                                                        int tiles_per_block, const FsDiv dTX, const FsDiv dTY,
+                                                        const FsDiv dIPG) {
   typedef bf16 T;
   __shared__ uint4 lds_w[CO * TAPS];
   __shared__ uint4 lds_x[PH * PW];
@@ -82,11 +83,11 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const FsConvArgs p, int 
   };
 
   for (int tile = tile0; tile < tile1; ++tile) {
-    const int tx_i = tile % tiles_x; const int q = tile / tiles_x;
-    const int ty_i = q % tiles_y; const int n = q / tiles_y;
+    const int q = fs_div(tile, dTX); const int tx_i = tile - q * tiles_x;
+    const int n = fs_div(q, dTY); const int ty_i = q - n * tiles_y;
     const int y0 = ty_i * TY, x0 = tx_i * TX;
     if (p.stats) {
-      const int group = p.stat_group_rows > 0 ? (int)(((long)n * p.Hd * p.Wd) / p.stat_group_rows) : 0;
+      const int group = p.stat_group_rows > 0 ? fs_div(n, dIPG) : 0;
       if (group != cur_group) {
         if (cur_group >= 0) flush_stats(cur_group);
         cur_group = group;
@@ -165,7 +166,13 @@ extern "C" int fs_conv_stem(const FsConvArgs* a, int dtype, void* stream) {
   // persistent blocks: two per CU (62 KB of LDS each), each walking a contiguous run of tiles with the weights resident
   const int per = (int)std::max<long>(1, (ntiles + 511) / 512);
   const int blocks = (int)((ntiles + per - 1) / per);
+  FsDiv ipg = fs_make_div(1);
+  if (a->stat_group_rows > 0) {
+    const long hw = (long)a->Hd * a->Wd;
+    if (a->stat_group_rows % hw != 0) return FS_EINVAL;        // statistics groups are whole images
+    ipg = fs_make_div((int)(a->stat_group_rows / hw));
+  }
   hipLaunchKernelGGL(conv_stem_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a, tiles_x,
-                     tiles_y, (int)ntiles, per);
+                     tiles_y, (int)ntiles, per, fs_make_div(tiles_x), fs_make_div(tiles_y), ipg);
   return fs_launch_status();
 }

@@ -18,7 +18,7 @@ namespace {
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 template <typename T, int COT, int CLT, int WR, int CH>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const FsWgradArgs p) {
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const FsWgradArgs p, const FsDiv dW, const FsDiv dH) {
   using TR = ElemTraits<T>;
   constexpr int EG = TR::EG;
   constexpr int WCn = 4 / WR;                 // waves along columns
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const FsWgradArgs p) {
     bc[i] = e & 0xffff; br[i] = (e >> 16) & 0xff; bs[i] = (e >> 24) & 0x7f;
     long m = m_begin + pix;
     bm[i] = m;
-    bx[i] = (int)(m % p.Wd); long q = m / p.Wd; by[i] = (int)(q % p.Hd); bn[i] = (int)(q / p.Hd);
+    const int q = fs_div((int)m, dW); bx[i] = (int)m - q * p.Wd; bn[i] = fs_div(q, dH); by[i] = q - bn[i] * p.Hd;
   }
 
   uint4 ra[LA], rb[LB];
@@ -322,7 +322,8 @@ int launch_tile(const FsWgradArgs& a, hipStream_t st) {
   b.pix_per_split = (int)(cps * CH);
   b.nsplit = (int)((chunks + cps - 1) / cps);
   dim3 grid(ct, rt, b.nsplit);
-  hipLaunchKernelGGL((conv_wgrad_kernel<T, COT, CLT, WR, CH>), grid, dim3(256), 0, st, b);
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, COT, CLT, WR, CH>), grid, dim3(256), 0, st, b, fs_make_div(a.Wd),
+                     fs_make_div(a.Hd));
   if (b.nsplit > 1) {
     launch_reduce(b, a.Co, ncols, EG, st);
   }
@@ -336,7 +337,7 @@ int launch_tile(const FsWgradArgs& a, hipStream_t st) {
 // reads at shifted halo rows), i.e. 9x fewer input fetches and 72 MFMAs per wave between barriers; the
 // generic kernel above re-gathers the input per tap and synchronises every 4 MFMAs.
 // ---------------------------------------------------------------------------------------------
-struct WGeom { int TH, TW, tiles_x, tiles_y, N, Cs, nsplit; unsigned mTW, mHW; };
+struct WGeom { int TH, TW, tiles_x, tiles_y, N, Cs, nsplit; unsigned mTW, mHW; FsDiv dTX, dTY; };
 
 __device__ __forceinline__ uint4 wg_buf_load16(__amdgpu_buffer_rsrc_t rsrc, int voff) {
   return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const FsWgradArgs p,
   }
   uint4 ra[LA], rb[LB];
   auto load_regs = [&](int pt) {
-    int tx_i = pt % g.tiles_x; int q = pt / g.tiles_x; int ty_i = q % g.tiles_y; int n = q / g.tiles_y;
+    int q = fs_div(pt, g.dTX); int tx_i = pt - q * g.tiles_x; int n = fs_div(q, g.dTY); int ty_i = q - n * g.tiles_y;
     int y0 = ty_i * g.TH, x0 = tx_i * g.TW;
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_narrow_kernel(const FsWgradArgs 
   }
   uint4 ra[LA], rb[LB];
   auto load_regs = [&](int pt) {
-    int tx_i = pt % g.tiles_x; int q = pt / g.tiles_x; int ty_i = q % g.tiles_y; int n = q / g.tiles_y;
+    int q = fs_div(pt, g.dTX); int tx_i = pt - q * g.tiles_x; int n = fs_div(q, g.dTY); int ty_i = q - n * g.tiles_y;
     int y0 = ty_i * g.TH, x0 = tx_i * g.TW;
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
@@ -671,7 +672,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_narrow_kernel(const FsWgradArgs 
 // all 64 output channels and keeps them in accumulators over the block's tiles; one fp32 slab per block at the end.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void wgrad_stem_kernel(const FsWgradArgs p, int tiles_x, int tiles_y, int ntiles,
-                                                         int tiles_per_block) {
+                                                         int tiles_per_block, const FsDiv dTX, const FsDiv dTY) {
   typedef bf16 T;
   constexpr int TY = 8, TX = 16, PIXT = TY * TX, PH = 2 * TY + 5, PW = 2 * TX + 6;
   constexpr int SA = 64 + 8, OOB = 0x7fffffff;
@@ -687,7 +688,7 @@ __global__ __launch_bounds__(256) void wgrad_stem_kernel(const FsWgradArgs p, in
 
   uint4 ra[LA], rb[LB];
   auto load_regs = [&](int tile) {
-    const int tx_i = tile % tiles_x; const int q = tile / tiles_x; const int ty_i = q % tiles_y; const int n = q / tiles_y;
+    const int q = fs_div(tile, dTX); const int tx_i = tile - q * tiles_x; const int n = fs_div(q, dTY); const int ty_i = q - n * tiles_y;
     const int y0 = ty_i * TY, x0 = tx_i * TX;
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
@@ -781,7 +782,7 @@ __global__ __launch_bounds__(256) void wgrad_stem_kernel(const FsWgradArgs p, in
 }
 
 WGeom wgrad_pick_geom(int Hd, int Wd) {
-  WGeom best{0, 0, 0, 0, 0, 0, 1, 0u, 0u};
+  WGeom best{0, 0, 0, 0, 0, 0, 1, 0u, 0u, FsDiv{0u, 0u}, FsDiv{0u, 0u}};
   double best_cost = 1e30;
   for (int tw = std::min(4, Wd); tw <= std::min(Wd, 64); ++tw) {
     int th = std::min(128 / tw, Hd);
@@ -792,7 +793,10 @@ WGeom wgrad_pick_geom(int Hd, int Wd) {
     double cost = waste * (1.0 + 0.15 * halo);
     if (cost < best_cost - 1e-9) { best_cost = cost; best.TH = th; best.TW = tw; best.tiles_x = tx; best.tiles_y = ty; }
   }
-  if (best.TW > 0) { best.mTW = fs_div_magic(best.TW); best.mHW = fs_div_magic(best.TW + 2); }
+  if (best.TW > 0) {
+    best.mTW = fs_div_magic(best.TW); best.mHW = fs_div_magic(best.TW + 2);
+    best.dTX = fs_make_div(best.tiles_x); best.dTY = fs_make_div(best.tiles_y);
+  }
   return best;
 }
 
@@ -870,7 +874,8 @@ int launch_wgrad_stem(const FsWgradArgs& a, hipStream_t st) {
   const int per = (int)((ntiles + max_blocks - 1) / max_blocks);
   const int blocks = (int)((ntiles + per - 1) / per);
   b.nsplit = blocks;
-  hipLaunchKernelGGL(wgrad_stem_kernel, dim3(blocks), dim3(256), 0, st, b, tiles_x, tiles_y, (int)ntiles, per);
+  hipLaunchKernelGGL(wgrad_stem_kernel, dim3(blocks), dim3(256), 0, st, b, tiles_x, tiles_y, (int)ntiles, per,
+                     fs_make_div(tiles_x), fs_make_div(tiles_y));
   launch_reduce(b, a.Co, 49 * 8, 8, st);
   return fs_launch_status();
 }
