@@ -380,25 +380,30 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const FsWgradArgs p,
     const int bq = fs_fastdiv(min(hp, 4095), g.mHW);
     bhy[i] = hp < nhalo ? bq : -1; bhx[i] = hp < nhalo ? hp - bq * HW : 0;
   }
+  // byte offsets of the units relative to the tile origin (fixed over the tiles)
+  int arel[LA], brel[LB];
+#pragma unroll
+  for (int i = 0; i < LA; ++i) arel[i] = ((aty[i] * p.Wd + atx[i]) * p.Cd + co0 + ((t + i * 256) % UA) * 8) * 2;
+#pragma unroll
+  for (int i = 0; i < LB; ++i)
+    brel[i] = (int)(((long)bhy[i] * p.sH + (long)bhx[i] * p.sW + ci0 + ((t + i * 256) % UB) * 8) * 2);
   uint4 ra[LA], rb[LB];
   auto load_regs = [&](int pt) {
     int q = fs_div(pt, g.dTX); int tx_i = pt - q * g.tiles_x; int n = fs_div(q, g.dTY); int ty_i = q - n * g.tiles_y;
     int y0 = ty_i * g.TH, x0 = tx_i * g.TW;
+    // tile origin as 32-bit byte offsets (both tensors are below 2 GiB: the buffer descriptors require it)
+    const int abase = (((n * p.Hd + y0) * p.Wd + x0) * p.Cd) * 2;
+    const int bbase = (int)(((long)n * p.sN + (long)(y0 - p.pad) * p.sH + (long)(x0 - p.pad) * p.sW) * 2);
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-      int u = (t + i * 256) % UA;
-      int y = y0 + aty[i], x = x0 + atx[i];
-      bool ok = aty[i] >= 0 && y < p.Hd && x < p.Wd;
-      int voff = ok ? (int)((((long)n * p.Hd + y) * p.Wd + x) * p.Cd + co0 + u * 8) * 2 : OOB;
-      ra[i] = wg_buf_load16(rs_dy, voff);
+      const bool ok = aty[i] >= 0 && y0 + aty[i] < p.Hd && x0 + atx[i] < p.Wd;
+      ra[i] = wg_buf_load16(rs_dy, ok ? abase + arel[i] : OOB);
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
-      int u = (t + i * 256) % UB;
-      int sy = y0 - p.pad + bhy[i], sx = x0 - p.pad + bhx[i];
-      bool ok = bhy[i] >= 0 && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
-      int voff = ok ? (int)(((long)n * p.sN + (long)sy * p.sH + (long)sx * p.sW + ci0 + u * 8) * 2) : OOB;
-      rb[i] = wg_buf_load16(rs_x, voff);
+      const int sy = y0 - p.pad + bhy[i], sx = x0 - p.pad + bhx[i];
+      const bool ok = bhy[i] >= 0 && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
+      rb[i] = wg_buf_load16(rs_x, ok ? bbase + brel[i] : OOB);
     }
   };
   auto store_lds = [&]() {
@@ -539,25 +544,29 @@ __global__ __launch_bounds__(256) void wgrad3x3_narrow_kernel(const FsWgradArgs 
     const int bq = fs_fastdiv(min(hp, 4095), g.mHW);
     bhy[i] = hp < nhalo ? bq : -1; bhx[i] = hp < nhalo ? hp - bq * HW : 0;
   }
+  // byte offsets of the units relative to the tile origin (fixed over the tiles)
+  int arel[LA], brel[LB];
+#pragma unroll
+  for (int i = 0; i < LA; ++i) arel[i] = ((aty[i] * p.Wd + atx[i]) * p.Cd + ((t + i * 256) % UA) * 8) * 2;
+#pragma unroll
+  for (int i = 0; i < LB; ++i)
+    brel[i] = (int)(((long)bhy[i] * p.sH + (long)bhx[i] * p.sW + ci0 + ((t + i * 256) % UB) * 8) * 2);
   uint4 ra[LA], rb[LB];
   auto load_regs = [&](int pt) {
     int q = fs_div(pt, g.dTX); int tx_i = pt - q * g.tiles_x; int n = fs_div(q, g.dTY); int ty_i = q - n * g.tiles_y;
     int y0 = ty_i * g.TH, x0 = tx_i * g.TW;
+    const int abase = (((n * p.Hd + y0) * p.Wd + x0) * p.Cd) * 2;
+    const int bbase = (int)(((long)n * p.sN + (long)(y0 - p.pad) * p.sH + (long)(x0 - p.pad) * p.sW) * 2);
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-      int u = (t + i * 256) % UA;
-      int y = y0 + aty[i], x = x0 + atx[i];
-      bool ok = aty[i] >= 0 && y < p.Hd && x < p.Wd;
-      int voff = ok ? (int)((((long)n * p.Hd + y) * p.Wd + x) * p.Cd + u * 8) * 2 : OOB;
-      ra[i] = wg_buf_load16(rs_dy, voff);
+      const bool ok = aty[i] >= 0 && y0 + aty[i] < p.Hd && x0 + atx[i] < p.Wd;
+      ra[i] = wg_buf_load16(rs_dy, ok ? abase + arel[i] : OOB);
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
-      int u = (t + i * 256) % UB;
-      int sy = y0 - p.pad + bhy[i], sx = x0 - p.pad + bhx[i];
-      bool ok = bhy[i] >= 0 && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
-      int voff = ok ? (int)(((long)n * p.sN + (long)sy * p.sH + (long)sx * p.sW + ci0 + u * 8) * 2) : OOB;
-      rb[i] = wg_buf_load16(rs_x, voff);
+      const int sy = y0 - p.pad + bhy[i], sx = x0 - p.pad + bhx[i];
+      const bool ok = bhy[i] >= 0 && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
+      rb[i] = wg_buf_load16(rs_x, ok ? bbase + brel[i] : OOB);
     }
   };
   auto store_lds = [&]() {
