@@ -15,6 +15,56 @@ namespace {
 // depth head: one lane per pixel, K logits (fp32) contiguous per pixel
 // ---------------------------------------------------------------------------------------------
 template <int K>
+__device__ __forceinline__ void head_fwd_row(const float* __restrict__ logits, const float* sb, float* __restrict__ depth,
+                                             float* __restrict__ disp, long m, int Cl, float inv_rng, float max_d) {
+  float v[K];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < K; k += 4) {
+    float4 t = *reinterpret_cast<const float4*>(logits + m * Cl + k);
+    v[k] = t.x; v[k + 1] = t.y; v[k + 2] = t.z; v[k + 3] = t.w;
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) { v[k] = fminf(fmaxf(v[k], -10.f), 10.f); mx = fmaxf(mx, v[k]); }
+  float se = 0.f, sd = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) { float e = expf(v[k] - mx); se += e; sd += e * sb[k]; }
+  float d = sd / se;
+  depth[m] = d;
+  disp[m] = (1.f / d - 1.f / max_d) * inv_rng;
+}
+
+template <int K, typename T>
+__device__ __forceinline__ void head_bwd_row(const float* __restrict__ logits, const float* sb,
+                                             const float* __restrict__ d_depth, const float* __restrict__ d_disp,
+                                             T* __restrict__ dlogits, long m, int Cl, float inv_rng) {
+  float v[K], raw[K];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < K; k += 4) {
+    float4 t = *reinterpret_cast<const float4*>(logits + m * Cl + k);
+    raw[k] = t.x; raw[k + 1] = t.y; raw[k + 2] = t.z; raw[k + 3] = t.w;
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) { v[k] = fminf(fmaxf(raw[k], -10.f), 10.f); mx = fmaxf(mx, v[k]); }
+  float se = 0.f, sd = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) { v[k] = expf(v[k] - mx); se += v[k]; sd += v[k] * sb[k]; }
+  float d = sd / se;
+  float g = (d_depth ? d_depth[m] : 0.f);
+  if (d_disp) g += d_disp[m] * (-inv_rng / (d * d));
+  float o[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float pk = v[k] / se;
+    bool inside = raw[k] >= -10.f && raw[k] <= 10.f;  // clamp passes gradient on the closed interval
+    o[k] = inside ? pk * (sb[k] - d) * g : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < K; k += 4) store4<T>(dlogits + m * Cl + k, &o[k]);
+}
+
+template <int K>
 __global__ __launch_bounds__(256) void depth_head_fwd_kernel(const float* __restrict__ logits,
                                                              const float* __restrict__ bins, float* __restrict__ depth,
                                                              float* __restrict__ disp, long M, int Cl, float min_d,
@@ -23,23 +73,8 @@ __global__ __launch_bounds__(256) void depth_head_fwd_kernel(const float* __rest
   if (threadIdx.x < K) sb[threadIdx.x] = bins[threadIdx.x];
   __syncthreads();
   const float inv_rng = 1.f / (1.f / min_d - 1.f / max_d);
-  for (long m = (long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long)gridDim.x * 256) {
-    float v[K];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < K; k += 4) {
-      float4 t = *reinterpret_cast<const float4*>(logits + m * Cl + k);
-      v[k] = t.x; v[k + 1] = t.y; v[k + 2] = t.z; v[k + 3] = t.w;
-    }
-#pragma unroll
-    for (int k = 0; k < K; ++k) { v[k] = fminf(fmaxf(v[k], -10.f), 10.f); mx = fmaxf(mx, v[k]); }
-    float se = 0.f, sd = 0.f;
-#pragma unroll
-    for (int k = 0; k < K; ++k) { float e = expf(v[k] - mx); se += e; sd += e * sb[k]; }
-    float d = sd / se;
-    depth[m] = d;
-    disp[m] = (1.f / d - 1.f / max_d) * inv_rng;
-  }
+  for (long m = (long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long)gridDim.x * 256)
+    head_fwd_row<K>(logits, sb, depth, disp, m, Cl, inv_rng, max_d);
 }
 
 template <int K, typename T>
@@ -52,32 +87,42 @@ __global__ __launch_bounds__(256) void depth_head_bwd_kernel(const float* __rest
   if (threadIdx.x < K) sb[threadIdx.x] = bins[threadIdx.x];
   __syncthreads();
   const float inv_rng = 1.f / (1.f / min_d - 1.f / max_d);
-  for (long m = (long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long)gridDim.x * 256) {
-    float v[K], raw[K];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < K; k += 4) {
-      float4 t = *reinterpret_cast<const float4*>(logits + m * Cl + k);
-      raw[k] = t.x; raw[k + 1] = t.y; raw[k + 2] = t.z; raw[k + 3] = t.w;
-    }
-#pragma unroll
-    for (int k = 0; k < K; ++k) { v[k] = fminf(fmaxf(raw[k], -10.f), 10.f); mx = fmaxf(mx, v[k]); }
-    float se = 0.f, sd = 0.f;
-#pragma unroll
-    for (int k = 0; k < K; ++k) { v[k] = expf(v[k] - mx); se += v[k]; sd += v[k] * sb[k]; }
-    float d = sd / se;
-    float g = (d_depth ? d_depth[m] : 0.f);
-    if (d_disp) g += d_disp[m] * (-inv_rng / (d * d));
-    float o[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      float pk = v[k] / se;
-      bool inside = raw[k] >= -10.f && raw[k] <= 10.f;  // clamp passes gradient on the closed interval
-      o[k] = inside ? pk * (sb[k] - d) * g : 0.f;
-    }
-#pragma unroll
-    for (int k = 0; k < K; k += 4) store4<T>(dlogits + m * Cl + k, &o[k]);
-  }
+  for (long m = (long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long)gridDim.x * 256)
+    head_bwd_row<K, T>(logits, sb, d_depth, d_disp, dlogits, m, Cl, inv_rng);
+}
+
+// all scales of the decoder in ONE launch (the per-scale launches are 10-15 us latency-bound nodes on the serial
+// part of the step: four after the decoder's forward, four at the head of its backward)
+struct HeadBlocks { int start[FS_HEAD_MAX + 1]; };
+
+template <int K>
+__global__ __launch_bounds__(256) void depth_head_fwd_multi_kernel(const FsHeadBatch hb, const HeadBlocks blk,
+                                                                   const float* __restrict__ bins, int Cl, float min_d,
+                                                                   float max_d) {
+  __shared__ float sb[K];
+  if (threadIdx.x < K) sb[threadIdx.x] = bins[threadIdx.x];
+  __syncthreads();
+  const float inv_rng = 1.f / (1.f / min_d - 1.f / max_d);
+  int s = 0;
+  while (s + 1 < hb.n && (int)blockIdx.x >= blk.start[s + 1]) ++s;
+  const long nb = blk.start[s + 1] - blk.start[s], lb = blockIdx.x - blk.start[s];
+  for (long m = lb * 256 + threadIdx.x; m < hb.M[s]; m += nb * 256)
+    head_fwd_row<K>(hb.logits[s], sb, hb.depth[s], hb.disp[s], m, Cl, inv_rng, max_d);
+}
+
+template <int K, typename T>
+__global__ __launch_bounds__(256) void depth_head_bwd_multi_kernel(const FsHeadBatch hb, const HeadBlocks blk,
+                                                                   const float* __restrict__ bins, int Cl, float min_d,
+                                                                   float max_d) {
+  __shared__ float sb[K];
+  if (threadIdx.x < K) sb[threadIdx.x] = bins[threadIdx.x];
+  __syncthreads();
+  const float inv_rng = 1.f / (1.f / min_d - 1.f / max_d);
+  int s = 0;
+  while (s + 1 < hb.n && (int)blockIdx.x >= blk.start[s + 1]) ++s;
+  const long nb = blk.start[s + 1] - blk.start[s], lb = blockIdx.x - blk.start[s];
+  for (long m = lb * 256 + threadIdx.x; m < hb.M[s]; m += nb * 256)
+    head_bwd_row<K, T>(hb.logits[s], sb, hb.d_depth[s], hb.d_disp[s], reinterpret_cast<T*>(hb.dlogits[s]), m, Cl, inv_rng);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -221,6 +266,50 @@ extern "C" int fs_depth_head_bwd(const float* logits, const float* bins, const f
     if (K == 16) FS_DH(16, float); else if (K == 32) FS_DH(32, float); else if (K == 64) FS_DH(64, float); else return FS_EINVAL;
   } else return FS_EINVAL;
 #undef FS_DH
+  return fs_launch_status();
+}
+
+namespace {
+bool head_blocks(const FsHeadBatch* hb, bool bwd, HeadBlocks& blk, int& total) {
+  if (!hb || hb->n < 1 || hb->n > FS_HEAD_MAX) return false;
+  total = 0;
+  for (int s = 0; s < hb->n; ++s) {
+    if (!hb->logits[s] || hb->M[s] <= 0) return false;
+    if (bwd ? !hb->dlogits[s] : (!hb->depth[s] || !hb->disp[s])) return false;
+    blk.start[s] = total;
+    total += grid_for(hb->M[s]);
+  }
+  blk.start[hb->n] = total;
+  return true;
+}
+}  // namespace
+
+extern "C" int fs_depth_head_fwd_multi(const FsHeadBatch* hb, const float* bins, int K, int Cl, float min_depth,
+                                       float max_depth, void* stream) {
+  HeadBlocks blk; int total = 0;
+  if (!bins || Cl < K || !head_blocks(hb, false, blk, total)) return FS_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(total);
+  if (K == 16) hipLaunchKernelGGL(depth_head_fwd_multi_kernel<16>, grid, dim3(256), 0, st, *hb, blk, bins, Cl, min_depth, max_depth);
+  else if (K == 32) hipLaunchKernelGGL(depth_head_fwd_multi_kernel<32>, grid, dim3(256), 0, st, *hb, blk, bins, Cl, min_depth, max_depth);
+  else if (K == 64) hipLaunchKernelGGL(depth_head_fwd_multi_kernel<64>, grid, dim3(256), 0, st, *hb, blk, bins, Cl, min_depth, max_depth);
+  else return FS_EINVAL;
+  return fs_launch_status();
+}
+
+extern "C" int fs_depth_head_bwd_multi(const FsHeadBatch* hb, const float* bins, int K, int Cl, float min_depth,
+                                       float max_depth, int dtype, void* stream) {
+  HeadBlocks blk; int total = 0;
+  if (!bins || Cl < K || !head_blocks(hb, true, blk, total)) return FS_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(total);
+#define FS_DHM(KK, TT) hipLaunchKernelGGL((depth_head_bwd_multi_kernel<KK, TT>), grid, dim3(256), 0, st, *hb, blk, bins, Cl, min_depth, max_depth)
+  if (dtype == FS_DTYPE_BF16) {
+    if (K == 16) FS_DHM(16, bf16); else if (K == 32) FS_DHM(32, bf16); else if (K == 64) FS_DHM(64, bf16); else return FS_EINVAL;
+  } else if (dtype == FS_DTYPE_F32) {
+    if (K == 16) FS_DHM(16, float); else if (K == 32) FS_DHM(32, float); else if (K == 64) FS_DHM(64, float); else return FS_EINVAL;
+  } else return FS_EINVAL;
+#undef FS_DHM
   return fs_launch_status();
 }
 

@@ -553,17 +553,21 @@ class DepthDecoderRunner:
                 cld = self.disp[i]
                 opd = cld.ready(dt, dev)
                 logits = opd.forward(y1p, bias=cld.bias, out_f32=True)
-                depth, disp = ops.depth_head_fwd(logits, m.depth_bins, K, m.min_depth, m.max_depth)
                 lv["logits"] = logits
-                outs[i] = (logits, depth, disp)
                 if i in self.unc:
                     clu = self.unc[i]
                     opu = clu.ready(dt, dev)
-                    u = ops.sigmoid_head_fwd(opu.forward(y1p, bias=clu.bias, out_f32=True))
-                    lv["unc"] = u
-                    outs[i] = (logits, depth, disp, u)
+                    lv["unc"] = ops.sigmoid_head_fwd(opu.forward(y1p, bias=clu.bias, out_f32=True))
             ctx["lv"][i] = lv
             x = y1p[:, 1:-1, 1:-1]
+        # softmax-expectation heads of all scales in one launch (their outputs are only read by the loss)
+        sc = [i for i in range(4, -1, -1) if "logits" in ctx["lv"][i]]
+        if sc:
+            heads = ops.depth_head_fwd_multi([ctx["lv"][i]["logits"] for i in sc], m.depth_bins, K, m.min_depth,
+                                             m.max_depth)
+            for i, (depth, disp) in zip(sc, heads):
+                lv = ctx["lv"][i]
+                outs[i] = (lv["logits"], depth, disp) + ((lv["unc"],) if "unc" in lv else ())
         return outs, ctx
 
     def backward(self, ctx, g_depth, g_disp, g_unc=None):
@@ -576,16 +580,24 @@ class DepthDecoderRunner:
         gfeats = [None] * 5
         bwd_pool_reset(dev)
 
+        # logit gradients of every scale that received one, in one launch at the head of the backward
+        sc = [i for i in range(5) if i in m.scales and (g_depth.get(i) is not None or g_disp.get(i) is not None)]
+        dls = {}
+        if sc:
+            res = ops.depth_head_bwd_multi([ctx["lv"][i]["logits"] for i in sc], m.depth_bins,
+                                           [g_depth.get(i) for i in sc], [g_disp.get(i) for i in sc], K, m.min_depth,
+                                           m.max_depth, dt)
+            dls = dict(zip(sc, res))
+
         def disp_grad(i):
             """padded-domain gradient of y1p_i from its dispconv (or zeros)."""
             lv = ctx["lv"][i]
             y1p = lv["y1p"]
             G = None
-            if i in m.scales and (g_depth.get(i) is not None or g_disp.get(i) is not None):
+            if i in dls:
                 cld = self.disp[i]
                 opd = cld.ready(dt, dev)
-                dl = ops.depth_head_bwd(lv["logits"], m.depth_bins, g_depth.get(i), g_disp.get(i), K, m.min_depth,
-                                        m.max_depth, dt)
+                dl = dls[i]
                 cld.accumulate_param_grads(opd, dl, y1p)
                 G = opd.dgrad(dl, y1p.shape[1], y1p.shape[2])
             if i in self.unc and g_unc.get(i) is not None:

@@ -66,6 +66,14 @@ class FsAugArgs(C.Structure):
     ]
 
 
+class FsHeadBatch(C.Structure):
+    _fields_ = [
+        ("logits", C.c_void_p * 4), ("depth", C.c_void_p * 4), ("disp", C.c_void_p * 4),
+        ("d_depth", C.c_void_p * 4), ("d_disp", C.c_void_p * 4), ("dlogits", C.c_void_p * 4),
+        ("M", C.c_int64 * 4), ("n", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
 class FsResizeArgs(C.Structure):
     _fields_ = [
         ("src", C.c_void_p), ("dims", C.c_void_p), ("image", C.c_void_p),

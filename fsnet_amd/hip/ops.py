@@ -188,6 +188,44 @@ def depth_head_bwd(logits, bins, d_depth, d_disp, K, min_depth, max_depth, dtype
     return dl
 
 
+def depth_head_fwd_multi(logits_list, bins, K, min_depth, max_depth):
+    """[logits [N,H,W,Cl] fp32 per scale] -> [(depth, disp)] in one launch (<= 4 scales, same Cl)"""
+    from .binding import FsHeadBatch
+    hb = FsHeadBatch()
+    hb.n = len(logits_list)
+    Cl = logits_list[0].shape[3]
+    outs = []
+    for s, lg in enumerate(logits_list):
+        N, H, W, c = lg.shape
+        assert c == Cl and lg.dtype == torch.float32 and lg.is_contiguous()
+        depth = torch.empty(N, 1, H, W, dtype=torch.float32, device=lg.device)
+        disp = torch.empty(N, 1, H, W, dtype=torch.float32, device=lg.device)
+        hb.logits[s], hb.depth[s], hb.disp[s], hb.M[s] = lg.data_ptr(), depth.data_ptr(), disp.data_ptr(), N * H * W
+        outs.append((depth, disp))
+    check(lib.fs_depth_head_fwd_multi(C.byref(hb), bins.data_ptr(), K, Cl, float(min_depth), float(max_depth),
+                                      stream_ptr()), "depth_head_fwd_multi")
+    return outs
+
+
+def depth_head_bwd_multi(logits_list, bins, d_depths, d_disps, K, min_depth, max_depth, dtype):
+    """gradients of all scales' logits in one launch; d_depths / d_disps entries may be None"""
+    from .binding import FsHeadBatch
+    hb = FsHeadBatch()
+    hb.n = len(logits_list)
+    Cl = logits_list[0].shape[3]
+    outs = []
+    for s, lg in enumerate(logits_list):
+        N, H, W, c = lg.shape
+        assert c == Cl
+        dl = torch.empty(N, H, W, Cl, dtype=dtype, device=lg.device)
+        hb.logits[s], hb.dlogits[s], hb.M[s] = lg.data_ptr(), dl.data_ptr(), N * H * W
+        hb.d_depth[s], hb.d_disp[s] = _p(d_depths[s]), _p(d_disps[s])
+        outs.append(dl)
+    check(lib.fs_depth_head_bwd_multi(C.byref(hb), bins.data_ptr(), K, Cl, float(min_depth), float(max_depth),
+                                      dtype_code(dtype), stream_ptr()), "depth_head_bwd_multi")
+    return outs
+
+
 def pose_tail_fwd(x, nframes, invert, scale=0.01):
     B, h, w, Cx = x.shape
     aa = torch.empty(B, nframes, 1, 3, dtype=torch.float32, device=x.device)

@@ -36,6 +36,8 @@ SIGNATURES = {
     "fs_channel_sum": (C.c_int, [P, P, L, I, I, I, P]),
     "fs_depth_head_fwd": (C.c_int, [P, P, P, P, L, I, I, F, F, P]),
     "fs_depth_head_bwd": (C.c_int, [P, P, P, P, P, L, I, I, F, F, I, P]),
+    "fs_depth_head_fwd_multi": (C.c_int, [P, P, I, I, F, F, P]),
+    "fs_depth_head_bwd_multi": (C.c_int, [P, P, I, I, F, F, I, P]),
     "fs_pose_tail_fwd": (C.c_int, [P, P, P, P, I, I, I, I, I, F, P]),
     "fs_pose_tail_bwd": (C.c_int, [P, P, P, I, I, I, I, I, F, I, P]),
     "fs_photo_setup": (C.c_int, [P, P, P, P, I, P, P]),

@@ -330,6 +330,25 @@ int fs_depth_head_bwd(const float* logits, const float* bins, const float* d_dep
                       void* dlogits, int64_t M, int K, int Cl, float min_depth, float max_depth, int dtype,
                       void* stream);
 
+/* The same for up to FS_HEAD_MAX decoder scales in one launch (entries 0..n-1 are used; the backward leaves depth /
+ * disp unused, the forward d_depth / d_disp / dlogits; a NULL d_depth or d_disp means "no gradient from that output"). */
+#define FS_HEAD_MAX 4          /* = the array extents below */
+typedef struct FsHeadBatch {
+  const float* logits[4];
+  float* depth[4];
+  float* disp[4];
+  const float* d_depth[4];
+  const float* d_disp[4];
+  void* dlogits[4];
+  int64_t M[4];
+  int32_t n;
+  int32_t reserved;
+} FsHeadBatch;
+int fs_depth_head_fwd_multi(const FsHeadBatch* batch, const float* bins, int K, int Cl, float min_depth,
+                            float max_depth, void* stream);
+int fs_depth_head_bwd_multi(const FsHeadBatch* batch, const float* bins, int K, int Cl, float min_depth,
+                            float max_depth, int dtype, void* stream);
+
 /* Pose tail: x = last pose conv output fp32 [B][hw][Cx]; mean over hw, x0.01, split into
  * axisangle / translation [B][nframes][3] (pose_decoder.py:39-45) and the 4x4 transform of frame 0
  * (transformation_from_parameters, monodepth_utils.py:31-63,298-337; invert for negative frame ids,

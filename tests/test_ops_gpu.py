@@ -212,6 +212,28 @@ def test_depth_head_golden_and_grad(dev):
     assert (nchw(dl) - lr.grad).abs().max() < 1e-4 * lr.grad.abs().max()
 
 
+def test_depth_head_multi_scale_launch_equals_per_scale(dev):
+    """fs_depth_head_fwd_multi / bwd_multi (all decoder scales in one launch) give bit-identical results to the
+    per-scale entry points, with missing gradients (None) and ragged sizes"""
+    from fsnet_amd.hip import ops
+    g = torch.Generator().manual_seed(4)
+    bins = torch.logspace(-0.3, 2.0, 16).to(dev)
+    shapes = [(2, 24, 40), (2, 12, 20), (2, 6, 10), (2, 3, 5)]
+    logits = [(torch.randn(n, h, w, 16, generator=g) * 6).to(dev) for n, h, w in shapes]
+    multi = ops.depth_head_fwd_multi(logits, bins, 16, 0.5, 100.0)
+    for lg, (depth, disp) in zip(logits, multi):
+        d1, p1 = ops.depth_head_fwd(lg, bins, 16, 0.5, 100.0)
+        assert torch.equal(depth, d1) and torch.equal(disp, p1)
+    gds = [torch.randn(n, 1, h, w, generator=g).to(dev) for n, h, w in shapes]
+    gps = [torch.randn(n, 1, h, w, generator=g).to(dev) for n, h, w in shapes]
+    gds[1], gps[2] = None, None
+    for dt in (torch.float32, torch.bfloat16):
+        dls = ops.depth_head_bwd_multi(logits, bins, gds, gps, 16, 0.5, 100.0, dt)
+        for lg, a, b, dl in zip(logits, gds, gps, dls):
+            assert torch.equal(dl, ops.depth_head_bwd(lg, bins, a, b, 16, 0.5, 100.0, dt))
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("invert", [False, True])
 def test_pose_tail(dev, invert):
     from fsnet_amd.hip import ops
