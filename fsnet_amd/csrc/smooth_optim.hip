@@ -118,7 +118,8 @@ __global__ __launch_bounds__(256) void smooth_bwd_apply_kernel(const FsSmoothArg
 
 // loss assembly: out[0..S) = loss/s (f64), out[S..2S) = smooth_loss/s, out[2S] = total
 __global__ void loss_finalize_kernel(const double* __restrict__ loss_sums, const double* __restrict__ mask_sum,
-                                     const double* __restrict__ sm_sums, const FsSmoothArgs p, double* __restrict__ out) {
+                                     const double* __restrict__ sm_sums, const FsSmoothArgs p, double* __restrict__ out,
+                                     double* __restrict__ total_out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double total = 0.0, msum = 0.0;
   for (int b = 0; b < p.B; ++b) msum += mask_sum[b];
@@ -134,6 +135,7 @@ __global__ void loss_finalize_kernel(const double* __restrict__ loss_sums, const
     total += l;
   }
   out[2 * p.S] = total / (double)p.S;
+  if (total_out) *total_out = total / (double)p.S;     // the scalar the caller differentiates: no device copy needed
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -235,9 +237,10 @@ extern "C" int fs_smooth_bwd(const FsSmoothArgs* a, void* stream) {
   return fs_launch_status();
 }
 extern "C" int fs_loss_finalize(const double* loss_sums, const double* mask_sum, const double* sm_sums,
-                                const FsSmoothArgs* a, double* out, void* stream) {
+                                const FsSmoothArgs* a, double* out, double* total_out, void* stream) {
   if (!loss_sums || !mask_sum || !sm_sums || !a || !out) return FS_EINVAL;
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), loss_sums, mask_sum, sm_sums, *a, out);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), loss_sums, mask_sum, sm_sums, *a, out,
+                     total_out);
   return fs_launch_status();
 }
 

@@ -362,8 +362,12 @@ class PhotometricLoss:
         _timed("photo_loss_fwd", fwd_bytes * 0.5, lambda: check(lib.fs_photo_loss_fwd(pa, st), "photo_loss_fwd"))
         check(lib.fs_smooth_mean(sa, st), "smooth_mean")
         check(lib.fs_smooth_fwd(sa, st), "smooth_fwd")
+        # fresh result tensors per call (the previous step's stay valid for whoever kept them) — the kernel writes
+        # the per-scale vector and the scalar the caller differentiates, so nothing has to be cloned on the device
+        self.out = torch.empty(2 * self.S + 1, dtype=torch.float64, device=img0.device)
+        self.total = torch.empty((), dtype=torch.float64, device=img0.device)
         check(lib.fs_loss_finalize(self.loss_sums.data_ptr(), self.mask_sum.data_ptr(), self.sm_sums.data_ptr(), sa,
-                                   self.out.data_ptr(), st), "loss_finalize")
+                                   self.out.data_ptr(), self.total.data_ptr(), st), "loss_finalize")
         return self.out
 
     def backward(self, gout=None):

@@ -53,7 +53,7 @@ SIGNATURES = {
     "fs_smooth_mean": (C.c_int, [P, P]),
     "fs_smooth_fwd": (C.c_int, [P, P]),
     "fs_smooth_bwd": (C.c_int, [P, P]),
-    "fs_loss_finalize": (C.c_int, [P, P, P, P, P, P]),
+    "fs_loss_finalize": (C.c_int, [P, P, P, P, P, P, P]),
     "fs_sumsq": (C.c_int, [P, L, P, P, P]),
     "fs_counter_incr": (C.c_int, [P, P]),
     "fs_adam_step": (C.c_int, [P, P, P, P, L, F, F, F, F, F, I, F, P, F, P, P, P]),

@@ -24,9 +24,9 @@ class _PhotoLossFn(torch.autograd.Function):
                          P2.contiguous().float(), [T_a.contiguous().float(), T_b.contiguous().float()], patched_mask,
                          depths, disps, noise_seed=seed)
         ctx.pl, ctx.S = pl, S
-        vec = out.clone()
+        vec = out                       # fresh tensors of this call (ops.PhotometricLoss.forward): no copies
         ctx.mark_non_differentiable(vec)
-        return vec[2 * S].clone(), vec
+        return pl.total, vec
 
     @staticmethod
     def backward(ctx, g_total, _g_vec):

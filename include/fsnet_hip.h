@@ -422,7 +422,7 @@ int fs_smooth_mean(const FsSmoothArgs* args, void* stream);
 int fs_smooth_fwd(const FsSmoothArgs* args, void* stream);
 int fs_smooth_bwd(const FsSmoothArgs* args, void* stream);
 int fs_loss_finalize(const double* loss_sums, const double* mask_sum, const double* sm_sums,
-                     const FsSmoothArgs* args, double* out, void* stream);
+                     const FsSmoothArgs* args, double* out, double* total_out, void* stream);
 
 /* Optimizer over a flat fp32 arena: global grad sum-of-squares, then clip + Adam in one pass
  * (clip_grad_norm_ + torch.optim.Adam.step, base_training_hooks.py:46-49; optimizers.py:7-8).
