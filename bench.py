@@ -171,13 +171,18 @@ def main():
         extra["conv_wgrad"] = {"achieved_tflops": round(tf(wg), 2), "launches_per_step": wg[0] // nprof,
                                "avg_launch_us": round(wg[2] / wg[0] * 1e6, 2)}
         allc = [ch, cg, wg]
+        if "conv_stem" in agg:      # 7x7 stems (forward) have their own kernel
+            cs = agg["conv_stem"]
+            extra["conv_stem"] = {"achieved_tflops": round(tf(cs), 2), "launches_per_step": cs[0] // nprof,
+                                  "avg_launch_us": round(cs[2] / cs[0] * 1e6, 2)}
+            allc.append(cs)
         extra["conv_all"] = {"achieved_tflops": round(sum(a[1] for a in allc) / sum(a[2] for a in allc) / 1e12, 2),
                              "frac_mfma_peak": round(sum(a[1] for a in allc) / sum(a[2] for a in allc) / 1e12 / PEAK_TFLOPS[args.dtype], 4)}
         for k in ("photo_warp", "photo_loss_fwd", "photo_loss_bwd"):
             a = agg[k]
             extra[k] = {"algorithmic_GBps": round(a[1] / a[2] / 1e9, 1), "frac_hbm_peak": round(a[1] / a[2] / 1e9 / PEAK_HBM_GBS, 4),
                         "avg_launch_us": round(a[2] / a[0] * 1e6, 2)}
-        conv_time = (ch[2] + cg[2] + wg[2]) / nprof
+        conv_time = sum(a[2] for a in allc) / nprof
         extra["conv_time_ms_per_step"] = round(conv_time * 1e3, 3)
 
     if rank == 0:
