@@ -116,26 +116,36 @@ __global__ __launch_bounds__(256) void smooth_bwd_apply_kernel(const FsSmoothArg
     dd[i] = dd[i] * inv - corr;        // dd holds dnd from pass 1
 }
 
-// loss assembly: out[0..S) = loss/s (f64), out[S..2S) = smooth_loss/s, out[2S] = total
-__global__ void loss_finalize_kernel(const double* __restrict__ loss_sums, const double* __restrict__ mask_sum,
-                                     const double* __restrict__ sm_sums, const FsSmoothArgs p, double* __restrict__ out,
-                                     double* __restrict__ total_out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double total = 0.0, msum = 0.0;
-  for (int b = 0; b < p.B; ++b) msum += mask_sum[b];
+// loss assembly: out[0..S) = loss/s (f64), out[S..2S) = smooth_loss/s, out[2S] = total.  One wave: lane b sums batch
+// element b (b, b + 64, ...), wave sums combine them — the single-thread version walked ~100 dependent loads (9 us on
+// the serial path between the loss forward and backward).
+__global__ __launch_bounds__(64) void loss_finalize_kernel(const double* __restrict__ loss_sums,
+                                                           const double* __restrict__ mask_sum,
+                                                           const double* __restrict__ sm_sums, const FsSmoothArgs p,
+                                                           double* __restrict__ out, double* __restrict__ total_out) {
+  const int lane = threadIdx.x;
+  double msum = 0.0;
+  for (int b = lane; b < p.B; b += 64) msum += mask_sum[b];
+  msum = wave_sum_d(msum);
+  double total = 0.0;
   for (int s = 0; s < p.S; ++s) {
     const int h = p.h[s], w = p.w[s];
     double ax = 0.0, ay = 0.0, ls = 0.0;
-    for (int b = 0; b < p.B; ++b) { ax += sm_sums[(s * p.B + b) * 2]; ay += sm_sums[(s * p.B + b) * 2 + 1]; ls += loss_sums[s * p.B + b]; }
+    for (int b = lane; b < p.B; b += 64) {
+      ax += sm_sums[(s * p.B + b) * 2]; ay += sm_sums[(s * p.B + b) * 2 + 1]; ls += loss_sums[s * p.B + b];
+    }
+    ax = wave_sum_d(ax); ay = wave_sum_d(ay); ls = wave_sum_d(ls);
     float sx = (float)(ax / (double)((long)p.B * h * (w - 1)));
     float sy = (float)(ay / (double)((long)p.B * (h - 1) * w));
     float sm = (sx + sy) * 1e-5f / (float)(1 << p.scale_id[s]);   // fp32 like the reference's smooth_loss
     double l = ls / (msum + 1e-6) + (double)sm;
-    out[s] = l; out[p.S + s] = (double)sm;
+    if (lane == 0) { out[s] = l; out[p.S + s] = (double)sm; }
     total += l;
   }
-  out[2 * p.S] = total / (double)p.S;
-  if (total_out) *total_out = total / (double)p.S;     // the scalar the caller differentiates: no device copy needed
+  if (lane == 0) {
+    out[2 * p.S] = total / (double)p.S;
+    if (total_out) *total_out = total / (double)p.S;     // the scalar the caller differentiates: no device copy needed
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
