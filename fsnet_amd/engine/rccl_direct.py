@@ -97,11 +97,13 @@ class DirectComm(object):
         if status != 0:
             raise RuntimeError("%s failed: %s" % (what, lib.ncclGetErrorString(status).decode()))
 
-    def all_reduce_sum(self, t):
-        """in-place SUM over the ranks, enqueued on the current HIP stream"""
+    def all_reduce_sum(self, t, out=None):
+        """SUM over the ranks into `out` (default: in place), enqueued on the current HIP stream"""
         from ..hip.binding import raw_stream
         assert t.is_cuda and t.is_contiguous()
-        self._check(self.lib, self.lib.ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), NCCL_DTYPE[t.dtype], NCCL_SUM,
+        dst = t if out is None else out
+        assert dst.is_contiguous() and dst.numel() == t.numel() and dst.dtype == t.dtype
+        self._check(self.lib, self.lib.ncclAllReduce(t.data_ptr(), dst.data_ptr(), t.numel(), NCCL_DTYPE[t.dtype], NCCL_SUM,
                                                      self.comm, C.c_void_p(raw_stream(t.device.index))), "ncclAllReduce")
 
     def _self_test(self, group):

@@ -112,9 +112,11 @@ def bn_backward(dout, y, x, gamma, st, dx, dgamma, dbeta, H, W, relu=True, fold=
         _timed("bn_bwd_reduce", nb * (2 + (y is not None)),
                lambda: check(lib.fs_bn_bwd_reduce(C.byref(a), code, stream_ptr()), "bn_bwd_reduce"), tag=shp)
     if allreduce is not None:
-        local = sums.clone()
-        a.sums_local = local.data_ptr()
-        allreduce(sums)
+        # SyncBN: dgamma / dbeta come from the local sums, dx from the global ones — reduce out of place instead
+        # of cloning the local copy first (one device copy per BatchNorm and step)
+        glob = torch.empty_like(sums)
+        allreduce(sums, out=glob)
+        a.sums_local, a.sums = sums.data_ptr(), glob.data_ptr()
     _timed("bn_bwd_apply", nb * (3 + (y is not None) + (g_out is not None)),
            lambda: check(lib.fs_bn_bwd_apply(C.byref(a), code, stream_ptr()), "bn_bwd_apply"), tag=shp)
     return dx

@@ -13,6 +13,13 @@ model = build(**meta_arch_cfg(192, 640, with_pose=True)).to(dev).train()
 tc = training_cfg(clip_gradients=35.0, lr=1e-4)
 opt = build_optimizer(model, **tc.optimizer)
 hook = build(use_graph=False, **tc.training_hook)
+if os.environ.get("FSNET_PROF_DP", "0") != "0":     # data-parallel bookkeeping at world size 1 over RCCL
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    from fsnet_amd.engine.dataparallel import DataParallelContext
+    model.ensure_arena()
+    RT.dp = DataParallelContext(model)
 batches = bench.synthetic_device_batches(12, 192, 640, dev, 0)
 for i in range(4):
     hook(dict(batches[i % len(batches)]), model, opt)
