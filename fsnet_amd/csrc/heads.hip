@@ -14,9 +14,13 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // depth head: one lane per pixel, K logits (fp32) contiguous per pixel
 // ---------------------------------------------------------------------------------------------
+// sc: per-image depth scale P2[0,0] / base_fx (DepthDecoder._get_scale, depth_encoder.py:36-43) or 0 = none; with a
+// scale the depth is the expectation x sc and the disparity is taken against (min x sc, max x sc) (gather_output
+// :115-121)
 template <int K>
 __device__ __forceinline__ void head_fwd_row(const float* __restrict__ logits, const float* sb, float* __restrict__ depth,
-                                             float* __restrict__ disp, long m, int Cl, float inv_rng, float max_d) {
+                                             float* __restrict__ disp, long m, int Cl, float inv_rng, float max_d,
+                                             float sc = 0.f, float min_d = 0.f) {
   float v[K];
   float mx = -INFINITY;
 #pragma unroll
@@ -30,6 +34,13 @@ __device__ __forceinline__ void head_fwd_row(const float* __restrict__ logits, c
 #pragma unroll
   for (int k = 0; k < K; ++k) { float e = expf(v[k] - mx); se += e; sd += e * sb[k]; }
   float d = sd / se;
+  if (sc != 0.f) {
+    d = d * sc;
+    const float mn = min_d * sc, mx2 = max_d * sc;
+    depth[m] = d;
+    disp[m] = (1.f / d - 1.f / mx2) / (1.f / mn - 1.f / mx2);
+    return;
+  }
   depth[m] = d;
   disp[m] = (1.f / d - 1.f / max_d) * inv_rng;
 }
@@ -37,7 +48,8 @@ __device__ __forceinline__ void head_fwd_row(const float* __restrict__ logits, c
 template <int K, typename T>
 __device__ __forceinline__ void head_bwd_row(const float* __restrict__ logits, const float* sb,
                                              const float* __restrict__ d_depth, const float* __restrict__ d_disp,
-                                             T* __restrict__ dlogits, long m, int Cl, float inv_rng) {
+                                             T* __restrict__ dlogits, long m, int Cl, float inv_rng,
+                                             float sc = 0.f, float min_d = 0.f, float max_d = 0.f) {
   float v[K], raw[K];
   float mx = -INFINITY;
 #pragma unroll
@@ -52,7 +64,12 @@ __device__ __forceinline__ void head_bwd_row(const float* __restrict__ logits, c
   for (int k = 0; k < K; ++k) { v[k] = expf(v[k] - mx); se += v[k]; sd += v[k] * sb[k]; }
   float d = sd / se;
   float g = (d_depth ? d_depth[m] : 0.f);
-  if (d_disp) g += d_disp[m] * (-inv_rng / (d * d));
+  if (sc != 0.f) {
+    // depth = d sc, disp = (1/depth - 1/(max sc)) / (1/(min sc) - 1/(max sc))
+    const float ds = d * sc;
+    if (d_disp) g += d_disp[m] * (-1.f / (ds * ds)) / (1.f / (min_d * sc) - 1.f / (max_d * sc));
+    g *= sc;
+  } else if (d_disp) g += d_disp[m] * (-inv_rng / (d * d));
   float o[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -106,8 +123,11 @@ __global__ __launch_bounds__(256) void depth_head_fwd_multi_kernel(const FsHeadB
   int s = 0;
   while (s + 1 < hb.n && (int)blockIdx.x >= blk.start[s + 1]) ++s;
   const long nb = blk.start[s + 1] - blk.start[s], lb = blockIdx.x - blk.start[s];
-  for (long m = lb * 256 + threadIdx.x; m < hb.M[s]; m += nb * 256)
-    head_fwd_row<K>(hb.logits[s], sb, hb.depth[s], hb.disp[s], m, Cl, inv_rng, max_d);
+  const long rows_img = hb.nimg > 0 ? hb.M[s] / hb.nimg : 0;
+  for (long m = lb * 256 + threadIdx.x; m < hb.M[s]; m += nb * 256) {
+    const float sc = hb.P2 ? hb.P2[(m / rows_img) * 12] / hb.base_fx : 0.f;
+    head_fwd_row<K>(hb.logits[s], sb, hb.depth[s], hb.disp[s], m, Cl, inv_rng, max_d, sc, min_d);
+  }
 }
 
 template <int K, typename T>
@@ -121,8 +141,12 @@ __global__ __launch_bounds__(256) void depth_head_bwd_multi_kernel(const FsHeadB
   int s = 0;
   while (s + 1 < hb.n && (int)blockIdx.x >= blk.start[s + 1]) ++s;
   const long nb = blk.start[s + 1] - blk.start[s], lb = blockIdx.x - blk.start[s];
-  for (long m = lb * 256 + threadIdx.x; m < hb.M[s]; m += nb * 256)
-    head_bwd_row<K, T>(hb.logits[s], sb, hb.d_depth[s], hb.d_disp[s], reinterpret_cast<T*>(hb.dlogits[s]), m, Cl, inv_rng);
+  const long rows_img = hb.nimg > 0 ? hb.M[s] / hb.nimg : 0;
+  for (long m = lb * 256 + threadIdx.x; m < hb.M[s]; m += nb * 256) {
+    const float sc = hb.P2 ? hb.P2[(m / rows_img) * 12] / hb.base_fx : 0.f;
+    head_bwd_row<K, T>(hb.logits[s], sb, hb.d_depth[s], hb.d_disp[s], reinterpret_cast<T*>(hb.dlogits[s]), m, Cl, inv_rng,
+                       sc, min_d, max_d);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -272,9 +296,11 @@ extern "C" int fs_depth_head_bwd(const float* logits, const float* bins, const f
 namespace {
 bool head_blocks(const FsHeadBatch* hb, bool bwd, HeadBlocks& blk, int& total) {
   if (!hb || hb->n < 1 || hb->n > FS_HEAD_MAX) return false;
+  if (hb->P2 && (hb->nimg < 1 || !(hb->base_fx > 0.f))) return false;
   total = 0;
   for (int s = 0; s < hb->n; ++s) {
     if (!hb->logits[s] || hb->M[s] <= 0) return false;
+    if (hb->P2 && hb->M[s] % hb->nimg != 0) return false;
     if (bwd ? !hb->dlogits[s] : (!hb->depth[s] || !hb->disp[s])) return false;
     blk.start[s] = total;
     total += grid_for(hb->M[s]);

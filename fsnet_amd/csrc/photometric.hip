@@ -26,12 +26,14 @@ __device__ __forceinline__ int refl(int i, int n) { return i < 0 ? -i : (i >= n 
 // ---------------------------------------------------------------------------------------------
 __global__ void photo_setup_kernel(const float* __restrict__ P2, const float* __restrict__ T0,
                                    const float* __restrict__ T1, float* __restrict__ geo, int B,
-                                   int* __restrict__ seed_counter) {
+                                   int* __restrict__ seed_counter, int fisheye) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (seed_counter && b == 0) *seed_counter += 1;      // tie-break noise seed of this step (read by the loss forward)
   if (b >= B) return;
   double k[3][3];
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) k[i][j] = (double)P2[b * 12 + i * 4 + j];
+  // fisheye: the transform acts on the ray-table point directly (monodepth2_decoder.py:379-381), the camera model
+  // follows it (cam2image) -> "K" is the identity here, P_f = T_f[:3], and fs_photo_pose_grad's K^T dP is dT itself
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) k[i][j] = fisheye ? (i == j ? 1.0 : 0.0) : (double)P2[b * 12 + i * 4 + j];
   double c00 = k[1][1] * k[2][2] - k[1][2] * k[2][1];
   double c01 = k[1][2] * k[2][0] - k[1][0] * k[2][2];
   double c02 = k[1][0] * k[2][1] - k[1][1] * k[2][0];
@@ -61,13 +63,53 @@ __global__ void photo_setup_kernel(const float* __restrict__ P2, const float* __
 // shared per-pixel geometry: depth upsample -> backproject -> project -> sample coordinates
 // ---------------------------------------------------------------------------------------------
 struct Geo {
-  float D;             // upsampled depth
+  float D;             // upsampled depth (fisheye: ray norm)
   int y0, x0, y1, x1;  // low-res taps
   float ly, lx;        // low-res lambdas
-  float r[3];          // K^-1 [x y 1]
-  float X, Y, Zp;      // projected point, Zp = Z + eps
+  float r[3];          // K^-1 [x y 1]  (fisheye: the ray-table entry X, Y, Z of the pixel)
+  float X, Y, Zp;      // projected point, Zp = Z + eps  (fisheye: the transformed point, no eps)
   float ixu, iyu;      // unnormalised (unclamped) sample coordinates
 };
+
+// Mei unified camera model, _cam2image + mei_distort (mei_fisheye_utils.py:14-51) in the reference's fp32 operation
+// order.  m = {k1, k2, xi, gamma1, gamma2, u0, v0}.
+__device__ __forceinline__ void mei_cam2image(const float* __restrict__ m, float qx, float qy, float qz, float& u,
+                                              float& v) {
+  const float eps = 1e-6f;
+  float n = sqrtf(qx * qx + qy * qy + qz * qz);
+  float s = n + eps;
+  float x = qx / s, y = qy / s, z = qz / s;
+  float a = z + m[2] + eps;
+  x = x / a; y = y / a;
+  float ro2 = x * x + y * y;
+  float d = 1.f + m[0] * ro2 + m[1] * ro2 * ro2;
+  u = m[3] * (x * d) + m[5];
+  v = m[4] * (y * d) + m[6];
+}
+
+// reverse mode of mei_cam2image: (gu, gv) = d loss / d (u, v)  ->  d loss / d q
+__device__ __forceinline__ void mei_cam2image_bwd(const float* __restrict__ m, float qx, float qy, float qz, float gu,
+                                                  float gv, float (&dq)[3]) {
+  const float eps = 1e-6f;
+  float n = sqrtf(qx * qx + qy * qy + qz * qz);
+  float s = n + eps;
+  float xs = qx / s, ys = qy / s, zs = qz / s;
+  float a = zs + m[2] + eps;
+  float xm = xs / a, ym = ys / a;
+  float ro2 = xm * xm + ym * ym;
+  float d = 1.f + m[0] * ro2 + m[1] * ro2 * ro2;
+  float g_xd = m[3] * gu, g_yd = m[4] * gv;
+  float g_d = g_xd * xm + g_yd * ym;
+  float g_ro2 = g_d * (m[0] + 2.f * m[1] * ro2);
+  float g_xm = g_xd * d + g_ro2 * 2.f * xm, g_ym = g_yd * d + g_ro2 * 2.f * ym;
+  float g_xs = g_xm / a, g_ys = g_ym / a;
+  float g_zs = -(g_xm * xm + g_ym * ym) / a;
+  float g_s = -(g_xs * xs + g_ys * ys + g_zs * zs) / s;
+  float inv_n = n > 0.f ? 1.f / n : 0.f;
+  dq[0] = g_xs / s + g_s * qx * inv_n;
+  dq[1] = g_ys / s + g_s * qy * inv_n;
+  dq[2] = g_zs / s + g_s * qz * inv_n;
+}
 
 __device__ __forceinline__ void upsample_taps(int y, int x, int H, int W, int h, int w, Geo& g) {
   // ATen upsample_bilinear2d, align_corners=True: scale = (in-1)/(out-1)
@@ -79,17 +121,34 @@ __device__ __forceinline__ void upsample_taps(int y, int x, int H, int W, int h,
   g.ly = fy - (float)g.y0; g.lx = fx - (float)g.x0;
 }
 
-__device__ __forceinline__ void project_pixel(const float* __restrict__ depth, int b, int y, int x, int H, int W,
-                                              int h, int w, const float* __restrict__ ge, int f, Geo& g) {
+__device__ __forceinline__ void project_pixel(const FsPhotoArgs& p, const float* __restrict__ depth, int b, int y,
+                                              int x, int H, int W, int h, int w, const float* __restrict__ ge, int f,
+                                              Geo& g) {
   upsample_taps(y, x, H, W, h, w, g);
   const float* d = depth + (long)b * h * w;
   float d00 = d[g.y0 * w + g.x0], d01 = d[g.y0 * w + g.x1], d10 = d[g.y1 * w + g.x0], d11 = d[g.y1 * w + g.x1];
   g.D = (1.f - g.ly) * ((1.f - g.lx) * d00 + g.lx * d01) + g.ly * ((1.f - g.lx) * d10 + g.lx * d11);
+  const float* P = ge + 18 + f * 12;
+  if (p.lut_ptrs) {
+    // FishEyeDecoder._generate_images_pred (monodepth2_decoder.py:355-387): point = ray table x norm, T, cam2image
+    const float* lut = p.lut_ptrs[b];
+    const long HW = (long)H * W, o = (long)y * W + x;
+    g.r[0] = lut[o]; g.r[1] = lut[HW + o]; g.r[2] = lut[2 * HW + o];
+    float cx = g.r[0] * g.D, cy = g.r[1] * g.D, cz = g.r[2] * g.D;
+    g.X = P[0] * cx + P[1] * cy + P[2] * cz + P[3];
+    g.Y = P[4] * cx + P[5] * cy + P[6] * cz + P[7];
+    g.Zp = P[8] * cx + P[9] * cy + P[10] * cz + P[11];
+    float u, v;
+    mei_cam2image(p.mei + (long)b * 8, g.X, g.Y, g.Zp, u, v);
+    float un = u / (float)max(W - 1, 1) * 2.f - 1.f, vn = v / (float)max(H - 1, 1) * 2.f - 1.f;
+    g.ixu = (un + 1.f) * 0.5f * (float)(W - 1);
+    g.iyu = (vn + 1.f) * 0.5f * (float)(H - 1);
+    return;
+  }
   float px = (float)x, py = (float)y;
   g.r[0] = ge[0] * px + ge[1] * py + ge[2];
   g.r[1] = ge[3] * px + ge[4] * py + ge[5];
   g.r[2] = ge[6] * px + ge[7] * py + ge[8];
-  const float* P = ge + 18 + f * 12;
   float cx = g.D * g.r[0], cy = g.D * g.r[1], cz = g.D * g.r[2];
   g.X = P[0] * cx + P[1] * cy + P[2] * cz + P[3];
   g.Y = P[4] * cx + P[5] * cy + P[6] * cz + P[7];
@@ -178,7 +237,7 @@ __global__ __launch_bounds__(256) void photo_warp_kernel(const FsPhotoArgs p) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
     int y = (int)(i / p.W), x = (int)(i % p.W);
     Geo g;
-    project_pixel(p.depth[s], b, y, x, p.H, p.W, p.dh[s], p.dw[s], ge, f, g);
+    project_pixel(p, p.depth[s], b, y, x, p.H, p.W, p.dh[s], p.dw[s], ge, f, g);
     Taps t;
     bilinear_taps(g.ixu, g.iyu, p.H, p.W, t);
 #pragma unroll
@@ -192,7 +251,11 @@ __global__ __launch_bounds__(256) void photo_warp_kernel(const FsPhotoArgs p) {
     float xn = nearbyintf(g.ixu), yn = nearbyintf(g.iyu);
     bool inb = xn >= 0.f && xn <= (float)(p.W - 1) && yn >= 0.f && yn <= (float)(p.H - 1);
     float mv = 0.f;
-    if (inb) mv = p.patched_mask ? (float)p.patched_mask[(long)b * HW + (long)yn * p.W + (long)xn] : 1.f;
+    if (inb) {
+      const long o = (long)b * HW + (long)yn * p.W + (long)xn;
+      // fisheye: patched_mask x ray-table mask as one float plane (monodepth2_decoder.py:409)
+      mv = p.warp_mask ? p.warp_mask[o] : (p.patched_mask ? (float)p.patched_mask[o] : 1.f);
+    }
     ov[i] = (mv == 1.f) ? 1 : 0;
   }
 }
@@ -516,7 +579,7 @@ __global__ __launch_bounds__(256) void photo_loss_bwd_kernel(const FsPhotoArgs p
     for (int k = 0; k < 12; ++k) dP[k] = 0.f;
     if (qin && (dpred[f][0] != 0.f || dpred[f][1] != 0.f || dpred[f][2] != 0.f)) {
       Geo gq;
-      project_pixel(p.depth[s], b, qy, qx, H, W, p.dh[s], p.dw[s], ge, f, gq);
+      project_pixel(p, p.depth[s], b, qy, qx, H, W, p.dh[s], p.dw[s], ge, f, gq);
       Taps t;
       bilinear_taps(gq.ixu, gq.iyu, H, W, t);
       const float* src = p.img_src[f] + (long)b * 3 * HW;
@@ -530,9 +593,16 @@ __global__ __launch_bounds__(256) void photo_loss_bwd_kernel(const FsPhotoArgs p
         giy += dpred[f][c] * ((v10 - v00) * (1.f - t.wx) + (v11 - v01) * t.wx);
       }
       float du = gix * t.mx, dv = giy * t.my;   // (W-1)/2 of the sampler cancels 2/(W-1) of Project3D
-      float iz = 1.f / gq.Zp;
-      float dX = du * iz, dY = dv * iz;
-      float dZ = -(du * gq.X + dv * gq.Y) * iz * iz;
+      float dX, dY, dZ;
+      if (p.lut_ptrs) {
+        float dq[3];
+        mei_cam2image_bwd(p.mei + (long)b * 8, gq.X, gq.Y, gq.Zp, du, dv, dq);
+        dX = dq[0]; dY = dq[1]; dZ = dq[2];
+      } else {
+        float iz = 1.f / gq.Zp;
+        dX = du * iz; dY = dv * iz;
+        dZ = -(du * gq.X + dv * gq.Y) * iz * iz;
+      }
       const float* P = ge + 18 + f * 12;
       float pr0 = P[0] * gq.r[0] + P[1] * gq.r[1] + P[2] * gq.r[2];
       float pr1 = P[4] * gq.r[0] + P[5] * gq.r[1] + P[6] * gq.r[2];
@@ -633,16 +703,18 @@ __global__ __launch_bounds__(256) void photo_pose_grad_kernel(const float* __res
 bool valid(const FsPhotoArgs* a) {
   if (!a || !a->img0 || !a->img_src[0] || !a->img_src[1] || !a->geo) return false;
   if (a->S < 1 || a->S > 4 || a->B < 1 || a->H < 2 || a->W < 2) return false;
+  if ((a->lut_ptrs != nullptr) != (a->mei != nullptr)) return false;   // the ray tables come with their parameters
   return true;
 }
 
 }  // namespace
 
 extern "C" int fs_photo_setup(const float* P2, const float* T0, const float* T1, float* geo, int B, int* seed_counter,
-                              void* stream) {
+                              int fisheye, void* stream) {
   if (!P2 || !T0 || !T1 || !geo) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(photo_setup_kernel, dim3((B + 63) / 64), dim3(64), 0, st, P2, T0, T1, geo, B, seed_counter);
+  hipLaunchKernelGGL(photo_setup_kernel, dim3((B + 63) / 64), dim3(64), 0, st, P2, T0, T1, geo, B, seed_counter,
+                     fisheye);
   return fs_launch_status();
 }
 

@@ -512,8 +512,9 @@ class DepthDecoderRunner:
                     for s in module.scales if ("uncertain_logz", s) in module.convs}
         self.pool = None
 
-    def forward(self, feats, train, depth_scale=None):
-        """feats: 5 NHWC dense tensors.  Returns ({scale: (logits, depth, disp[, uncertain_z])}, ctx)."""
+    def forward(self, feats, train, P2=None):
+        """feats: 5 NHWC dense tensors.  Returns ({scale: (logits, depth, disp[, uncertain_z])}, ctx).
+        P2 ([N,3,4] fp32 on the device) with module.base_fx set: focal-length depth scaling (depth_encoder.py:36-43)."""
         m = self.m
         dev, dt = feats[-1].device, feats[-1].dtype
         if self.pool is None or self.pool.buf.device != dev:
@@ -521,7 +522,12 @@ class DepthDecoderRunner:
         self.pool.reset()
         if train:
             _check_train_bn(self.up0[4][1], "DepthDecoder")
-        ctx = {"lv": {}, "feats": feats}
+        base_fx = getattr(m, "base_fx", None)
+        if base_fx is None or P2 is None:
+            P2, base_fx = None, None
+        else:
+            P2 = P2.detach().to(dev, torch.float32).contiguous()
+        ctx = {"lv": {}, "feats": feats, "P2": P2, "base_fx": base_fx}
         outs = {}
         x = feats[-1]
         K = int(m.num_output_channels)
@@ -564,7 +570,7 @@ class DepthDecoderRunner:
         sc = [i for i in range(4, -1, -1) if "logits" in ctx["lv"][i]]
         if sc:
             heads = ops.depth_head_fwd_multi([ctx["lv"][i]["logits"] for i in sc], m.depth_bins, K, m.min_depth,
-                                             m.max_depth)
+                                             m.max_depth, P2=P2, base_fx=base_fx)
             for i, (depth, disp) in zip(sc, heads):
                 lv = ctx["lv"][i]
                 outs[i] = (lv["logits"], depth, disp) + ((lv["unc"],) if "unc" in lv else ())
@@ -586,7 +592,7 @@ class DepthDecoderRunner:
         if sc:
             res = ops.depth_head_bwd_multi([ctx["lv"][i]["logits"] for i in sc], m.depth_bins,
                                            [g_depth.get(i) for i in sc], [g_disp.get(i) for i in sc], K, m.min_depth,
-                                           m.max_depth, dt)
+                                           m.max_depth, dt, P2=ctx["P2"], base_fx=ctx["base_fx"])
             dls = dict(zip(sc, res))
 
         def disp_grad(i):

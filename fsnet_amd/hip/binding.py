@@ -70,7 +70,8 @@ class FsHeadBatch(C.Structure):
     _fields_ = [
         ("logits", C.c_void_p * 4), ("depth", C.c_void_p * 4), ("disp", C.c_void_p * 4),
         ("d_depth", C.c_void_p * 4), ("d_disp", C.c_void_p * 4), ("dlogits", C.c_void_p * 4),
-        ("M", C.c_int64 * 4), ("n", C.c_int32), ("reserved", C.c_int32),
+        ("M", C.c_int64 * 4), ("n", C.c_int32), ("nimg", C.c_int32), ("P2", C.c_void_p), ("base_fx", C.c_float),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -123,6 +124,7 @@ class FsPhotoArgs(C.Structure):
         ("dh", C.c_int32 * 4), ("dw", C.c_int32 * 4),
         ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("S", C.c_int32),
         ("noise_seed", C.c_int32), ("noise_seed_ptr", C.c_void_p),
+        ("lut_ptrs", C.c_void_p), ("mei", C.c_void_p), ("warp_mask", C.c_void_p),
     ]
 
 

@@ -190,10 +190,20 @@ def depth_head_bwd(logits, bins, d_depth, d_disp, K, min_depth, max_depth, dtype
     return dl
 
 
-def depth_head_fwd_multi(logits_list, bins, K, min_depth, max_depth):
-    """[logits [N,H,W,Cl] fp32 per scale] -> [(depth, disp)] in one launch (<= 4 scales, same Cl)"""
+def _head_scale(hb, logits_list, P2, base_fx):
+    if P2 is None or base_fx is None:
+        return
+    assert P2.is_cuda and P2.dtype == torch.float32 and P2.is_contiguous() and P2.shape[1:] == (3, 4)
+    assert P2.shape[0] == logits_list[0].shape[0]
+    hb.P2, hb.base_fx, hb.nimg = P2.data_ptr(), float(base_fx), P2.shape[0]
+
+
+def depth_head_fwd_multi(logits_list, bins, K, min_depth, max_depth, P2=None, base_fx=None):
+    """[logits [N,H,W,Cl] fp32 per scale] -> [(depth, disp)] in one launch (<= 4 scales, same Cl).
+    P2 + base_fx: focal-length depth scaling (depth_encoder.py:36-43)"""
     from .binding import FsHeadBatch
     hb = FsHeadBatch()
+    _head_scale(hb, logits_list, P2, base_fx)
     hb.n = len(logits_list)
     Cl = logits_list[0].shape[3]
     outs = []
@@ -209,10 +219,11 @@ def depth_head_fwd_multi(logits_list, bins, K, min_depth, max_depth):
     return outs
 
 
-def depth_head_bwd_multi(logits_list, bins, d_depths, d_disps, K, min_depth, max_depth, dtype):
+def depth_head_bwd_multi(logits_list, bins, d_depths, d_disps, K, min_depth, max_depth, dtype, P2=None, base_fx=None):
     """gradients of all scales' logits in one launch; d_depths / d_disps entries may be None"""
     from .binding import FsHeadBatch
     hb = FsHeadBatch()
+    _head_scale(hb, logits_list, P2, base_fx)
     hb.n = len(logits_list)
     Cl = logits_list[0].shape[3]
     outs = []
@@ -291,6 +302,31 @@ class PhotometricLoss:
         self._sa = FsSmoothArgs()
         self.seed_buf = torch.zeros(1, dtype=torch.int32, device=device)   # device-resident tie-break seed
         self._prefetched = None
+        # fisheye (Mei model): persistent per-sample table pointers / parameters / mask plane, refreshed per step by
+        # stage_fisheye() so that a captured hipGraph keeps reading the same addresses
+        self.fisheye = False
+        self.lut_table = self.mei = self.warp_mask = None
+        self._lut_keep = None
+
+    def stage_fisheye(self, tables, mei_rows):
+        """tables: B device tensors [4,H,W] (fs_mei_lut); mei_rows: host float32 [B,8] = k1 k2 xi g1 g2 u0 v0 0.
+        Copies the pointer table and the parameters into persistent device buffers on the current stream."""
+        B, dev = self.B, self.device
+        if self.lut_table is None:
+            self.lut_table = torch.zeros(B, dtype=torch.int64, device=dev)
+            self.mei = torch.zeros(B, 8, dtype=torch.float32, device=dev)
+            self.warp_mask = torch.empty(B, self.H, self.W, dtype=torch.float32, device=dev)
+        assert len(tables) == B and all(t.shape == (4, self.H, self.W) and t.is_contiguous() for t in tables)
+        ptrs = [t.data_ptr() for t in tables]
+        if self._lut_keep is not None and self._lut_keep[1] == ptrs and bool((self._lut_keep[2] == mei_rows).all()):
+            self.fisheye = True
+            return                                    # same calibrations as the previous step: nothing to upload
+        # fresh pinned staging buffers per upload: the caching host allocator keeps them alive until the asynchronous
+        # copy has run (a reused buffer could be overwritten by the next step's staging before that)
+        self.lut_table.copy_(torch.tensor(ptrs, dtype=torch.int64).pin_memory(), non_blocking=True)
+        self.mei.copy_(torch.from_numpy(mei_rows.copy()).pin_memory(), non_blocking=True)
+        self._lut_keep = (list(tables), ptrs, mei_rows.copy())
+        self.fisheye = True
 
     def prefetch(self, img0, srcs, patched_mask):
         """The part of the chain that only needs the batch (accumulator reset, colour pyramid, identity
@@ -327,6 +363,10 @@ class PhotometricLoss:
         pa.B, pa.H, pa.W, pa.S = self.B, self.H, self.W, self.S
         pa.noise_seed = -1 if noise_seed is None else int(noise_seed)
         pa.noise_seed_ptr = self.seed_buf.data_ptr() if noise_seed is None else None
+        if self.fisheye:
+            pa.lut_ptrs, pa.mei, pa.warp_mask = self.lut_table.data_ptr(), self.mei.data_ptr(), self.warp_mask.data_ptr()
+        else:
+            pa.lut_ptrs = pa.mei = pa.warp_mask = None
         sa.disp_sum, sa.sm_sums, sa.dot = self.disp_sum.data_ptr(), self.sm_sums.data_ptr(), self.dot.data_ptr()
         sa.gout = _p(gout)
         sa.B, sa.S = self.B, self.S
@@ -353,8 +393,11 @@ class PhotometricLoss:
         pa, sa = C.byref(self._pa), C.byref(self._sa)
         # (noise_seed None: the setup kernel bumps the device seed — fresh noise every step, also on a graph replay)
         check(lib.fs_photo_setup(P2.data_ptr(), Ts[0].data_ptr(), Ts[1].data_ptr(), self.geo.data_ptr(), self.B,
-                                 self.seed_buf.data_ptr() if noise_seed is None else None, st),
+                                 self.seed_buf.data_ptr() if noise_seed is None else None, int(self.fisheye), st),
               "photo_setup")
+        if self.fisheye:
+            check(lib.fs_mei_stage_mask(self.lut_table.data_ptr(), _p(patched_mask), self.warp_mask.data_ptr(), self.B,
+                                        self.H, self.W, st), "mei_stage_mask")
         if not have_inputs:
             self._input_only(img0, pa, st)
         N_px = float(self.B * self.H * self.W)

@@ -40,7 +40,10 @@ SIGNATURES = {
     "fs_depth_head_bwd_multi": (C.c_int, [P, P, I, I, F, F, I, P]),
     "fs_pose_tail_fwd": (C.c_int, [P, P, P, P, I, I, I, I, I, F, P]),
     "fs_pose_tail_bwd": (C.c_int, [P, P, P, I, I, I, I, I, F, I, P]),
-    "fs_photo_setup": (C.c_int, [P, P, P, P, I, P, P]),
+    "fs_photo_setup": (C.c_int, [P, P, P, P, I, P, I, P]),
+    "fs_mei_lut": (C.c_int, [P, I, I, F, F, F, F, D, D, D, P]),
+    "fs_mei_stage_mask": (C.c_int, [P, P, P, I, I, I, P]),
+    "fs_mei_points": (C.c_int, [P, P, P, I, I, I, P]),
     "fs_photo_identity": (C.c_int, [P, P]),
     "fs_photo_warp": (C.c_int, [P, P]),
     "fs_photo_loss_fwd": (C.c_int, [P, P]),

@@ -107,11 +107,22 @@ class MonoDepth2Decoder(nn.Module):
 
     def _loss_engine(self, img0):
         B, _, H, W = img0.shape
-        key = (B, H, W, tuple(self.scales), img0.device)
+        return self._loss_engine_for(B, H, W, img0.device)
+
+    def _loss_engine_for(self, B, H, W, device):
+        key = (B, H, W, tuple(self.scales), device)
         if self._pl is None or self._pl_key != key:
-            self._pl = ops.PhotometricLoss(B, H, W, self.scales, img0.device, self.min_depth, self.max_depth)
+            self._pl = ops.PhotometricLoss(B, H, W, self.scales, device, self.min_depth, self.max_depth)
             self._pl_key = key
         return self._pl
+
+    def _stage_geometry(self, input_dict):
+        """camera-model inputs of the loss engine beyond P2 (none for the pinhole model)"""
+        self._pl.fisheye = False
+
+    def stage_step_inputs(self, input_dict):
+        """host-side per-step staging the training hook runs before replaying a captured step (non-tensor inputs)"""
+        return
 
     @staticmethod
     def _mask64(input_dict):
@@ -148,6 +159,7 @@ class MonoDepth2Decoder(nn.Module):
             if d.shape[2] != (H >> s) or d.shape[3] != (W >> s):
                 raise NotImplementedError("depth at scale %d must be %dx%d" % (s, H >> s, W >> s))
         self._loss_engine(img0)
+        self._stage_geometry(input_dict)
         fa, fb = self.frame_ids[1], self.frame_ids[2]
         pm = self._mask64(input_dict)
         depths = [output_dict[("depth", s, s)] for s in self.scales]
@@ -192,3 +204,54 @@ class MonoDepth2Decoder(nn.Module):
         if not getattr(self, "is_log_image", True):
             hm = {}
         return {"loss": total, "loss_dict": losses, "hm": hm}
+
+
+class FishEyeDecoder(MonoDepth2Decoder):
+    """MonoDepth2Decoder for the Mei unified fisheye model (monodepth2_decoder.py:350-420): the network output is the
+    ray norm, the 3-D point is the per-calibration ray table x norm, the relative pose acts on it directly and
+    cam2image (mirror + radial distortion) maps it into the source frame; the overlap mask samples
+    patched_mask x table mask.  Same fused HIP loss chain, ray-table variant (FsPhotoArgs.lut_ptrs)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        from fsnet_amd.monodepth.networks.utils.mei_fisheye_utils import MeiCameraProjection
+        self.mei_projection = MeiCameraProjection()
+        self._staged = None          # (P2 tensor, its version, calib list) of the last staging: strong references,
+        self._hook_staged = False    # so an equal identity really is the same batch object
+
+    def stage_step_inputs(self, input_dict, from_hook=True):
+        """ray tables of this batch's calibrations (built once each, cached by the reference's key) -> the loss
+        engine's persistent pointer table.  Host side; the training hook runs it before every step (before the H2D
+        move, so P2 is normally still a host tensor) and before every hipGraph replay."""
+        P, calib = input_dict["P2"], input_dict["calib_meta"]
+        img0 = input_dict[("original_image", 0)]
+        B, _, H, W = img0.shape
+        dev = img0.device if img0.is_cuda else next(self.parameters()).device
+        pl = self._loss_engine_for(B, H, W, dev)
+        self._hook_staged = from_hook
+        st = self._staged
+        if st is not None and st[0] is P and st[1] == P._version and st[2] is calib and st[3] is pl and pl.fisheye:
+            return
+        tabs, rows = self.mei_projection.tables(H, W, P, calib, dev)
+        pl.stage_fisheye(tabs, rows)
+        self._staged = (P, P._version, calib, pl)
+
+    def _stage_geometry(self, input_dict):
+        if "calib_meta" not in input_dict:
+            raise KeyError("FishEyeDecoder.loss needs input_dict['calib_meta'] (list of Mei calibration dicts)")
+        if torch.cuda.is_current_stream_capturing():
+            if not self._pl.fisheye:
+                raise RuntimeError("FishEyeDecoder: stage_step_inputs() must run before the step is captured")
+        elif self._hook_staged and self._pl.fisheye:
+            pass                      # the hook staged this step's calibrations already
+        else:
+            self.stage_step_inputs(input_dict, from_hook=False)
+        self._hook_staged = False
+
+    def prefetch_loss_inputs(self, input_dict):
+        return        # MonoDepthWPose has no side stream; the identity terms run inside loss()
+
+    def get_prediction(self, input_dict, output_dict):
+        norm = output_dict[("depth", 0, 0)]
+        points, _ = self.mei_projection.image2cam(norm, input_dict["P2"], input_dict["calib_meta"])
+        return dict(depth=points[..., 2], norm=norm)

@@ -71,6 +71,8 @@ class BaseTrainingHook(object):
             arena.zero_grads()
         else:
             optimizer.zero_grad()
+        if hasattr(meta_arch, "stage_step_inputs"):
+            meta_arch.stage_step_inputs(data)        # non-tensor inputs (fisheye calibrations), before the H2D move
         for key in data:
             if isinstance(data[key], torch.Tensor):
                 if self.tensor_keys is None or key in self.tensor_keys:
@@ -93,6 +95,8 @@ class BaseTrainingHook(object):
         sdata = dict(data)
         sdata.update(static)
         self._stage(data, static)
+        if hasattr(meta_arch, "stage_step_inputs"):
+            meta_arch.stage_step_inputs(data)
         optimizer.sync_lr()
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
@@ -108,7 +112,8 @@ class BaseTrainingHook(object):
             optimizer.step(max_norm=self.clip_gradients, grad_scale=grad_scale)
         # capture records, it does not run: host bookkeeping happened once above, the first replay is that step
         assert optimizer._step_count_fused == steps_before + 1
-        self._g = dict(graph=graph, sig=sig, static=static, output=output, arena=arena)
+        self._g = dict(graph=graph, sig=sig, static=static, output=output, arena=arena,
+                       stage_meta=getattr(meta_arch, "stage_step_inputs", None))
         graph.replay()
         RT.bump_weights()
         return output
@@ -116,6 +121,8 @@ class BaseTrainingHook(object):
     def _replay(self, data, optimizer):
         g = self._g
         self._stage(data, g["static"])
+        if g["stage_meta"] is not None:
+            g["stage_meta"](data)
         optimizer.prepare_replay()
         g["graph"].replay()
         optimizer.note_step()

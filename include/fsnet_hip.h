@@ -342,6 +342,11 @@ typedef struct FsHeadBatch {
   void* dlogits[4];
   int64_t M[4];
   int32_t n;
+  int32_t nimg;        /* images in the batch (rows of P2); only read when P2 is given */
+  const float* P2;     /* [nimg][12] intrinsics or NULL.  With P2: depth *= P2[n][0] / base_fx and the disparity is taken
+                          against (min_depth, max_depth) x that scale (DepthDecoder._get_scale / gather_output,
+                          depth_encoder.py:36-43,115-121; configs/multi_dataset_example:256) */
+  float base_fx;
   int32_t reserved;
 } FsHeadBatch;
 int fs_depth_head_fwd_multi(const FsHeadBatch* batch, const float* bins, int K, int Cl, float min_depth,
@@ -391,9 +396,18 @@ typedef struct FsPhotoArgs {
   int32_t B, H, W, S;
   int32_t noise_seed;
   const int32_t* noise_seed_ptr;  /* device-resident seed (overrides noise_seed when non-NULL; hipGraph replay) */
+  /* Fisheye / Mei unified camera model (FishEyeDecoder._generate_images_pred, monodepth2_decoder.py:355-411): all three
+   * NULL on the pinhole path.  `depth` is then the ray norm, the 3-D point is ray-table x norm, the transform acts on
+   * it directly and mei_fisheye_utils._cam2image (:23-51) maps it to pixels (fs_photo_setup(fisheye=1) stores
+   * P_f = T_f[:3] and K = identity, so fs_photo_pose_grad returns dT itself). */
+  const float* const* lut_ptrs;   /* device array [B]: per-sample ray table [4][H][W] = X, Y, Z, mask (fs_mei_lut) */
+  const float* mei;               /* device [B][8]: k1, k2, xi, gamma1, gamma2, u0, v0, 0 */
+  const float* warp_mask;         /* [B][H][W] fp32 = patched_mask x ray-table mask (fs_mei_stage_mask): the plane the
+                                     nearest-neighbour overlap sample reads (:409-411) */
 } FsPhotoArgs;
 int fs_photo_setup(const float* P2, const float* T0, const float* T1, float* geo, int B, int* seed_counter,
-                   void* stream);   /* seed_counter (or NULL): device int bumped by one — the noise seed of this step */
+                   int fisheye, void* stream);   /* seed_counter (or NULL): device int bumped by one — the noise seed of
+                                                    this step */
 int fs_photo_identity(const FsPhotoArgs* args, void* stream);
 int fs_photo_warp(const FsPhotoArgs* args, void* stream);
 int fs_photo_loss_fwd(const FsPhotoArgs* args, void* stream);
@@ -401,6 +415,20 @@ int fs_photo_loss_bwd(const FsPhotoArgs* args, void* stream);
 int64_t fs_photo_bwd_tiles(int H, int W);
 int fs_photo_pose_grad(const float* geo, const float* dP, float* dT0, float* dT1, int B, int S, int tiles,
                        void* stream);
+
+/* Mei unified fisheye camera model (mei_fisheye_utils.py:14-187; configs/kitti360_fisheye_example:198-207).
+ * fs_mei_lut: the per-calibration table MeiCameraProjection.image2cam caches (:150-166) — for every pixel the radial
+ *   distortion is inverted by Newton (newton_methods :70-79) and the mirror equation by bisection (bisection_methods
+ *   :85-101), both in f64 as numba types them; lut = [4][H][W] fp32 planes X, Y, Z, mask (invalid pixels: -1 * (xi - 1),
+ *   -1 * (xi - 1), -1, 0 exactly as the reference leaves them).  gamma1/gamma2/u0/v0 are the fp32 entries of P2.
+ * fs_mei_stage_mask: warp_mask[b] = float(patched_mask[b] * table_mask[b]) (monodepth2_decoder.py:409).
+ * fs_mei_points: points[B][H][W][3] = table x norm (image2cam :183-187; get_prediction reads z, decoder :413-420).
+ */
+int fs_mei_lut(float* lut, int H, int W, float gamma1, float gamma2, float u0, float v0, double k1, double k2,
+               double xi, void* stream);
+int fs_mei_stage_mask(const float* const* lut_ptrs, const double* patched_mask, float* warp_mask, int B, int H, int W,
+                      void* stream);
+int fs_mei_points(const float* const* lut_ptrs, const float* norm, float* points, int B, int H, int W, void* stream);
 
 /* Edge-aware smoothness (monodepth_utils.py:168-181; monodepth2_decoder.py:214-219,294-299) and
  * loss assembly (:292-304).  fs_color_pyramid = adaptive_avg_pool2d with an integer ratio.

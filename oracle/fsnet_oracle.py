@@ -210,9 +210,14 @@ def gather_activation(logits, bins):
     return torch.sum(act * bins.reshape(1, -1, 1, 1), dim=1, keepdim=True)
 
 
-def depth_decoder_forward(sd, prefix, feats, min_depth, max_depth, scales=(0, 1, 2, 3), train=True):
-    """depth_encoder.py:119-139 (MultiChannelDepthDecoder.forward / gather_output), base_fx=None."""
+def depth_decoder_forward(sd, prefix, feats, min_depth, max_depth, scales=(0, 1, 2, 3), train=True, P2=None,
+                          base_fx=None):
+    """depth_encoder.py:119-139 (MultiChannelDepthDecoder.forward / gather_output); with base_fx and P2 the
+    focal-length scale of _get_scale (:36-43): depth *= fx / base_fx, disparity against the scaled range."""
     out = {}
+    depth_scale = 1
+    if base_fx is not None and P2 is not None:
+        depth_scale = (P2[:, 0, 0] / base_fx).reshape([-1, 1, 1, 1])
     x = feats[-1]
     idx = 0
     disp_base = 10
@@ -231,9 +236,11 @@ def depth_decoder_forward(sd, prefix, feats, min_depth, max_depth, scales=(0, 1,
             logits = _conv_pad(x, sd["%sdecoder.%d.weight" % (prefix, k)], sd["%sdecoder.%d.bias" % (prefix, k)],
                                "replicate")
             depth = gather_activation(logits, sd[prefix + "depth_bins"])
+            if base_fx is not None:
+                depth = depth * depth_scale
             out[("logits", i)] = logits
             out[("depth", i, i)] = depth
-            out[("disp", i)] = depth_to_disp(depth, min_depth, max_depth)
+            out[("disp", i)] = depth_to_disp(depth, min_depth * depth_scale, max_depth * depth_scale)
     return out
 
 
@@ -403,11 +410,13 @@ def photometric_loss(outputs, inputs, frame_ids=(0, 1, -1), scales=(0, 1, 2, 3),
 # meta-arch forward and one optimisation step
 # ----------------------------------------------------------------------------------------------
 def forward_train(sd, data, depth=18, with_pose=True, min_depth=0.5, max_depth=100.0,
-                  frame_ids=(0, 1, -1), scales=(0, 1, 2, 3), overlapped_mask=True, noise=None):
+                  frame_ids=(0, 1, -1), scales=(0, 1, 2, 3), overlapped_mask=True, noise=None, base_fx=None):
     """MonoDepthMeta.forward_train (monodepth2_model.py:24-46) when with_pose, else
     MonoDepthWPose.forward_train (85-130, dataset poses, no residual pose net)."""
     feats = resnet_forward(sd, "depth_backbone.", data[("image", 0)], depth)
-    outputs = depth_decoder_forward(sd, "head.depth_decoder.", feats, min_depth, max_depth, scales)
+    # MonoDepthWPose hands P2 to the decoder only when base_fx is set (monodepth2_model.py:91)
+    outputs = depth_decoder_forward(sd, "head.depth_decoder.", feats, min_depth, max_depth, scales,
+                                    P2=(data["P2"] if base_fx is not None else None), base_fx=base_fx)
     for f in frame_ids[1:]:
         if with_pose:
             pair = [data[("image", f)], data[("image", 0)]] if f < 0 else [data[("image", 0)], data[("image", f)]]
@@ -445,7 +454,8 @@ class OracleTrainer:
     loss.mean().backward(), clip_grad_norm_, Adam.step)."""
 
     def __init__(self, sd, depth=18, with_pose=True, lr=1e-4, clip=35.0, min_depth=0.5, max_depth=100.0,
-                 weight_decay=0.0):
+                 weight_decay=0.0, base_fx=None):
+        self.base_fx = base_fx
         self.sd = {k: v.clone() for k, v in sd.items()}
         self.names = [k for k in self.sd if is_param(k)]
         self.depth, self.with_pose, self.lr, self.clip = depth, with_pose, lr, clip
@@ -458,7 +468,7 @@ class OracleTrainer:
         for k in self.names:
             self.sd[k] = self.sd[k].detach().requires_grad_(True)
         total, losses, outputs = forward_train(self.sd, data, self.depth, self.with_pose, self.min_depth,
-                                               self.max_depth, noise=noise)
+                                               self.max_depth, noise=noise, base_fx=self.base_fx)
         grads = torch.autograd.grad(total.mean(), [self.sd[k] for k in self.names], allow_unused=True)
         grads = [g if g is not None else torch.zeros_like(self.sd[k]) for g, k in zip(grads, self.names)]
         raw = dict(zip(self.names, grads))

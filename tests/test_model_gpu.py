@@ -244,3 +244,53 @@ def test_deepcopied_model_repacks_its_own_weights(dev):
         fr = ref(x)[-1].float()
     assert float((fb - fr).abs().max()) < 1e-4 * float(fr.abs().max())
     assert float((fb - fa).abs().max()) > 1e-3 * float(fa.abs().max())
+
+
+@gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_resnet50_basefx_matches_reference_golden(dev, dtype):
+    """BASELINE configs[4] wiring — MonoDepthWPose, ResNet-50, 64 depth bins, base_fx = 492, two focal lengths in the
+    batch — against the REAL reference (tests/golden/model_r50fx.npz): depth / disparity, loss, gradient norms."""
+    from fsnet_amd.configs import meta_arch_cfg
+    from fsnet_amd.engine.runtime import RT
+    from fsnet_amd.vision_base.utils.builder import build
+    from tests.test_oracle_golden import r50fx_batch
+    g = np.load(os.path.join(GOLD, "model_r50fx.npz"))
+    B, H, W = int(g["B"]), int(g["H"]), int(g["W"])
+    RT.set_compute_dtype(dtype)
+    RT.tie_noise = False
+    sd0 = O.init_state(seed=int(g["init_seed"]), depth=50, with_pose=False, num_out=64)
+    m = build(**meta_arch_cfg(H, W, with_pose=False, depth=50, num_output_channels=64, base_fx=float(g["base_fx"])))
+    m.load_state_dict({k: v.clone() for k, v in sd0.items()}, strict=True)
+    m = m.to(dev).train()
+    data = to_dev(r50fx_batch(g), dev)
+    out = m(dict(data), dict(is_training=True))
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    fp32 = dtype == torch.float32
+    assert abs(float(out["loss"].detach()) - float(g["loss"])) < (2e-5 if fp32 else 2e-2) * abs(float(g["loss"]))
+    gn = torch.stack([p.grad.norm() for p in m.parameters()]).cpu()
+    ref = torch.from_numpy(g["gradnorm"])
+    big = ref > 1e-3 * ref.max()
+    dev_rel = ((gn - ref).abs() / ref)[big]
+    if fp32:
+        assert float(dev_rel.max()) < 3e-2, float(dev_rel.max())
+    else:
+        assert float(dev_rel.median()) < 0.15, float(dev_rel.median())
+    # forward tensors from a fresh copy (train-mode BatchNorm, same batch)
+    m2 = build(**meta_arch_cfg(H, W, with_pose=False, depth=50, num_output_channels=64, base_fx=float(g["base_fx"])))
+    m2.load_state_dict({k: v.clone() for k, v in sd0.items()}, strict=True)
+    m2 = m2.to(dev).train()
+    with torch.no_grad():
+        feats = m2.depth_backbone(data[("image", 0)])
+        outs = m2.head.forward_depth(feats, data["P2"])
+    torch.cuda.synchronize()
+    for s in range(4):
+        refd = torch.from_numpy(g["depth_%d" % s])
+        rel = ((outs[("depth", s, s)].cpu() - refd).abs() / refd).max()
+        refp = torch.from_numpy(g["disp_%d" % s])
+        relp = ((outs[("disp", s)].cpu() - refp).abs() / refp.abs().clamp_min(1e-6))
+        if fp32:
+            assert float(rel) < 1e-3 and float(relp.max()) < 1e-3, (s, float(rel), float(relp.max()))
+        else:
+            assert float(relp.mean()) < 4e-2, (s, float(relp.mean()))

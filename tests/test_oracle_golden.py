@@ -162,3 +162,89 @@ def test_distill_oracle_matches_reference_golden():
         assert abs(float(losses["distilation/%d" % s]) - float(g["ld_distilation_%d" % s])) < 1e-5 * float(g["ld_distilation_%d" % s])
     assert float((sd["head.depth_decoder.decoder.14.weight"].grad - torch.from_numpy(g["unc_w_grad"])).abs().max()) \
         < 1e-5 * float(np.abs(g["unc_w_grad"]).max())
+
+
+def fisheye_chain_inputs(g):
+    """batch + synthetic network outputs of tests/golden/fisheye.npz (shared with the GPU parity test)"""
+    data = _chain_inputs(g)
+    data["calib_meta"] = [{"distortion_parameters": {"k1": float(c[0]), "k2": float(c[1])},
+                           "mirror_parameters": {"xi": float(c[2])}} for c in g["calib"]]
+    return data
+
+
+def test_fisheye_oracle_matches_reference_golden():
+    """oracle/fisheye_oracle.py against the REAL MeiCameraProjection / FishEyeDecoder (tests/golden/fisheye.npz):
+    LUT (X, Y, Z, mask), cam2image, loss chain with gradients, get_prediction"""
+    from oracle import fisheye_oracle as FO
+    g = np.load(os.path.join(GOLD, "fisheye.npz"))
+    for v in range(2):
+        P, (k1, k2, xi) = g["lut%d_P" % v], g["lut%d_calib" % v]
+        lut = np.stack(FO.mei_lut(48, 48, float(P[0, 0]), float(P[1, 1]), float(P[0, 2]), float(P[1, 2]), k1, k2, xi), 0)
+        assert (lut[3] == g["lut%d" % v][3]).all()
+        assert np.abs(lut[:3] - g["lut%d" % v][:3]).max() < 1e-6
+        assert 0.5 < lut[3].mean() < 0.8          # the mirror equation has no solution in the image corners
+    P, calib = FO.synthetic_calib(48, 48, 0)
+    u, v_ = FO.cam2image(T(g["c2i_points"]), P, calib)
+    assert maxdev(torch.stack([u, v_], -1), g["c2i_uvz"][..., :2]) < 1e-4
+    data = fisheye_chain_inputs(g)
+    outputs, leaves, pose = {}, {}, {}
+    for s in range(4):
+        d = T(g["depth_%d" % s]).clone().requires_grad_(True)
+        leaves[s] = d
+        outputs[("depth", s, s)] = d
+        outputs[("disp", s)] = O.depth_to_disp(d, 0.5, 150.0)
+    for f, tag in ((1, "p"), (-1, "m")):
+        aa = T(g["aa_" + tag]).clone().requires_grad_(True)
+        tr = T(g["tr_" + tag]).clone().requires_grad_(True)
+        pose[tag] = (aa, tr)
+        outputs[("cam_T_cam", f)] = O.transformation_from_parameters(aa, tr, invert=(f < 0))
+    total, ld = FO.photometric_loss(outputs, data)
+    total.backward()
+    assert total.dtype == torch.float64
+    assert abs(float(total.detach()) - float(g["total_loss"])) < 2e-7
+    for s in range(4):
+        assert abs(float(ld["loss/%d" % s]) - float(g["ld_loss_%d" % s])) < 5e-7
+        ref = T(g["gdepth_%d" % s])
+        assert float((leaves[s].grad - ref).norm() / ref.norm()) < 2e-3
+    for tag in ("p", "m"):
+        f = 1 if tag == "p" else -1
+        for got, key in ((pose[tag][0].grad, "gaa_" + tag), (pose[tag][1].grad, "gtr_" + tag)):
+            ref = T(g[key])
+            # (the reference run carries its randn*1e-5 tie-break noise; the rotation gradient is a small sum of
+            # large cancelling terms)
+            assert maxdev(got, ref) < 5e-3 * float(ref.abs().max()) + 1e-9
+        assert maxdev(outputs[("original_image", f, 0)][:, :, ::2, ::2], g["warp0_" + tag]) < 1e-5
+        assert (outputs[("overlapped_mask", f, 0)].numpy() == g["ovmask0_" + tag]).mean() > 0.9999
+    assert maxdev(FO.get_prediction(leaves[0].detach(), data["P2"], data["calib_meta"]), g["pred_depth"]) < 1e-5
+
+
+def r50fx_batch(g):
+    data = O.synthetic_batch(int(g["B"]), int(g["H"]), int(g["W"]), seed=int(g["batch_seed"]))
+    for b, mul in enumerate(g["fx_mul"]):
+        data["P2"][b, 0, 0] *= float(mul)
+    return data
+
+
+def test_r50_basefx_oracle_matches_reference_golden():
+    """BASELINE configs[4] wiring (ResNet-50 Bottleneck, 64 bins, base_fx = 492, per-sample focal lengths) against
+    the REAL MonoDepthWPose (tests/golden/model_r50fx.npz): forward tensors, loss, gradient norms"""
+    g = np.load(os.path.join(GOLD, "model_r50fx.npz"))
+    sd0 = O.init_state(seed=int(g["init_seed"]), depth=50, with_pose=False, num_out=64)
+    data = r50fx_batch(g)
+    sd = {k: v.clone() for k, v in sd0.items()}
+    feats = O.resnet_forward(sd, "depth_backbone.", data[("image", 0)], depth=50)
+    outs = O.depth_decoder_forward(sd, "head.depth_decoder.", feats, 0.5, 100.0, P2=data["P2"], base_fx=float(g["base_fx"]))
+    assert maxdev(feats[4][:, ::16], g["feat4"]) < 1e-4
+    for s in range(4):
+        assert maxdev(outs[("depth", s, s)], g["depth_%d" % s]) <= 1e-5 * float(np.abs(g["depth_%d" % s]).max())
+        assert maxdev(outs[("disp", s)], g["disp_%d" % s]) <= 1e-5
+    # the focal-length scale really is per sample: fx = 0.58 W x (1.4, 1.0) over base_fx 492
+    ratio = float(outs[("depth", 0, 0)][0].mean() / outs[("depth", 0, 0)][1].mean())
+    assert 1.2 < ratio < 1.6
+    trn = O.OracleTrainer(sd0, depth=50, with_pose=False, base_fx=float(g["base_fx"]))
+    total, ld, _, raw, norm = trn.step(data)
+    assert abs(float(total) - float(g["loss"])) < 5e-5 * abs(float(g["loss"]))
+    gn = torch.stack([raw[k].norm() for k in trn.names])
+    ref = T(g["gradnorm"])
+    big = ref > 1e-3 * ref.max()
+    assert float(((gn - ref).abs() / ref)[big].max()) < 3e-2

@@ -423,9 +423,162 @@ def gen_augment():
     np.savez_compressed(os.path.join(GOLD, "augment.npz"), **res)
 
 
+def gen_fisheye():
+    """Fisheye path (BASELINE configs[3]) through the REAL classes: MeiCameraProjection LUT + cam2image
+    (mei_fisheye_utils.py:14-187) and FishEyeDecoder.loss with gradients (monodepth2_decoder.py:350-420)."""
+    from monodepth.networks.utils.mei_fisheye_utils import MeiCameraProjection
+    from oracle import fisheye_oracle as FO
+    out = {}
+    proj = MeiCameraProjection()
+    # --- LUT at 48x48 for two calibrations ---
+    H = W = 48
+    for v in range(2):
+        P, calib = FO.synthetic_calib(H, W, v)
+        norm = torch.ones(1, 1, H, W)
+        pts, mask = proj.image2cam(norm, P[None], [calib])
+        lut = np.stack([npy(pts[0, 0, ..., 0]), npy(pts[0, 0, ..., 1]), npy(pts[0, 0, ..., 2]), npy(mask[0, 0])], 0)
+        out["lut%d" % v] = lut
+        out["lut%d_P" % v] = npy(P)
+        out["lut%d_calib" % v] = np.array([calib["distortion_parameters"]["k1"], calib["distortion_parameters"]["k2"],
+                                           calib["mirror_parameters"]["xi"]])
+        mine = np.stack(FO.mei_lut(H, W, P[0, 0].item(), P[1, 1].item(), P[0, 2].item(), P[1, 2].item(),
+                                   calib["distortion_parameters"]["k1"], calib["distortion_parameters"]["k2"],
+                                   calib["mirror_parameters"]["xi"]), 0)
+        print("fisheye LUT %d: valid %.1f %%, oracle max dev %.3e, mask mismatches %d" % (
+            v, 100 * lut[3].mean(), np.abs(mine[:3] - lut[:3]).max(), int((mine[3] != lut[3]).sum())))
+    # --- cam2image on random points in front of / beside the camera ---
+    g = torch.Generator().manual_seed(5)
+    pts = torch.randn(64, 3, generator=g) * torch.tensor([3.0, 3.0, 2.0]) + torch.tensor([0.0, 0.0, 2.5])
+    P, calib = FO.synthetic_calib(H, W, 0)
+    uvz = proj.cam2image(pts, P, calib)
+    out["c2i_points"], out["c2i_uvz"] = npy(pts), npy(uvz)
+    u, v_ = FO.cam2image(pts, P, calib)
+    print("fisheye cam2image oracle dev", dev(torch.stack([u, v_], -1), uvz[..., :2]))
+    # --- loss chain with gradients ---
+    B, H, W = 2, 64, 64
+    data = O.synthetic_batch(B, H, W, seed=31)
+    data['patched_mask'][:, :5, :] = 0
+    Ps, calibs = zip(*[FO.synthetic_calib(H, W, v) for v in range(B)])
+    data["P2"] = torch.stack(Ps, 0)
+    data["calib_meta"] = list(calibs)
+    g = torch.Generator().manual_seed(4)
+    dec = build(name='monodepth.networks.models.heads.monodepth2_decoder.FishEyeDecoder', scales=[0, 1, 2, 3],
+                height=H, width=W, frame_ids=[0, 1, -1], min_depth=0.5, max_depth=150.0, overlapped_mask=True,
+                is_log_image=False,
+                depth_decoder_cfg=dict(name='monodepth.networks.models.heads.depth_encoder.MultiChannelDepthDecoder',
+                                       num_ch_enc=np.array([64, 64, 128, 256, 512]), num_output_channels=64,
+                                       use_skips=True, scales=[0, 1, 2, 3], min_depth=0.5, max_depth=150))
+    outputs, leaves = {}, {}
+    for s in range(4):
+        h, w = H >> s, W >> s
+        ys = torch.linspace(0, 1, h).view(1, 1, h, 1)
+        d = (5 + 20 * (1 - ys) + 3 * torch.rand(B, 1, h, w, generator=g)).requires_grad_(True)
+        leaves[("depth", s)] = d
+        outputs[("depth", s, s)] = d
+        outputs[("disp", s)] = mu.depth_to_disp(d, 0.5, 150.0)
+    for f in (1, -1):
+        aa = (0.01 * torch.randn(B, 1, 3, generator=g)).requires_grad_(True)
+        tr = torch.tensor([[[0.6 if f > 0 else -0.6, -0.01, 0.03]]]).repeat(B, 1, 1) + 0.02 * torch.randn(B, 1, 3, generator=g)
+        tr.requires_grad_(True)
+        leaves[("aa", f)], leaves[("tr", f)] = aa, tr
+        outputs[("cam_T_cam", f)] = mu.transformation_from_parameters(aa, tr, invert=(f < 0))
+    torch.manual_seed(0)
+    res = dec.loss(outputs, data)
+    res['loss'].backward()
+    out.update(H=H, W=W, seed=31, total_loss=npy(res['loss']))
+    for k, v in res['loss_dict'].items():
+        out["ld_" + k.replace('/', '_')] = npy(v)
+    for s in range(4):
+        out["depth_%d" % s] = npy(leaves[("depth", s)])
+        out["gdepth_%d" % s] = npy(leaves[("depth", s)].grad)
+    for f in (1, -1):
+        tag = "p" if f > 0 else "m"
+        out["aa_" + tag], out["tr_" + tag] = npy(leaves[("aa", f)]), npy(leaves[("tr", f)])
+        out["gaa_" + tag], out["gtr_" + tag] = npy(leaves[("aa", f)].grad), npy(leaves[("tr", f)].grad)
+        out["warp0_" + tag] = npy(outputs[("original_image", f, 0)])[:, :, ::2, ::2]
+        out["ovmask0_" + tag] = npy(outputs[("overlapped_mask", f, 0)])
+    for f in (0, 1, -1):
+        out["img_%s" % {0: "0", 1: "p", -1: "m"}[f]] = npy(data[("original_image", f)])
+    out["P2"] = npy(data["P2"]); out["patched_mask"] = npy(data["patched_mask"])
+    out["calib"] = np.array([[c["distortion_parameters"]["k1"], c["distortion_parameters"]["k2"],
+                              c["mirror_parameters"]["xi"]] for c in calibs])
+    pred = dec.get_prediction(data, {("depth", 0, 0): leaves[("depth", 0)].detach()})
+    out["pred_depth"] = npy(pred["depth"])
+    # cross-check the oracle
+    o2, lv = {}, {}
+    for s in range(4):
+        d = leaves[("depth", s)].detach().clone().requires_grad_(True); lv[s] = d
+        o2[("depth", s, s)] = d; o2[("disp", s)] = O.depth_to_disp(d, 0.5, 150.0)
+    for f in (1, -1):
+        o2[("cam_T_cam", f)] = outputs[("cam_T_cam", f)].detach()
+    tot, ld = FO.photometric_loss(o2, data)
+    tot.backward()
+    print("fisheye chain: ref loss %.9f oracle %.9f | gdepth0 dev rel %.3e | warp dev %.3e | ov mismatches %d" % (
+        float(res['loss']), float(tot),
+        dev(lv[0].grad, leaves[("depth", 0)].grad) / float(leaves[("depth", 0)].grad.abs().max()),
+        dev(o2[("original_image", 1, 0)], outputs[("original_image", 1, 0)]),
+        int((o2[("overlapped_mask", 1, 0)] != outputs[("overlapped_mask", 1, 0)]).sum())))
+    np.savez_compressed(os.path.join(GOLD, "fisheye.npz"), **out)
+
+
+def gen_model_r50fx():
+    """BASELINE configs[4] wiring at a small size: MonoDepthWPose, ResNet-50 (Bottleneck), 64 depth bins,
+    base_fx = 492 (configs/multi_dataset_example:227-257) with per-sample focal lengths; forward tensors, loss_dict and
+    per-parameter gradient norms of one step from the REAL reference."""
+    B, H, W = 2, 64, 128
+    enc = [64, 256, 512, 1024, 2048]
+    bb = dict(name='vision_base.networks.models.backbone.resnet.resnet', depth=50, pretrained=False,
+              frozen_stages=-1, num_stages=4, out_indices=(-1, 0, 1, 2, 3), norm_eval=False, dilations=(1, 1, 1, 1))
+    head = dict(name='monodepth.networks.models.heads.monodepth2_decoder.MonoDepth2Decoder', scales=[0, 1, 2, 3],
+                height=H, width=W, min_depth=0.5, max_depth=100.0, overlapped_mask=True, is_log_image=False,
+                depth_decoder_cfg=dict(name='monodepth.networks.models.heads.depth_encoder.MultiChannelDepthDecoder',
+                                       num_ch_enc=np.array(enc), num_output_channels=64, use_skips=True,
+                                       scales=[0, 1, 2, 3], min_depth=0.5, max_depth=100, base_fx=492))
+    m = build(name='monodepth.networks.models.meta_archs.monodepth2_model.MonoDepthWPose', depth_backbone_cfg=bb,
+              head_cfg=head, train_cfg=EasyDict(frame_ids=[0, 1, -1]), test_cfg=EasyDict())
+    sd0 = O.init_state(seed=7, depth=50, with_pose=False, num_out=64)
+    m.load_state_dict({k: v.clone() for k, v in sd0.items()}, strict=True)
+    m.train()
+    data = O.synthetic_batch(B, H, W, seed=300)
+    data["P2"][0, 0, 0] *= 1.4          # two focal lengths in the batch: depth scales 0.211 and 0.151
+    data["P2"][1, 0, 0] *= 1.0
+    torch.manual_seed(0)
+    res = m(dict(data), dict(is_training=True))
+    res['loss'].mean().backward()
+    out = {"B": B, "H": H, "W": W, "init_seed": 7, "batch_seed": 300, "base_fx": 492.0, "fx_mul": np.array([1.4, 1.0]),
+           "loss": npy(res['loss'])}
+    for k, v in res['loss_dict'].items():
+        out["ld_" + k.replace('/', '_')] = npy(v)
+    out["gradnorm"] = npy(torch.stack([p.grad.norm() for p in m.parameters()]))
+    m2 = build(name='monodepth.networks.models.meta_archs.monodepth2_model.MonoDepthWPose', depth_backbone_cfg=bb,
+               head_cfg=head, train_cfg=EasyDict(frame_ids=[0, 1, -1]), test_cfg=EasyDict())
+    m2.load_state_dict({k: v.clone() for k, v in sd0.items()}, strict=True)
+    m2.train()
+    feats = m2.depth_backbone(data[('image', 0)])
+    outs = m2.head.forward_depth(feats, data['P2'])
+    for s in range(4):
+        out["disp_%d" % s] = npy(outs[('disp', s)])
+        out["depth_%d" % s] = npy(outs[('depth', s, s)])
+    out["feat4"] = npy(feats[4])[:, ::16]
+    tr = O.OracleTrainer(sd0, depth=50, with_pose=False, base_fx=492.0)
+    tot, ld, o_out, raw, norm = tr.step(data)
+    gn_o = torch.stack([raw[k].norm() for k in tr.names])
+    gn = torch.from_numpy(out["gradnorm"])
+    print("[r50fx] ref loss %.9f oracle %.9f | gradnorm rel dev %.2e | depth0 dev %.2e" % (
+        float(res['loss']), float(tot), float(((gn - gn_o).abs() / (gn + 1e-12)).max()),
+        dev(o_out[('depth', 0, 0)], outs[('depth', 0, 0)])))
+    np.savez_compressed(os.path.join(GOLD, "model_r50fx.npz"), **out)
+
+
 if __name__ == "__main__":
     if "--only-augment" in sys.argv:
         gen_augment()
+        sys.exit(0)
+    if "--only-fisheye" in sys.argv:
+        gen_fisheye()
+        sys.exit(0)
+    if "--only-r50fx" in sys.argv:
+        gen_model_r50fx()
         sys.exit(0)
     gen_ops()
     gen_loss_chain()
@@ -434,5 +587,7 @@ if __name__ == "__main__":
     gen_eval()
     gen_distill()
     gen_augment()
+    gen_fisheye()
+    gen_model_r50fx()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")
