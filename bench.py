@@ -178,7 +178,9 @@ def main():
             allc.append(cs)
         extra["conv_all"] = {"achieved_tflops": round(sum(a[1] for a in allc) / sum(a[2] for a in allc) / 1e12, 2),
                              "frac_mfma_peak": round(sum(a[1] for a in allc) / sum(a[2] for a in allc) / 1e12 / PEAK_TFLOPS[args.dtype], 4)}
-        for k in ("photo_warp", "photo_loss_fwd", "photo_loss_bwd"):
+        for k in ("photo_warp", "photo_loss_fwd", "photo_loss_bwd", "photo_fused_fwd", "photo_fused_bwd"):
+            if k not in agg:
+                continue
             a = agg[k]
             extra[k] = {"algorithmic_GBps": round(a[1] / a[2] / 1e9, 1), "frac_hbm_peak": round(a[1] / a[2] / 1e9 / PEAK_HBM_GBS, 4),
                         "avg_launch_us": round(a[2] / a[0] * 1e6, 2)}

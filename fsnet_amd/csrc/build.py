@@ -25,6 +25,16 @@ def _digest(paths):
     return h.hexdigest()
 
 
+def extra_flags(src):
+    """per-file compiler flags: a `// FS_HIPCC_FLAGS: ...` line in the first lines of the source"""
+    with open(src) as f:
+        for _ in range(40):
+            line = f.readline()
+            if "FS_HIPCC_FLAGS:" in line:
+                return line.split("FS_HIPCC_FLAGS:", 1)[1].split()
+    return []
+
+
 def sources():
     return sorted(os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".hip"))
 
@@ -51,7 +61,7 @@ def build(force=False, verbose=True):
 
     def compile_one(job):
         src, obj, stamp, want = job
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + extra_flags(src) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-6000:]))

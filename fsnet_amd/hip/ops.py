@@ -258,19 +258,30 @@ def pose_tail_bwd(x, dT, nframes, invert, dtype, scale=0.01, out=None):
     return dx
 
 
+import os as _os
+
+PHOTO_FUSED = _os.environ.get("FSNET_AMD_PHOTO_FUSED", "1") != "0"   # one-launch warp + loss forward (photo_fused.hip)
+
+
 class PhotometricLoss:
     """Fused loss chain for one batch geometry (B, H, W, scales).  forward() returns the loss
-    vector (f64 [2S+1]: loss/s, smooth_loss/s, total); backward() returns d depth_s and dT_f."""
+    vector (f64 [2S+1]: loss/s, smooth_loss/s, total); backward() returns d depth_s and dT_f.
+    want_pred: also materialise the warped images / overlap masks (self.pred, self.ov) — only needed for logging and
+    for the ("original_image", f, s) entries the reference leaves in its output dict."""
 
-    def __init__(self, B, H, W, scales, device, min_depth, max_depth):
+    def __init__(self, B, H, W, scales, device, min_depth, max_depth, want_pred=True):
         self.B, self.H, self.W = B, H, W
         self.scales = list(scales)
         S = self.S = len(self.scales)
         self.device = device
         f32, f64, u8 = torch.float32, torch.float64, torch.uint8
         self.geo = torch.zeros(B, 48, dtype=f32, device=device)
-        self.pred = torch.empty(S, 2, B, 3, H, W, dtype=f32, device=device)
-        self.ov = torch.empty(S, 2, B, H, W, dtype=u8, device=device)
+        self.want_pred = bool(want_pred)
+        self.fused = PHOTO_FUSED
+        self.pred = self.ov = None
+        if self.want_pred or not self.fused:
+            self.pred = torch.empty(S, 2, B, 3, H, W, dtype=f32, device=device)
+            self.ov = torch.empty(S, 2, B, H, W, dtype=u8, device=device)
         self.ident = torch.empty(B, 2, H, W, dtype=f32, device=device)
         self.sel = torch.empty(S, B, H, W, dtype=u8, device=device)
         # accumulators zeroed every step in one memset: loss_sums[S*B] mask_sum[B] disp_sum[S*B] sm_sums[2*S*B] dot[S*B]
@@ -285,7 +296,7 @@ class PhotometricLoss:
         self.out = torch.zeros(2 * S + 1, dtype=f64, device=device)
         self.hw = [(H >> s, W >> s) for s in self.scales]
         self.color = [None] * S
-        self.bwd_tiles = int(lib.fs_photo_bwd_tiles(H, W))
+        self.bwd_tiles = int(lib.fs_photo_fused_bwd_tiles(H, W) if PHOTO_FUSED else lib.fs_photo_bwd_tiles(H, W))
         self.dP = torch.zeros(self.S * B * self.bwd_tiles, 2, 12, dtype=f32, device=device)   # per-tile partials
         # one flat buffer behind the per-scale depth gradients: a single memset per backward instead of one per scale
         sizes = [B * h * w for (h, w) in self.hw]
@@ -356,7 +367,7 @@ class PhotometricLoss:
         pa.img_src[0], pa.img_src[1] = srcs[0].data_ptr(), srcs[1].data_ptr()
         pa.patched_mask = _p(patched_mask)
         pa.geo = self.geo.data_ptr()
-        pa.pred, pa.ov, pa.ident, pa.sel = self.pred.data_ptr(), self.ov.data_ptr(), self.ident.data_ptr(), self.sel.data_ptr()
+        pa.pred, pa.ov, pa.ident, pa.sel = _p(self.pred), _p(self.ov), self.ident.data_ptr(), self.sel.data_ptr()
         pa.loss_sums, pa.mask_sum = self.loss_sums.data_ptr(), self.mask_sum.data_ptr()
         pa.dP = self.dP.data_ptr()
         pa.gout = _p(gout)
@@ -403,8 +414,11 @@ class PhotometricLoss:
         N_px = float(self.B * self.H * self.W)
         # algorithmic bytes: per scale, target 12N + 2 sources 24N + depth 4N/4^s + result 4N
         fwd_bytes = sum(40.0 * N_px + 4.0 * N_px / (4 ** s) for s in self.scales)
-        _timed("photo_warp", fwd_bytes * 0.5, lambda: check(lib.fs_photo_warp(pa, st), "photo_warp"))
-        _timed("photo_loss_fwd", fwd_bytes * 0.5, lambda: check(lib.fs_photo_loss_fwd(pa, st), "photo_loss_fwd"))
+        if self.fused:
+            _timed("photo_fused_fwd", fwd_bytes, lambda: check(lib.fs_photo_fused_fwd(pa, st), "photo_fused_fwd"))
+        else:
+            _timed("photo_warp", fwd_bytes * 0.5, lambda: check(lib.fs_photo_warp(pa, st), "photo_warp"))
+            _timed("photo_loss_fwd", fwd_bytes * 0.5, lambda: check(lib.fs_photo_loss_fwd(pa, st), "photo_loss_fwd"))
         check(lib.fs_smooth_mean(sa, st), "smooth_mean")
         check(lib.fs_smooth_fwd(sa, st), "smooth_fwd")
         # fresh result tensors per call (the previous step's stay valid for whoever kept them) — the kernel writes
@@ -424,7 +438,10 @@ class PhotometricLoss:
         self._dd_flat.zero_()
         N_px = float(self.B * self.H * self.W)
         bwd_bytes = sum(40.0 * N_px + 8.0 * N_px / (4 ** s) for s in self.scales)
-        _timed("photo_loss_bwd", bwd_bytes, lambda: check(lib.fs_photo_loss_bwd(pa, st), "photo_loss_bwd"))
+        if self.fused:
+            _timed("photo_fused_bwd", bwd_bytes, lambda: check(lib.fs_photo_fused_bwd(pa, st), "photo_fused_bwd"))
+        else:
+            _timed("photo_loss_bwd", bwd_bytes, lambda: check(lib.fs_photo_loss_bwd(pa, st), "photo_loss_bwd"))
         check(lib.fs_photo_pose_grad(self.geo.data_ptr(), self.dP.data_ptr(), self.dT[0].data_ptr(),
                                      self.dT[1].data_ptr(), self.B, self.S, self.bwd_tiles, st), "photo_pose_grad")
         check(lib.fs_smooth_bwd(sa, st), "smooth_bwd")

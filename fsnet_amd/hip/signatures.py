@@ -48,6 +48,9 @@ SIGNATURES = {
     "fs_photo_warp": (C.c_int, [P, P]),
     "fs_photo_loss_fwd": (C.c_int, [P, P]),
     "fs_photo_loss_bwd": (C.c_int, [P, P]),
+    "fs_photo_fused_fwd": (C.c_int, [P, P]),
+    "fs_photo_fused_bwd": (C.c_int, [P, P]),
+    "fs_photo_fused_bwd_tiles": (C.c_int64, [I, I]),
     "fs_photo_pose_grad": (C.c_int, [P, P, P, P, I, I, I, P]),
     "fs_photo_bwd_tiles": (C.c_int64, [I, I]),
     "fs_augment_frames": (C.c_int, [P, P]),

@@ -112,7 +112,10 @@ class MonoDepth2Decoder(nn.Module):
     def _loss_engine_for(self, B, H, W, device):
         key = (B, H, W, tuple(self.scales), device)
         if self._pl is None or self._pl_key != key:
-            self._pl = ops.PhotometricLoss(B, H, W, self.scales, device, self.min_depth, self.max_depth)
+            # the warped images only reach HBM when somebody looks at them (logging; output_dict entries below)
+            self._pl = ops.PhotometricLoss(B, H, W, self.scales, device, self.min_depth, self.max_depth,
+                                           want_pred=bool(getattr(self, "is_log_image", True)
+                                                          or getattr(self, "keep_warped_images", False)))
             self._pl_key = key
         return self._pl
 
@@ -172,13 +175,16 @@ class MonoDepth2Decoder(nn.Module):
         for k, s in enumerate(self.scales):
             losses["loss/%d" % s] = vec[k]
             losses["smooth_loss/%d" % s] = vec[S + k]
-        # warped images / masks the reference leaves in output_dict (_generate_images_pred :98-116)
-        for k, s in enumerate(self.scales):
-            for j, f in enumerate((fa, fb)):
-                output_dict[("original_image", f, s)] = self._pl.pred[k, j]
-                output_dict[("overlapped_mask", f, s)] = self._pl.ov[k, j].view(torch.bool)   # 0/1 bytes: no kernel
+        # warped images / masks the reference leaves in output_dict (_generate_images_pred :98-116).  The fused loss
+        # kernels keep them in registers: they are written out when is_log_image (the reference default) or
+        # keep_warped_images=True asks for them
+        if self._pl.pred is not None:
+            for k, s in enumerate(self.scales):
+                for j, f in enumerate((fa, fb)):
+                    output_dict[("original_image", f, s)] = self._pl.pred[k, j]
+                    output_dict[("overlapped_mask", f, s)] = self._pl.ov[k, j].view(torch.bool)   # 0/1 bytes: no kernel
         hm = {}
-        if getattr(self, "is_log_image", True):
+        if getattr(self, "is_log_image", True) and self._pl.pred is not None:
             hm["original_image"] = img0[0:1]
             for j, f in enumerate((fa, fb)):
                 hm["predicted_image_%s" % f] = self._pl.pred[0, j, 0:1]

@@ -412,6 +412,15 @@ int fs_photo_identity(const FsPhotoArgs* args, void* stream);
 int fs_photo_warp(const FsPhotoArgs* args, void* stream);
 int fs_photo_loss_fwd(const FsPhotoArgs* args, void* stream);
 int fs_photo_loss_bwd(const FsPhotoArgs* args, void* stream);
+/* fs_photo_fused_fwd = fs_photo_warp + fs_photo_loss_fwd in ONE launch for all scales and both frames: the warped
+ * images stay in registers (pred / ov may be NULL; when given they are written as fs_photo_warp writes them, for
+ * logging and for outputs[("original_image", f, s)] of _generate_images_pred :98-116).  Needs ident, sel, loss_sums. */
+int fs_photo_fused_fwd(const FsPhotoArgs* args, void* stream);
+/* fs_photo_fused_bwd = fs_photo_loss_bwd without `pred`: the warp is recomputed (gathers through L2) instead of
+ * reading eight warped images back.  Same outputs: d_depth[s] (accumulated: zero it first) and the per-strip partials
+ * dP[S][B][tiles][2][12] with tiles = fs_photo_fused_bwd_tiles(H, W), reduced by fs_photo_pose_grad. */
+int fs_photo_fused_bwd(const FsPhotoArgs* args, void* stream);
+int64_t fs_photo_fused_bwd_tiles(int H, int W);
 int64_t fs_photo_bwd_tiles(int H, int W);
 int fs_photo_pose_grad(const float* geo, const float* dP, float* dT0, float* dT1, int B, int S, int tiles,
                        void* stream);
