@@ -27,6 +27,16 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, int vof
   return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
 }
 
+// workgroup barrier that orders LDS traffic only.  __syncthreads() also carries a workgroup-scope fence, which on
+// gfx9 is `s_waitcnt vmcnt(0)`: every barrier then waits for the block's outstanding global loads AND stores (one
+// L2 round trip per barrier — PMC on the layer-1 shapes: waves parked 58 % of their cycles).  LDS hand-offs between
+// the waves of a block only need the DS counter drained.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 struct HaloGeom {
   int TH, TW;        // pixel tile
   int tiles_x, tiles_y;
@@ -150,9 +160,9 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
   const int nchunk = (p.Cs * (int)sizeof(T) + 63) / 64;
   load_regs(0);
   for (int cc = 0; cc < nchunk; ++cc) {
-    __syncthreads();                 // previous chunk fully multiplied
+    lds_barrier();                 // previous chunk fully multiplied
     store_lds();
-    __syncthreads();
+    lds_barrier();
     if (cc + 1 < nchunk) load_regs(cc + 1);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -250,7 +260,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
     }
   }
   if (p.stats) {
-    __syncthreads();
+    lds_barrier();
     float* red = reinterpret_cast<float*>(&lds_w[0]);   // [WP][CO][2]
 #pragma unroll
     for (int a = 0; a < TC; ++a)
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
           red[(wp * CO + cl) * 2] = u; red[(wp * CO + cl) * 2 + 1] = w;
         }
       }
-    __syncthreads();
+    lds_barrier();
     if (t < CO) {
       float u = 0.f, w = 0.f;
 #pragma unroll
@@ -315,13 +325,10 @@ int launch_halo(const FsConvArgs& a, hipStream_t st) {
   return fs_launch_status();
 }
 
+// persistent launch: (channel tiles) x (as many blocks per tile as keep `per_cu` blocks on every CU)
 template <typename T>
 int dispatch(const FsConvArgs& a, hipStream_t st) {
   const int cop = a.Co_p;
-  auto blocks_for = [&](int PIX, int CO) {
-    HaloGeom g = pick_geom(a.Hd, a.Wd, PIX, PIX == 256 ? 360 : (PIX == 128 ? 208 : 120));
-    return g.TH == 0 ? 0L : (long)a.N * g.tiles_x * g.tiles_y * (cop / CO);
-  };
   if (cop % 32 == 0) {
     // Occupancy decides here, not operand reuse: these launches are latency-bound (one wave of blocks, each a chain
     // of load -> LDS -> MFMA -> store phases).  A 64-channel tile stages 36.8 KB of weights per chunk and only two

@@ -3,7 +3,7 @@ import sys; sys.path.insert(0, '.')
 import torch
 from fsnet_amd.hip.conv import ConvOp
 dev = torch.device('cuda:0'); dt = torch.bfloat16
-B = 12
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 SHAPES = [  # name, Ci, Co, k, stride, pad, H, W (input)
     ("stem3", 3, 64, 7, 2, 3, 192, 640), ("l1 64-64", 64, 64, 3, 1, 1, 48, 160), ("l2.0 64-128s2", 64, 128, 3, 2, 1, 48, 160),
     ("l2 128-128", 128, 128, 3, 1, 1, 24, 80), ("l3 256-256", 256, 256, 3, 1, 1, 12, 40), ("l4 512-512", 512, 512, 3, 1, 1, 6, 20),
