@@ -325,10 +325,13 @@ int launch_halo(const FsConvArgs& a, hipStream_t st) {
   return fs_launch_status();
 }
 
-// persistent launch: (channel tiles) x (as many blocks per tile as keep `per_cu` blocks on every CU)
 template <typename T>
 int dispatch(const FsConvArgs& a, hipStream_t st) {
   const int cop = a.Co_p;
+  auto blocks_for = [&](int PIX, int CO) {
+    HaloGeom g = pick_geom(a.Hd, a.Wd, PIX, PIX == 256 ? 360 : (PIX == 128 ? 208 : 120));
+    return g.TH == 0 ? 0L : (long)a.N * g.tiles_x * g.tiles_y * (cop / CO);
+  };
   if (cop % 32 == 0) {
     // Occupancy decides here, not operand reuse: these launches are latency-bound (one wave of blocks, each a chain
     // of load -> LDS -> MFMA -> store phases).  A 64-channel tile stages 36.8 KB of weights per chunk and only two

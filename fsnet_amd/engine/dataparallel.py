@@ -4,12 +4,23 @@ What the reference gets implicitly from SyncBatchNorm + DistributedDataParallel
 (scripts/train.py:100-102), restated explicitly for the HIP engine:
   * BatchNorm batch statistics / backward sums: all-reduce(SUM) of the small f64 buffers between the
     two kernels that produce and consume them (global-batch statistics, count x world).
-  * parameter gradients: each network's slice of the flat gradient arena is all-reduced (SUM, async)
-    as soon as that network's backward has finished, overlapping the remaining backward; the
-    1/world average is folded into the optimizer kernel (grad_scale).
-  * rank 0's buffers (BN running stats, depth_bins) are broadcast once at start (DDP's
-    broadcast_buffers) — afterwards every rank computes identical running statistics.
+  * parameter gradients: slices of the flat gradient arena are all-reduced (SUM) as soon as the weight gradients of
+    a ResNet stage / decoder have been issued — buckets in reverse parameter order like DDP's, on a communication
+    stream beside the rest of the backward; the 1/world average is folded into the optimizer kernel (grad_scale).
+  * rank 0's parameters and buffers (BN running stats, depth_bins) are broadcast once at start (DDP's
+    broadcast) — afterwards every rank computes identical updates.
+
+Transport.  With the nccl backend every collective of a step — the ~100 small SyncBN exchanges and the gradient
+buckets — goes through ONE direct RCCL communicator (rccl_direct.py: ncclAllReduce on the engine's own HIP
+streams).  torch.distributed's communicator is then only used at set-up and for barriers, never concurrently with
+the direct one (two communicators executing collectives on one device at the same time can deadlock when the
+device-side order differs across ranks).  No c10d work objects exist during a step, so the step can be captured
+into a hipGraph: RCCL's launches become graph nodes, RCCL itself orders the launches of one communicator across the
+chain streams.  With gloo (CPU tests, shared-device rigs), or if the direct path fails its start-up self-test, the
+collectives fall back to torch.distributed and the step is issued eagerly.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -21,22 +32,30 @@ class DataParallelContext:
         self.rank = dist.get_rank(group)
         self.handles = []
         self.meta = meta_arch
-        self.bucket_of = {}
+        self._slices = {}          # id(module) -> (arena, (lo, hi) or None)
+        self._done = {}            # id(module) -> [(lo, hi)] reduced in this step
+        self._expected = {}        # id(module) -> module: ran a training forward in this step
         self._synced = False
-        # the 100 small SyncBN exchanges per step go straight to the process group object: the checks and logging
-        # of the dist.all_reduce wrapper cost more host time than the exchange itself
         self._pg = group if group is not None else dist.distributed_c10d._get_default_group()
         self._sum = dist.AllreduceOptions()
         self._sum.reduceOp = dist.ReduceOp.SUM
-        # ... and, over RCCL, straight to ncclAllReduce on the current stream (rccl_direct.py; None: torch.distributed)
         from .rccl_direct import DirectComm
         self._direct = DirectComm.create(group)
+        self._comm_stream = None
+        self.capturable = False
+        if self._direct is not None:
+            self._comm_stream = torch.cuda.Stream(device=self._direct.device)
+            self.capturable = self._direct.capture_ok
+
+    @property
+    def direct(self):
+        return self._direct is not None
 
     # ---- small latency-bound exchanges (BN) ------------------------------------------------
     def allreduce_small(self, t, out=None):
         """SUM over the ranks, in place or into `out` (t then keeps the local values)"""
-        if self._direct is not None and not torch.cuda.is_current_stream_capturing():
-            self._direct.all_reduce_sum(t, out)
+        if self._direct is not None:
+            self._direct.all_reduce_sum(t, out)          # current stream; a graph node under capture
             return
         if out is not None:
             out.copy_(t)
@@ -51,29 +70,78 @@ class DataParallelContext:
                 dist.broadcast(arena.data, src=0, group=self.group)
                 for b in meta_arch.buffers():
                     dist.broadcast(b, src=0, group=self.group)
+            from .runtime import RT
+            RT.bump_weights()        # packed MFMA operands follow the broadcast weights
+            torch.cuda.synchronize() if torch.cuda.is_available() else None
             self._synced = True
+        # a forward that never met its backward (validation-style call, caught exception) must not leave a network
+        # waiting forever: the pending counters restart with every step
+        for m in meta_arch.modules():
+            if "_pending" in m.__dict__ and isinstance(m.__dict__["_pending"], int):
+                m._pending = 0
         self.handles = []
+        self._done = {}
+        self._expected = {}
 
-    def grads_ready(self, module):
-        """called by a network's autograd Function when its last pending backward has finished."""
-        arena = self.meta._arena
-        ent = self.bucket_of.get(id(module))         # walking module.parameters() costs ~0.2 ms per call
+    def note_forward(self, module):
+        """a network ran a training forward: its gradients must be reduced before finish()"""
+        self._expected[id(module)] = module
+
+    def _slice(self, module, arena):
+        ent = self._slices.get(id(module))         # walking module.parameters() costs ~0.2 ms per call
         if ent is None or ent[0] is not arena:
-            params = [p for p in module.parameters()]
-            ent = self.bucket_of[id(module)] = (arena, arena.slice_of(params) if params else None)
-        if ent[1] is None:
+            params = [p for p in module.parameters() if arena.owns(p)]
+            ent = self._slices[id(module)] = (arena, arena.slice_of(params) if params else None)
+        return ent[1]
+
+    def _reduce_range(self, arena, lo, hi):
+        if hi <= lo:
+            return
+        g = arena.grad[lo:hi]
+        if self._direct is not None:
+            # the bucket's weight gradients were issued on the current (chain) stream: the communication stream
+            # picks up from there, the chain goes on with the rest of the backward
+            cur = torch.cuda.current_stream(g.device)
+            self._comm_stream.wait_stream(cur)
+            with torch.cuda.stream(self._comm_stream):
+                self._direct.all_reduce_sum(g)
             return
         from .nets import flush_deferred, join_companions
-        if self.world > 1 and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
-            # under capture join_companions() leaves the companion joins to the end of the step (ROCm 7.2 nested
-            # fork-join crash), so this all-reduce node would not depend on the weight-gradient kernels; harmless at
-            # world size 1 (the experiment FSNET_AMD_GRAPH_DP=1 covers), wrong beyond it -> the hook falls back to eager
-            raise RuntimeError("graph-captured data-parallel steps are not validated beyond world size 1")
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("torch.distributed gradient buckets cannot be captured into a hipGraph")
         flush_deferred()          # weight-gradient kernels handed to companion streams must have landed in the
         join_companions()         # arena slice before it is reduced
-        lo, hi = ent[1]
-        h = dist.all_reduce(arena.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self.handles.append(h)
+        self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def partial_ready(self, module, sub_modules):
+        """the weight gradients of `sub_modules` (children of `module`, e.g. one ResNet stage) are issued: reduce
+        their slice now.  grads_ready(module) later reduces what is left."""
+        arena = self.meta._arena
+        sl = self._slice(module, arena)
+        if sl is None:
+            return
+        params = [p for m in sub_modules for p in m.parameters() if arena.owns(p)]
+        if not params:
+            return
+        lo, hi = arena.slice_of(params)
+        assert sl[0] <= lo and hi <= sl[1]
+        self._done.setdefault(id(module), []).append((lo, hi))
+        self._reduce_range(arena, lo, hi)
+
+    def grads_ready(self, module):
+        """called by a network's autograd Function when its last pending backward has finished: reduces the part of
+        the network's arena slice that partial_ready() has not covered yet."""
+        arena = self.meta._arena
+        sl = self._slice(module, arena)
+        if sl is None:
+            return
+        done = sorted(self._done.get(id(module), []))
+        pos = sl[0]
+        for lo, hi in done:
+            self._reduce_range(arena, pos, lo)
+            pos = max(pos, hi)
+        self._reduce_range(arena, pos, sl[1])
+        self._done[id(module)] = [(sl[0], sl[1])]
 
     def close(self):
         """release the direct RCCL communicator (before the process group is destroyed)"""
@@ -82,8 +150,25 @@ class DataParallelContext:
             self._direct = None
 
     def finish(self):
-        """wait for the outstanding gradient all-reduces; returns the scale that turns SUM into MEAN."""
+        """wait for the outstanding gradient all-reduces; returns the scale that turns SUM into MEAN.  Raises if a
+        network that ran a training forward in this step never had its gradients reduced (ranks would diverge
+        silently)."""
+        arena = self.meta._arena
+        for mid, module in self._expected.items():
+            sl = self._slice(module, arena)
+            if sl is not None and self._done.get(mid) != [(sl[0], sl[1])]:
+                raise RuntimeError("data parallel: gradients of %s were not all-reduced in this step (forward without a "
+                                   "completed backward?)" % type(module).__name__)
+        if self._direct is not None:
+            torch.cuda.current_stream(self._direct.device).wait_stream(self._comm_stream)
         for h in self.handles:
             h.wait()
         self.handles = []
         return 1.0 / self.world
+
+
+def graph_dp_enabled():
+    """hipGraph capture of data-parallel steps: on when every collective runs on the direct communicator and its
+    start-up self-test (collectives on two streams inside a captured graph, replayed) passed; FSNET_AMD_GRAPH_DP=0
+    keeps the step eager."""
+    return os.environ.get("FSNET_AMD_GRAPH_DP", "1") != "0"

@@ -255,7 +255,9 @@ class ConvLayer:
         gw = grad_of(self.m.weight)
         gb = grad_of(self.m.bias) if self.m.bias is not None else None
         item = (op, dc, x, gw, gb, self.m.bias.numel() if gb is not None else 0)
-        mode = RT.wgrad_streams if (dc.is_cuda and RT.overlap) else 0
+        # (data parallel: inline on the chain stream, so that one event after a stage's last weight gradient covers
+        # the arena slice its gradient bucket reduces — also inside a captured step)
+        mode = RT.wgrad_streams if (dc.is_cuda and RT.overlap and RT.dp is None) else 0
         if mode:
             cur = _current_stream(dc.device)
             if mode == 3:
@@ -484,6 +486,10 @@ class ResNetRunner:
                     # feature gradient still has to be added to it first (stage boundary without downsample)
                     prev = (pu[2], pu[1], pu[3])
                 dout, dsums = self._block_bwd(units, ds, ctx["blocks"][bi], dout, extra, dout_sums=dsums, prev=prev)
+            if RT.dp is not None and si >= 2:
+                # gradient bucket of this stage (reverse parameter order, like DDP): layer4 and layer3 carry 94 % of
+                # the encoder's parameters and finish first
+                RT.dp.partial_ready(self.m, [getattr(self.m, "layer%d" % (si + 1))])
         y0 = ctx["y0"]
         d0 = ops.maxpool_bwd(dout, ctx["idx"], y0.shape[1], y0.shape[2], addend=gfeats[0])
         dc0 = _bn_bwd(d0, y0, ctx["c0"], self.m.bn1, ctx["st0"], y0.shape[1], y0.shape[2], relu=True)

@@ -1,16 +1,19 @@
-"""Direct RCCL calls for the small, latency-bound SyncBatchNorm exchanges.
+"""Direct RCCL calls: every collective of a data-parallel step on the engine's own HIP streams.
 
-A data-parallel step issues 100 all-reduces of a few hundred bytes.  Through torch.distributed each
-costs ~30 us of host time — tensor checks, the event hand-shake with the process group's internal stream, the work
-object and its watchdog bookkeeping — which makes the eager N > 1 step host-bound.  The exchange itself is one
-ncclAllReduce on the stream the producing and consuming kernels already run on, so this module opens a second RCCL
-communicator over the same ranks (unique id from rank 0, distributed with torch.distributed) and calls
-ncclAllReduce through ctypes on the current HIP stream: stream order does the rest, nothing else is launched.
+A data-parallel step issues 100 all-reduces of a few hundred bytes for SyncBatchNorm plus the gradient buckets
+(DESIGN.md 6).  Through torch.distributed each small exchange costs ~30 us of host time — tensor checks, the event
+hand-shake with the process group's internal stream, the work object and its watchdog bookkeeping — which makes the
+eager N > 1 step host-bound, and the work objects keep the step from being captured into a hipGraph.  The exchange
+itself is one ncclAllReduce on the stream the producing and consuming kernels already run on, so this module opens
+an RCCL communicator over the same ranks (unique id from rank 0, distributed with torch.distributed) and calls
+ncclAllReduce through ctypes on the current HIP stream: stream order does the rest, nothing else is launched, and
+under stream capture the launch becomes a graph node.  Once it exists, the engine sends ALL of a step's collectives
+through this one communicator (dataparallel.py); torch.distributed's own communicator is idle during a step.
 
-Gradient buckets stay on torch.distributed (large, asynchronous, overlapped on the process group's stream).
 Everything here fails soft: any error while loading the library, creating the communicator or in the start-up
-self-test (a known f64 vector reduced both ways must agree) leaves `DirectComm.create` returning None and the
-torch.distributed path in use.
+self-tests leaves `DirectComm.create` returning None and the torch.distributed path in use.  Self-tests: (1) a
+known f64 vector reduced both ways must agree on every rank; (2) `capture_ok`: all-reduces on two streams captured
+into a hipGraph and replayed twice must give the exact sums — only then are data-parallel steps captured.
 """
 import ctypes as C
 import os
@@ -45,6 +48,7 @@ def _load():
 class DirectComm(object):
     def __init__(self, lib, comm, world, rank, device):
         self.lib, self.comm, self.world, self.rank, self.device = lib, comm, world, rank, device
+        self.capture_ok = False
 
     @classmethod
     def create(cls, group=None, device=None):
@@ -79,6 +83,7 @@ class DirectComm(object):
             if not self._self_test(group):
                 self.close()
                 return None
+            self.capture_ok = self._capture_test(group)
             return self
         except Exception as e:      # noqa: BLE001 — any failure means "use torch.distributed"
             import warnings
@@ -116,3 +121,44 @@ class DirectComm(object):
         ok = torch.tensor([1 if torch.equal(a, b) else 0], dtype=torch.int32, device=self.device)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)      # every rank takes the same decision
         return bool(int(ok) == 1)
+
+    def _capture_test(self, group):
+        """all-reduces on a capture stream and a forked stream inside one hipGraph, replayed twice: exact sums on
+        every rank, or data-parallel steps stay eager"""
+        if os.environ.get("FSNET_AMD_GRAPH_DP", "1") == "0":
+            return False
+        dev, W = self.device, self.world
+
+        def agree(flag):
+            ok = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            torch.cuda.synchronize(dev)
+            return bool(int(ok) == 1)
+
+        graph, a, b = None, None, None
+        try:
+            a = torch.full((257,), float(self.rank + 1), dtype=torch.float64, device=dev)
+            b = torch.full((70001,), float(self.rank + 1), dtype=torch.float32, device=dev)
+            main, side = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=main, capture_error_mode="thread_local"):
+                self.all_reduce_sum(a)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    self.all_reduce_sum(b)
+                torch.cuda.current_stream(dev).wait_stream(side)
+            captured = True
+        except Exception as e:      # noqa: BLE001
+            import warnings
+            warnings.warn("fsnet_amd: RCCL collectives could not be captured into a hipGraph (%s: %s); data-parallel "
+                          "steps run eagerly" % (type(e).__name__, e))
+            captured = False
+        if not agree(captured):          # nobody replays unless everybody captured
+            return False
+        graph.replay()
+        graph.replay()
+        torch.cuda.synchronize(dev)
+        s1 = W * (W + 1) / 2.0
+        good = bool((a == s1 * W).all()) and bool((b == s1 * W).all())
+        return agree(good)

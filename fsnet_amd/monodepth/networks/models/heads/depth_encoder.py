@@ -20,6 +20,8 @@ class _DepthDecoderFn(torch.autograd.Function):
         outs, c = mod._runner.forward(feats, train=True, P2=P2)
         ctx.mod, ctx.c, ctx.nfeat, ctx.nparam = mod, c, nfeat, len(args) - nfeat
         mod._pending += 1
+        if RT.dp is not None:
+            RT.dp.note_forward(mod)
         flat = []
         for s in mod.scales:
             logits, depth, disp = outs[s][:3]

@@ -18,6 +18,8 @@ class _PoseFn(torch.autograd.Function):
         aa, tr, T, c = mod._runner.forward(nhwc_dense(feat, feat.dtype), invert)
         ctx.mod, ctx.c, ctx.nparam = mod, c, len(params)
         mod._pending += 1
+        if RT.dp is not None:
+            RT.dp.note_forward(mod)
         return aa, tr, T
 
     @staticmethod
@@ -45,6 +47,8 @@ class _PosePairsFn(torch.autograd.Function):
         aa, tr, T, c = mod._runner.forward(nhwc_dense(feat, feat.dtype), inverts)
         ctx.mod, ctx.c, ctx.nparam, ctx.G = mod, c, len(params), len(inverts)
         mod._pending += 1
+        if RT.dp is not None:
+            RT.dp.note_forward(mod)
         return tuple(aa) + tuple(tr) + tuple(T)
 
     @staticmethod

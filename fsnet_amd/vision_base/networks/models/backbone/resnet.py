@@ -59,6 +59,8 @@ class _ResNetFn(torch.autograd.Function):
         feats, c = mod._runner.forward(x, train=True, groups=groups)
         ctx.mod, ctx.c, ctx.dtype = mod, c, x.dtype
         mod._pending += 1
+        if RT.dp is not None:
+            RT.dp.note_forward(mod)
         return tuple(f.permute(0, 3, 1, 2) for f in feats)
 
     @staticmethod

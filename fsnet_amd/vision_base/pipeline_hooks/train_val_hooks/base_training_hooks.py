@@ -26,10 +26,11 @@ class BaseTrainingHook(object):
         if use_graph is None:
             use_graph = os.environ.get("FSNET_AMD_GRAPH", "1") != "0"
         self.use_graph = bool(use_graph)
-        # FSNET_AMD_GRAPH_DP=1: also capture data-parallel steps (SyncBN / gradient all-reduces become graph nodes).
-        # Experimental, off by default: exercised at world size 1 only, and one of ~15 runs aborted in the capture
-        # (process-group watchdog polling events while the capture was open).
-        self.graph_dp = os.environ.get("FSNET_AMD_GRAPH_DP", "0") != "0"
+        # data-parallel steps are captured too when every collective of the step runs on the engine's direct RCCL
+        # communicator and its start-up capture self-test passed on all ranks (engine/dataparallel.py, rccl_direct.py):
+        # SyncBN exchanges and gradient buckets are then graph nodes and no torch.distributed work object exists while
+        # the capture is open.  FSNET_AMD_GRAPH_DP=0 keeps them eager.
+        self.graph_dp = os.environ.get("FSNET_AMD_GRAPH_DP", "1") != "0"
         self.graph_warmup = int(graph_warmup)   # eager steps before the capture (at least 2: see __call__)
         self.graph_captures = 0
         self._g = None            # dict(graph, sig, static, output, stream, ...) once captured
@@ -53,10 +54,11 @@ class BaseTrainingHook(object):
     def _graph_ok(self, meta_arch, optimizer, arena, fused):
         if not (self.use_graph and fused and arena is not None and torch.cuda.is_available()):
             return False
-        if not self.graph_dp and (RT.dp is not None or (
-                torch.distributed.is_available() and torch.distributed.is_initialized()
-                and torch.distributed.get_world_size() > 1)):
-            return False      # data-parallel steps replay RCCL collectives from the graph only on request
+        if RT.dp is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
+                                 and torch.distributed.get_world_size() > 1):
+            # (RT.dp is created by the first forward: the warm-up steps run before this can say yes)
+            if not (self.graph_dp and RT.dp is not None and RT.dp.capturable):
+                return False
         if not next(meta_arch.parameters()).is_cuda:
             return False
         return True

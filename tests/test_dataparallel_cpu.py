@@ -113,6 +113,62 @@ def _grad_bucket_case(rank, world):
     return err, float(p_after.sum()), float(net.a[1].running_mean.sum()), [float(p.grad.sum()) for p in net.parameters()][:2]
 
 
+def _partial_bucket_case(rank, world):
+    """stage-level buckets: partial_ready() reduces a child's slice early, grads_ready() the rest of the network —
+    every element reduced exactly once; finish() raises when a network that ran a forward was never reduced, and
+    begin_step() resets pending counters a forward without backward left behind."""
+    import torch.nn as nn
+    from fsnet_amd.engine.dataparallel import DataParallelContext
+    from fsnet_amd.engine.runtime import ParamArena
+
+    class Enc(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1 = nn.Conv2d(3, 4, 3)
+            self.layer1 = nn.Sequential(nn.Conv2d(4, 4, 3), nn.BatchNorm2d(4))
+            self.layer2 = nn.Sequential(nn.Conv2d(4, 8, 3), nn.BatchNorm2d(8))
+            self._pending = 0
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.enc = Enc()
+            self.head = nn.Linear(5, 7)
+            self.head._pending = 0
+    torch.manual_seed(2)
+    net = Net()
+    arena = ParamArena(list(net.named_parameters()), torch.device("cpu"))
+    net._arena = arena
+    dp = DataParallelContext(net)
+    net.enc._pending = 3                      # a forward that never saw its backward
+    dp.begin_step(net)
+    assert net.enc._pending == 0
+    arena.zero_grads()
+    torch.manual_seed(200 + rank)
+    for p in net.parameters():
+        p.grad.copy_(torch.randn_like(p))
+    local = arena.grad.clone()
+    dp.note_forward(net.enc); dp.note_forward(net.head)
+    dp.partial_ready(net.enc, [net.enc.layer2])       # reverse parameter order, like DDP's buckets
+    dp.grads_ready(net.head)
+    raised = False
+    try:
+        dp.finish()                                    # enc's conv1 / layer1 not reduced yet
+    except RuntimeError:
+        raised = True
+    dp.grads_ready(net.enc)
+    scale = dp.finish()
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    expect = sum(gathered) / world
+    return float((arena.grad * scale - expect).abs().max()), raised
+
+
+def test_stage_buckets_reduce_every_gradient_once_and_finish_checks_coverage():
+    res = _run(_partial_bucket_case)
+    assert all(v[0] < 1e-6 and v[1] for v in res.values()), res
+
+
 def test_gradient_buckets_and_initial_broadcast():
     res = _run(_grad_bucket_case)
     assert all(v[0] < 1e-6 for v in res.values())

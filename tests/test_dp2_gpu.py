@@ -82,6 +82,7 @@ def test_two_ranks_equal_one_process_on_the_full_batch(dev, tmp_path):
     assert float((r0["running"] - r1["running"]).abs().max()) == 0.0
 
     m, opt, hook = _build(dev)
+    p_init = torch.cat([p.detach().flatten() for p in m.parameters()]).cpu()
     losses = []
     for it in range(STEPS):
         out = hook(dict(_full_batch(it)), m, opt)
@@ -92,6 +93,9 @@ def test_two_ranks_equal_one_process_on_the_full_batch(dev, tmp_path):
     for it in range(STEPS):
         dp_loss = 0.5 * (r0["losses"][it] + r1["losses"][it])       # mean over the global batch
         assert abs(dp_loss - losses[it]) < 2e-5 * abs(losses[it]), (it, dp_loss, losses[it])
-    # same trajectory up to fp32 summation order (sign-noise parameters move by <= one Adam step, lr = 1e-4)
-    assert float((r0["params"] - params).abs().max()) < 2.5e-4
+    # same trajectory up to fp32 summation order.  (|dp - single| < lr would hold for ANY gradient — Adam moves each
+    # weight by ~lr per step — so compare the updates themselves: direction and relative size)
+    from tests.test_dp_gpu import same_update
+    agree, rel = same_update(r0["params"] - p_init, params - p_init)
+    assert agree > 0.97 and rel < 0.2, (agree, rel)
     assert float(((r0["running"] - running).abs() / running.abs().clamp_min(1.0)).max()) < 1e-3

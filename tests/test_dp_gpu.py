@@ -41,13 +41,25 @@ def _run_steps(dev, use_dp):
         m.ensure_arena()
         RT.dp = DataParallelContext(m)        # world_size 1: every collective is an identity, but it is issued
     losses = []
+    p0 = torch.cat([p.detach().flatten() for p in m.parameters()]).cpu()
     for it in range(2):
         out = hook(dict(O.synthetic_batch(2, 64, 128, seed=50 + it)), m, opt)
         losses.append(float(out["loss"].detach()))
     torch.cuda.synchronize()
-    calls = None if RT.dp is None else (RT.dp.world, RT.dp._direct is not None)
+    calls = None if RT.dp is None else (RT.dp.world, RT.dp._direct is not None, RT.dp.capturable)
+    if RT.dp is not None:
+        RT.dp.close()
     RT.dp = None
-    return losses, torch.cat([p.detach().flatten() for p in m.parameters()]).cpu(), calls
+    return losses, torch.cat([p.detach().flatten() for p in m.parameters()]).cpu() - p0, calls
+
+
+def same_update(da, db):
+    """two parameter updates after a few Adam steps agree in DIRECTION: Adam moves every weight by ~lr per step
+    whatever the gradient's size, so |da - db| < lr-ish holds for any gradient — the sign pattern does not"""
+    big = (da.abs() > 2e-5) | (db.abs() > 2e-5)
+    agree = float((torch.sign(da[big]) == torch.sign(db[big])).float().mean())
+    rel = float((da - db).norm() / db.norm())
+    return agree, rel
 
 
 def test_dp_path_on_rccl_matches_single_process(dev):
@@ -58,10 +70,11 @@ def test_dp_path_on_rccl_matches_single_process(dev):
     finally:
         dist.destroy_process_group()
     l_ref, p_ref, _ = _run_steps(dev, False)
-    assert world == (1, True)          # RCCL backend: the SyncBN exchanges went through the direct communicator
+    assert world[:2] == (1, True)      # RCCL backend: every collective went through the direct communicator
     # two runs differ only by fp32 atomic ordering (depth-gradient scatter): ~1e-6 relative
     assert l_dp == pytest.approx(l_ref, rel=2e-4)
-    assert float((p_dp - p_ref).abs().max()) < 2.5e-4   # <= one Adam step of lr=1e-4 on sign-noise parameters
+    agree, rel = same_update(p_dp, p_ref)
+    assert agree > 0.98 and rel < 0.15, (agree, rel)
 
 
 def test_direct_rccl_communicator(dev):
@@ -91,39 +104,46 @@ def test_direct_rccl_communicator(dev):
         dist.destroy_process_group()
 
 
-@pytest.mark.skipif(os.environ.get("FSNET_AMD_TEST_GRAPH_DP", "0") == "0",
-                    reason="experimental path: capturing RCCL collectives raced the process-group watchdog once in "
-                           "~15 runs (process abort); run with FSNET_AMD_TEST_GRAPH_DP=1")
-def test_dp_step_replayed_from_a_hipgraph_on_rccl(dev, monkeypatch):
-    """opt-in FSNET_AMD_GRAPH_DP=1: the data-parallel step (RCCL collectives included) captured and replayed"""
+def test_dp_step_replayed_from_a_hipgraph_on_rccl(dev):
+    """the data-parallel step — SyncBN exchanges on both chain streams and the gradient buckets on the communication
+    stream, all on the direct RCCL communicator — captured into a hipGraph and replayed; three independent captures
+    (the round-1 capture raced the process group's watchdog once in ~15 runs: no torch.distributed work object exists
+    during a step any more)"""
     from fsnet_amd.configs import meta_arch_cfg, training_cfg
     from fsnet_amd.engine.dataparallel import DataParallelContext
     from fsnet_amd.engine.runtime import RT
     from fsnet_amd.vision_base.networks.optimizers.optimizers import build_optimizer
     from fsnet_amd.vision_base.utils.builder import build
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    monkeypatch.setenv("FSNET_AMD_GRAPH_DP", "1")
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
+    all_losses = []
     try:
-        RT.set_compute_dtype(torch.float32)
-        RT.tie_noise = False
-        m = build(**meta_arch_cfg(64, 128, with_pose=True))
-        m.load_state_dict(O.init_state(seed=6, with_pose=True), strict=True)
-        m = m.to(dev).train()
-        tc = training_cfg()
-        opt = build_optimizer(m, **tc.optimizer)
-        hook = build(graph_warmup=2, **tc.training_hook)
-        m.ensure_arena()
-        RT.dp = DataParallelContext(m)
-        losses = []
-        for it in range(5):
-            out = hook(dict(O.synthetic_batch(2, 64, 128, seed=50 + it)), m, opt)
-            losses.append(float(out["loss"].detach()))
-        torch.cuda.synchronize()
-        assert hook.graph_captures == 1 and hook.graph_replays == 2 and hook.use_graph
+        for rep in range(3):
+            RT.set_compute_dtype(torch.float32)
+            RT.tie_noise = False
+            m = build(**meta_arch_cfg(64, 128, with_pose=True))
+            m.load_state_dict(O.init_state(seed=6, with_pose=True), strict=True)
+            m = m.to(dev).train()
+            tc = training_cfg()
+            opt = build_optimizer(m, **tc.optimizer)
+            hook = build(graph_warmup=2, **tc.training_hook)
+            m.ensure_arena()
+            RT.dp = DataParallelContext(m)
+            assert RT.dp.direct and RT.dp.capturable
+            losses = []
+            for it in range(6):
+                out = hook(dict(O.synthetic_batch(2, 64, 128, seed=50 + it)), m, opt)
+                losses.append(float(out["loss"].detach()))
+            torch.cuda.synchronize()
+            assert hook.graph_captures == 1 and hook.graph_replays == 3 and hook.use_graph
+            all_losses.append(losses)
+            RT.dp.close()
+            RT.dp = None
     finally:
         RT.dp = None
         dist.destroy_process_group()
     l_ref, _, _ = _run_steps(dev, False)
-    assert losses[:2] == pytest.approx(l_ref, rel=2e-4)   # second step: see tests/test_graph_gpu.py on the run-to-run spread
-    assert all(l == l and l < 10 for l in losses)
+    for losses in all_losses:
+        assert losses[:2] == pytest.approx(l_ref, rel=2e-4)   # (later steps: tests/test_graph_gpu.py on the run-to-run spread)
+        assert all(l == l and l < 10 for l in losses)
+        assert losses == pytest.approx(all_losses[0], rel=1e-3)
