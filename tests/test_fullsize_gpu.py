@@ -117,3 +117,68 @@ def test_full_size_training_steps(dev):
     assert bool(torch.isfinite(flat).all())
     assert float(opt.grad_norm()) > 0
     RT.tie_noise = False
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE configs[2] / [4]: ResNet-50 (Bottleneck) at 320x1024
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Ci,Co,k,h,w", [(256, 64, 1, 80, 256), (64, 256, 1, 80, 256), (1024, 2048, 1, 10, 32),
+                                         (512, 512, 3, 10, 32), (2048, 256, 3, 10, 32), (1280, 256, 3, 20, 64)])
+def test_r50_conv_shapes_linearity_and_adjoint_at_320x1024(dev, Ci, Co, k, h, w):
+    """the Bottleneck's 1x1 convolutions with up to 2048 channels and the R50 decoder's wide skip-concat convolutions
+     at their real sizes, batch 4: linearity, weight-gradient additivity, adjoint identity"""
+    from fsnet_amd.hip.conv import ConvOp
+    dt, Bs = torch.bfloat16, 4
+    g = torch.Generator().manual_seed(Ci + Co + h)
+    op = ConvOp(Ci, Co, k, k, 1, k // 2, dt, dev)
+    op.pack((torch.randn(Co, Ci, k, k, generator=g) / (k * Ci ** 0.5)).to(dev))
+    x1 = (torch.randint(-8, 9, (Bs, h, w, op.Ci_p), generator=g).float() / 8).to(dev).to(dt)
+    x2 = (torch.randint(-8, 9, (Bs, h, w, op.Ci_p), generator=g).float() / 8).to(dev).to(dt)
+    y1, y2, y12 = op.forward(x1, out_f32=True), op.forward(x2, out_f32=True), op.forward(x1 + x2, out_f32=True)
+    assert float((y12 - (y1 + y2)).abs().max()) <= 2e-5 * float(y12.abs().max())
+    dy = (torch.randint(-4, 5, (Bs, h, w, op.Co_p), generator=g).float() / 4).to(dev).to(dt)
+    full, parts = torch.zeros(Co, Ci, k, k, device=dev), torch.zeros(Co, Ci, k, k, device=dev)
+    op.wgrad(dy, x1, full)
+    for lo, hi in ((0, 1), (1, Bs)):
+        op.wgrad(dy[lo:hi].contiguous(), x1[lo:hi].contiguous(), parts)
+    torch.cuda.synchronize()
+    assert float((full - parts).abs().max()) <= 1e-4 * float(full.abs().max())
+    lhs = float((y1.double() * dy.double()).sum())
+    dx = op.dgrad(dy, h, w).double()
+    rhs = float((x1.double() * dx).sum())
+    # dx is stored in bf16: every term x * dx carries an independent relative rounding error of 2^-9, so the sum's
+    # error is a random walk of size 2^-9 sqrt(sum (x dx)^2) — six standard deviations
+    sigma = 2.0 ** -9 * float(((x1.double() * dx) ** 2).sum().sqrt())
+    assert abs(lhs - rhs) <= 6 * sigma + 1e-6 * abs(lhs), (lhs, rhs, sigma)
+
+
+@pytest.mark.parametrize("with_pose,base_fx,bins", [(True, None, 16), (False, 492.0, 64)],
+                         ids=["configs2-depth+pose", "configs4-wpose-64bins-basefx"])
+def test_r50_full_size_training_steps_320x1024(dev, with_pose, base_fx, bins):
+    """ResNet-50 at 320x1024, bf16, batch 4: eight steps through the hook (hipGraph replay included) stay finite and
+    bounded (a randomly initialised ResNet-50 does not improve monotonically in eight clipped steps: no claim about the
+    loss going down), gradients flow, every parameter stays finite"""
+    from fsnet_amd.configs import meta_arch_cfg, training_cfg
+    from fsnet_amd.engine.runtime import RT
+    from fsnet_amd.vision_base.networks.optimizers.optimizers import build_optimizer
+    from fsnet_amd.vision_base.utils.builder import build
+    Hh, Ww, Bs = 320, 1024, 4
+    RT.set_compute_dtype(torch.bfloat16)
+    RT.tie_noise = True
+    torch.manual_seed(0)
+    m = build(**meta_arch_cfg(Hh, Ww, with_pose=with_pose, depth=50, num_output_channels=bins, base_fx=base_fx)).to(dev).train()
+    tc = training_cfg(clip_gradients=1.0, lr=1e-4)          # configs/multi_dataset_example clips at 1.0
+    opt = build_optimizer(m, **tc.optimizer)
+    hook = build(graph_warmup=2, **tc.training_hook)
+    batch = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in O.synthetic_batch(Bs, Hh, Ww, seed=2).items()}
+    losses = []
+    for it in range(8):
+        out = hook(dict(batch), m, opt)
+        losses.append(float(out["loss"].detach()))
+    torch.cuda.synchronize()
+    assert hook.graph_captures == 1 and hook.graph_replays == 5
+    assert all(l == l and 0 < l < 10 for l in losses), losses
+    assert max(losses) < 1.5 * losses[0], losses
+    assert float(opt.grad_norm()) > 0
+    assert bool(torch.isfinite(torch.cat([p.detach().flatten() for p in m.parameters()])).all())
+    RT.tie_noise = False
