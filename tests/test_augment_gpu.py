@@ -170,3 +170,43 @@ def test_validation_resize_matches_reference_vectors(dev):
         if len(samples) == 2:
             want = A.run_val_sample(frame[:-3, :-5], (48, 160), g["mean"], g["std"], **kw)
             assert np.array_equal(batch[('image', 0)][1].cpu().numpy(), want)
+
+
+def test_kitti_dataset_through_device_pipeline_into_a_training_step(dev, tmp_path):
+    """KittiDepthMonoDataset (PNG decode, calibration, poses) -> DataLoader with DeviceAugment.collate ->
+    fs_augment_frames -> one optimisation step: the whole data side of configs/kitti_wpose_example on the mirror"""
+    from torch.utils.data import DataLoader
+    from fsnet_amd.configs import meta_arch_cfg, training_cfg
+    from fsnet_amd.engine.runtime import RT
+    from fsnet_amd.monodepth.data.datasets.mono_dataset import KittiDepthMonoDataset
+    from fsnet_amd.vision_base.data.augmentations.augmentations import DeviceAugment
+    from fsnet_amd.vision_base.networks.optimizers.optimizers import build_optimizer
+    from fsnet_amd.vision_base.utils.builder import build
+    from tests import helpers_kitti as HK
+    H, W = 64, 128
+    g = dict(HA.golden())
+    g["out_h"], g["out_w"] = np.int64(H), np.int64(W)
+    raw, split = HK.make_tree(str(tmp_path), seed=5)
+    cfg = HK.dataset_cfg(raw, split, prefix='fsnet_amd.')
+    cfg["augmentation"] = HA.pipeline_cfg(g)
+    ds = KittiDepthMonoDataset(**cfg)
+    aug = DeviceAugment(HA.FRAME_IDXS)
+    np.random.seed(3)
+    loader = DataLoader(ds, batch_size=3, collate_fn=aug.collate, num_workers=0)
+    RT.set_compute_dtype(torch.float32)
+    torch.manual_seed(0)
+    m = build(**meta_arch_cfg(H, W, with_pose=False)).to(dev).train()
+    tc = training_cfg()
+    opt = build_optimizer(m, **tc.optimizer)
+    hook = build(use_graph=False, **tc.training_hook)
+    n = 0
+    for batch in loader:
+        batch = aug.materialize(batch, dev)
+        assert batch[("image", 0)].shape == (3, 3, H, W) and batch[("relative_pose", 1)].shape == (3, 4, 4)
+        assert batch["P2"].shape == (3, 3, 4) and batch["patched_mask"].dtype == torch.float64
+        out = hook(batch, m, opt)
+        loss = float(out["loss"].detach())
+        assert loss == loss and 0 < loss < 10
+        n += 1
+    assert n == 1
+    RT.set_compute_dtype(torch.bfloat16)

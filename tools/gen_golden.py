@@ -570,12 +570,39 @@ def gen_model_r50fx():
     np.savez_compressed(os.path.join(GOLD, "model_r50fx.npz"), **out)
 
 
+def gen_kitti_dataset():
+    """the REAL KittiDepthMonoDataset (mono_dataset.py:108-250) over the seeded fake KITTI tree of
+    tests/helpers_kitti.py: filtered index, relative poses, P2, image tensors"""
+    import tempfile
+    from tests import helpers_kitti as HK
+    from monodepth.data.datasets.mono_dataset import KittiDepthMonoDataset
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        raw, split = HK.make_tree(d, seed=5)
+        ds = KittiDepthMonoDataset(**HK.dataset_cfg(raw, split, prefix=''))
+        out["n"] = len(ds)
+        out["index"] = np.array([[o["index"], 0 if o["side"] == "l" else 1] for o in ds.imdb])
+        for i in range(len(ds)):
+            smp = ds[i]
+            for f, tag in ((0, "0"), (1, "p"), (-1, "m")):
+                out["s%d_image_%s" % (i, tag)] = npy(smp[("image", f)])
+                out["s%d_orig_%s" % (i, tag)] = npy(smp[("original_image", f)])
+            out["s%d_pose_p" % i], out["s%d_pose_m" % i] = np.asarray(smp[("relative_pose", 1)]), np.asarray(smp[("relative_pose", -1)])
+            out["s%d_P2" % i], out["s%d_original_P2" % i] = np.asarray(smp["P2"]), np.asarray(smp["original_P2"])
+            out["s%d_mask" % i] = npy(smp["patched_mask"])
+    print("kitti dataset: %d of 5 split entries kept, sides %s" % (out["n"], out["index"][:, 1].tolist()))
+    np.savez_compressed(os.path.join(GOLD, "kitti_dataset.npz"), **out)
+
+
 if __name__ == "__main__":
     if "--only-augment" in sys.argv:
         gen_augment()
         sys.exit(0)
     if "--only-fisheye" in sys.argv:
         gen_fisheye()
+        sys.exit(0)
+    if "--only-kitti" in sys.argv:
+        gen_kitti_dataset()
         sys.exit(0)
     if "--only-r50fx" in sys.argv:
         gen_model_r50fx()
@@ -589,5 +616,6 @@ if __name__ == "__main__":
     gen_augment()
     gen_fisheye()
     gen_model_r50fx()
+    gen_kitti_dataset()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")
