@@ -8,6 +8,11 @@ from fsnet_amd.vision_base.networks.models.meta_archs.base_meta import BaseMetaA
 from fsnet_amd.vision_base.utils.builder import build
 
 
+from fsnet_amd.engine import torch_compat as _torch_compat
+
+_torch_compat.install()      # scripts/train.py:100-102 wraps the meta-arch in SyncBatchNorm / DistributedDataParallel
+
+
 class _HipMetaArch(BaseMetaArch):
     """shared plumbing: flat parameter arena, data-parallel context, compute dtype."""
 

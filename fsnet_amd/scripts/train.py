@@ -10,6 +10,7 @@ statistics and gradients itself over RCCL), no tensorboard/git requirements (wri
 hooks are out of scope for this path and are skipped unless importable.
 """
 import argparse
+import ast
 import os
 import sys
 
@@ -33,8 +34,8 @@ def parse_overrides(argv):
         if a.startswith("--") and "=" in a:
             k, v = a[2:].split("=", 1)
             try:
-                v = eval(v, {}, {})  # noqa: S307 - same convenience as python-fire in the reference
-            except Exception:
+                v = ast.literal_eval(v)     # literals only, like python-fire in the reference
+            except (ValueError, SyntaxError):
                 pass
             out[k] = v
     return out
@@ -47,8 +48,9 @@ def main(argv=None):
     args, rest = ap.parse_known_args(argv)
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "-1")) if world_size > 1 else -1
+    rank = int(os.environ.get("RANK", "0")) if world_size > 1 else -1     # global rank: sampler shard + logging gate
     is_distributed = world_size > 1
-    is_logging = local_rank <= 0
+    is_logging = rank <= 0
 
     cfg = update_cfg(cfg_from_file(args.config), **parse_overrides(rest))
     gpu = local_rank if is_distributed else min(getattr(cfg.trainer, "gpu", 0), torch.cuda.device_count() - 1)
@@ -60,7 +62,7 @@ def main(argv=None):
 
     dataset_train = build(**cfg.train_dataset)
     dataloader_train = build_dataloader(dataset_train, num_workers=cfg.data.num_workers, batch_size=cfg.data.batch_size,
-                                        collate_fn=collate_fn, local_rank=local_rank, world_size=world_size,
+                                        collate_fn=collate_fn, local_rank=rank, world_size=world_size,
                                         sampler_cfg=getattr(cfg.data, "sampler", dict()))
     meta_arch = build(**cfg.meta_arch)
     assert isinstance(meta_arch, BaseMetaArch)
@@ -84,8 +86,24 @@ def main(argv=None):
     assert isinstance(training_hook, BaseTrainingHook)
 
     timer = Timer()
-    global_step = 0
     ckpt_dir = getattr(cfg.path, "checkpoint_path", None) if "path" in cfg else None
+    max_iters = getattr(cfg.trainer, "max_iters", None)
+    try:
+        _loop(cfg, meta_arch, optimizer, scheduler, is_iter_based, training_hook, training_loss_logger, dataloader_train,
+              timer, ckpt_dir, is_logging, is_distributed, world_size, max_iters)
+    finally:
+        from fsnet_amd.engine.runtime import RT
+        if RT.dp is not None:
+            RT.dp.close()                     # the engine's RCCL communicator, before the process group goes
+            RT.dp = None
+        if is_distributed and torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+    return meta_arch
+
+
+def _loop(cfg, meta_arch, optimizer, scheduler, is_iter_based, training_hook, training_loss_logger, dataloader_train,
+          timer, ckpt_dir, is_logging, is_distributed, world_size, max_iters):
+    global_step = 0
     for epoch_num in range(cfg.trainer.max_epochs):
         meta_arch.train()
         if training_loss_logger:
@@ -99,7 +117,7 @@ def main(argv=None):
                 print("Epoch: {} | Iteration: {}  | Running loss: {:1.5f} | eta:{}".format(
                     epoch_num, iter_num, training_loss_logger.loss_stats["total_loss"].avg,
                     timer.compute_eta(global_step, len(dataloader_train) * cfg.trainer.max_epochs / world_size)), end="\r")
-            if getattr(cfg.trainer, "max_iters", None) and global_step >= cfg.trainer.max_iters:
+            if max_iters and global_step >= max_iters:
                 break
         if not is_iter_based:
             scheduler.step()
@@ -110,9 +128,10 @@ def main(argv=None):
                 save_models(os.path.join(ckpt_dir, "%s_%d.pth" % (cfg.meta_arch.name, epoch_num)), meta_arch, optimizer)
         if is_distributed:
             torch.distributed.barrier()
+        if max_iters and global_step >= max_iters:
+            break                              # leave the epoch loop too
     if is_logging:
         print("\nfinished %d steps" % global_step)
-    return meta_arch
 
 
 if __name__ == "__main__":

@@ -73,8 +73,9 @@ class BaseTrainingHook(object):
             arena.zero_grads()
         else:
             optimizer.zero_grad()
-        if hasattr(meta_arch, "stage_step_inputs"):
-            meta_arch.stage_step_inputs(data)        # non-tensor inputs (fisheye calibrations), before the H2D move
+        stage = getattr(getattr(meta_arch, "module", meta_arch), "stage_step_inputs", None)
+        if stage is not None:
+            stage(data)        # non-tensor inputs (fisheye calibrations), before the H2D move
         for key in data:
             if isinstance(data[key], torch.Tensor):
                 if self.tensor_keys is None or key in self.tensor_keys:
@@ -97,8 +98,9 @@ class BaseTrainingHook(object):
         sdata = dict(data)
         sdata.update(static)
         self._stage(data, static)
-        if hasattr(meta_arch, "stage_step_inputs"):
-            meta_arch.stage_step_inputs(data)
+        stage = getattr(getattr(meta_arch, "module", meta_arch), "stage_step_inputs", None)
+        if stage is not None:
+            stage(data)
         optimizer.sync_lr()
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
@@ -115,7 +117,7 @@ class BaseTrainingHook(object):
         # capture records, it does not run: host bookkeeping happened once above, the first replay is that step
         assert optimizer._step_count_fused == steps_before + 1
         self._g = dict(graph=graph, sig=sig, static=static, output=output, arena=arena,
-                       stage_meta=getattr(meta_arch, "stage_step_inputs", None))
+                       stage_meta=stage)
         graph.replay()
         RT.bump_weights()
         return output
@@ -152,8 +154,10 @@ class BaseTrainingHook(object):
     @profile('Training hook', 0, 100)
     def __call__(self, data, meta_arch, optimizer, writer=None, training_loss_logger=None, global_step=0,
                  epoch_num=0):
+        from fsnet_amd.engine.torch_compat import adopt_optimizer
         from fsnet_amd.vision_base.networks.optimizers.optimizers import FusedAdam
         inner = getattr(meta_arch, "module", meta_arch)
+        optimizer = adopt_optimizer(optimizer, meta_arch)     # torch.optim.Adam from the reference's build_optimizer
         arena = inner.ensure_arena() if hasattr(inner, "ensure_arena") else None
         fused = isinstance(optimizer, FusedAdam)
         meta = dict(epoch_num=epoch_num, global_step=global_step, is_training=True)

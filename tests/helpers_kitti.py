@@ -9,7 +9,7 @@ DATE, DRIVE = "2011_09_26", "2011_09_26_drive_0001_sync"
 H, W, NFRAMES = 24, 80, 8
 
 
-def make_tree(root, seed=5):
+def make_tree(root, seed=5, H=H, W=W):
     import scipy.io as sio
     from PIL import Image
     from scipy.spatial.transform import Rotation as R

@@ -186,7 +186,7 @@ def test_kitti_dataset_through_device_pipeline_into_a_training_step(dev, tmp_pat
     H, W = 64, 128
     g = dict(HA.golden())
     g["out_h"], g["out_w"] = np.int64(H), np.int64(W)
-    raw, split = HK.make_tree(str(tmp_path), seed=5)
+    raw, split = HK.make_tree(str(tmp_path), seed=5, H=300, W=420)      # room for the warp's crop centre
     cfg = HK.dataset_cfg(raw, split, prefix='fsnet_amd.')
     cfg["augmentation"] = HA.pipeline_cfg(g)
     ds = KittiDepthMonoDataset(**cfg)

@@ -39,3 +39,52 @@ def test_driver_runs_and_checkpoints(dev):
         st = ck["optimizer_state_dict"]["state"]
         assert len(st) == len(list(model.parameters())) and float(st[0]["step"]) == 8.0
         assert ck["optimizer_state_dict"]["param_groups"][0]["lr"] == 0.0002
+
+
+def test_reference_wiring_torch_adam_and_ddp_wrapper(dev):
+    """what the reference's scripts/train.py builds (torch.optim.Adam from its build_optimizer, the meta-arch inside
+    DistributedDataParallel) drives the same fused step as the mirrored driver: identical losses and parameters,
+    torch.optim.Adam-format optimizer state with the right step count"""
+    from fsnet_amd.configs import meta_arch_cfg, training_cfg
+    from fsnet_amd.engine.runtime import RT
+    from fsnet_amd.vision_base.networks.optimizers.optimizers import build_optimizer
+    from fsnet_amd.vision_base.utils.builder import build
+    from oracle import fsnet_oracle as O
+    RT.set_compute_dtype(torch.float32)
+    RT.tie_noise = False
+    sd0 = O.init_state(seed=4, with_pose=False)
+    runs = {}
+    for mode in ("mirror", "reference"):
+        m = build(**meta_arch_cfg(64, 128, with_pose=False))
+        m.load_state_dict({k: v.clone() for k, v in sd0.items()}, strict=True)
+        tc = training_cfg()
+        hook = build(**tc.training_hook)
+        if mode == "mirror":
+            model = m.to(dev).train()
+            opt = build_optimizer(model, **tc.optimizer)
+        else:
+            m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m)
+            model = torch.nn.parallel.DistributedDataParallel(m.cuda(), device_ids=[0], output_device=0)
+            model.train()
+            opt = torch.optim.Adam(model.parameters(), lr=tc.optimizer.lr, weight_decay=0)   # reference optimizers.py:7-8
+        sched = torch.optim.lr_scheduler.StepLR(opt, step_size=2)
+        losses = []
+        for it in range(5):
+            out = hook({k: v for k, v in O.synthetic_batch(2, 64, 128, seed=80 + it).items()}, model, opt)
+            losses.append(float(out["loss"].detach()))
+            if it % 2 == 1:
+                sched.step()
+        torch.cuda.synchronize()
+        inner = getattr(model, "module", model)
+        runs[mode] = (losses, torch.cat([p.detach().flatten() for p in inner.parameters()]).cpu(), opt.state_dict(), hook)
+    la, pa, _, _ = runs["mirror"]
+    lb, pb, sdb, hook_b = runs["reference"]
+    assert lb == pytest.approx(la, rel=2e-4)
+    from tests.test_dp_gpu import same_update
+    p0 = torch.cat([sd0[k].flatten() for k in sd0 if O.is_param(k)])
+    agree, rel = same_update(pa - p0, pb - p0)                  # same kernels, same hyper-parameters: same trajectory
+    assert agree > 0.98 and rel < 0.1, (agree, rel)
+    assert hook_b.graph_replays >= 1                            # the adopted optimizer replays from the hipGraph too
+    assert float(sdb["state"][0]["step"]) == 5.0 and sdb["param_groups"][0]["lr"] == pytest.approx(1e-5)
+    assert tuple(sdb["state"][0]["exp_avg"].shape) == tuple(next(iter(sd0.values())).shape)
+    RT.set_compute_dtype(torch.bfloat16)
