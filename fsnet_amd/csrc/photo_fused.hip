@@ -234,12 +234,14 @@ __global__ __launch_bounds__(256) void photo_fused_fwd_kernel(const FsPhotoArgs 
     }
     if (col_out && yc < H) {       // (yc >= ys always: it >= 2)
       const unsigned i = (unsigned)(yc * W + x);
-      float best = 0.f; int bi = 0;
+      float best = INFINITY; int bi = 2;
+      if (!p.motion_mask) {          // identity candidates (the auto-mask); a motion mask replaces them (:243-246)
 #pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        uint32_t key = (uint32_t)((((long)s * 2 + f) * p.B + b) * HW + i);
-        float v = ldg(identb + f * HW, i * 4u) + tie_noise(seed, key);
-        if (f == 0 || v < best) { best = v; bi = f; }
+        for (int f = 0; f < 2; ++f) {
+          uint32_t key = (uint32_t)((((long)s * 2 + f) * p.B + b) * HW + i);
+          float v = ldg(identb + f * HW, i * 4u) + tie_noise(seed, key);
+          if (f == 0 || v < best) { best = v; bi = f; }
+        }
       }
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
@@ -247,6 +249,9 @@ __global__ __launch_bounds__(256) void photo_fused_fwd_kernel(const FsPhotoArgs 
         float v = r1.ov[f] ? rv : 100.f;
         if (v < best) { best = v; bi = 2 + f; }
       }
+      // a selected reprojection term whose sample missed the source frame is the constant 100 (:231-235): value only,
+      // no gradient (cannot happen next to the identity candidates, which are always below 100)
+      if (bi >= 2 && !r1.ov[bi - 2]) bi = 4;
       selb[i] = (uint8_t)bi;
       double pm = p.patched_mask ? p.patched_mask[(long)b * HW + i] : 1.0;
       acc += (double)best * pm;
@@ -381,6 +386,7 @@ __global__ __launch_bounds__(256) void photo_fused_bwd_kernel(const FsPhotoArgs 
     for (int c = 0; c < 3; ++c) r0.rt[c] = ldg(timg + c * HW, ob);
     r0.sel = (x_real && y_real) ? (int)selb[(unsigned)(yr * W + xr)] : -1;
     r0.pm = (x_real && y_real) ? (p.patched_mask ? (float)p.patched_mask[(long)b * HW + (unsigned)(yr * W + xr)] : 1.f) : 0.f;
+    if (p.motion_mask && x_real && y_real) r0.pm *= 1.f - p.motion_mask[(long)b * HW + (unsigned)(yr * W + xr)];
     {
       const float fyu = sh * (float)yr;
       const int dy0 = h > 1 ? min((int)fyu, h - 2) : 0;
@@ -571,7 +577,8 @@ __global__ __launch_bounds__(256) void photo_fused_bwd_kernel(const FsPhotoArgs 
 }  // namespace
 
 extern "C" int fs_photo_fused_fwd(const FsPhotoArgs* a, void* stream) {
-  if (!a || !a->img0 || !a->img_src[0] || !a->img_src[1] || !a->geo || !a->ident || !a->sel || !a->loss_sums)
+  if (!a || !a->img0 || !a->img_src[0] || !a->img_src[1] || !a->geo || (!a->ident && !a->motion_mask) || !a->sel ||
+      !a->loss_sums)
     return FS_EINVAL;
   if (a->S < 1 || a->S > 4 || a->B < 1 || a->H < 2 || a->W < 2) return FS_EINVAL;
   if ((a->lut_ptrs != nullptr) != (a->mei != nullptr)) return FS_EINVAL;

@@ -602,6 +602,7 @@ extern "C" int fs_photo_warp(const FsPhotoArgs* a, void* stream) {
 
 extern "C" int fs_photo_loss_fwd(const FsPhotoArgs* a, void* stream) {
   if (!valid(a) || !a->pred || !a->ov || !a->ident || !a->sel || !a->loss_sums) return FS_EINVAL;
+  if (a->motion_mask) return FS_EINVAL;                 // only the fused kernels know the motion mask
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   long HW = (long)a->H * a->W;
   dim3 grid((a->W + TW - 1) / TW, (a->H + TH - 1) / TH, a->S * a->B);
@@ -610,7 +611,7 @@ extern "C" int fs_photo_loss_fwd(const FsPhotoArgs* a, void* stream) {
 }
 
 extern "C" int fs_photo_loss_bwd(const FsPhotoArgs* a, void* stream) {
-  if (!valid(a) || !a->pred || !a->sel || !a->dP || !a->mask_sum) return FS_EINVAL;
+  if (!valid(a) || !a->pred || !a->sel || !a->dP || !a->mask_sum || a->motion_mask) return FS_EINVAL;
   for (int s = 0; s < a->S; ++s) if (!a->depth[s] || !a->d_depth[s]) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((a->W + TW - 1) / TW, (a->H + TH - 1) / TH, a->S * a->B);

@@ -316,6 +316,7 @@ class PhotometricLoss:
         # fisheye (Mei model): persistent per-sample table pointers / parameters / mask plane, refreshed per step by
         # stage_fisheye() so that a captured hipGraph keeps reading the same addresses
         self.fisheye = False
+        self.motion_mask = None      # [B,H,W] fp32 or None: precomputed motion mask (monodepth2_decoder.py:243-246)
         self.lut_table = self.mei = self.warp_mask = None
         self._lut_keep = None
 
@@ -378,6 +379,7 @@ class PhotometricLoss:
             pa.lut_ptrs, pa.mei, pa.warp_mask = self.lut_table.data_ptr(), self.mei.data_ptr(), self.warp_mask.data_ptr()
         else:
             pa.lut_ptrs = pa.mei = pa.warp_mask = None
+        pa.motion_mask = _p(self.motion_mask)
         sa.disp_sum, sa.sm_sums, sa.dot = self.disp_sum.data_ptr(), self.sm_sums.data_ptr(), self.dot.data_ptr()
         sa.gout = _p(gout)
         sa.B, sa.S = self.B, self.S
@@ -390,10 +392,15 @@ class PhotometricLoss:
             sa.d_disp[i] = self.d_disp[i].data_ptr()
             sa.h[i], sa.w[i], sa.scale_id[i] = h, w, self.scales[i]
 
-    def forward(self, img0, srcs, P2, Ts, patched_mask, depths, disps, noise_seed=-1):
+    def forward(self, img0, srcs, P2, Ts, patched_mask, depths, disps, noise_seed=-1, motion_mask=None):
         """img0, srcs[2]: NCHW fp32; P2 [B,3,4] fp32; Ts[2]: [B,4,4] fp32; patched_mask f64 [B,H,W] or None;
-        depths/disps: per scale [B,1,h,w] fp32 contiguous."""
+        depths/disps: per scale [B,1,h,w] fp32 contiguous; motion_mask: fp32 [B,H,W] or None."""
         st = stream_ptr()
+        if motion_mask is not None:
+            assert motion_mask.dtype == torch.float32 and motion_mask.is_contiguous() and motion_mask.shape == (self.B, self.H, self.W)
+            if not self.fused:
+                raise NotImplementedError("motion_mask needs the fused photometric kernels (FSNET_AMD_PHOTO_FUSED=1)")
+        self.motion_mask = motion_mask
         assert img0.is_contiguous() and all(s.is_contiguous() for s in srcs)
         if patched_mask is not None:
             assert patched_mask.dtype == torch.float64 and patched_mask.is_contiguous()

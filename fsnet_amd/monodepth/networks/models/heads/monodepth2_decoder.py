@@ -15,14 +15,15 @@ _UNSUPPORTED_FLAGS = ("is_residual_flow", "is_light_compensate", "learnable_phot
 
 class _PhotoLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pl, S, img0, src_a, src_b, P2, patched_mask, T_a, T_b, *dd):
+    def forward(ctx, pl, S, img0, src_a, src_b, P2, patched_mask, motion_mask, T_a, T_b, *dd):
         ctx.set_materialize_grads(False)
         depths = [d.contiguous().float() for d in dd[:S]]
         disps = [d.contiguous().float() for d in dd[S:]]
         seed = None if RT.tie_noise else -1     # None: device-resident seed, bumped in-stream every step
         out = pl.forward(img0.contiguous().float(), [src_a.contiguous().float(), src_b.contiguous().float()],
                          P2.contiguous().float(), [T_a.contiguous().float(), T_b.contiguous().float()], patched_mask,
-                         depths, disps, noise_seed=seed)
+                         depths, disps, noise_seed=seed,
+                         motion_mask=None if motion_mask is None else motion_mask.contiguous().float())
         ctx.pl, ctx.S = pl, S
         vec = out                       # fresh tensors of this call (ops.PhotometricLoss.forward): no copies
         ctx.mark_non_differentiable(vec)
@@ -35,7 +36,7 @@ class _PhotoLossFn(torch.autograd.Function):
         if g_total is not None:
             gout = g_total.detach().double().contiguous()
         d_depth, d_disp, dT = pl.backward(gout)
-        return (None, None, None, None, None, None, None, dT[0], dT[1]) + tuple(d_depth) + tuple(d_disp)
+        return (None, None, None, None, None, None, None, None, dT[0], dT[1]) + tuple(d_depth) + tuple(d_disp)
 
 
 class _DistillFn(torch.autograd.Function):
@@ -93,15 +94,12 @@ class MonoDepth2Decoder(nn.Module):
         for flag in _UNSUPPORTED_FLAGS:
             if getattr(self, flag, False):
                 raise NotImplementedError("MonoDepth2Decoder option %s is not implemented in the HIP loss chain" % flag)
-        for w in ("pose_loss_weight", "residualflow_weight"):
-            if getattr(self, w, 0) > 0:
-                raise NotImplementedError("MonoDepth2Decoder term %s > 0 is not implemented in the HIP loss chain" % w)
+        if getattr(self, "residualflow_weight", 0) > 0:
+            raise NotImplementedError("MonoDepth2Decoder term residualflow_weight > 0 is not implemented in the HIP loss chain")
         if getattr(self, "distillation_loss_weight", 0) > 0 and getattr(self, "is_unscaled_distill", False):
             raise NotImplementedError("is_unscaled_distill=True is not implemented (no shipped config enables it)")
         if not getattr(self, "overlapped_mask", False):
             raise NotImplementedError("overlapped_mask=False is not implemented (all shipped configs enable it)")
-        if "motion_mask" in input_dict:
-            raise NotImplementedError("precomputed motion_mask branch is not implemented in the HIP loss chain")
         if len(self.frame_ids) != 3 or "s" in self.frame_ids:
             raise NotImplementedError("the HIP loss chain handles frame_ids=[0, a, b] (two temporal source frames)")
 
@@ -137,7 +135,7 @@ class MonoDepth2Decoder(nn.Module):
     def prefetch_loss_inputs(self, input_dict):
         """launch the input-only part of the loss chain (identity reprojection, colour pyramid) on the current
         stream — the meta-arch calls this on the pose stream, off the depth chain's critical path"""
-        if len(self.frame_ids) != 3 or "s" in self.frame_ids or "motion_mask" in input_dict:
+        if len(self.frame_ids) != 3 or "s" in self.frame_ids:
             return
         img0 = input_dict[("original_image", 0)]
         if not (img0.is_cuda and img0.dtype == torch.float32 and img0.is_contiguous()):
@@ -169,6 +167,7 @@ class MonoDepth2Decoder(nn.Module):
         disps = [output_dict[("disp", s)] for s in self.scales]
         total, vec = _PhotoLossFn.apply(self._pl, S, img0, input_dict[("original_image", fa)],
                                         input_dict[("original_image", fb)], input_dict["P2"], pm,
+                                        input_dict.get("motion_mask", None),
                                         output_dict[("cam_T_cam", fa)], output_dict[("cam_T_cam", fb)],
                                         *depths, *disps)
         losses = {}
@@ -191,6 +190,15 @@ class MonoDepth2Decoder(nn.Module):
             hm["loss_mask_%d" % self.scales[0]] = dict(data=(self._pl.sel[0, 0:1] >= 2).unsqueeze(1))
         return losses, hm, total
 
+    def compute_pose_loss(self, output_dict, input_dict):
+        """sum over the source frames of mean |relative_pose - cam_T_cam| (reference :176-183): the mean-absolute-difference
+        kernel of the distillation term on the 4x4 matrices; its gradient reaches the pose networks through cam_T_cam"""
+        pose_loss = 0
+        for f in self.frame_ids[1:]:
+            target = input_dict[('relative_pose', f)].detach()
+            pose_loss = pose_loss + _DistillFn.apply(output_dict[("cam_T_cam", f)], target, None)
+        return pose_loss
+
     def compute_distill_loss(self, output_dict, input_dict, scale):
         """monodepth2_decoder.py:185-203: mean |teacher - pred| (/ uncertain_z + log(uncertain_z + 1e-5))"""
         pred = output_dict[('depth', scale, scale)]
@@ -200,6 +208,11 @@ class MonoDepth2Decoder(nn.Module):
 
     def loss(self, output_dict, input_dict):
         losses, hm, total = self.compute_total_reprojection_loss(output_dict, input_dict)
+        pose_weight = getattr(self, 'pose_loss_weight', 0)
+        if pose_weight > 0:                                           # reference :176-183, 322-326
+            pose_loss = self.compute_pose_loss(output_dict, input_dict)
+            losses['pose_loss'] = pose_loss.detach()
+            total = total + pose_weight * pose_loss
         distillation_weight = getattr(self, 'distillation_loss_weight', 0)
         if distillation_weight > 0:                                   # reference :328-334
             for scale in self.scales:

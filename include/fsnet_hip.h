@@ -404,6 +404,10 @@ typedef struct FsPhotoArgs {
   const float* mei;               /* device [B][8]: k1, k2, xi, gamma1, gamma2, u0, v0, 0 */
   const float* warp_mask;         /* [B][H][W] fp32 = patched_mask x ray-table mask (fs_mei_stage_mask): the plane the
                                      nearest-neighbour overlap sample reads (:409-411) */
+  /* precomputed motion mask (monodepth2_decoder.py:243-246; fused kernels only): [B][H][W] fp32 or NULL.  With it the
+   * per-pixel minimum runs over the two reprojection terms alone (no identity auto-mask) and the gradient of a pixel
+   * is scaled by (1 - motion_mask): to_optimise.detach() * m + to_optimise * (1 - m). */
+  const float* motion_mask;
 } FsPhotoArgs;
 int fs_photo_setup(const float* P2, const float* T0, const float* T1, float* geo, int B, int* seed_counter,
                    int fisheye, void* stream);   /* seed_counter (or NULL): device int bumped by one — the noise seed of

@@ -385,11 +385,19 @@ def photometric_loss(outputs, inputs, frame_ids=(0, 1, -1), scales=(0, 1, 2, 3),
                 pl = torch.where(ov, pl, torch.full_like(pl, 100.0))  # 231-235 (blocks the gradient)
             reproj.append(pl)
         reproj = torch.cat(reproj, 1)
-        ident = torch.cat([reprojection_loss(inputs[("original_image", f)], target) for f in frame_ids[1:]], 1)
-        if noise is not None:
-            ident = ident + noise[scale]
-        combined = torch.cat((ident, reproj), dim=1)
-        to_opt, idxs = torch.min(combined, dim=1)
+        if "motion_mask" in inputs:
+            # precomputed motion mask instead of the identity auto-mask (monodepth2_decoder.py:243-246): the value is
+            # unchanged, the gradient is blocked where the mask is set
+            mm = inputs["motion_mask"]
+            to_opt, idxs = torch.min(reproj, dim=1)
+            to_opt = to_opt.detach() * mm + to_opt * (1 - mm)
+            idxs = idxs + 2
+        else:
+            ident = torch.cat([reprojection_loss(inputs[("original_image", f)], target) for f in frame_ids[1:]], 1)
+            if noise is not None:
+                ident = ident + noise[scale]
+            combined = torch.cat((ident, reproj), dim=1)
+            to_opt, idxs = torch.min(combined, dim=1)
         outputs[("min_idx", scale)] = idxs
         to_opt = to_opt * pm  # float64 promotion when patched_mask is float64 (270-272)
         loss = to_opt.sum() / (pm.sum() + 1e-6)

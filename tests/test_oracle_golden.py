@@ -248,3 +248,41 @@ def test_r50_basefx_oracle_matches_reference_golden():
     ref = T(g["gradnorm"])
     big = ref > 1e-3 * ref.max()
     assert float(((gn - ref).abs() / ref)[big].max()) < 3e-2
+
+
+def loss_options_case(g):
+    """inputs of tests/golden/loss_options.npz (shared with the GPU test)"""
+    data = O.synthetic_batch(2, int(g["H"]), int(g["W"]), seed=int(g["seed"]))
+    data["motion_mask"] = T(g["motion_mask"])
+    return data
+
+
+def test_motion_mask_and_pose_term_oracle_matches_reference_golden():
+    """precomputed motion mask (monodepth2_decoder.py:243-246) + pose L1 term (:176-183) against the REAL decoder"""
+    g = np.load(os.path.join(GOLD, "loss_options.npz"))
+    data = loss_options_case(g)
+    outputs, leaves, pose = {}, {}, {}
+    for s in range(4):
+        d = T(g["depth_%d" % s]).clone().requires_grad_(True)
+        leaves[s] = d
+        outputs[("depth", s, s)] = d
+        outputs[("disp", s)] = O.depth_to_disp(d, 0.5, 100.0)
+    for f, tag in ((1, "p"), (-1, "m")):
+        aa = T(g["aa_" + tag]).clone().requires_grad_(True)
+        tr = T(g["tr_" + tag]).clone().requires_grad_(True)
+        pose[tag] = (aa, tr)
+        outputs[("cam_T_cam", f)] = O.transformation_from_parameters(aa, tr, invert=(f < 0))
+    total, ld = O.photometric_loss(outputs, data)
+    pl = sum((data[("relative_pose", f)] - outputs[("cam_T_cam", f)]).abs().mean() for f in (1, -1))
+    total = total + float(g["pose_loss_weight"]) * pl
+    total.backward()
+    assert abs(float(total.detach()) - float(g["total_loss"])) < 1e-6 * float(g["total_loss"])
+    assert abs(float(pl.detach()) - float(g["ld_pose_loss"])) < 1e-7
+    for s in range(4):
+        ref = T(g["gdepth_%d" % s])
+        assert float((leaves[s].grad - ref).norm() / ref.norm()) < 1e-4
+        assert int((outputs[("min_idx", s)] < 2).sum()) == 0          # no identity candidates with a motion mask
+    for tag in ("p", "m"):
+        for got, key in ((pose[tag][0].grad, "gaa_" + tag), (pose[tag][1].grad, "gtr_" + tag)):
+            ref = T(g[key])
+            assert maxdev(got, ref) < 1e-4 * float(ref.abs().max()) + 1e-9

@@ -594,12 +594,67 @@ def gen_kitti_dataset():
     np.savez_compressed(os.path.join(GOLD, "kitti_dataset.npz"), **out)
 
 
+def gen_loss_options():
+    """optional terms of MonoDepth2Decoder.loss no shipped config enables: precomputed motion_mask
+    (monodepth2_decoder.py:243-246) and the pose L1 term (:176-183, 322-326), from the REAL decoder"""
+    B, H, W = 2, 64, 96
+    data = O.synthetic_batch(B, H, W, seed=41)
+    g = torch.Generator().manual_seed(8)
+    mm = (torch.rand(B, H // 8, W // 8, generator=g) > 0.6).float()
+    data["motion_mask"] = torch.nn.functional.interpolate(mm[:, None], size=(H, W), mode="nearest")[:, 0]   # blocky 0/1
+    dec = ref_model(H, W, True).head
+    dec.pose_loss_weight = 0.5
+    outputs, leaves = {}, {}
+    for s in range(4):
+        h, w = H >> s, W >> s
+        ys = torch.linspace(0, 1, h).view(1, 1, h, 1)
+        d = (4 + 25 * (1 - ys) + 3 * torch.rand(B, 1, h, w, generator=g)).requires_grad_(True)
+        leaves[("depth", s)] = d
+        outputs[("depth", s, s)] = d
+        outputs[("disp", s)] = mu.depth_to_disp(d, 0.5, 100.0)
+    for f in (1, -1):
+        aa = (0.01 * torch.randn(B, 1, 3, generator=g)).requires_grad_(True)
+        tr = (torch.tensor([[[0.02, -0.01, -0.6 if f > 0 else 0.6]]]).repeat(B, 1, 1) + 0.02 * torch.randn(B, 1, 3, generator=g)).requires_grad_(True)
+        leaves[("aa", f)], leaves[("tr", f)] = aa, tr
+        outputs[("cam_T_cam", f)] = mu.transformation_from_parameters(aa, tr, invert=(f < 0))
+    res = dec.loss(outputs, data)
+    res['loss'].backward()
+    out = {"H": H, "W": W, "seed": 41, "pose_loss_weight": 0.5, "total_loss": npy(res['loss']), "motion_mask": npy(data["motion_mask"])}
+    for k, v in res['loss_dict'].items():
+        out["ld_" + k.replace('/', '_')] = npy(v)
+    for s in range(4):
+        out["depth_%d" % s] = npy(leaves[("depth", s)])
+        out["gdepth_%d" % s] = npy(leaves[("depth", s)].grad)
+    for f in (1, -1):
+        tag = "p" if f > 0 else "m"
+        out["aa_" + tag], out["tr_" + tag] = npy(leaves[("aa", f)]), npy(leaves[("tr", f)])
+        out["gaa_" + tag], out["gtr_" + tag] = npy(leaves[("aa", f)].grad), npy(leaves[("tr", f)].grad)
+        out["pose_" + tag] = npy(data[("relative_pose", f)])
+    # oracle cross-check
+    o2, lv = {}, {}
+    for s in range(4):
+        d = leaves[("depth", s)].detach().clone().requires_grad_(True); lv[s] = d
+        o2[("depth", s, s)] = d; o2[("disp", s)] = O.depth_to_disp(d, 0.5, 100.0)
+    for f in (1, -1):
+        o2[("cam_T_cam", f)] = outputs[("cam_T_cam", f)].detach()
+    tot, ld = O.photometric_loss(o2, data)
+    pl = sum((data[("relative_pose", f)] - o2[("cam_T_cam", f)]).abs().mean() for f in (1, -1))
+    (tot + 0.5 * pl).backward()
+    print("loss options: ref total %.9f oracle %.9f | gdepth0 rel dev %.2e" % (
+        float(res['loss']), float(tot + 0.5 * pl),
+        dev(lv[0].grad, leaves[("depth", 0)].grad) / float(leaves[("depth", 0)].grad.abs().max())))
+    np.savez_compressed(os.path.join(GOLD, "loss_options.npz"), **out)
+
+
 if __name__ == "__main__":
     if "--only-augment" in sys.argv:
         gen_augment()
         sys.exit(0)
     if "--only-fisheye" in sys.argv:
         gen_fisheye()
+        sys.exit(0)
+    if "--only-options" in sys.argv:
+        gen_loss_options()
         sys.exit(0)
     if "--only-kitti" in sys.argv:
         gen_kitti_dataset()
@@ -617,5 +672,6 @@ if __name__ == "__main__":
     gen_fisheye()
     gen_model_r50fx()
     gen_kitti_dataset()
+    gen_loss_options()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")
