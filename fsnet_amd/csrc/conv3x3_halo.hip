@@ -18,6 +18,7 @@
 #include "common.h"
 #include "fsnet_hip_internal.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -43,6 +44,7 @@ struct HaloGeom {
   unsigned mTW, mHW; // fs_div_magic(TW), fs_div_magic(TW + 2)
   FsDiv dTX, dTY;    // tiles_x, tiles_y
   FsDiv dIPG;        // images per BatchNorm statistics group (stat_group_rows / (Hd*Wd)); unused when 0 groups
+  int pix_major;     // block -> tile mapping keeps a pixel tile's channel tiles on one XCD (else: a channel tile's)
 };
 
 template <typename T, int PIX, int CO, int WP>
@@ -77,7 +79,12 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
   int px, cy;
   {
     const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
-    if (nco % 8 == 0) { const int q = nco >> 3; cy = xcd + 8 * (slot % q); px = slot / q; }
+    if (g.pix_major) {
+      // activations outweigh the weights (layer 1 / 2, the decoder): the channel tiles of ONE pixel tile run on the
+      // same XCD in consecutive slots, so the halo is fetched across the fabric once and re-read from that L2
+      cy = slot % nco; px = (slot / nco) * 8 + xcd;
+    }
+    else if (nco % 8 == 0) { const int q = nco >> 3; cy = xcd + 8 * (slot % q); px = slot / q; }
     else if (8 % nco == 0) { const int q = 8 / nco; cy = xcd % nco; px = slot * q + xcd / nco; }
     else { cy = id % nco; px = id / nco; }
     if (px >= npix) return;
@@ -289,9 +296,11 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
   }
 }
 
+static const bool kNoPixMajor = [] { const char* e = getenv("FSNET_AMD_HALO_PIXMAJOR"); return e && e[0] == '0'; }();
+
 // pick the pixel tile (TH x TW <= PIX, halo <= hmax) that wastes the fewest lanes, preferring wide tiles
 HaloGeom pick_geom(int Hd, int Wd, int PIX, int hmax) {
-  HaloGeom best{0, 0, 0, 0, 0u, 0u, FsDiv{0u, 0u}, FsDiv{0u, 0u}, FsDiv{0u, 0u}};
+  HaloGeom best{0, 0, 0, 0, 0u, 0u, FsDiv{0u, 0u}, FsDiv{0u, 0u}, FsDiv{0u, 0u}, 0};
   double best_cost = 1e30;
   for (int tw = std::min(4, Wd); tw <= std::min(Wd, 64); ++tw) {
     int th = std::min(PIX / tw, Hd);
@@ -320,7 +329,10 @@ int launch_halo(const FsConvArgs& a, hipStream_t st) {
   }
   const int npix = a.N * g.tiles_x * g.tiles_y, nco = a.Co_p / CO;
   int blocks = npix * nco;
-  if (nco % 8 != 0 && 8 % nco == 0) { const int q = 8 / nco; blocks = 8 * ((npix + q - 1) / q); }
+  // which operand is worth keeping XCD-local: the input activation (fetched once per channel tile) or the weights
+  g.pix_major = (nco > 1 && a.src_bytes > 2 * a.wgt_bytes && !kNoPixMajor) ? 1 : 0;
+  if (g.pix_major) blocks = 8 * ((npix + 7) / 8) * nco;
+  else if (nco % 8 != 0 && 8 % nco == 0) { const int q = 8 / nco; blocks = 8 * ((npix + q - 1) / q); }
   hipLaunchKernelGGL((conv3x3_halo_kernel<T, PIX, CO, WP>), dim3(blocks), dim3(256), 0, st, a, g);
   return fs_launch_status();
 }

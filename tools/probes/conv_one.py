@@ -8,7 +8,8 @@ dev = torch.device('cuda:0'); dt = torch.bfloat16
 op = ConvOp(Ci, Co, k, k, 1, k // 2, dt, dev)
 op.pack(torch.randn(Co, Ci, k, k, device=dev) * 0.05)
 x = torch.randn(B, H, W, op.Ci_p, device=dev).to(dt)
-stats = torch.zeros(8, 2, op.Co_p, dtype=torch.float64, device=dev)
+import os
+stats = None if os.environ.get('NOSTATS') else torch.zeros(8, 2, op.Co_p, dtype=torch.float64, device=dev)
 y = op.forward(x, stats=stats)
 gy = torch.randn_like(y)
 for _ in range(6):
