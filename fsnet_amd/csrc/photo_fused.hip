@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void photo_fused_fwd_kernel(const FsPhotoArgs 
       }
       // a selected reprojection term whose sample missed the source frame is the constant 100 (:231-235): value only,
       // no gradient (cannot happen next to the identity candidates, which are always below 100)
-      if (bi >= 2 && !r1.ov[bi - 2]) bi = 4;
+      if ((bi == 2 && !r1.ov[0]) || (bi == 3 && !r1.ov[1])) bi = 4;   // (static indices: a runtime index spills the row)
       selb[i] = (uint8_t)bi;
       double pm = p.patched_mask ? p.patched_mask[(long)b * HW + i] : 1.0;
       acc += (double)best * pm;

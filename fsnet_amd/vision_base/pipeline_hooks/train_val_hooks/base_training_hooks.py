@@ -103,7 +103,10 @@ class BaseTrainingHook(object):
             stage(data)
         optimizer.sync_lr()
         torch.cuda.synchronize(dev)
-        graph = torch.cuda.CUDAGraph()
+        dot = os.environ.get("FSNET_AMD_GRAPH_DOT")      # debugging: the captured topology as a DOT file
+        graph = torch.cuda.CUDAGraph(keep_graph=True) if dot else torch.cuda.CUDAGraph()
+        if dot:
+            graph.enable_debug_mode()
         steps_before = optimizer._step_count_fused
         # (with a process group alive its watchdog thread polls events: only this thread's calls may fail the capture)
         mode = "thread_local" if RT.dp is not None else "global"
@@ -114,6 +117,9 @@ class BaseTrainingHook(object):
             (loss if loss.dim() == 0 else loss.mean()).backward()
             grad_scale = RT.dp.finish() if RT.dp is not None else 1.0
             optimizer.step(max_norm=self.clip_gradients, grad_scale=grad_scale)
+        if dot:
+            graph.instantiate()
+            graph.debug_dump(dot)
         # capture records, it does not run: host bookkeeping happened once above, the first replay is that step
         assert optimizer._step_count_fused == steps_before + 1
         self._g = dict(graph=graph, sig=sig, static=static, output=output, arena=arena,

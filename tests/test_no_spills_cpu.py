@@ -1,0 +1,31 @@
+"""The hot kernels must not spill registers to scratch memory: a runtime-indexed register array or an unlucky
+occupancy heuristic turns a 160 us kernel into a 360 us one without failing any numerical test (it happened:
+photo_fused_fwd, `r1.ov[bi - 2]`).  Compiles the device code of the hot files to assembly and reads the
+per-kernel resource summary."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+from fsnet_amd.csrc import build as B
+
+HOT = ["photo_fused.hip", "conv3x3_halo.hip", "conv_igemm.hip", "conv_wgrad.hip", "bn.hip"]
+
+
+@pytest.mark.skipif(shutil.which(B.HIPCC) is None and not os.path.exists(B.HIPCC), reason="hipcc not available")
+@pytest.mark.parametrize("name", HOT)
+def test_no_scratch(name):
+    src = os.path.join(os.path.dirname(B.__file__), name)
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        flags = [f for f in B.FLAGS if f != "-fPIC"] + B.extra_flags(src)
+        subprocess.run([B.HIPCC] + flags + ["-S", "--cuda-device-only", src, "-o", out], check=True,
+                       stderr=subprocess.DEVNULL)
+        txt = open(out).read()
+    kernels = re.findall(r"^\s*\.amdhsa_kernel (\S+)", txt, re.M)
+    scratch = [int(x) for x in re.findall(r"^; ScratchSize: (\d+)", txt, re.M)]
+    assert kernels and len(scratch) >= len(kernels)
+    assert max(scratch) == 0, "register spills in %s: %s" % (name, scratch)
