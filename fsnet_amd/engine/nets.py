@@ -465,6 +465,8 @@ class ResNetRunner:
         """gfeats: list of 5 NHWC dense gradients (or None).  Accumulates parameter gradients."""
         nst = len(self.stages)
         bwd_pool_reset(ctx["x"].device)
+        tag = "enc%d" % ctx["x"].shape[0]
+        RT.mark(tag + ".bwd.start")
         dout = gfeats[nst]
         last = ctx["blocks"][-1]["u"][-1][2]
         if dout is None:
@@ -495,6 +497,7 @@ class ResNetRunner:
         dc0 = _bn_bwd(d0, y0, ctx["c0"], self.m.bn1, ctx["st0"], y0.shape[1], y0.shape[2], relu=True)
         op = self.stem.ready(y0.dtype, y0.device)
         self.stem.accumulate_param_grads(op, dc0, ctx["x"])
+        RT.mark(tag + ".bwd.end")
         if RT.wgrad_streams != 3:
             flush_deferred(_current_stream())
 
@@ -591,6 +594,7 @@ class DepthDecoderRunner:
         K = int(m.num_output_channels)
         gfeats = [None] * 5
         bwd_pool_reset(dev)
+        RT.mark("ddec.bwd.start")
 
         # logit gradients of every scale that received one, in one launch at the head of the backward
         sc = [i for i in range(5) if i in m.scales and (g_depth.get(i) is not None or g_disp.get(i) is not None)]
@@ -644,6 +648,7 @@ class DepthDecoderRunner:
                 op0.dgrad(dc0, h, w, out=interior, addend=interior)
             else:
                 gfeats[4] = op0.dgrad(dc0, h, w)
+        RT.mark("ddec.bwd.end")
         if RT.wgrad_streams != 3:
             flush_deferred(_current_stream())
         return gfeats
@@ -684,6 +689,7 @@ class PoseDecoderRunner:
     def backward(self, ctx, dT):
         acts, x3 = ctx["acts"], ctx["x3"]
         dt, dev = acts[0].dtype, acts[0].device
+        RT.mark("pdec.bwd.start")
         if isinstance(ctx["invert"], tuple):
             G = len(ctx["invert"])
             B = x3.shape[0] // G

@@ -32,6 +32,31 @@ class _Runtime:
         # the pose encoder's image pairs as one stacked pass with per-pair BatchNorm statistics
         self.batch_pose_pairs = os.environ.get("FSNET_AMD_BATCH_POSE", "1") != "0"
         self._side = {}
+        # FSNET_AMD_MARKS=1: device-clock marks along the step (mark() below), read back with marks_report()
+        self._marks = {} if os.environ.get("FSNET_AMD_MARKS", "0") != "0" else None
+        self._mark_buf = None
+
+    def mark(self, name):
+        """debugging: stamp the device clock on the current stream (a graph node under capture)"""
+        if self._marks is None or not torch.cuda.is_available():
+            return
+        from ..hip.binding import check, lib, stream_ptr
+        if self._mark_buf is None:
+            self._mark_buf = torch.zeros(512, dtype=torch.int64, device="cuda")
+        idx = self._marks.get(name)
+        if idx is None:
+            idx = self._marks[name] = len(self._marks)
+        check(lib.fs_debug_timestamp(self._mark_buf.data_ptr() + 8 * idx, stream_ptr()), "fs_debug_timestamp")
+
+    def marks_report(self):
+        """[(name, ms since the earliest mark)] of the last executed step, sorted by time"""
+        if not self._marks:
+            return []
+        torch.cuda.synchronize()
+        t = self._mark_buf.cpu().tolist()
+        rows = [(n, t[i]) for n, i in self._marks.items() if t[i] > 0]
+        t0 = min(v for _, v in rows)
+        return sorted(((n, (v - t0) / 1e5) for n, v in rows), key=lambda r: r[1])
 
     def side_stream(self, device):
         s = self._side.get(device)

@@ -11,6 +11,7 @@ D = C.c_double
 SIGNATURES = {
     "fs_abi_version": (C.c_int, []),
     "fs_target_arch": (C.c_char_p, []),
+    "fs_debug_timestamp": (C.c_int, [P, P]),
     "fs_conv_igemm": (C.c_int, [P, I, P]),
     "fs_conv3x3_halo": (C.c_int, [P, I, P]),
     "fs_conv_stem": (C.c_int, [P, I, P]),

@@ -20,6 +20,7 @@ class _PhotoLossFn(torch.autograd.Function):
         depths = [d.contiguous().float() for d in dd[:S]]
         disps = [d.contiguous().float() for d in dd[S:]]
         seed = None if RT.tie_noise else -1     # None: device-resident seed, bumped in-stream every step
+        RT.mark("photo.fwd.start")
         out = pl.forward(img0.contiguous().float(), [src_a.contiguous().float(), src_b.contiguous().float()],
                          P2.contiguous().float(), [T_a.contiguous().float(), T_b.contiguous().float()], patched_mask,
                          depths, disps, noise_seed=seed,
@@ -35,7 +36,9 @@ class _PhotoLossFn(torch.autograd.Function):
         gout = None
         if g_total is not None:
             gout = g_total.detach().double().contiguous()
+        RT.mark("photo.bwd.start")
         d_depth, d_disp, dT = pl.backward(gout)
+        RT.mark("photo.bwd.end")
         return (None, None, None, None, None, None, None, None, dT[0], dT[1]) + tuple(d_depth) + tuple(d_disp)
 
 

@@ -1,6 +1,8 @@
 """Meta-archs with the reference's constructor contract (monodepth2_model.py:8-148):
 MonoDepthMeta (learned pose, "depth+pose") and MonoDepthWPose (dataset pose).  Sub-networks are built
 through build(**cfg) exactly like the reference, so configs only change `name=` strings."""
+import os
+
 import torch
 
 from fsnet_amd.engine.runtime import RT, ParamArena, register_arena
@@ -98,18 +100,36 @@ class MonoDepthMeta(_HipMetaArch):
         overlap = RT.overlap and image_0.is_cuda
         if overlap:
             # fork: pose chain (2 encoder passes + pose decoder) on the side stream, depth chain on the main one;
-            # autograd replays each chain's backward on the stream its forward ran on, so the backward overlaps too
+            # autograd replays each chain's backward on the stream its forward ran on, so the backward overlaps too.
+            # FSNET_AMD_POSE_FIRST=0 issues the depth chain first (the fork is an event, so the captured topology is
+            # the same): autograd then issues the POSE backward first.
             main = torch.cuda.current_stream(image_0.device)
             side = RT.side_stream(image_0.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                if hasattr(self.head, "prefetch_loss_inputs"):
-                    self.head.prefetch_loss_inputs(data)      # needs only the batch: off the depth chain
-                self._pose_chain(data, image_0, pose_out)
+            fork = torch.cuda.Event()
+            fork.record(main)
+
+            def pose_side():
+                side.wait_event(fork)
+                with torch.cuda.stream(side):
+                    RT.mark("side.fork")
+                    if hasattr(self.head, "prefetch_loss_inputs"):
+                        self.head.prefetch_loss_inputs(data)      # needs only the batch: off the depth chain
+                    RT.mark("pose.fwd.start")
+                    self._pose_chain(data, image_0, pose_out)
+                    RT.mark("pose.fwd.end")
+            pose_first = os.environ.get("FSNET_AMD_POSE_FIRST", "1") != "0"
+            if pose_first:
+                pose_side()
+        RT.mark("depth.fwd.start")
         features = self.depth_backbone(image_0)
+        RT.mark("denc.fwd.end")
         outputs = self.head.forward_depth(features)
+        RT.mark("ddec.fwd.end")
         if overlap:
+            if not pose_first:
+                pose_side()
             main.wait_stream(side)            # join before the loss consumes cam_T_cam
+            RT.mark("join")
             for v in pose_out.values():
                 v.record_stream(main)
         else:

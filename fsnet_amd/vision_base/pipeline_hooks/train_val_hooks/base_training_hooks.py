@@ -111,12 +111,16 @@ class BaseTrainingHook(object):
         # (with a process group alive its watchdog thread polls events: only this thread's calls may fail the capture)
         mode = "thread_local" if RT.dp is not None else "global"
         with torch.cuda.graph(graph, stream=self._g_stream, capture_error_mode=mode):
+            RT.mark("step.start")
             arena.zero_grads()
             output = meta_arch(sdata, meta)
             loss = output['loss']
+            RT.mark("loss.fwd.end")
             (loss if loss.dim() == 0 else loss.mean()).backward()
+            RT.mark("bwd.joined")
             grad_scale = RT.dp.finish() if RT.dp is not None else 1.0
             optimizer.step(max_norm=self.clip_gradients, grad_scale=grad_scale)
+            RT.mark("step.end")
         if dot:
             graph.instantiate()
             graph.debug_dump(dot)

@@ -34,6 +34,9 @@ extern "C" {
 /* library/ABI version and the ISA the kernels were compiled for ("gfx950") */
 int fs_abi_version(void);
 const char* fs_target_arch(void);
+/* debugging aid: writes the device's constant-rate clock (wall_clock64, 100 MHz) into *slot (u64) on `stream`;
+ * capturable.  No reference counterpart (the engine's FSNET_AMD_MARKS=1 step timeline). */
+int fs_debug_timestamp(void* slot, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Convolution forward / data-gradient (implicit GEMM on MFMA).
