@@ -42,6 +42,7 @@ class DataParallelContext:
         from .rccl_direct import DirectComm
         self._direct = DirectComm.create(group)
         self._comm_stream = None
+        self._graph_owners = []    # weak references to hooks whose captured step contains this communicator's nodes
         self.capturable = False
         if self._direct is not None:
             self._comm_stream = torch.cuda.Stream(device=self._direct.device)
@@ -143,8 +144,20 @@ class DataParallelContext:
         self._reduce_range(arena, pos, sl[1])
         self._done[id(module)] = [(sl[0], sl[1])]
 
+    def note_graph_owner(self, owner):
+        """`owner.reset_graph()` drops a hipGraph captured with this context's collectives"""
+        import weakref
+        self._graph_owners.append(weakref.ref(owner))
+
     def close(self):
-        """release the direct RCCL communicator (before the process group is destroyed)"""
+        """release the direct RCCL communicator (before the process group is destroyed).  Captured steps that contain
+        its collectives are destroyed first: RCCL keeps per-communicator state for graph-captured launches and a
+        graph outliving its communicator aborts the process when it is finally freed."""
+        for ref in self._graph_owners:
+            owner = ref()
+            if owner is not None:
+                owner.reset_graph()
+        self._graph_owners = []
         if self._direct is not None:
             self._direct.close()
             self._direct = None

@@ -83,12 +83,13 @@ def _defer_param_grads(cur, item):
         # synchronises the streams it used with the caller's stream
         torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
         _CALLBACK_QUEUED[0] = True
-    if RT.wgrad_streams != 3 and len(ent[1]) >= RT.wgrad_flush:
+    if RT.wgrad_streams not in (3, 4) and len(ent[1]) >= RT.wgrad_flush:
         flush_deferred(cur)
 
 
-def flush_deferred(cur=None):
-    """hand the collected weight-gradient work of chain stream `cur` (default: all chains) to its companion"""
+def flush_deferred(cur=None, spread=False):
+    """hand the collected weight-gradient work of chain stream `cur` (default: all chains) to its companion;
+    `spread`: the batch that ends a network's backward may also use the other chains' companions"""
     for key in ([cur.cuda_stream] if cur is not None else list(_DEFERRED.keys())):
         ent = _DEFERRED.get(key)
         if ent is None or not ent[1]:
@@ -96,15 +97,40 @@ def flush_deferred(cur=None):
         chain, items = ent
         if RT.wgrad_streams == 3:
             # the pose chain's stream: shorter than the depth chain's, so its tail is idle GPU time
-            ws = RT.side_stream(chain.device)
+            targets = [RT.side_stream(chain.device)]
+            tail = int(os.environ.get("FSNET_AMD_WGRAD_TAIL", "1"))
+            if tail >= 2:
+                targets.append(chain)
+            if tail >= 3:
+                targets.append(RT.companion_stream(chain.device, chain)[1])
+        elif RT.wgrad_streams == 4:
+            # everything the depth chain collected, once, when that chain has run out of other work: on the chain
+            # itself and on two companions, next to the rest of the pose chain
+            targets = [chain, RT.companion_stream(chain.device, chain)[1],
+                       RT.companion_stream(chain.device, RT.side_stream(chain.device))[1]]
         else:
-            _, ws = RT.companion_stream(chain.device, chain)
-        ws.wait_stream(chain)                       # one cross-stream edge per batch
-        with torch.cuda.stream(ws):
-            for it in items:
-                _run_param_grads(*it)
+            targets = [RT.companion_stream(chain.device, chain)[1]]
+            if spread and (RT.wgrad_spread == 2 or (RT.wgrad_spread == 1 and RT.is_side(chain))):
+                # the last batch of a chain (its largest layers) otherwise runs serially after everything else has
+                # finished: the other chains' companions are idle by then and take every other layer
+                for key2, (chain2, _) in _DEFERRED.items():
+                    if key2 != key:
+                        targets.append(RT.companion_stream(chain2.device, chain2)[1])
+        for k, ws in enumerate(targets):
+            mine = items[k::len(targets)]
+            if not mine:
+                continue
+            if ws is chain or ws.cuda_stream == chain.cuda_stream:
+                with torch.cuda.stream(chain):
+                    for it in mine:
+                        _run_param_grads(*it)
+                continue
+            ws.wait_stream(chain)                   # one cross-stream edge per batch
+            with torch.cuda.stream(ws):
+                for it in mine:
+                    _run_param_grads(*it)
+            _PENDING_JOIN.add((chain, ws))
         _PENDING_KEEP.extend(items)
-        _PENDING_JOIN.add((chain, ws))
         ent[1].clear()
 
 
@@ -264,6 +290,10 @@ class ConvLayer:
                 # only while the budget lasts: hand over about as much as balances the two chains
                 ent = _DEFERRED.get(cur.cuda_stream)
                 if not RT.is_side(cur) and (ent is None or len(ent[1]) < RT.wgrad_side_budget):
+                    _defer_param_grads(cur, item)
+                    return
+            elif mode == 4:
+                if not RT.is_side(cur):
                     _defer_param_grads(cur, item)
                     return
             elif mode == 2 or not RT.is_side(cur):
@@ -499,7 +529,7 @@ class ResNetRunner:
         self.stem.accumulate_param_grads(op, dc0, ctx["x"])
         RT.mark(tag + ".bwd.end")
         if RT.wgrad_streams != 3:
-            flush_deferred(_current_stream())
+            flush_deferred(_current_stream(), spread=True)
 
 
 # ==============================================================================================
@@ -649,7 +679,7 @@ class DepthDecoderRunner:
             else:
                 gfeats[4] = op0.dgrad(dc0, h, w)
         RT.mark("ddec.bwd.end")
-        if RT.wgrad_streams != 3:
+        if RT.wgrad_streams not in (3, 4):
             flush_deferred(_current_stream())
         return gfeats
 

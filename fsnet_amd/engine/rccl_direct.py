@@ -45,6 +45,18 @@ def _load():
     return lib
 
 
+def quiesce_watchdog(device):
+    """Call before opening a hipGraph capture while a torch.distributed NCCL process group is alive.  Its watchdog
+    thread polls the events of every collective it has not reaped yet (100 ms cadence); such a poll landing inside
+    an open capture raises in that thread and std::terminate()s the process (backtrace: ProcessGroupNCCL::Watchdog::
+    run -> rethrow_exception; seen in ~50 % of captures that started within 100 ms of a broadcast / all_reduce).  With
+    the device idle, three watchdog periods are enough for its work list to drain — the engine itself issues no
+    torch.distributed collective during a step."""
+    import time
+    torch.cuda.synchronize(device)
+    time.sleep(0.35)
+
+
 class DirectComm(object):
     def __init__(self, lib, comm, world, rank, device):
         self.lib, self.comm, self.world, self.rank, self.device = lib, comm, world, rank, device
@@ -140,7 +152,7 @@ class DirectComm(object):
             a = torch.full((257,), float(self.rank + 1), dtype=torch.float64, device=dev)
             b = torch.full((70001,), float(self.rank + 1), dtype=torch.float32, device=dev)
             main, side = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-            torch.cuda.synchronize(dev)
+            quiesce_watchdog(dev)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=main, capture_error_mode="thread_local"):
                 self.all_reduce_sum(a)

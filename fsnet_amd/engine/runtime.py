@@ -26,6 +26,8 @@ class _Runtime:
         # variant was slower than inline.  The gain is sensitive to the batch size (6: -4 %, 16: -3 %).
         self.wgrad_streams = int(os.environ.get("FSNET_AMD_WGRAD_STREAMS", "2"))
         self.wgrad_flush = int(os.environ.get("FSNET_AMD_WGRAD_FLUSH", "8"))
+        # 1: the pose chain's last batch (it ends the backward) also uses the depth chain's idle companion; 2: both
+        self.wgrad_spread = int(os.environ.get("FSNET_AMD_WGRAD_SPREAD", "1"))
         # 3 = the first `wgrad_side_budget` weight gradients of the main chain's backward (the decoder's, then
         # the encoder's deepest stages) run at the tail of the pose chain's stream, which finishes earlier
         self.wgrad_side_budget = int(os.environ.get("FSNET_AMD_WGRAD_SIDE_BUDGET", "12"))

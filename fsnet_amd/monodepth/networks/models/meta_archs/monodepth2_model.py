@@ -105,11 +105,17 @@ class MonoDepthMeta(_HipMetaArch):
             # the same): autograd then issues the POSE backward first.
             main = torch.cuda.current_stream(image_0.device)
             side = RT.side_stream(image_0.device)
-            fork = torch.cuda.Event()
-            fork.record(main)
+            pose_first = os.environ.get("FSNET_AMD_POSE_FIRST", "1") != "0"
+            fork = None
+            if not pose_first:
+                fork = torch.cuda.Event()
+                fork.record(main)
 
             def pose_side():
-                side.wait_event(fork)
+                if fork is None:
+                    side.wait_stream(main)
+                else:
+                    side.wait_event(fork)
                 with torch.cuda.stream(side):
                     RT.mark("side.fork")
                     if hasattr(self.head, "prefetch_loss_inputs"):
@@ -117,7 +123,6 @@ class MonoDepthMeta(_HipMetaArch):
                     RT.mark("pose.fwd.start")
                     self._pose_chain(data, image_0, pose_out)
                     RT.mark("pose.fwd.end")
-            pose_first = os.environ.get("FSNET_AMD_POSE_FIRST", "1") != "0"
             if pose_first:
                 pose_side()
         RT.mark("depth.fwd.start")

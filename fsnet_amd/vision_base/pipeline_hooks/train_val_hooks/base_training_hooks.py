@@ -103,6 +103,9 @@ class BaseTrainingHook(object):
             stage(data)
         optimizer.sync_lr()
         torch.cuda.synchronize(dev)
+        if RT.dp is not None:
+            from fsnet_amd.engine.rccl_direct import quiesce_watchdog
+            quiesce_watchdog(dev)
         dot = os.environ.get("FSNET_AMD_GRAPH_DOT")      # debugging: the captured topology as a DOT file
         graph = torch.cuda.CUDAGraph(keep_graph=True) if dot else torch.cuda.CUDAGraph()
         if dot:
@@ -128,6 +131,8 @@ class BaseTrainingHook(object):
         assert optimizer._step_count_fused == steps_before + 1
         self._g = dict(graph=graph, sig=sig, static=static, output=output, arena=arena,
                        stage_meta=stage)
+        if RT.dp is not None:
+            RT.dp.note_graph_owner(self)     # the graph holds RCCL nodes: it must go before the communicator does
         graph.replay()
         RT.bump_weights()
         return output
