@@ -45,7 +45,8 @@ class DataParallelContext:
         self._graph_owners = []    # weak references to hooks whose captured step contains this communicator's nodes
         self.capturable = False
         if self._direct is not None:
-            self._comm_stream = torch.cuda.Stream(device=self._direct.device)
+            from .runtime import RT
+            self._comm_stream = RT.new_stream(self._direct.device)
             self.capturable = self._direct.capture_ok
 
     @property
@@ -161,6 +162,10 @@ class DataParallelContext:
         if self._direct is not None:
             self._direct.close()
             self._direct = None
+        if self._comm_stream is not None:
+            from .runtime import RT
+            RT.release_stream(self._comm_stream.cuda_stream)
+            self._comm_stream = None
 
     def finish(self):
         """wait for the outstanding gradient all-reduces; returns the scale that turns SUM into MEAN.  Raises if a

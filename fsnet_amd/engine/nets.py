@@ -51,6 +51,7 @@ _PENDING_KEEP = []      # tensors the companion kernels still read: kept alive u
                         # bookkeeping in the allocator, and safe inside a hipGraph capture's private pool)
 _DEFERRED = {}          # chain stream id -> (chain stream, [weight-gradient work items not yet handed over])
 _CALLBACK_QUEUED = [False]
+_ACTIVE_CHAINS = set()  # chain stream ids that deferred work during the running backward pass
 
 
 _STREAM_OBJS = {}
@@ -78,6 +79,7 @@ def _defer_param_grads(cur, item):
     if ent is None:
         ent = _DEFERRED[cur.cuda_stream] = (cur, [])
     ent[1].append(item)
+    _ACTIVE_CHAINS.add(cur.cuda_stream)
     if not _CALLBACK_QUEUED[0]:
         # runs once, when the autograd engine has executed every node of this backward pass and before it
         # synchronises the streams it used with the caller's stream
@@ -113,8 +115,9 @@ def flush_deferred(cur=None, spread=False):
             if spread and (RT.wgrad_spread == 2 or (RT.wgrad_spread == 1 and RT.is_side(chain))):
                 # the last batch of a chain (its largest layers) otherwise runs serially after everything else has
                 # finished: the other chains' companions are idle by then and take every other layer
-                for key2, (chain2, _) in _DEFERRED.items():
+                for key2 in _ACTIVE_CHAINS:         # chains of THIS backward pass only
                     if key2 != key:
+                        chain2 = _DEFERRED[key2][0]
                         targets.append(RT.companion_stream(chain2.device, chain2)[1])
         for k, ws in enumerate(targets):
             mine = items[k::len(targets)]
@@ -137,6 +140,7 @@ def flush_deferred(cur=None, spread=False):
 def _end_of_backward():
     _CALLBACK_QUEUED[0] = False
     flush_deferred()
+    _ACTIVE_CHAINS.clear()
     join_companions()
 
 

@@ -34,6 +34,7 @@ class _Runtime:
         # the pose encoder's image pairs as one stacked pass with per-pair BatchNorm statistics
         self.batch_pose_pairs = os.environ.get("FSNET_AMD_BATCH_POSE", "1") != "0"
         self._side = {}
+        self._held = {}           # raw stream handle -> Stream: every stream the engine created (see new_stream)
         # FSNET_AMD_MARKS=1: device-clock marks along the step (mark() below), read back with marks_report()
         self._marks = {} if os.environ.get("FSNET_AMD_MARKS", "0") != "0" else None
         self._mark_buf = None
@@ -60,10 +61,26 @@ class _Runtime:
         t0 = min(v for _, v in rows)
         return sorted(((n, (v - t0) / 1e5) for n, v in rows), key=lambda r: r[1])
 
+    def new_stream(self, device):
+        """a HIP stream no other part of the engine holds.  torch.cuda.Stream() hands out a pool of 32 streams per
+        device round-robin: the 33rd request aliases the first, and two roles of one step (capture stream, pose
+        chain, a companion) landing on one stream turns a fork/join into a self-wait inside the capture (seen as a
+        segfault in hipGraphLaunch once a process had built many hooks)."""
+        for _ in range(64):
+            s = torch.cuda.Stream(device=device)
+            if s.cuda_stream not in self._held:
+                self._held[s.cuda_stream] = s
+                return s
+        raise RuntimeError("no free HIP stream in torch's pool (every pooled stream is held by the engine)")
+
+    def release_stream(self, handle):
+        """give a stream from new_stream() back (its owner is gone)"""
+        self._held.pop(handle, None)
+
     def side_stream(self, device):
         s = self._side.get(device)
         if s is None:
-            s = self._side[device] = torch.cuda.Stream(device=device)
+            s = self._side[device] = self.new_stream(device)
         return s
 
     def companion_stream(self, device, cur=None):
@@ -73,7 +90,7 @@ class _Runtime:
         key = (device, cur.cuda_stream, "wgrad")
         s = self._side.get(key)
         if s is None:
-            s = self._side[key] = torch.cuda.Stream(device=device)
+            s = self._side[key] = self.new_stream(device)
         return cur, s
 
     def is_side(self, stream):

@@ -12,6 +12,7 @@ tensors are the graph's static outputs, valid until the next call (loss_dict ent
 is attached).  Eager execution stays in use while a data-parallel context is active, for non-fused
 optimizers, and whenever the batch signature changes."""
 import os
+import weakref
 
 import torch
 
@@ -185,7 +186,8 @@ class BaseTrainingHook(object):
         if sig != self._g_sig or (self._g is not None and not self._g["arena"] is arena):
             self._g, self._g_sig, self._g_eager = None, sig, 0
         if self._g_stream is None:
-            self._g_stream = torch.cuda.Stream(device=next(meta_arch.parameters()).device)
+            self._g_stream = RT.new_stream(next(meta_arch.parameters()).device)
+            weakref.finalize(self, RT.release_stream, self._g_stream.cuda_stream)
         cur = torch.cuda.current_stream()
         if self._g is None and self._g_eager < max(2, self.graph_warmup):
             # warm-up on the capture stream: lazy buffers, per-stream pools and tables exist before the capture
