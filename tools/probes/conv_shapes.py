@@ -7,7 +7,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 SHAPES = [  # name, Ci, Co, k, stride, pad, H, W (input)
     ("stem3", 3, 64, 7, 2, 3, 192, 640), ("l1 64-64", 64, 64, 3, 1, 1, 48, 160), ("l2.0 64-128s2", 64, 128, 3, 2, 1, 48, 160),
     ("l2 128-128", 128, 128, 3, 1, 1, 24, 80), ("l3 256-256", 256, 256, 3, 1, 1, 12, 40), ("l4 512-512", 512, 512, 3, 1, 1, 6, 20),
-    ("ds 64-128 1x1s2", 64, 128, 1, 2, 0, 48, 160), ("dec 512-256", 512, 256, 3, 1, 1, 6, 20), ("dec 512-256@12", 512, 256, 3, 1, 0, 14, 42),
+    ("l3.0 128-256s2", 128, 256, 3, 2, 1, 24, 80), ("l4.0 256-512s2", 256, 512, 3, 2, 1, 12, 40),
+    ("ds 64-128 1x1s2", 64, 128, 1, 2, 0, 48, 160), ("ds 128-256 1x1s2", 128, 256, 1, 2, 0, 24, 80), ("ds 256-512 1x1s2", 256, 512, 1, 2, 0, 12, 40), ("dec 512-256", 512, 256, 3, 1, 1, 6, 20), ("dec 512-256@12", 512, 256, 3, 1, 0, 14, 42),
     ("dec 256-128@24", 256, 128, 3, 1, 0, 26, 82), ("dec 128-64@48", 128, 64, 3, 1, 0, 50, 162), ("dec 96-32@96", 96, 32, 3, 1, 0, 98, 322),
     ("dec 32-16@96", 32, 16, 3, 1, 1, 96, 320), ("dec 16-16@192", 16, 16, 3, 1, 0, 194, 642), ("pose 256-256", 256, 256, 3, 1, 1, 6, 20),
 ]
