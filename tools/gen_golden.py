@@ -646,7 +646,30 @@ def gen_loss_options():
     np.savez_compressed(os.path.join(GOLD, "loss_options.npz"), **out)
 
 
+def gen_teacher_keys():
+    """monodepth/transform_teacher.py on a checkpoint of the reference depth+pose meta-arch: the key list of the
+    teacher state_dict (order included) and a checksum per kept tensor."""
+    import json
+    import tempfile
+    from monodepth.transform_teacher import transform_teacher_model
+    m = ref_model(64, 128, True)
+    m.load_state_dict({k: v.clone() for k, v in O.init_state(seed=1, with_pose=True).items()}, strict=True)
+    with tempfile.TemporaryDirectory() as d:
+        src, dst = os.path.join(d, "stage1.pth"), os.path.join(d, "teacher.pth")
+        torch.save({"model_state_dict": m.state_dict(), "optimizer_state_dict": {}}, src)
+        transform_teacher_model(src, dst)
+        out = torch.load(dst, map_location="cpu")
+    rec = {"src_keys": list(m.state_dict().keys()), "dst_keys": list(out.keys()),
+           "dst_sums": [float(v.double().sum()) for v in out.values()], "is_bare_state_dict": isinstance(out, dict)
+           and "model_state_dict" not in out}
+    json.dump(rec, open(os.path.join(GOLD, "teacher_keys.json"), "w"))
+    print("teacher keys: %d of %d kept" % (len(rec["dst_keys"]), len(rec["src_keys"])))
+
+
 if __name__ == "__main__":
+    if "--only-teacher" in sys.argv:
+        gen_teacher_keys()
+        sys.exit(0)
     if "--only-augment" in sys.argv:
         gen_augment()
         sys.exit(0)
@@ -673,5 +696,6 @@ if __name__ == "__main__":
     gen_model_r50fx()
     gen_kitti_dataset()
     gen_loss_options()
+    gen_teacher_keys()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")
