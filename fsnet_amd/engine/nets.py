@@ -609,8 +609,22 @@ class DepthDecoderRunner:
                     lv["unc"] = ops.sigmoid_head_fwd(opu.forward(y1p, bias=clu.bias, out_f32=True))
             ctx["lv"][i] = lv
             x = y1p[:, 1:-1, 1:-1]
-        # softmax-expectation heads of all scales in one launch (their outputs are only read by the loss)
         sc = [i for i in range(4, -1, -1) if "logits" in ctx["lv"][i]]
+        if getattr(m, "sigmoid_head", False):
+            # base-class DepthDecoder (depth_encoder.py:90-111): disp = sigmoid(dispconv), depth = scale / (min_disp +
+            # (max_disp - min_disp) * disp) — the sigmoid is the uncertainty head's kernel, the three element-wise ops
+            # on a one-channel map stay in torch
+            a, bq = 1.0 / float(m.max_depth), 1.0 / float(m.min_depth) - 1.0 / float(m.max_depth)
+            scale = None if P2 is None else (P2[:, 0, 0] / float(base_fx)).view(-1, 1, 1, 1)
+            for i in sc:
+                lv = ctx["lv"][i]
+                u = ops.sigmoid_head_fwd(lv["logits"])
+                inv = torch.reciprocal(a + bq * u)
+                depth = inv if scale is None else inv * scale
+                lv["sig"] = (u, depth)
+                outs[i] = (lv["logits"], depth, u)
+            return outs, ctx
+        # softmax-expectation heads of all scales in one launch (their outputs are only read by the loss)
         if sc:
             heads = ops.depth_head_fwd_multi([ctx["lv"][i]["logits"] for i in sc], m.depth_bins, K, m.min_depth,
                                              m.max_depth, P2=P2, base_fx=base_fx)
@@ -633,7 +647,16 @@ class DepthDecoderRunner:
         # logit gradients of every scale that received one, in one launch at the head of the backward
         sc = [i for i in range(5) if i in m.scales and (g_depth.get(i) is not None or g_disp.get(i) is not None)]
         dls = {}
-        if sc:
+        if sc and getattr(m, "sigmoid_head", False):
+            a, bq = 1.0 / float(m.max_depth), 1.0 / float(m.min_depth) - 1.0 / float(m.max_depth)
+            for i in sc:
+                u, depth = ctx["lv"][i]["sig"]
+                du = g_disp[i] if g_disp.get(i) is not None else torch.zeros_like(u)
+                if g_depth.get(i) is not None:
+                    # d depth / d u = -scale * bq / (a + bq u)^2 = -bq * depth / (a + bq u)
+                    du = du - g_depth[i] * depth * (bq / (a + bq * u))
+                dls[i] = ops.sigmoid_head_bwd(u, du, self.disp[i].ready(dt, dev).Co_p, dt)
+        elif sc:
             res = ops.depth_head_bwd_multi([ctx["lv"][i]["logits"] for i in sc], m.depth_bins,
                                            [g_depth.get(i) for i in sc], [g_disp.get(i) for i in sc], K, m.min_depth,
                                            m.max_depth, dt, P2=ctx["P2"], base_fx=ctx["base_fx"])

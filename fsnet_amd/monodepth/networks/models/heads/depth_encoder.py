@@ -88,18 +88,15 @@ class DepthDecoder(nn.Module):
         lo, hi = np.log(min_depth), np.log(max_depth)
         self.register_buffer("depth_bins", torch.exp(torch.arange(lo, hi, (hi - lo) / num_bins)))
 
-    def forward(self, input_features, P2=None):
-        raise NotImplementedError("the sigmoid-disparity DepthDecoder is not on the shipped monodepth path; "
-                                  "use MultiChannelDepthDecoder (configs/*_example)")
+    sigmoid_head = True       # ('disp', s) = sigmoid(dispconv_s), depth by disp_to_depth (depth_encoder.py:90-111)
 
-
-class MultiChannelDepthDecoder(DepthDecoder):
-    """softmax-over-log-spaced-depth-bins head (depth_encoder.py:114-139)."""
+    def _check_head(self):
+        if self.num_output_channels != 1:
+            raise NotImplementedError("the sigmoid-disparity DepthDecoder has one output channel")
 
     def forward(self, input_features, P2=None):
-        require_gpu(input_features[-1], "MultiChannelDepthDecoder.forward")
-        if self.num_output_channels not in (16, 32, 64):
-            raise NotImplementedError("depth-bin head supports 16/32/64 bins")
+        require_gpu(input_features[-1], type(self).__name__ + ".forward")
+        self._check_head()
         feats = list(input_features)
         outputs = {}
         if torch.is_grad_enabled() and self.training:
@@ -122,6 +119,15 @@ class MultiChannelDepthDecoder(DepthDecoder):
             if self._nout == 4:
                 outputs[('uncertain_z', s)] = outs[s][3]
         return outputs
+
+
+class MultiChannelDepthDecoder(DepthDecoder):
+    """softmax-over-log-spaced-depth-bins head (depth_encoder.py:114-139)."""
+    sigmoid_head = False
+
+    def _check_head(self):
+        if self.num_output_channels not in (16, 32, 64):
+            raise NotImplementedError("depth-bin head supports 16/32/64 bins")
 
 
 class MultiChannelDepthDecoderUncertain(MultiChannelDepthDecoder):

@@ -211,9 +211,11 @@ def gather_activation(logits, bins):
 
 
 def depth_decoder_forward(sd, prefix, feats, min_depth, max_depth, scales=(0, 1, 2, 3), train=True, P2=None,
-                          base_fx=None):
+                          base_fx=None, sigmoid=False):
     """depth_encoder.py:119-139 (MultiChannelDepthDecoder.forward / gather_output); with base_fx and P2 the
-    focal-length scale of _get_scale (:36-43): depth *= fx / base_fx, disparity against the scaled range."""
+    focal-length scale of _get_scale (:36-43): depth *= fx / base_fx, disparity against the scaled range.
+    sigmoid=True: the base class DepthDecoder.forward (:90-111) — disp = sigmoid(dispconv), depth through
+    disp_to_depth (monodepth_utils.py:8-17) times the focal-length scale."""
     out = {}
     depth_scale = 1
     if base_fx is not None and P2 is not None:
@@ -235,10 +237,16 @@ def depth_decoder_forward(sd, prefix, feats, min_depth, max_depth, scales=(0, 1,
             k = disp_base + list(scales).index(i)
             logits = _conv_pad(x, sd["%sdecoder.%d.weight" % (prefix, k)], sd["%sdecoder.%d.bias" % (prefix, k)],
                                "replicate")
+            out[("logits", i)] = logits
+            if sigmoid:
+                disp = torch.sigmoid(logits)
+                scaled = 1 / max_depth + (1 / min_depth - 1 / max_depth) * disp
+                out[("disp", i)] = disp
+                out[("depth", i, i)] = (1 / scaled) * depth_scale
+                continue
             depth = gather_activation(logits, sd[prefix + "depth_bins"])
             if base_fx is not None:
                 depth = depth * depth_scale
-            out[("logits", i)] = logits
             out[("depth", i, i)] = depth
             out[("disp", i)] = depth_to_disp(depth, min_depth * depth_scale, max_depth * depth_scale)
     return out

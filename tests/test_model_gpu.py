@@ -391,3 +391,43 @@ def test_resnet50_depth_pose_step_matches_oracle(dev, dtype):
         gn_ref = float(torch.sqrt(sum((r ** 2).sum() for r in raw.values())))
         assert gn == gn and 0.5 < gn / gn_ref < 2.0, (gn, gn_ref)
     RT.set_compute_dtype(torch.bfloat16)
+
+
+@pytest.mark.parametrize("base_fx", [None, 600.0])
+def test_sigmoid_depth_decoder_matches_oracle(dev, base_fx):
+    """the base-class DepthDecoder (sigmoid disparity head, depth_encoder.py:17-111) on the HIP engine against the
+    oracle (pinned to the reference's class by sigmoid_decoder.npz): outputs, feature and parameter gradients"""
+    from fsnet_amd.engine.runtime import RT
+    from fsnet_amd.vision_base.utils.builder import build
+    from tests.helpers_sigmoid import case, oracle_run
+    import numpy as np
+    RT.set_compute_dtype(torch.float32)
+    try:
+        feats, sd, P2, wd, wq = case()
+        m = build(name="fsnet_amd.monodepth.networks.models.heads.depth_encoder.DepthDecoder",
+                  num_ch_enc=np.array([64, 64, 128, 256, 512]), scales=[0, 1, 2, 3], num_output_channels=1, use_skips=True,
+                  min_depth=0.5, max_depth=100, base_fx=base_fx)
+        m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+        m = m.to(dev).train()
+        fl = [f.to(dev).requires_grad_(True) for f in feats]
+        res = m(fl, P2.to(dev) if base_fx is not None else None)
+        loss = sum((res[("depth", s, s)] * wd[s].to(dev)).sum() * 1e-2 + (res[("disp", s)] * wq[s].to(dev)).sum()
+                   for s in range(4))
+        loss.backward()
+        o, ofl, oparams, oloss = oracle_run(base_fx, torch.float64)
+        assert float(loss) == pytest.approx(float(oloss), rel=2e-4)
+        for s in range(4):
+            d = res[("depth", s, s)].cpu().double()
+            assert float((d - o[("depth", s, s)]).abs().max() / o[("depth", s, s)].abs().max()) < 2e-4
+            assert float((res[("disp", s)].cpu().double() - o[("disp", s)]).abs().max()) < 2e-5
+            assert res[("logits", s)].shape == o[("logits", s)].shape
+        for a, b in zip(fl, ofl):
+            assert float((a.grad.cpu().double() - b.grad).norm() / b.grad.norm()) < 2e-3
+        got = {k: p.grad.cpu().double() for k, p in m.named_parameters()}
+        top = max(float(v.grad.norm()) for v in oparams.values())
+        for k, v in oparams.items():
+            g = got[k[2:]]
+            # (a conv bias in front of a training-mode BatchNorm has a zero gradient: both sides are rounding noise)
+            assert float((g - v.grad).norm()) < 5e-3 * float(v.grad.norm()) + 1e-5 * top, k
+    finally:
+        RT.set_compute_dtype(torch.bfloat16)

@@ -286,3 +286,21 @@ def test_motion_mask_and_pose_term_oracle_matches_reference_golden():
         for got, key in ((pose[tag][0].grad, "gaa_" + tag), (pose[tag][1].grad, "gtr_" + tag)):
             ref = T(g[key])
             assert maxdev(got, ref) < 1e-4 * float(ref.abs().max()) + 1e-9
+
+
+def test_sigmoid_depth_decoder_matches_reference():
+    """the oracle's restatement of the base-class DepthDecoder (sigmoid disparity, disp_to_depth, base_fx scale)
+    against the reference's class: outputs, feature gradients, parameter-gradient norms (sigmoid_decoder.npz)"""
+    from tests.helpers_sigmoid import oracle_run, thin
+    G = np.load(os.path.join(GOLD, "sigmoid_decoder.npz"))
+    for tag, base_fx in (("plain", None), ("fx", 600.0)):
+        o, fl, params, loss = oracle_run(base_fx, torch.float32)
+        assert float(loss) == pytest.approx(float(G[tag + "_loss"]), rel=1e-5)
+        for s in range(4):
+            np.testing.assert_allclose(thin(o[("depth", s, s)]), G["%s_depth%d" % (tag, s)], rtol=2e-5, atol=1e-6)
+            np.testing.assert_allclose(thin(o[("disp", s)]), G["%s_disp%d" % (tag, s)], rtol=2e-5, atol=1e-7)
+        for k, f in enumerate(fl):
+            ref = G["%s_gfeat%d" % (tag, k)]
+            np.testing.assert_allclose(thin(f.grad), ref, rtol=2e-3, atol=2e-4 * float(np.abs(ref).max()))
+        gn = np.array([float(v.grad.norm()) for v in params.values()])
+        np.testing.assert_allclose(gn, G[tag + "_gnorm"], rtol=2e-3)

@@ -646,6 +646,57 @@ def gen_loss_options():
     np.savez_compressed(os.path.join(GOLD, "loss_options.npz"), **out)
 
 
+def thin(t, limit=4096):
+    """every k-th element of the flattened tensor (k = the smallest stride that leaves <= `limit` values), float32;
+    tests apply the same rule to what they compare"""
+    a = t.detach().reshape(-1)
+    k = max(1, -(-a.numel() // limit))
+    return a[::k].to(torch.float32).numpy().copy()
+
+
+def sigmoid_decoder_case():
+    """seeded inputs of the sigmoid-disparity DepthDecoder golden (shared with tests/)"""
+    g = torch.Generator().manual_seed(77)
+    B, H, W = 2, 64, 128
+    chans = [64, 64, 128, 256, 512]
+    feats = [torch.randn(B, c, H >> (k + 1), W >> (k + 1), generator=g) * 0.5 for k, c in enumerate(chans)]
+    sd = {k[len("head.depth_decoder."):]: v for k, v in O.init_state(seed=9, with_pose=False, num_out=1).items()
+          if k.startswith("head.depth_decoder.")}
+    P2 = torch.tensor([[[700.0, 0, 64, 0], [0, 700, 32, 0], [0, 0, 1, 0]], [[540.0, 0, 60, 0], [0, 540, 30, 0], [0, 0, 1, 0]]])
+    wd = [torch.randn(B, 1, H >> s, W >> s, generator=g) for s in range(4)]
+    wq = [torch.randn(B, 1, H >> s, W >> s, generator=g) for s in range(4)]
+    return feats, sd, P2, wd, wq
+
+
+def gen_sigmoid_decoder():
+    """The base-class DepthDecoder (sigmoid disparity, depth_encoder.py:17-111) with and without base_fx: outputs,
+    feature gradients and parameter-gradient norms of sum_s <depth_s, wd_s> * 1e-2 + <disp_s, wq_s>."""
+    from monodepth.networks.models.heads.depth_encoder import DepthDecoder
+    feats, sd, P2, wd, wq = sigmoid_decoder_case()
+    out = {}
+    for tag, base_fx in (("plain", None), ("fx", 600.0)):
+        m = DepthDecoder(num_ch_enc=np.array([64, 64, 128, 256, 512]), scales=[0, 1, 2, 3], num_output_channels=1,
+                         use_skips=True, min_depth=0.5, max_depth=100, base_fx=base_fx)
+        m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+        m.train()
+        fl = [f.clone().requires_grad_(True) for f in feats]
+        res = m(fl, P2 if base_fx is not None else None)
+        loss = sum((res[("depth", s, s)] * wd[s]).sum() * 1e-2 + (res[("disp", s)] * wq[s]).sum() for s in range(4))
+        loss.backward()
+        o = O.depth_decoder_forward({("d." + k): v for k, v in sd.items()}, "d.", [f.clone() for f in feats], 0.5, 100.0,
+                                    P2=P2 if base_fx is not None else None, base_fx=base_fx, sigmoid=True)
+        print("sigmoid decoder [%s]: oracle depth dev %.2e disp dev %.2e" % (
+            tag, dev(o[("depth", 0, 0)], res[("depth", 0, 0)]), dev(o[("disp", 0)], res[("disp", 0)])))
+        out[tag + "_loss"] = npy(loss)
+        for s in range(4):
+            out["%s_depth%d" % (tag, s)] = thin(res[("depth", s, s)])
+            out["%s_disp%d" % (tag, s)] = thin(res[("disp", s)])
+        for k, f in enumerate(fl):
+            out["%s_gfeat%d" % (tag, k)] = thin(f.grad)
+        out[tag + "_gnorm"] = npy(torch.stack([p.grad.norm() for p in m.parameters()]))
+    np.savez_compressed(os.path.join(GOLD, "sigmoid_decoder.npz"), **out)
+
+
 def gen_teacher_keys():
     """monodepth/transform_teacher.py on a checkpoint of the reference depth+pose meta-arch: the key list of the
     teacher state_dict (order included) and a checksum per kept tensor."""
@@ -667,6 +718,9 @@ def gen_teacher_keys():
 
 
 if __name__ == "__main__":
+    if "--only-sigmoid" in sys.argv:
+        gen_sigmoid_decoder()
+        sys.exit(0)
     if "--only-teacher" in sys.argv:
         gen_teacher_keys()
         sys.exit(0)
@@ -697,5 +751,6 @@ if __name__ == "__main__":
     gen_kitti_dataset()
     gen_loss_options()
     gen_teacher_keys()
+    gen_sigmoid_decoder()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")
