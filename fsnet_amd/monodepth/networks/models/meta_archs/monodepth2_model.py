@@ -118,11 +118,17 @@ class MonoDepthMeta(_HipMetaArch):
                     side.wait_event(fork)
                 with torch.cuda.stream(side):
                     RT.mark("side.fork")
-                    if hasattr(self.head, "prefetch_loss_inputs"):
-                        self.head.prefetch_loss_inputs(data)      # needs only the batch: off the depth chain
+                    late = os.environ.get("FSNET_AMD_LOSS_INPUTS_LATE", "1") != "0"
+                    if not late and hasattr(self.head, "prefetch_loss_inputs"):
+                        self.head.prefetch_loss_inputs(data)
                     RT.mark("pose.fwd.start")
                     self._pose_chain(data, image_0, pose_out)
                     RT.mark("pose.fwd.end")
+                    if late and hasattr(self.head, "prefetch_loss_inputs"):
+                        # the loss chain's image-only inputs (colour pyramid, identity reprojection terms) need only
+                        # the batch and are first read by the loss: they fill the pose stream's idle tail beside the
+                        # depth decoder instead of delaying both encoders at the head of the step
+                        self.head.prefetch_loss_inputs(data)
             if pose_first:
                 pose_side()
         RT.mark("depth.fwd.start")
