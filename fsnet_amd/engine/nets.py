@@ -284,6 +284,10 @@ class ConvLayer:
         backward pass, so they run on a companion stream while the chain continues with the dgrad."""
         gw = grad_of(self.m.weight)
         gb = grad_of(self.m.bias) if self.m.bias is not None else None
+        if gw is None:                       # frozen layer: nothing to accumulate (a lone trainable bias: its sum)
+            if gb is not None:
+                ops.channel_sum(dc, gb, self.m.bias.numel())
+            return
         item = (op, dc, x, gw, gb, self.m.bias.numel() if gb is not None else 0)
         # (data parallel: inline on the chain stream, so that one event after a stage's last weight gradient covers
         # the arena slice its gradient bucket reduces — also inside a captured step)
@@ -350,17 +354,19 @@ def _bn_bwd(dout, y, c, bn, st, H, W, relu=True, fold=False, g_out=None, sums=No
     reduced = sums is not None
     if sums is None:
         sums = _bwd_sums(c, st)
+    # (eval-mode BatchNorm: st.count is inf — no batch-statistics terms in dx, hence no exchange of the sums either)
+    sync = RT.dp is not None and st.count != float("inf")
     ops.bn_backward(dout, y, c, bn.weight.data, st, dc, grad_of(bn.weight), grad_of(bn.bias), H, W, relu=relu,
                     fold=fold, g_out=g_out, sums=sums, sums_zeroed=True, reduced=reduced,
-                    allreduce=(RT.dp.allreduce_small if RT.dp is not None else None))
+                    allreduce=(RT.dp.allreduce_small if sync else None))
     return dc
 
 
 def _check_train_bn(bn, what):
     if not bn.training:
         raise NotImplementedError(
-            "%s: BatchNorm in eval mode inside a training step (norm_eval / frozen stages) is not implemented "
-            "in the HIP engine yet" % what)
+            "%s: BatchNorm in eval mode inside a training step is only implemented for the ResNet encoders "
+            "(norm_eval / frozen_stages); the reference has no such switch for this module" % what)
 
 
 # ==============================================================================================
@@ -391,16 +397,22 @@ class ResNetRunner:
         op = cl.ready(x.dtype, x.device)
         N, H, W, _ = x.shape
         Ho, Wo = op.out_hw(H, W)
-        G = self.groups if train else 1
-        stats = self.pool.take(op.Co_p, G) if train else None
+        # a BatchNorm in eval mode inside a training step (norm_eval / frozen stages, resnet.py:169-197): running
+        # statistics, no update of them, one statistics group; its backward is the batch-statistics formula with the
+        # mean terms switched off (count = inf), dgamma / dbeta from the same sums
+        bt = train and bn.training
+        assert ds_bn is None or (train and ds_bn.training) == bt, "main and downsample BatchNorm modes differ"
+        G = self.groups if bt else 1
+        stats = self.pool.take(op.Co_p, G) if bt else None
         c = op.forward(x, stats=stats, stat_groups=G)
-        world = _dp_stats(stats) if train else 1
+        world = _dp_stats(stats) if bt else 1
         y = torch.empty(N, Ho, Wo, op.Co_p, dtype=x.dtype, device=x.device)
         st = ops.BnState(op.Co_p, x.device, G)
         st2 = ops.BnState(op.Co_p, x.device, G) if ds_bn is not None else None
-        ops.bn_apply(c, stats, bn_tensors(bn), st, y, Ho, Wo, (N // G) * Ho * Wo * world, relu=relu,
-                     res=(ds_c if ds_bn is not None else res), stats2=ds_stats,
-                     bn2=(bn_tensors(ds_bn) if ds_bn is not None else None), st2=st2, track=train, groups=G)
+        count = (N // G) * Ho * Wo * world if (bt or not train) else float("inf")
+        ops.bn_apply(c, stats, bn_tensors(bn), st, y, Ho, Wo, count, relu=relu,
+                     res=(ds_c if ds_bn is not None else res), stats2=(ds_stats if bt else None),
+                     bn2=(bn_tensors(ds_bn) if ds_bn is not None else None), st2=st2, track=bt, groups=G)
         return c, y, st, st2
 
     def forward(self, x, train, groups=1):
@@ -413,8 +425,6 @@ class ResNetRunner:
         self.pool.reset()
         self.groups = groups if train else 1
         assert x.shape[0] % self.groups == 0
-        if train:
-            _check_train_bn(self.m.bn1, "ResNet")
         ctx = {"x": x, "blocks": []}
         c0, y0, st0, _ = self._unit_fwd(self.stem, self.m.bn1, x, train)
         pooled, idx = ops.maxpool_fwd(y0)
@@ -433,9 +443,10 @@ class ResNetRunner:
                     else:
                         if ds is not None:
                             dop = ds[0].ready(cur.dtype, cur.device)
-                            dstats = self.pool.take(dop.Co_p, self.groups) if train else None
-                            c_ds = dop.forward(cur, stats=dstats, stat_groups=self.groups)
-                            if train:
+                            dbt = train and ds[1].training
+                            dstats = self.pool.take(dop.Co_p, self.groups) if dbt else None
+                            c_ds = dop.forward(cur, stats=dstats, stat_groups=(self.groups if dbt else 1))
+                            if dbt:
                                 _dp_stats(dstats)
                             c, y, st, st2 = self._unit_fwd(cl, bn, inp, train, ds_c=c_ds, ds_stats=dstats, ds_bn=ds[1])
                             bctx["ds"] = (c_ds, st2)

@@ -187,7 +187,10 @@ def register_arena(a):
 
 
 def grad_of(p):
-    """Gradient buffer to accumulate into (kernels write/accumulate through raw pointers)."""
+    """Gradient buffer to accumulate into (kernels write/accumulate through raw pointers); None for a frozen
+    parameter (requires_grad False: frozen stages, resnet.py:179-193) — its kernels are skipped."""
+    if not p.requires_grad:
+        return None
     if p.grad is None:
         for a in _ARENAS:
             if a.owns(p):

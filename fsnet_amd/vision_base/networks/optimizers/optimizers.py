@@ -70,6 +70,10 @@ class FusedAdam(optim.Optimizer):
         g0 = self.param_groups[0]
         join_companions_final()        # weight-gradient kernels still in flight on companion streams
         if arena is not None:
+            if g0["weight_decay"] and any(not p.requires_grad for p in arena.params):
+                # frozen parameters keep a zero gradient in the arena, which Adam turns into a zero update — but L2
+                # weight decay would still shrink them (torch.optim.Adam skips parameters without a gradient)
+                raise NotImplementedError("FusedAdam: weight_decay with frozen parameters in the arena")
             m, v = self._flat_state(arena)
             dev = arena.data.device
             if self._step_buf is None or self._step_buf.device != dev:

@@ -159,16 +159,29 @@ def _bn(sd, name, x, train=True):
                         sd[name + ".bias"], training=train, momentum=BN_MOMENTUM, eps=BN_EPS)
 
 
-def resnet_forward(sd, prefix, x, depth=18, train=True):
+def frozen_names(prefix, frozen_stages):
+    """parameter-name prefixes that ResNet.freeze_stages (resnet.py:179-193) takes out of training"""
+    out = []
+    if frozen_stages >= 0:
+        out += [prefix + "conv1.", prefix + "bn1."]
+    out += ["%slayer%d." % (prefix, i) for i in range(1, frozen_stages + 1)]
+    return tuple(out)
+
+
+def resnet_forward(sd, prefix, x, depth=18, train=True, frozen_stages=-1, norm_eval=False):
     """resnet.py:199-213 (forward, out_indices=(-1,0,1,2,3)), 33-50 (BasicBlock), 70-89
-    (Bottleneck, stride on the 3x3)."""
+    (Bottleneck, stride on the 3x3).  frozen_stages / norm_eval: ResNet.train() (:169-197) leaves the BatchNorms of
+    the frozen stem / stages — or all of them — in eval mode inside a training step."""
     kind, layers = {18: ("basic", [2, 2, 2, 2]), 34: ("basic", [3, 4, 6, 3]), 50: ("bottleneck", [3, 4, 6, 3])}[depth]
     outs = []
+    glob_train = train
+    train = glob_train and not norm_eval and frozen_stages < 0
     x = F.conv2d(x, sd[prefix + "conv1.weight"], None, stride=2, padding=3)
     x = F.relu(_bn(sd, prefix + "bn1", x, train))
     outs.append(x)
     x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
     for li, nblk in enumerate(layers):
+        train = glob_train and not norm_eval and (li + 1) > frozen_stages
         for b in range(nblk):
             p = "%slayer%d.%d." % (prefix, li + 1, b)
             stride = 2 if (li > 0 and b == 0) else 1
@@ -426,17 +439,20 @@ def photometric_loss(outputs, inputs, frame_ids=(0, 1, -1), scales=(0, 1, 2, 3),
 # meta-arch forward and one optimisation step
 # ----------------------------------------------------------------------------------------------
 def forward_train(sd, data, depth=18, with_pose=True, min_depth=0.5, max_depth=100.0,
-                  frame_ids=(0, 1, -1), scales=(0, 1, 2, 3), overlapped_mask=True, noise=None, base_fx=None):
+                  frame_ids=(0, 1, -1), scales=(0, 1, 2, 3), overlapped_mask=True, noise=None, base_fx=None,
+                  frozen_stages=-1, norm_eval=False):
     """MonoDepthMeta.forward_train (monodepth2_model.py:24-46) when with_pose, else
     MonoDepthWPose.forward_train (85-130, dataset poses, no residual pose net)."""
-    feats = resnet_forward(sd, "depth_backbone.", data[("image", 0)], depth)
+    feats = resnet_forward(sd, "depth_backbone.", data[("image", 0)], depth, frozen_stages=frozen_stages,
+                           norm_eval=norm_eval)
     # MonoDepthWPose hands P2 to the decoder only when base_fx is set (monodepth2_model.py:91)
     outputs = depth_decoder_forward(sd, "head.depth_decoder.", feats, min_depth, max_depth, scales,
                                     P2=(data["P2"] if base_fx is not None else None), base_fx=base_fx)
     for f in frame_ids[1:]:
         if with_pose:
             pair = [data[("image", f)], data[("image", 0)]] if f < 0 else [data[("image", 0)], data[("image", f)]]
-            pf = resnet_forward(sd, "pose_backbone.", torch.cat(pair, 1), depth)
+            pf = resnet_forward(sd, "pose_backbone.", torch.cat(pair, 1), depth, frozen_stages=frozen_stages,
+                                norm_eval=norm_eval)
             aa, tr = pose_decoder_forward(sd, "head.pose_decoder.", pf[-1])
             outputs[("axisangle", f)], outputs[("translation", f)] = aa, tr
             outputs[("cam_T_cam", f)] = transformation_from_parameters(aa[:, 0], tr[:, 0], invert=(f < 0))
@@ -470,8 +486,11 @@ class OracleTrainer:
     loss.mean().backward(), clip_grad_norm_, Adam.step)."""
 
     def __init__(self, sd, depth=18, with_pose=True, lr=1e-4, clip=35.0, min_depth=0.5, max_depth=100.0,
-                 weight_decay=0.0, base_fx=None):
+                 weight_decay=0.0, base_fx=None, frozen_stages=-1, norm_eval=False):
         self.base_fx = base_fx
+        self.frozen_stages, self.norm_eval = frozen_stages, norm_eval
+        # torch.optim.Adam never touches a parameter without a gradient (requires_grad False after freeze_stages)
+        self.frozen = frozen_names("depth_backbone.", frozen_stages) + frozen_names("pose_backbone.", frozen_stages)
         self.sd = {k: v.clone() for k, v in sd.items()}
         self.names = [k for k in self.sd if is_param(k)]
         self.depth, self.with_pose, self.lr, self.clip = depth, with_pose, lr, clip
@@ -484,9 +503,11 @@ class OracleTrainer:
         for k in self.names:
             self.sd[k] = self.sd[k].detach().requires_grad_(True)
         total, losses, outputs = forward_train(self.sd, data, self.depth, self.with_pose, self.min_depth,
-                                               self.max_depth, noise=noise, base_fx=self.base_fx)
+                                               self.max_depth, noise=noise, base_fx=self.base_fx,
+                                               frozen_stages=self.frozen_stages, norm_eval=self.norm_eval)
         grads = torch.autograd.grad(total.mean(), [self.sd[k] for k in self.names], allow_unused=True)
-        grads = [g if g is not None else torch.zeros_like(self.sd[k]) for g, k in zip(grads, self.names)]
+        grads = [g if (g is not None and not k.startswith(self.frozen)) else torch.zeros_like(self.sd[k])
+                 for g, k in zip(grads, self.names)]
         raw = dict(zip(self.names, grads))
         norm = None
         if self.clip is not None:
@@ -495,6 +516,9 @@ class OracleTrainer:
         with torch.no_grad():
             for k, g in zip(self.names, grads):
                 p = self.sd[k].detach()
+                if k.startswith(self.frozen):
+                    self.sd[k] = p
+                    continue
                 adam_step(p, g, self.m[k], self.v[k], self.t, self.lr, weight_decay=self.wd)
                 self.sd[k] = p
         return total.detach(), losses, outputs, raw, norm

@@ -304,3 +304,41 @@ def test_sigmoid_depth_decoder_matches_reference():
             np.testing.assert_allclose(thin(f.grad), ref, rtol=2e-3, atol=2e-4 * float(np.abs(ref).max()))
         gn = np.array([float(v.grad.norm()) for v in params.values()])
         np.testing.assert_allclose(gn, G[tag + "_gnorm"], rtol=2e-3)
+
+
+def frozen_state(seed=3):
+    """initial state of the frozen-stage goldens: running statistics away from (0, 1)"""
+    sd0 = O.init_state(seed=seed, with_pose=False)
+    g = torch.Generator().manual_seed(5)
+    for k in sd0:
+        if k.endswith("running_mean"):
+            sd0[k] = 0.1 * torch.randn(sd0[k].shape, generator=g)
+        elif k.endswith("running_var"):
+            sd0[k] = 0.5 + torch.rand(sd0[k].shape, generator=g)
+    return sd0
+
+
+@pytest.mark.parametrize("tag,fs,ne", [("fs1", 1, False), ("ne", -1, True)])
+def test_frozen_stages_and_norm_eval_match_reference(tag, fs, ne):
+    """ResNet.train() with frozen_stages / norm_eval (resnet.py:169-197): eval-mode BatchNorms and frozen parameters
+    inside three training steps of the reference (frozen.npz)"""
+    g = np.load(os.path.join(GOLD, "frozen.npz"))
+    sd0 = frozen_state()
+    trn = O.OracleTrainer(sd0, with_pose=False, frozen_stages=fs, norm_eval=ne)
+    names = [k for k in sd0 if O.is_param(k)]
+    for it in range(3):
+        total, ld, _, raw, norm = trn.step(O.synthetic_batch(2, 64, 128, seed=300 + it))
+        assert abs(float(total) - float(g["%s_loss_%d" % (tag, it)])) < 1e-4 * abs(float(g["%s_loss_%d" % (tag, it)]))
+        ps = torch.stack([trn.sd[k].double().sum() for k in names]).numpy()
+        ref = g["%s_psum_%d" % (tag, it)]
+        # a weight moves by <= lr per step: sums agree to a few lr x numel; frozen ones exactly
+        numel = np.array([trn.sd[k].numel() for k in names], dtype=np.float64)
+        assert np.all(np.abs(ps - ref) <= 3e-4 * (it + 1) * np.sqrt(numel) + 1e-6 * np.abs(ref))
+        for k, a, b in zip(names, ps, ref):
+            if k.startswith(trn.frozen):
+                assert abs(a - float(sd0[k].double().sum())) < 1e-9 and abs(b - a) < 1e-4 * max(1.0, abs(a)), k
+    rm = torch.cat([trn.sd[k].flatten() for k in trn.sd if k.endswith("running_mean")]).numpy()
+    np.testing.assert_allclose(rm, g[tag + "_rm_final"], atol=5e-3 if ne else 1e-5)
+    nbt = np.array([int(trn.sd[k]) for k in trn.sd if k.endswith("num_batches_tracked")])
+    assert np.array_equal(nbt, g[tag + "_nbt_final"])
+    assert (nbt == 0).sum() == {"fs1": 5, "ne": 20}[tag]        # the eval-mode BatchNorms never count a batch

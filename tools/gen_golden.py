@@ -37,10 +37,11 @@ def npy(t):
     return t.detach().cpu().numpy()
 
 
-def ref_model(H, W, with_pose=True, depth=18):
+def ref_model(H, W, with_pose=True, depth=18, frozen_stages=-1, norm_eval=False):
     enc = [64, 64, 128, 256, 512]
     bb = dict(name='vision_base.networks.models.backbone.resnet.resnet', depth=depth, pretrained=False,
-              frozen_stages=-1, num_stages=4, out_indices=(-1, 0, 1, 2, 3), norm_eval=False, dilations=(1, 1, 1, 1))
+              frozen_stages=frozen_stages, num_stages=4, out_indices=(-1, 0, 1, 2, 3), norm_eval=norm_eval,
+              dilations=(1, 1, 1, 1))
     head = dict(name='monodepth.networks.models.heads.monodepth2_decoder.MonoDepth2Decoder', scales=[0, 1, 2, 3],
                 height=H, width=W, min_depth=0.5, max_depth=100.0, overlapped_mask=True, is_log_image=False,
                 depth_decoder_cfg=dict(name='monodepth.networks.models.heads.depth_encoder.MultiChannelDepthDecoder',
@@ -697,6 +698,52 @@ def gen_sigmoid_decoder():
     np.savez_compressed(os.path.join(GOLD, "sigmoid_decoder.npz"), **out)
 
 
+def gen_frozen():
+    """ResNet.train() with frozen_stages / norm_eval (resnet.py:169-197) inside the training step of the reference's
+    own hook: 3 Adam steps of the dataset-pose meta-arch, with (a) stem + layer1 frozen, (b) every BatchNorm in eval
+    mode.  Losses, gradient norms, parameter sums per step, final running statistics."""
+    from vision_base.pipeline_hooks.train_val_hooks.base_training_hooks import BaseTrainingHook
+    B, H, W = 2, 64, 128
+    out = {}
+    for tag, fs, ne in (("fs1", 1, False), ("ne", -1, True)):
+        sd0 = O.init_state(seed=3, with_pose=False)
+        # running statistics away from (0, 1): an eval-mode BatchNorm must really use them
+        g = torch.Generator().manual_seed(5)
+        for k in sd0:
+            if k.endswith("running_mean"):
+                sd0[k] = 0.1 * torch.randn(sd0[k].shape, generator=g)
+            elif k.endswith("running_var"):
+                sd0[k] = 0.5 + torch.rand(sd0[k].shape, generator=g)
+        m = ref_model(H, W, False, frozen_stages=fs, norm_eval=ne)
+        m.load_state_dict({k: v.clone() for k, v in sd0.items()}, strict=True)
+        m.train()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+        hook = BaseTrainingHook(clip_gradients=35.0)
+        tr = O.OracleTrainer(sd0, with_pose=False, frozen_stages=fs, norm_eval=ne)
+        for it in range(3):
+            data = O.synthetic_batch(B, H, W, seed=300 + it)
+            # the hook's body (base_training_hooks.py:30-49) without its .cuda() calls
+            opt.zero_grad()
+            torch.manual_seed(0)
+            res = m(dict(data), dict(is_training=True))
+            res['loss'].mean().backward()
+            torch.nn.utils.clip_grad_norm_(m.parameters(), hook.clip_gradients)
+            opt.step()
+            out["%s_loss_%d" % (tag, it)] = npy(res['loss'])
+            out["%s_psum_%d" % (tag, it)] = npy(torch.stack([p.double().sum() for p in m.parameters()]))
+            tot, ld, o_out, raw, norm = tr.step(data)
+            print("[frozen %s] step %d: ref loss %.9f oracle %.9f" % (tag, it, float(res['loss']), float(tot)))
+        sd_ref = m.state_dict()
+        print("[frozen %s] max param dev oracle vs ref %.3e; running_mean dev %.3e; trainable %d of %d" % (
+            tag, max(dev(tr.sd[k], sd_ref[k]) for k in tr.names),
+            max(dev(tr.sd[k], sd_ref[k]) for k in sd_ref if k.endswith('running_mean')),
+            sum(p.requires_grad for p in m.parameters()), len(list(m.parameters()))))
+        out[tag + "_rm_final"] = npy(torch.cat([sd_ref[k].flatten() for k in sd_ref if k.endswith('running_mean')]))
+        out[tag + "_rv_final"] = npy(torch.cat([sd_ref[k].flatten() for k in sd_ref if k.endswith('running_var')]))
+        out[tag + "_nbt_final"] = npy(torch.stack([sd_ref[k] for k in sd_ref if k.endswith('num_batches_tracked')]))
+    np.savez_compressed(os.path.join(GOLD, "frozen.npz"), **out)
+
+
 def gen_teacher_keys():
     """monodepth/transform_teacher.py on a checkpoint of the reference depth+pose meta-arch: the key list of the
     teacher state_dict (order included) and a checksum per kept tensor."""
@@ -718,6 +765,9 @@ def gen_teacher_keys():
 
 
 if __name__ == "__main__":
+    if "--only-frozen" in sys.argv:
+        gen_frozen()
+        sys.exit(0)
     if "--only-sigmoid" in sys.argv:
         gen_sigmoid_decoder()
         sys.exit(0)
@@ -752,5 +802,6 @@ if __name__ == "__main__":
     gen_loss_options()
     gen_teacher_keys()
     gen_sigmoid_decoder()
+    gen_frozen()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")
