@@ -393,6 +393,7 @@ def test_resnet50_depth_pose_step_matches_oracle(dev, dtype):
     RT.set_compute_dtype(torch.bfloat16)
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("base_fx", [None, 600.0])
 def test_sigmoid_depth_decoder_matches_oracle(dev, base_fx):
     """the base-class DepthDecoder (sigmoid disparity head, depth_encoder.py:17-111) on the HIP engine against the
@@ -433,6 +434,7 @@ def test_sigmoid_depth_decoder_matches_oracle(dev, base_fx):
         RT.set_compute_dtype(torch.bfloat16)
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("fs,ne", [(1, False), (-1, True)])
 def test_frozen_stages_and_norm_eval_training_steps(dev, fs, ne):
     """ResNet.train() with frozen_stages / norm_eval (resnet.py:169-197) inside the fused training step: eval-mode
