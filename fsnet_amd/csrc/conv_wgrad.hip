@@ -12,6 +12,7 @@
 #include "common.h"
 #include "fsnet_hip_internal.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -343,18 +344,27 @@ __device__ __forceinline__ uint4 wg_buf_load16(__amdgpu_buffer_rsrc_t rsrc, int 
   return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
 }
 
-template <int COT, int CIT>
-__global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const FsWgradArgs p, const WGeom g) {
+// KG = 2: two groups of four waves share the block's output tile and split its pixel tiles between them (each group
+// stages its own tile); the second group's accumulators are added through LDS before the slab is written.  The grid
+// — and with it the slab traffic — stays what it was, but a CU holds two waves per SIMD instead of one: with one, a
+// wave's LDS -> MFMA chain (88 transposing reads and 116 waits around 72 MFMAs per tile) had nobody to overlap with.
+template <int COT, int CIT, int KG>
+__global__ __launch_bounds__(256 * KG) void wgrad3x3_halo_kernel(const FsWgradArgs p, const WGeom g) {
   typedef bf16 T;
   constexpr int PIXT = 128, HMAX = 208, OOB = 0x7fffffff;
   constexpr int SA = COT + 8, SB = CIT + 8;
   constexpr int TA = COT / 32, TB = CIT / 32;          // per-wave 16x16 sub-tiles (2 x 2 waves)
   constexpr int UA = COT / 8, UB = CIT / 8;            // 16-byte units per pixel row
   constexpr int LA = (PIXT * UA + 255) / 256, LB = (HMAX * UB + 255) / 256;
-  __shared__ __attribute__((aligned(16))) T lds_a[PIXT * SA];
-  __shared__ __attribute__((aligned(16))) T lds_b[HMAX * SB];
+  constexpr int STAGE_BYTES = (PIXT * SA + HMAX * SB) * 2;
+  constexpr int RED_BYTES = KG > 1 ? 9 * TA * TB * 4 * 256 * 4 : 0;
+  constexpr int LDS_BYTES = STAGE_BYTES * KG > RED_BYTES ? STAGE_BYTES * KG : RED_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+  const int grp = KG > 1 ? (int)(threadIdx.x >> 8) : 0;
+  T* lds_a = reinterpret_cast<T*>(lds_raw + grp * STAGE_BYTES);
+  T* lds_b = lds_a + PIXT * SA;
 
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x & 255, lane = t & 63, wave = t >> 6;
   const int wr = wave & 1, wcn = wave >> 1;
   const int li = lane & 15, lg = lane >> 4;
   const int HW = g.TW + 2, nhalo = (g.TH + 2) * HW, ntile = g.TH * g.TW;
@@ -440,13 +450,19 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const FsWgradArgs p,
 #pragma unroll
       for (int b = 0; b < TB; ++b) acc[tp][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  int pt = blockIdx.z;
+  // the block's pixel tiles z, z + nsplit, ...: group `grp` takes every KG-th of them; the barrier count is the
+  // block's (the group with one tile fewer idles through its last round)
+  const int step = g.nsplit * KG;
+  int pt = blockIdx.z + grp * g.nsplit;
+  const int ntz = (npix - (int)blockIdx.z + g.nsplit - 1) / g.nsplit;
+  const int rounds = (ntz + KG - 1) / KG;
   if (pt < npix) load_regs(pt);
-  for (; pt < npix; pt += g.nsplit) {
+  for (int rd = 0; rd < rounds; ++rd, pt += step) {
     __syncthreads();
-    store_lds();
+    if (pt < npix) store_lds();
     __syncthreads();
-    if (pt + g.nsplit < npix) load_regs(pt + g.nsplit);
+    if (pt >= npix) continue;
+    if (pt + step < npix) load_regs(pt + step);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       bf16x8 fa[TA];
@@ -474,6 +490,33 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const FsWgradArgs p,
     }
   }
 
+  if constexpr (KG > 1) {
+    // second group's partial sums -> LDS ([value][thread]: conflict-free), first group adds them
+    float* red = reinterpret_cast<float*>(lds_raw);
+    __syncthreads();                       // every wave is done with the staging buffers
+    if (grp == 1) {
+      int q = 0;
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int a = 0; a < TA; ++a)
+#pragma unroll
+          for (int b = 0; b < TB; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j, ++q) red[q * 256 + t] = acc[tp][a][b][j];
+    }
+    __syncthreads();
+    if (grp != 0) return;
+    int q = 0;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+      for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < TB; ++b)
+#pragma unroll
+          for (int j = 0; j < 4; ++j, ++q) acc[tp][a][b][j] += red[q * 256 + t];
+  }
   // ---- epilogue: D rows = co (lg*4 + j), cols = ci (li) ----
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp)
@@ -827,7 +870,16 @@ int launch_wgrad_halo_t(const FsWgradArgs& a, hipStream_t st) {
   else splits = std::min<long>(splits, std::max<long>(1, a.workspace_elems / slab));
   g.nsplit = (int)splits; b.nsplit = g.nsplit;
   dim3 grid(Cs / CIT, a.Cd / COT, g.nsplit);
-  hipLaunchKernelGGL((wgrad3x3_halo_kernel<COT, CIT>), grid, dim3(256), 0, st, b, g);
+  // Measured (B=12 bench shapes): KG = 2 makes the kernel itself 6-11 % faster (33.5 vs 35.5 us on the ResNet stages,
+  // 45 vs 50 us on the decoder's), but the step 1.5 % SLOWER (6.11 / 6.15 vs 5.99 / 6.05 ms, same box, alternating):
+  // on its companion stream the fatter kernel takes CU time from the data-gradient chain, which is the critical
+  // path; with the weight gradients inline (the data-parallel placement) the two are equal (6.31 vs 6.34 ms).
+  static const int kg = [] { const char* e = getenv("FSNET_AMD_WGRAD_KG"); return e ? atoi(e) : 1; }();
+  // (two wave groups need at least two pixel tiles per block to split)
+  if (kg == 2 && npix >= 2 * g.nsplit)
+    hipLaunchKernelGGL((wgrad3x3_halo_kernel<COT, CIT, 2>), grid, dim3(512), 0, st, b, g);
+  else
+    hipLaunchKernelGGL((wgrad3x3_halo_kernel<COT, CIT, 1>), grid, dim3(256), 0, st, b, g);
   if (b.nsplit > 1) {
     const int ncols = 9 * Cs;
     launch_reduce(b, a.Co, ncols, 8, st);
