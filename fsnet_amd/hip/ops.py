@@ -1,6 +1,7 @@
 """Thin host wrappers (ctypes -> libfsnet_hip.so) for the non-conv kernels.  torch tensors are used
 only as device memory + stream ordering; every arithmetic step runs in the HIP library."""
 import ctypes as C
+import os
 
 import torch
 
@@ -418,6 +419,18 @@ class PhotometricLoss:
                                         self.H, self.W, st), "mei_stage_mask")
         if not have_inputs:
             self._input_only(img0, pa, st)
+        # the edge-aware smoothness term needs only the disparities and the colour pyramid: on the (by now idle) pose
+        # stream beside the photometric kernels instead of after them — this stretch of the step is serial
+        fork = self._fork(img0.device)
+        if fork is not None:
+            fork[1].wait_stream(fork[0])
+            with torch.cuda.stream(fork[1]):
+                st2 = stream_ptr()
+                check(lib.fs_smooth_mean(sa, st2), "smooth_mean")
+                check(lib.fs_smooth_fwd(sa, st2), "smooth_fwd")
+        else:
+            check(lib.fs_smooth_mean(sa, st), "smooth_mean")
+            check(lib.fs_smooth_fwd(sa, st), "smooth_fwd")
         N_px = float(self.B * self.H * self.W)
         # algorithmic bytes: per scale, target 12N + 2 sources 24N + depth 4N/4^s + result 4N
         fwd_bytes = sum(40.0 * N_px + 4.0 * N_px / (4 ** s) for s in self.scales)
@@ -426,8 +439,8 @@ class PhotometricLoss:
         else:
             _timed("photo_warp", fwd_bytes * 0.5, lambda: check(lib.fs_photo_warp(pa, st), "photo_warp"))
             _timed("photo_loss_fwd", fwd_bytes * 0.5, lambda: check(lib.fs_photo_loss_fwd(pa, st), "photo_loss_fwd"))
-        check(lib.fs_smooth_mean(sa, st), "smooth_mean")
-        check(lib.fs_smooth_fwd(sa, st), "smooth_fwd")
+        if fork is not None:
+            fork[0].wait_stream(fork[1])         # smoothness sums (side stream) before the finalize kernel
         # fresh result tensors per call (the previous step's stay valid for whoever kept them) — the kernel writes
         # the per-scale vector and the scalar the caller differentiates, so nothing has to be cloned on the device
         self.out = torch.empty(2 * self.S + 1, dtype=torch.float64, device=img0.device)
@@ -436,6 +449,15 @@ class PhotometricLoss:
                                    self.out.data_ptr(), self.total.data_ptr(), st), "loss_finalize")
         return self.out
 
+    @staticmethod
+    def _fork(device):
+        """(current stream, pose stream) when the smoothness kernels may run beside the photometric ones"""
+        from ..engine.runtime import RT
+        if not (RT.overlap and device.type == "cuda") or os.environ.get("FSNET_AMD_SMOOTH_SIDE", "1") == "0":
+            return None
+        cur, side = torch.cuda.current_stream(device), RT.side_stream(device)
+        return None if cur.cuda_stream == side.cuda_stream else (cur, side)
+
     def backward(self, gout=None):
         """gout: device f64 scalar (upstream grad of total loss) or None (=1)."""
         st = stream_ptr()
@@ -443,6 +465,11 @@ class PhotometricLoss:
         self._fill(img0, srcs, patched_mask, depths, disps, noise_seed, gout)
         pa, sa = C.byref(self._pa), C.byref(self._sa)
         self._dd_flat.zero_()
+        fork = self._fork(img0.device)
+        if fork is not None:                      # smoothness backward beside the photometric backward
+            fork[1].wait_stream(fork[0])
+            with torch.cuda.stream(fork[1]):
+                check(lib.fs_smooth_bwd(sa, stream_ptr()), "smooth_bwd")
         N_px = float(self.B * self.H * self.W)
         bwd_bytes = sum(40.0 * N_px + 8.0 * N_px / (4 ** s) for s in self.scales)
         if self.fused:
@@ -451,7 +478,10 @@ class PhotometricLoss:
             _timed("photo_loss_bwd", bwd_bytes, lambda: check(lib.fs_photo_loss_bwd(pa, st), "photo_loss_bwd"))
         check(lib.fs_photo_pose_grad(self.geo.data_ptr(), self.dP.data_ptr(), self.dT[0].data_ptr(),
                                      self.dT[1].data_ptr(), self.B, self.S, self.bwd_tiles, st), "photo_pose_grad")
-        check(lib.fs_smooth_bwd(sa, st), "smooth_bwd")
+        if fork is not None:
+            fork[0].wait_stream(fork[1])
+        else:
+            check(lib.fs_smooth_bwd(sa, st), "smooth_bwd")
         return self.d_depth, self.d_disp, self.dT
 
 
