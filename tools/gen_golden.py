@@ -744,6 +744,19 @@ def gen_frozen():
     np.savez_compressed(os.path.join(GOLD, "frozen.npz"), **out)
 
 
+def gen_concat():
+    """vision_base ConcatDataset over three tiny children: which (child, local index) every global index maps to,
+    and how common keywords / per-child overrides reach the children"""
+    import json
+    from vision_base.data.datasets.dataset_utils import ConcatDataset
+    cfgs = [dict(name="tiny_ds.Tiny", n=5, tag="a"), dict(name="tiny_ds.Tiny", n=3, tag="b", scale=10),
+            dict(name="tiny_ds.Tiny", n=7, tag="c")]
+    ds = ConcatDataset([EasyDict(c) for c in cfgs], scale=2)
+    rec = dict(cfgs=cfgs, common=dict(scale=2), length=int(len(ds)), items=[{k: (int(v) if k == "value" else v) for k, v in ds[i].items()} for i in range(len(ds))])
+    json.dump(rec, open(os.path.join(GOLD, "concat_dataset.json"), "w"))
+    print("concat dataset: %d items" % len(ds))
+
+
 def gen_teacher_keys():
     """monodepth/transform_teacher.py on a checkpoint of the reference depth+pose meta-arch: the key list of the
     teacher state_dict (order included) and a checksum per kept tensor."""
@@ -765,6 +778,9 @@ def gen_teacher_keys():
 
 
 if __name__ == "__main__":
+    if "--only-concat" in sys.argv:
+        gen_concat()
+        sys.exit(0)
     if "--only-frozen" in sys.argv:
         gen_frozen()
         sys.exit(0)
@@ -803,5 +819,6 @@ if __name__ == "__main__":
     gen_teacher_keys()
     gen_sigmoid_decoder()
     gen_frozen()
+    gen_concat()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")
