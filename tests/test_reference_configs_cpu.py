@@ -113,3 +113,59 @@ def test_reference_train_script_wiring_runs_unmodified(tmp_path):
     save_models(str(tmp_path / "ckpt.pth"), ddp, optimizer)
     ck = torch.load(str(tmp_path / "ckpt.pth"), map_location="cpu", weights_only=False)
     assert list(ck["model_state_dict"].keys()) == keys
+
+
+def _no_download(cfg):
+    for k in list(cfg.meta_arch.keys()):
+        v = cfg.meta_arch[k]
+        if isinstance(v, dict) and "pretrained" in v:
+            v["pretrained"] = False
+        if k == "teacher_net_cfg" and isinstance(v, dict) and "backbone_cfg" in v:
+            v["backbone_cfg"]["pretrained"] = False
+
+
+def test_multi_dataset_config_meta_arch_builds(tmp_path):
+    """configs/multi_dataset_example (BASELINE configs[4]): ResNet-50, 64 depth bins, base_fx, clip 35"""
+    from fsnet_amd.vision_base.utils.builder import build
+    cfg = _load_cfg(tmp_path, "multi_dataset_example")
+    _no_download(cfg)
+    m = build(**cfg.meta_arch)
+    dec = m.head.depth_decoder
+    assert type(m).__name__ == "MonoDepthWPose" and dec.num_output_channels == 64 and dec.base_fx is not None
+    assert sum(p.numel() for p in m.depth_backbone.parameters()) > 23e6            # ResNet-50
+    assert type(build(**cfg.trainer.training_hook)).__name__ == "BaseTrainingHook"
+    assert cfg.train_dataset.name.endswith("ConcatDataset")
+
+
+@pytest.mark.parametrize("name", ["distill_kitti_example", "distill_kitti360_example"])
+def test_distill_configs_build_with_a_converted_teacher(tmp_path, name):
+    """the second training stage's shipped configs: the teacher checkpoint they point at is made from a stage-1
+    checkpoint by the transform_teacher mirror, then DistillWPoseMeta builds and loads it"""
+    from fsnet_amd.monodepth.transform_teacher import transform_teacher_model
+    from fsnet_amd.vision_base.utils.builder import build
+    from fsnet_amd.vision_base.utils import utils as U
+    src = open(os.path.join(REF, "configs", name)).read()
+    teacher_file = [l for l in src.splitlines() if "teacher_net_path" in l][0].split("'")[-2]
+    # stage 1: the plain dataset-pose model of the same geometry
+    cfg1 = _load_cfg(tmp_path, name.replace("distill_", "").replace("_example", "_wpose_example"))
+    _no_download(cfg1)
+    stage1 = build(**cfg1.meta_arch)
+    os.makedirs(str(tmp_path / "FSNet"), exist_ok=True)
+    torch.save({"model_state_dict": stage1.state_dict(), "optimizer_state_dict": {}}, str(tmp_path / "stage1.pth"))
+    transform_teacher_model(str(tmp_path / "stage1.pth"), str(tmp_path / "FSNet" / teacher_file))
+    cfg = _load_cfg(tmp_path, name)
+    _no_download(cfg)
+    m = build(**cfg.meta_arch)
+    assert type(m).__name__ == "DistillWPoseMeta"
+    t = dict(m.teacher_net.state_dict())
+    s = stage1.state_dict()
+    assert all(torch.equal(t[k], s[k if k.startswith("depth_backbone") else "head." + k]) for k in t)
+    assert not any(p.requires_grad for p in m.teacher_net.parameters())
+
+
+def test_fisheye_config_of_the_reference_does_not_load_as_shipped(tmp_path):
+    """configs/kitti360_fisheye_example raises NameError in the reference too (its val augmentation uses
+    `color_augmented_image_keys` before any assignment): recorded so that nobody looks for the fault here.  The
+    fisheye meta-arch itself is covered by tests/test_fisheye_gpu.py with the config's values."""
+    with pytest.raises(NameError):
+        _load_cfg(tmp_path, "kitti360_fisheye_example")
