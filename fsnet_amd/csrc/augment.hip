@@ -54,6 +54,25 @@ __device__ __forceinline__ void hsv2rgb(float h, float s, float v, float& r, flo
   }
 }
 
+// Shuffle[RandomBrightness, RandomContrast, HSV round trip with RandomSaturation] in the drawn order (plan slots 0-2,
+// applied-bits in slot 3) on one pixel, 0..255 scale
+__device__ __forceinline__ void colour_chain(float (&c)[3], const int32_t* ip, const float* fp) {
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int op = ip[q];
+    if (op == 0) {
+      if (ip[3] & 1) { c[0] = c[0] + fp[0]; c[1] = c[1] + fp[0]; c[2] = c[2] + fp[0]; }
+    } else if (op == 1) {
+      if (ip[3] & 2) { c[0] = c[0] * fp[1]; c[1] = c[1] * fp[1]; c[2] = c[2] * fp[1]; }
+    } else if (op == 2 && (ip[3] & 8)) {      // ConvertColor(HSV) .. ConvertColor(RGB) with or without a draw
+      float h, s, v;
+      rgb2hsv(c[0], c[1], c[2], h, s, v);
+      if (ip[3] & 4) s = s * fp[2];
+      hsv2rgb(h, s, v, c[0], c[1], c[2]);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void augment_frames_kernel(const FsAugArgs p) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -102,27 +121,16 @@ __global__ __launch_bounds__(256) void augment_frames_kernel(const FsAugArgs p) 
       for (int k = 0; k < 3; ++k) p.original[o + k * HW] = c[k] / 255.0f;        // Normalize(mean 0, std 1)
     }
     if (p.image) {
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const int op = ip[q];
-        if (op == 0) {
-          if (ip[3] & 1) { c[0] = c[0] + fp[0]; c[1] = c[1] + fp[0]; c[2] = c[2] + fp[0]; }
-        } else if (op == 1) {
-          if (ip[3] & 2) { c[0] = c[0] * fp[1]; c[1] = c[1] * fp[1]; c[2] = c[2] * fp[1]; }
-        } else if (op == 2 && (ip[3] & 8)) {      // ConvertColor(HSV) .. ConvertColor(RGB) with or without a draw
-          float h, s, v;
-          rgb2hsv(c[0], c[1], c[2], h, s, v);
-          if (ip[3] & 4) s = s * fp[2];
-          hsv2rgb(h, s, v, c[0], c[1], c[2]);
-        }
-      }
+      colour_chain(c, ip, fp);
 #pragma unroll
       for (int k = 0; k < 3; ++k) p.image[o + k * HW] = (c[k] / 255.0f - p.mean[k]) / p.std[k];
     }
   }
 }
 
-// Validation input (configs/kitti_wpose_example:156-166): Resize = cv2.resize(float image, INTER_LINEAR) to
+// Resize-based inputs.  Validation (configs/kitti_wpose_example:156-166) and, with a per-sample plan, the training
+// input of the Resize-based configs (configs/multi_dataset_example:178-205: Resize of all frames + INTER_NEAREST
+// patched_mask, colour Shuffle, RandomMirror, two Normalizes).  Resize = cv2.resize(float image, INTER_LINEAR) to
 // rh x rw, zero-padded / cropped to H x W (augmentations.py:112-198), then Normalize and CHW.  OpenCV's float
 // path (resize.cpp resizeGeneric_ / HResizeLinear / VResizeLinear): source coordinate (d + 0.5) * scale - 0.5 in
 // f64, rounded to f32, floor + fraction; fraction 0 and index clamped at both borders; horizontal pass, then vertical.
@@ -139,10 +147,13 @@ __global__ __launch_bounds__(256) void resize_frames_kernel(const FsResizeArgs p
   const int b = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= p.H * p.W) return;
-  const int y = i / p.W, x = i - y * p.W;
+  const int y = i / p.W, xo = i - y * p.W;
   const int32_t* d = p.dims + b * 4;
   const int sh = d[0], sw = d[1], rh = d[2], rw = d[3];
-  const bool inside = y < rh && x < rw;                    // outside: np.pad zeros (normalised below)
+  const int32_t* ip = p.iplan ? p.iplan + b * FS_AUG_IPLAN : nullptr;
+  const float* fp = p.fplan ? p.fplan + b * FS_AUG_FPLAN : nullptr;
+  const int x = (ip && ip[4]) ? p.W - 1 - xo : xo;         // RandomMirror of the padded / cropped image
+  const bool inside = y < rh && x < rw;                    // outside: np.pad zeros (they pass the colour ops too)
   int x0 = 0, y0 = 0; float fx = 0.f, fy = 0.f;
   if (inside) {
     resize_coord(x, 1.0 / ((double)rw / (double)sw), sw, x0, fx);
@@ -150,9 +161,12 @@ __global__ __launch_bounds__(256) void resize_frames_kernel(const FsResizeArgs p
   }
   const int x1 = min(x0 + 1, sw - 1), y1 = min(y0 + 1, sh - 1);
   const long HW = (long)p.H * p.W;
+  // patched_mask: ones through cv2.resize(INTER_NEAREST) are ones; the padding is zero
+  if (p.mask) p.mask[((long)b * p.H + y) * p.W + xo] = inside ? 1.0 : 0.0;
   for (int f = 0; f < p.F; ++f) {
     const uint8_t* src = p.src + ((long)b * p.F + f) * p.Hs * p.Ws * 3;
-    const long o = (((long)f * p.B + b) * 3) * HW + (long)y * p.W + x;
+    const long o = (((long)f * p.B + b) * 3) * HW + (long)y * p.W + xo;
+    float c[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       float v = 0.f;
@@ -162,8 +176,15 @@ __global__ __launch_bounds__(256) void resize_frames_kernel(const FsResizeArgs p
         const float top = v00 * (1.f - fx) + v01 * fx, bot = v10 * (1.f - fx) + v11 * fx;
         v = top * (1.f - fy) + bot * fy;
       }
-      p.image[o + k * HW] = (v / 255.0f - p.mean[k]) / p.std[k];
+      c[k] = v;
     }
+    if (p.original) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) p.original[o + k * HW] = c[k] / 255.0f;
+    }
+    if (ip) colour_chain(c, ip, fp);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p.image[o + k * HW] = (c[k] / 255.0f - p.mean[k]) / p.std[k];
   }
 }
 
@@ -171,6 +192,7 @@ __global__ __launch_bounds__(256) void resize_frames_kernel(const FsResizeArgs p
 
 extern "C" int fs_resize_frames(const FsResizeArgs* a, void* stream) {
   if (!a || !a->src || !a->dims || !a->image) return FS_EINVAL;
+  if ((a->iplan != nullptr) != (a->fplan != nullptr)) return FS_EINVAL;
   if (a->B < 1 || a->F < 1 || a->H < 1 || a->W < 1 || a->Hs < 1 || a->Ws < 1) return FS_EINVAL;
   if ((long)a->Hs * a->Ws * 3 > 0x7fffffffL) return FS_EINVAL;
   for (int k = 0; k < 3; ++k) if (a->std[k] == 0.f) return FS_EINVAL;

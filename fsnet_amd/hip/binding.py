@@ -80,6 +80,7 @@ class FsResizeArgs(C.Structure):
         ("src", C.c_void_p), ("dims", C.c_void_p), ("image", C.c_void_p),
         ("mean", C.c_float * 3), ("std", C.c_float * 3),
         ("B", C.c_int32), ("F", C.c_int32), ("Hs", C.c_int32), ("Ws", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("iplan", C.c_void_p), ("fplan", C.c_void_p), ("original", C.c_void_p), ("mask", C.c_void_p),
     ]
 
 

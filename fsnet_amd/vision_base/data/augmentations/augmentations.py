@@ -74,19 +74,27 @@ class ConvertToFloat(object):
 
 
 class Resize(object):
-    """reference :112-198 (validation input): cv2.resize to (h, w), then crop / zero-pad to `size`; P2 rows scale."""
+    """reference :112-198: cv2.resize to (h, w), then crop / zero-pad to `size`; P2 rows scale.  The validation input
+    of every shipped config, and the first stage of the training input of the Resize-based ones
+    (configs/multi_dataset_example:183, nusc / kitti360_fisheye examples), where colour ops, RandomMirror and the
+    Normalizes follow and `gt_image_keys` carries the patched mask (cv2.INTER_NEAREST)."""
     def __init__(self, size, preserve_aspect_ratio=True, force_pad=True, image_keys=['image'], calib_keys=[],
                  gt_image_keys=[], **kwargs):
-        if gt_image_keys:
-            raise NotImplementedError("nearest-neighbour resize of ground-truth images is not on the device path")
+        if any(k != 'patched_mask' for k in gt_image_keys):
+            raise NotImplementedError("the only ground-truth image on the device path is 'patched_mask'")
         self.size, self.preserve_aspect_ratio, self.force_pad = size, preserve_aspect_ratio, force_pad
-        self.image_keys, self.calib_keys = image_keys, calib_keys
+        self.image_keys, self.calib_keys, self.gt_image_keys = image_keys, calib_keys, list(gt_image_keys)
 
     def __call__(self, data):
         shape = _frame_shape(data, self.image_keys[0])
         plan = _plan(data)
         if plan["warp"] is not None or plan.get("resize") is not None or plan["ops"] or plan["mirror"]:
-            raise NotImplementedError("Resize is the only geometric stage of the validation pipeline")
+            raise NotImplementedError("Resize is the first (and only geometric) stage of a device pipeline")
+        for key in self.gt_image_keys:
+            if key in data:
+                m = np.asarray(data[key])
+                if m.shape[:2] != tuple(shape[:2]) or not bool(np.all(m[::8, ::8] == 1)):
+                    raise NotImplementedError("the device path resizes an all-ones patched_mask of the frame's size")
         data[('image_resize', 'original_shape')] = np.array([shape[0], shape[1]]).astype(int)
         if self.preserve_aspect_ratio:
             scale_factor_x = self.size[0] / shape[0]
@@ -107,7 +115,7 @@ class Resize(object):
         if len(self.size) <= 1:
             raise NotImplementedError("Resize needs a (height, width) size on the device path")
         plan["resize"] = dict(h=h, w=w, mode=mode, out_h=self.size[0], out_w=self.size[1], keys=list(self.image_keys),
-                              src_hw=(shape[0], shape[1]))
+                              gt_keys=list(self.gt_image_keys), src_hw=(shape[0], shape[1]))
         for key in self.calib_keys:
             P = data[key]
             P[0, :] = P[0, :] * scale_factor_yx[1]
@@ -165,10 +173,15 @@ class RandomMirror(object):
 
     def __call__(self, data):
         plan = _plan(data)
-        width = plan["warp"]["out_w"] if plan["warp"] is not None else _frame_shape(data, self.image_keys[0])[1]
+        if plan["warp"] is not None:
+            width = plan["warp"]["out_w"]
+        elif plan.get("resize") is not None:
+            width = plan["resize"]["out_w"]
+        else:
+            width = _frame_shape(data, self.image_keys[0])[1]
         if random.rand() <= self.mirror_prob:
-            if plan["ops"]:
-                raise NotImplementedError("the device pipeline mirrors before the colour ops")
+            # (the colour ops are per-pixel: a flip before or after them is the same image, so the kernel's fixed
+            # order — sample mirrored, then colour — serves configs that mirror first and configs that mirror last)
             plan["mirror"] = not plan["mirror"]
             for key in self.calib_keys:
                 P = data[key]
@@ -320,9 +333,43 @@ class DeviceAugment(object):
         self.device = device
 
     # -- host side ---------------------------------------------------------------------------------
+    @staticmethod
+    def _colour_plan(p, iplan_row, fplan_row):
+        """pack one sample's colour ops / mirror flag into the kernels' plan rows (FsAugArgs layout)"""
+        ops = list(p["ops"])
+        if len(ops) > 3 or len({o for o, _ in ops}) != len(ops):
+            raise NotImplementedError("at most one brightness, contrast and saturation op per sample")
+        applied = 0
+        order = [o for o, _ in ops]
+        for o, v in ops:
+            if o == OP_SATURATION:
+                applied |= 8                      # the HSV round trip itself runs
+            if v is not None:
+                applied |= 1 << o
+                fplan_row[o] = v
+        while len(order) < 3:
+            order.append(3)                       # 3 = no-op slot
+        iplan_row[0:3] = order[:3]
+        iplan_row[3] = applied
+        iplan_row[4] = int(p["mirror"])
+
+    def _check_normalize(self, s, p, mean, std):
+        for idx in self.frame_idxs:
+            want = p["normalize"].get((self.image_family, idx), (mean, std))
+            if not (np.array_equal(want[0], mean) and np.array_equal(want[1], std)):
+                raise NotImplementedError("one mean/std for all augmented frames")
+            om, osd = p["normalize"].get((self.original_family, idx), (np.zeros(3, np.float32), np.ones(3, np.float32)))
+            if np.any(om != 0) or np.any(osd != 1):
+                raise NotImplementedError("('original_image', i) is normalised with mean 0 / std 1")
+
     def _collate_resize(self, samples, plans):
         B, F = len(samples), len(self.frame_idxs)
         r0 = plans[0]["resize"]
+        # training use (Resize-based configs): the resize also feeds ('original_image', i) and the patched mask, and
+        # colour ops / a mirror may follow it
+        train = any((self.original_family, i) in r0["keys"] for i in self.frame_idxs) or bool(r0.get("gt_keys"))
+        if train:
+            return self._collate_resize_train(samples, plans)
         Hs = max(p["resize"]["src_hw"][0] for p in plans)
         Ws = max(p["resize"]["src_hw"][1] for p in plans)
         src = torch.zeros(B, F, Hs, Ws, 3, dtype=torch.uint8)
@@ -341,6 +388,41 @@ class DeviceAugment(object):
             dims[b] = (h, w, r["h"], r["w"])
         batch = {PLAN: dict(src=src, dims=torch.from_numpy(dims), mean=mean, std=std, out_hw=(r0["out_h"], r0["out_w"]),
                             kind="resize")}
+        self._collate_rest(samples, batch)
+        return batch
+
+    def _collate_resize_train(self, samples, plans):
+        B, F = len(samples), len(self.frame_idxs)
+        r0 = plans[0]["resize"]
+        Hs = max(p["resize"]["src_hw"][0] for p in plans)
+        Ws = max(p["resize"]["src_hw"][1] for p in plans)
+        src = torch.zeros(B, F, Hs, Ws, 3, dtype=torch.uint8)
+        src_np = src.numpy()
+        dims = np.zeros((B, 4), dtype=np.int32)
+        iplan = np.zeros((B, 8), dtype=np.int32)
+        fplan = np.zeros((B, 4), dtype=np.float32)
+        key0 = (self.image_family, self.frame_idxs[0])
+        mean, std = plans[0]["normalize"].get(key0, (np.zeros(3, np.float32), np.ones(3, np.float32)))
+        for b, (s, p) in enumerate(zip(samples, plans)):
+            r = p["resize"]
+            if p["warp"] is not None or p["hsv"] or (r["out_h"], r["out_w"]) != (r0["out_h"], r0["out_w"]):
+                raise NotImplementedError("a Resize-based training batch shares one output size and ends in RGB")
+            h, w = r["src_hw"]
+            for f, idx in enumerate(self.frame_idxs):
+                frame = s[(self.image_family, idx)]
+                if frame.shape != (h, w, 3):
+                    raise ValueError("frames of one sample must share their size")
+                src_np[b, f, :h, :w] = frame
+                okey = (self.original_family, idx)
+                if okey in s and s[okey] is not frame and (
+                        s[okey].shape != frame.shape or not np.array_equal(s[okey][::16, ::16], frame[::16, ::16])):
+                    raise ValueError("%r is expected to be the unaugmented copy of the image" % (okey,))
+            self._check_normalize(s, p, mean, std)
+            dims[b] = (h, w, r["h"], r["w"])
+            self._colour_plan(p, iplan[b], fplan[b])
+        batch = {PLAN: dict(src=src, dims=torch.from_numpy(dims), iplan=torch.from_numpy(iplan),
+                            fplan=torch.from_numpy(fplan), mean=mean, std=std, out_hw=(r0["out_h"], r0["out_w"]),
+                            kind="resize", train=True, mask=bool(r0.get("gt_keys")))}
         self._collate_rest(samples, batch)
         return batch
 
@@ -395,29 +477,9 @@ class DeviceAugment(object):
                 if okey in s and s[okey] is not frame and (
                         s[okey].shape != frame.shape or not np.array_equal(s[okey][::16, ::16], frame[::16, ::16])):
                     raise ValueError("%r is expected to be the unaugmented copy of the image" % (okey,))
-                want = p["normalize"].get((self.image_family, idx), (mean, std))
-                if not (np.array_equal(want[0], mean) and np.array_equal(want[1], std)):
-                    raise NotImplementedError("one mean/std for all augmented frames")
-                om, osd = p["normalize"].get(okey, (np.zeros(3, np.float32), np.ones(3, np.float32)))
-                if np.any(om != 0) or np.any(osd != 1):
-                    raise NotImplementedError("('original_image', i) is normalised with mean 0 / std 1")
+            self._check_normalize(s, p, mean, std)
             minv[b] = invert_affine(p["warp"]["M"])
-            ops = list(p["ops"])
-            if len(ops) > 3 or len({o for o, _ in ops}) != len(ops):
-                raise NotImplementedError("at most one brightness, contrast and saturation op per sample")
-            applied = 0
-            order = [o for o, _ in ops]
-            for o, v in ops:
-                if o == OP_SATURATION:
-                    applied |= 8                      # the HSV round trip itself runs
-                if v is not None:
-                    applied |= 1 << o
-                    fplan[b, o] = v
-            while len(order) < 3:
-                order.append(3)                       # 3 = no-op slot
-            iplan[b, 0:3] = order[:3]
-            iplan[b, 3] = applied
-            iplan[b, 4] = int(p["mirror"])
+            self._colour_plan(p, iplan[b], fplan[b])
             iplan[b, 5], iplan[b, 6] = h, w
         batch = {PLAN: dict(src=src, minv=torch.from_numpy(minv), iplan=torch.from_numpy(iplan),
                             fplan=torch.from_numpy(fplan), mean=mean, std=std, out_hw=(out_h, out_w), kind="warp")}
@@ -440,9 +502,22 @@ class DeviceAugment(object):
             for k in range(3):
                 r.mean[k], r.std[k] = float(plan["mean"][k]), float(plan["std"][k])
             r.B, r.F, r.Hs, r.Ws, r.H, r.W = B, F, Hs, Ws, H, W
+            original = mask = None
+            if plan.get("train"):
+                iplan = plan["iplan"].to(device, non_blocking=True)
+                fplan = plan["fplan"].to(device, non_blocking=True)
+                original = torch.empty(F, B, 3, H, W, dtype=torch.float32, device=device)
+                r.iplan, r.fplan, r.original = iplan.data_ptr(), fplan.data_ptr(), original.data_ptr()
+                if plan.get("mask"):
+                    mask = torch.empty(B, H, W, dtype=torch.float64, device=device)
+                    r.mask = mask.data_ptr()
             check(lib.fs_resize_frames(C.byref(r), stream_ptr()), "resize_frames")
             for f, idx in enumerate(self.frame_idxs):
                 batch[(self.image_family, idx)] = image[f]
+                if original is not None:
+                    batch[(self.original_family, idx)] = original[f]
+            if mask is not None:
+                batch[self.mask_key] = mask
             for key, val in list(batch.items()):
                 if isinstance(val, torch.Tensor) and not val.is_cuda:
                     batch[key] = val.to(device, non_blocking=True)

@@ -221,6 +221,14 @@ typedef struct FsResizeArgs {
   float mean[3];
   float std[3];
   int32_t B, F, Hs, Ws, H, W;
+  /* Training use of the same Resize (configs/multi_dataset_example:178-205 and the nusc / kitti360_fisheye examples:
+   * Resize, Shuffle of the colour ops, RandomMirror, two Normalizes): iplan / fplan as in FsAugArgs (slots 5, 6
+   * unused), original [F][B][3][H][W] = the resized frame / 255, mask [B][H][W] f64 = patched_mask (all ones)
+   * resized with INTER_NEAREST and padded.  All NULL for the validation input. */
+  const int32_t* iplan;
+  const float* fplan;
+  float* original;
+  double* mask;
 } FsResizeArgs;
 int fs_resize_frames(const FsResizeArgs* args, void* stream);
 

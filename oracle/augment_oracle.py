@@ -299,3 +299,61 @@ def run_val_sample(frame_u8, size, mean, std, preserve_aspect_ratio=False, force
     if mode == 'pad_0':
         img = np.pad(img, [(0, size[0] - img.shape[0]), (0, 0), (0, 0)], 'constant')
     return normalize(img, mean, std).transpose(2, 0, 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# training input of the Resize-based configs (multi_dataset / nusc / kitti360_fisheye examples, e.g.
+# configs/multi_dataset_example:178-205): ConvertToFloat, Resize (frames bilinear, patched_mask nearest), Shuffle of the
+# colour ops, RandomMirror, Normalize x2, ConvertToTensor
+# ------------------------------------------------------------------------------------------------
+def resize_nearest(src, w, h):
+    """cv2.resize(src, (w, h), interpolation=INTER_NEAREST): source index = min(floor(d * scale), n - 1) with
+    scale = n_src / n_dst in f64 (OpenCV resize.cpp resizeNN).  UNPINNED restatement like resize_linear."""
+    src = np.asarray(src)
+    H, W = src.shape[:2]
+    xs = np.minimum(np.floor(np.arange(w, dtype=np.float64) * (1.0 / (float(w) / float(W)))).astype(np.int64), W - 1)
+    ys = np.minimum(np.floor(np.arange(h, dtype=np.float64) * (1.0 / (float(h) / float(H)))).astype(np.int64), H - 1)
+    return src[ys][:, xs]
+
+
+def draw_resize_plan(bright_rng, contrast_rng, sat_rng, mirror_prob=0.5, delta=32, c_lower=0.6, c_upper=1.4,
+                     s_lower=0.6, s_upper=1.4, distort_prob=1.0):
+    """draws of one sample in that chain's order: Shuffle's permutation from the GLOBAL np.random stream
+    (builder.py:61), each colour op's own Generator in the shuffled order, then RandomMirror's global rand (:410)"""
+    p = {"order": np.random.permutation(3), "brightness": None, "contrast": None, "saturation": None}
+    for k in p["order"]:
+        if k == 0 and bright_rng.random() <= distort_prob:
+            p["brightness"] = bright_rng.uniform(-delta, delta)
+        if k == 1 and contrast_rng.random() <= distort_prob:
+            p["contrast"] = contrast_rng.uniform(c_lower, c_upper)
+        if k == 2 and sat_rng.random() <= distort_prob:
+            p["saturation"] = sat_rng.uniform(s_lower, s_upper)
+    p["mirror"] = bool(np.random.rand() <= mirror_prob)
+    return p
+
+
+def _crop_pad(img, mode, size):
+    if mode == 'crop_1':
+        img = img[:, 0:size[1]]
+    if mode == 'pad_1':
+        img = np.pad(img, [(0, 0), (0, size[1] - img.shape[1])] + [(0, 0)] * (img.ndim - 2), 'constant')
+    if mode == 'pad_0':
+        img = np.pad(img, [(0, size[0] - img.shape[0]), (0, 0)] + [(0, 0)] * (img.ndim - 2), 'constant')
+    return img
+
+
+def run_resize_train_sample(frames_u8, plan, size, mean, std, preserve_aspect_ratio=True, force_pad=True):
+    """-> (images CHW list, original_images CHW list, patched_mask f64 [H, W], P2 scale (y, x))"""
+    h, w, mode, scale_yx = resize_plan(frames_u8[0].shape, size, preserve_aspect_ratio, force_pad)
+    images, originals = [], []
+    for f in frames_u8:
+        r = _crop_pad(resize_linear(f.astype(np.float32), w, h), mode, size)
+        c = colour_chain(r, plan)                      # the zero padding goes through the colour ops too
+        if plan["mirror"]:
+            r, c = np.ascontiguousarray(r[:, ::-1]), np.ascontiguousarray(c[:, ::-1])
+        originals.append(normalize(r, [0, 0, 0], [1, 1, 1]).transpose(2, 0, 1))
+        images.append(normalize(c, mean, std).transpose(2, 0, 1))
+    mask = _crop_pad(resize_nearest(np.ones(frames_u8[0].shape[:2]), w, h), mode, size)
+    if plan["mirror"]:
+        mask = np.ascontiguousarray(mask[:, ::-1])
+    return images, originals, mask, scale_yx

@@ -86,3 +86,47 @@ def val_frame(g, tag):
 
 
 VAL_P2 = np.array([[721.5, 0, 609.5, 44.8], [0, 721.5, 172.8, 0.2], [0, 0, 1, 0.0027]], dtype=np.float64)
+
+
+# ---- Resize-based training chain (configs/multi_dataset_example:178-205; tests/golden/augment_resize.npz) ----------
+GOLD_RESIZE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "augment_resize.npz")
+
+
+def resize_sample_inputs(g, n):
+    from scipy.spatial.transform import Rotation as R
+    H, W = (int(v) for v in g["shapes"][n])
+    fr = np.random.RandomState(int(g["frame_seed"]) + n)
+    frames = [fr.randint(0, 256, size=(H, W, 3)).astype(np.uint8) for _ in FRAME_IDXS]
+    P2 = np.array([[721.5, 0, 609.5, 44.8], [0, 721.5, 172.8, 0.2], [0, 0, 1, 0.0027]], dtype=np.float64)
+    poses = []
+    for _ in range(2):
+        T = np.eye(4, dtype=np.float32)
+        T[:3, :3] = R.from_euler('xyz', fr.uniform(-0.05, 0.05, 3)).as_matrix()
+        T[:3, 3] = fr.uniform(-1, 1, 3)
+        poses.append(T)
+    return frames, P2, poses
+
+
+def resize_pipeline_cfg(g, prefix='fsnet_amd.vision_base.data.augmentations.augmentations',
+                        builder='fsnet_amd.vision_base.utils.builder'):
+    size = tuple(int(v) for v in g["size"])
+    resize_keys = [('image', i) for i in FRAME_IDXS] + [('original_image', i) for i in FRAME_IDXS]
+    colour_keys = [('image', i) for i in FRAME_IDXS]
+    return dict(name=builder + '.Sequential', cfg_list=[
+        dict(name=prefix + '.ConvertToFloat'),
+        dict(name=prefix + '.Resize', size=size, preserve_aspect_ratio=True, force_pad=True),
+        dict(name=builder + '.Shuffle', cfg_list=[
+            dict(name=prefix + '.RandomBrightness', distort_prob=1.0, random_seed=int(g["seed_bright"])),
+            dict(name=prefix + '.RandomContrast', distort_prob=1.0, lower=0.6, upper=1.4, random_seed=int(g["seed_contrast"])),
+            dict(name=builder + '.Sequential', cfg_list=[
+                dict(name=prefix + '.ConvertColor', transform='HSV'),
+                dict(name=prefix + '.RandomSaturation', distort_prob=1.0, lower=0.6, upper=1.4, random_seed=int(g["seed_sat"])),
+                dict(name=prefix + '.ConvertColor', current='HSV', transform='RGB')])],
+             image_keys=colour_keys),
+        dict(name=prefix + '.RandomMirror', mirror_prob=0.5,
+             pose_axis_pairs=[(("relative_pose", i), 0) for i in FRAME_IDXS[1:]]),
+        dict(name=prefix + '.Normalize', mean=g["mean"], stds=g["std"], image_keys=colour_keys),
+        dict(name=prefix + '.Normalize', mean=np.array([0, 0, 0]), stds=np.array([1, 1, 1]),
+             image_keys=[('original_image', i) for i in FRAME_IDXS]),
+        dict(name=prefix + '.ConvertToTensor')],
+        image_keys=resize_keys, calib_keys=['P2'], gt_image_keys=['patched_mask'])

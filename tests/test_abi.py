@@ -65,7 +65,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, name), "libfsnet_hip.so does not export %s" % name
     lib.fs_abi_version.restype = C.c_int
     lib.fs_target_arch.restype = C.c_char_p
-    assert lib.fs_abi_version() == 2
+    assert lib.fs_abi_version() == 3
     assert lib.fs_target_arch() == b"gfx950"
 
 

@@ -136,3 +136,49 @@ def test_resize_known_answers():
     ramp = np.tile(np.arange(20, dtype=np.float32)[None, :, None], (12, 1, 3))
     out = A.resize_linear(ramp, 10, 12)                                            # 2x down: mean of the pair
     assert np.array_equal(out[:, :, 0], np.tile(np.arange(10, dtype=np.float32) * 2 + np.float32(0.5), (12, 1)))
+
+
+def test_resize_training_chain_oracle_and_host_classes_match_reference_vectors():
+    """the training input of the Resize-based shipped configs (multi_dataset / nusc / kitti360_fisheye examples):
+    oracle pixels bit for bit, host classes' draws and P2 / pose / mirror bookkeeping (augment_resize.npz)"""
+    from fsnet_amd.vision_base.data.augmentations.augmentations import PLAN
+    from fsnet_amd.vision_base.utils.builder import build
+    g = np.load(HA.GOLD_RESIZE)
+    size = tuple(int(v) for v in g["size"])
+    rngs = {k: np.random.default_rng(int(g["seed_" + k])) for k in ("bright", "contrast", "sat")}
+    transform = build(**HA.resize_pipeline_cfg(g))
+    np.random.seed(int(g["global_seed"]))
+    state = np.random.get_state()
+    mirrored = 0
+    for n in range(int(g["n"])):
+        frames, P2, poses = HA.resize_sample_inputs(g, n)
+        np.random.set_state(state)
+        plan = A.draw_resize_plan(rngs["bright"], rngs["contrast"], rngs["sat"])
+        imgs, origs, mask, syx = A.run_resize_train_sample(frames, plan, size, g["mean"], g["std"])
+        for j in range(3):
+            assert np.array_equal(imgs[j], g["s%d_image_%d" % (n, j)]) and np.array_equal(origs[j], g["s%d_orig_%d" % (n, j)])
+        assert np.array_equal(mask, g["s%d_mask" % n])
+        assert bool(g["s%d_mirror" % n]) == plan["mirror"] and list(g["s%d_order" % n]) == list(plan["order"])
+        # host classes from the same point of the global stream
+        np.random.set_state(state)
+        out = transform(HA.sample_dict(frames, P2, poses))
+        state = np.random.get_state()
+        hp = out[PLAN]
+        assert hp["mirror"] == plan["mirror"] and [o for o, _ in hp["ops"]] == list(plan["order"])
+        vals = dict(hp["ops"])
+        assert vals[0] == plan["brightness"] and vals[1] == plan["contrast"] and vals[2] == plan["saturation"]
+        assert np.allclose(out["P2"].numpy(), g["s%d_P2" % n], rtol=0, atol=1e-4)
+        for j, i in enumerate(HA.FRAME_IDXS[1:]):
+            assert np.allclose(np.asarray(out[("relative_pose", i)]), g["s%d_pose_%d" % (n, j)], atol=1e-6)
+        r = hp["resize"]
+        assert (r["out_h"], r["out_w"]) == size and r["gt_keys"] == ["patched_mask"]
+        mirrored += plan["mirror"]
+    assert 0 < mirrored < int(g["n"])
+
+
+def test_resize_nearest_known_answers():
+    src = np.arange(12, dtype=np.float64).reshape(3, 4)
+    assert np.array_equal(A.resize_nearest(src, 4, 3), src)
+    assert np.array_equal(A.resize_nearest(src, 2, 3), src[:, [0, 2]])            # floor(d * 2)
+    assert np.array_equal(A.resize_nearest(src, 8, 3)[0], np.repeat(src[0], 2))   # floor(d / 2)
+    assert np.array_equal(A.resize_nearest(np.ones((7, 5)), 3, 9), np.ones((9, 3)))

@@ -210,3 +210,27 @@ def test_kitti_dataset_through_device_pipeline_into_a_training_step(dev, tmp_pat
         n += 1
     assert n == 1
     RT.set_compute_dtype(torch.bfloat16)
+
+
+def test_resize_training_chain_matches_reference_vectors(dev):
+    """Resize -> colour Shuffle -> RandomMirror -> Normalize x2 (configs/multi_dataset_example:178-205) on the device:
+    one fs_resize_frames launch per batch, bit-exact against the vectors of the reference's own classes; the four
+    samples have different frame sizes (ragged batch) and pad on different sides"""
+    from fsnet_amd.vision_base.data.augmentations.augmentations import DeviceAugment
+    from fsnet_amd.vision_base.utils.builder import build
+    g = np.load(HA.GOLD_RESIZE)
+    transform = build(**HA.resize_pipeline_cfg(g))
+    np.random.seed(int(g["global_seed"]))
+    N = int(g["n"])
+    samples = [transform(HA.sample_dict(*HA.resize_sample_inputs(g, n))) for n in range(N)]
+    batch = DeviceAugment(HA.FRAME_IDXS)(samples, dev)
+    torch.cuda.synchronize()
+    for n in range(N):
+        for j, i in enumerate(HA.FRAME_IDXS):
+            assert np.array_equal(batch[("image", i)][n].cpu().numpy(), g["s%d_image_%d" % (n, j)]), (n, i)
+            assert np.array_equal(batch[("original_image", i)][n].cpu().numpy(), g["s%d_orig_%d" % (n, j)]), (n, i)
+        assert np.array_equal(batch["patched_mask"][n].cpu().numpy(), g["s%d_mask" % n])
+        assert np.allclose(batch["P2"][n].cpu().numpy(), g["s%d_P2" % n], rtol=0, atol=1e-4)
+    H, W = (int(v) for v in g["size"])
+    assert batch[("image", 0)].shape == (N, 3, H, W) and batch["patched_mask"].dtype == torch.float64
+    assert float(batch["patched_mask"].min()) == 0.0            # some sample was padded

@@ -135,6 +135,25 @@ def test_multi_dataset_config_meta_arch_builds(tmp_path):
     assert sum(p.numel() for p in m.depth_backbone.parameters()) > 23e6            # ResNet-50
     assert type(build(**cfg.trainer.training_hook)).__name__ == "BaseTrainingHook"
     assert cfg.train_dataset.name.endswith("ConcatDataset")
+    # its Resize-based training augmentation (Resize, colour Shuffle, RandomMirror, Normalize x2) plans device work
+    from fsnet_amd.vision_base.data.augmentations.augmentations import DeviceAugment, PLAN
+    train_aug = build(**cfg.train_dataset.augmentation)
+    assert callable(build(**cfg.val_dataset.augmentation))
+    rs = np.random.RandomState(0)
+    samples = []
+    for shape in ((376, 1408), (900, 1600)):                  # KITTI-360 and nuScenes frame sizes
+        data = {}
+        for i in cfg.data.frame_idxs:
+            data[("image", i)] = rs.randint(0, 256, size=shape + (3,)).astype(np.uint8)
+            data[("original_image", i)] = data[("image", i)].copy()
+        data["patched_mask"] = np.ones(shape)
+        data["P2"] = np.array([[552.5, 0, 682.0, 0], [0, 552.5, 238.8, 0], [0, 0, 1, 0]])
+        for i in cfg.data.frame_idxs[1:]:
+            data[("relative_pose", i)] = np.eye(4, dtype=np.float32)
+        samples.append(train_aug(data))
+    plan = DeviceAugment(list(cfg.data.frame_idxs)).collate(samples)[PLAN]
+    assert plan["kind"] == "resize" and plan["train"] and plan["mask"]
+    assert plan["out_hw"] == tuple(cfg.data.rgb_shape[:2]) and plan["dims"].shape == (2, 4)
 
 
 @pytest.mark.parametrize("name", ["distill_kitti_example", "distill_kitti360_example"])

@@ -424,6 +424,93 @@ def gen_augment():
     np.savez_compressed(os.path.join(GOLD, "augment.npz"), **res)
 
 
+def gen_augment_resize():
+    """Training input of the Resize-based shipped configs (configs/multi_dataset_example:178-205) through the REAL
+    reference classes: Resize of six frames + nearest patched_mask, Shuffle of the colour ops, RandomMirror AFTER
+    them, two Normalizes.  cv2.resize is the shim's restatement (unpinned, like warpAffine)."""
+    from oracle import augment_oracle as A
+    if not hasattr(np, "int"):
+        np.int = int
+    aug = 'vision_base.data.augmentations.augmentations'
+    frame_idxs = [0, 1, -1]
+    size = (48, 160)
+    resize_keys = [('image', i) for i in frame_idxs] + [('original_image', i) for i in frame_idxs]
+    colour_keys = [('image', i) for i in frame_idxs]
+    mean, std = np.array([0.485, 0.456, 0.406]), np.array([0.229, 0.224, 0.225])
+    seeds = dict(bright=202, contrast=203, sat=204)
+    E = EasyDict
+    cfg = E(name='vision_base.utils.builder.Sequential', cfg_list=[
+        E(name=aug + '.ConvertToFloat'),
+        E(name=aug + '.Resize', size=size, preserve_aspect_ratio=True, force_pad=True),
+        E(name='vision_base.utils.builder.Shuffle', cfg_list=[
+            E(name=aug + '.RandomBrightness', distort_prob=1.0, random_seed=seeds['bright']),
+            E(name=aug + '.RandomContrast', distort_prob=1.0, lower=0.6, upper=1.4, random_seed=seeds['contrast']),
+            E(name='vision_base.utils.builder.Sequential', cfg_list=[
+                E(name=aug + '.ConvertColor', transform='HSV'),
+                E(name=aug + '.RandomSaturation', distort_prob=1.0, lower=0.6, upper=1.4, random_seed=seeds['sat']),
+                E(name=aug + '.ConvertColor', current='HSV', transform='RGB')])],
+          image_keys=colour_keys),
+        E(name=aug + '.RandomMirror', mirror_prob=0.5, pose_axis_pairs=[(("relative_pose", i), 0) for i in frame_idxs[1:]]),
+        E(name=aug + '.Normalize', mean=mean, stds=std, image_keys=colour_keys),
+        E(name=aug + '.Normalize', mean=np.array([0, 0, 0]), stds=np.array([1, 1, 1]),
+          image_keys=[('original_image', i) for i in frame_idxs]),
+        E(name=aug + '.ConvertToTensor')],
+        image_keys=resize_keys, calib_keys=['P2'], gt_image_keys=['patched_mask'])
+    transform = build(**cfg)
+    rngs = {k: np.random.default_rng(v) for k, v in seeds.items()}
+    shapes = [(75, 250), (120, 250), (60, 400), (96, 320)]      # pad_1, pad_1, pad_0, exact fit
+    res = dict(size=np.array(size), mean=mean, std=std, n=len(shapes), frame_seed=1200, global_seed=88,
+               shapes=np.array(shapes), **{"seed_" + k: v for k, v in seeds.items()})
+    np.random.seed(88)
+    gstate = np.random.get_state()
+    maxdev = 0.0
+    for n, (H, W) in enumerate(shapes):
+        fr = np.random.RandomState(1200 + n)
+        frames = [fr.randint(0, 256, size=(H, W, 3)).astype(np.uint8) for _ in frame_idxs]
+        P2 = np.array([[721.5, 0, 609.5, 44.8], [0, 721.5, 172.8, 0.2], [0, 0, 1, 0.0027]], dtype=np.float64)
+        from scipy.spatial.transform import Rotation as R
+        poses = []
+        for j in range(2):
+            T = np.eye(4, dtype=np.float32)
+            T[:3, :3] = R.from_euler('xyz', fr.uniform(-0.05, 0.05, 3)).as_matrix()
+            T[:3, 3] = fr.uniform(-1, 1, 3)
+            poses.append(T)
+        data = {}
+        for i, f in zip(frame_idxs, frames):
+            data[('image', i)] = f.copy()
+            data[('original_image', i)] = f.copy()
+        data['patched_mask'] = np.ones([H, W])
+        data['P2'] = P2.copy()
+        for i, T in zip(frame_idxs[1:], poses):
+            data[('relative_pose', i)] = T.copy()
+        np.random.set_state(gstate)
+        out = transform(data)
+        np.random.set_state(gstate)
+        plan = A.draw_resize_plan(rngs['bright'], rngs['contrast'], rngs['sat'])
+        gstate = np.random.get_state()
+        imgs, origs, mask, syx = A.run_resize_train_sample(frames, plan, size, mean, std)
+        P = P2.copy()
+        P[0, :] *= syx[1]; P[1, :] *= syx[0]
+        if plan["mirror"]:
+            P = A.mirror_P2(P, size[1])
+        for j, i in enumerate(frame_idxs):
+            res["s%d_image_%d" % (n, j)] = npy(out[('image', i)])
+            res["s%d_orig_%d" % (n, j)] = npy(out[('original_image', i)])
+            maxdev = max(maxdev, float(np.abs(npy(out[('image', i)]) - imgs[j]).max()),
+                         float(np.abs(npy(out[('original_image', i)]) - origs[j]).max()))
+        res["s%d_mask" % n] = npy(out['patched_mask'])
+        res["s%d_P2" % n] = np.asarray(out['P2'])
+        res["s%d_mirror" % n] = plan["mirror"]
+        res["s%d_order" % n] = plan["order"]
+        for j, i in enumerate(frame_idxs[1:]):
+            res["s%d_pose_%d" % (n, j)] = np.asarray(out[('relative_pose', i)])
+            res["s%d_pose_in_%d" % (n, j)] = poses[j]
+        maxdev = max(maxdev, float(np.abs(mask - res["s%d_mask" % n]).max()), float(np.abs(P - res["s%d_P2" % n]).max()))
+        print("augment-resize sample %d: shape %s mirror=%s order=%s" % (n, (H, W), plan["mirror"], plan["order"]))
+    print("augment-resize: oracle vs reference classes, max abs deviation %.3e" % maxdev)
+    np.savez_compressed(os.path.join(GOLD, "augment_resize.npz"), **res)
+
+
 def gen_fisheye():
     """Fisheye path (BASELINE configs[3]) through the REAL classes: MeiCameraProjection LUT + cam2image
     (mei_fisheye_utils.py:14-187) and FishEyeDecoder.loss with gradients (monodepth2_decoder.py:350-420)."""
@@ -793,6 +880,9 @@ if __name__ == "__main__":
     if "--only-augment" in sys.argv:
         gen_augment()
         sys.exit(0)
+    if "--only-augment-resize" in sys.argv:
+        gen_augment_resize()
+        sys.exit(0)
     if "--only-fisheye" in sys.argv:
         gen_fisheye()
         sys.exit(0)
@@ -820,5 +910,6 @@ if __name__ == "__main__":
     gen_sigmoid_decoder()
     gen_frozen()
     gen_concat()
+    gen_augment_resize()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")

@@ -31,5 +31,7 @@ def cvtColor(src, code):
 
 def resize(src, dsize, interpolation=INTER_LINEAR):
     from oracle import augment_oracle as A
+    if interpolation == INTER_NEAREST:
+        return A.resize_nearest(src, dsize[0], dsize[1])
     assert interpolation == INTER_LINEAR and src.dtype.name == "float32"
     return A.resize_linear(src, dsize[0], dsize[1])
