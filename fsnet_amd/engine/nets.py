@@ -35,6 +35,16 @@ class StatsPool:
             self.buf[:self.off].zero_()     # everything beyond the bump pointer was never handed out: still zero
         self.off = 0
 
+    def span(self, a, b):
+        """one contiguous view over two slices taken back to back (a first), or None"""
+        if a is None or b is None or a.untyped_storage().data_ptr() != self.buf.untyped_storage().data_ptr() \
+                or b.untyped_storage().data_ptr() != self.buf.untyped_storage().data_ptr():
+            return None
+        oa, ob = a.storage_offset(), b.storage_offset()
+        if oa + a.numel() != ob:
+            return None
+        return self.buf[oa:ob + b.numel()]
+
     def take(self, C, groups=1):
         """[SLOTS][2][C] (one statistics group) or [G][SLOTS][2][C]"""
         n = groups * STAT_SLOTS * 2 * C
@@ -405,7 +415,18 @@ class ResNetRunner:
         G = self.groups if bt else 1
         stats = self.pool.take(op.Co_p, G) if bt else None
         c = op.forward(x, stats=stats, stat_groups=G)
-        world = _dp_stats(stats) if bt else 1
+        if bt and ds_stats is not None and RT.dp is not None:
+            # block end with a downsample branch: its statistics sit right before this conv's in the pool (taken
+            # back to back) and are consumed by the same bn_apply — one exchange for both
+            both = self.pool.span(ds_stats, stats)
+            if both is not None:
+                RT.dp.allreduce_small(both)
+                world = RT.dp.world
+            else:
+                _dp_stats(ds_stats)
+                world = _dp_stats(stats)
+        else:
+            world = _dp_stats(stats) if bt else 1
         y = torch.empty(N, Ho, Wo, op.Co_p, dtype=x.dtype, device=x.device)
         st = ops.BnState(op.Co_p, x.device, G)
         st2 = ops.BnState(op.Co_p, x.device, G) if ds_bn is not None else None
@@ -446,8 +467,7 @@ class ResNetRunner:
                             dbt = train and ds[1].training
                             dstats = self.pool.take(dop.Co_p, self.groups) if dbt else None
                             c_ds = dop.forward(cur, stats=dstats, stat_groups=(self.groups if dbt else 1))
-                            if dbt:
-                                _dp_stats(dstats)
+                            # (data parallel: exchanged together with the main branch's statistics in _unit_fwd)
                             c, y, st, st2 = self._unit_fwd(cl, bn, inp, train, ds_c=c_ds, ds_stats=dstats, ds_bn=ds[1])
                             bctx["ds"] = (c_ds, st2)
                         else:
