@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void photo_fused_fwd_kernel(const FsPhotoArgs 
   const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
   const float iwm1 = 1.f / wm1, ihm1 = 1.f / hm1;
   const bool have_mask = p.warp_mask || p.patched_mask;
+  const bool no_ovm = p.no_overlap_mask != 0;
 
   // per-lane invariants of the depth upsample (ATen upsample_bilinear2d, align_corners=True) and of the ray
   const float sh = (H > 1) ? (float)(h - 1) / (float)(H - 1) : 0.f;
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256) void photo_fused_fwd_kernel(const FsPhotoArgs 
         r0.xx[f][c] = hsum3(v * v);
         r0.xt[f][c] = hsum3(v * r0.rt[c]);
       }
-      r0.ov[f] = inb[f] && mv[f] == 1.f;
+      r0.ov[f] = no_ovm || (inb[f] && mv[f] == 1.f);   // overlapped_mask=False: every sample counts (border-clamped)
     }
     if (WRITE_PRED) {
       if (col_out && y >= ys && y < ys + FRH && y < H) {

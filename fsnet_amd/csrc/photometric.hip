@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void photo_warp_kernel(const FsPhotoArgs p) {
       // fisheye: patched_mask x ray-table mask as one float plane (monodepth2_decoder.py:409)
       mv = p.warp_mask ? p.warp_mask[o] : (p.patched_mask ? (float)p.patched_mask[o] : 1.f);
     }
-    ov[i] = (mv == 1.f) ? 1 : 0;
+    ov[i] = (p.no_overlap_mask || mv == 1.f) ? 1 : 0;
   }
 }
 

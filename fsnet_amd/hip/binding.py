@@ -126,6 +126,7 @@ class FsPhotoArgs(C.Structure):
         ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("S", C.c_int32),
         ("noise_seed", C.c_int32), ("noise_seed_ptr", C.c_void_p),
         ("lut_ptrs", C.c_void_p), ("mei", C.c_void_p), ("warp_mask", C.c_void_p), ("motion_mask", C.c_void_p),
+        ("no_overlap_mask", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

@@ -270,8 +270,11 @@ class PhotometricLoss:
     want_pred: also materialise the warped images / overlap masks (self.pred, self.ov) — only needed for logging and
     for the ("original_image", f, s) entries the reference leaves in its output dict."""
 
-    def __init__(self, B, H, W, scales, device, min_depth, max_depth, want_pred=True):
+    def __init__(self, B, H, W, scales, device, min_depth, max_depth, want_pred=True, overlapped_mask=True):
         self.B, self.H, self.W = B, H, W
+        # overlapped_mask=False (multi_dataset / nusc configs): reprojection terms are used wherever they are, with
+        # border-clamped samples (monodepth2_decoder.py:110-116, 230-235)
+        self.overlapped_mask = bool(overlapped_mask)
         self.scales = list(scales)
         S = self.S = len(self.scales)
         self.device = device
@@ -369,6 +372,7 @@ class PhotometricLoss:
         pa.img_src[0], pa.img_src[1] = srcs[0].data_ptr(), srcs[1].data_ptr()
         pa.patched_mask = _p(patched_mask)
         pa.geo = self.geo.data_ptr()
+        pa.no_overlap_mask = 0 if self.overlapped_mask else 1
         pa.pred, pa.ov, pa.ident, pa.sel = _p(self.pred), _p(self.ov), self.ident.data_ptr(), self.sel.data_ptr()
         pa.loss_sums, pa.mask_sum = self.loss_sums.data_ptr(), self.mask_sum.data_ptr()
         pa.dP = self.dP.data_ptr()

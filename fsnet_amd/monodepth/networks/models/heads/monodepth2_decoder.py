@@ -101,8 +101,6 @@ class MonoDepth2Decoder(nn.Module):
             raise NotImplementedError("MonoDepth2Decoder term residualflow_weight > 0 is not implemented in the HIP loss chain")
         if getattr(self, "distillation_loss_weight", 0) > 0 and getattr(self, "is_unscaled_distill", False):
             raise NotImplementedError("is_unscaled_distill=True is not implemented (no shipped config enables it)")
-        if not getattr(self, "overlapped_mask", False):
-            raise NotImplementedError("overlapped_mask=False is not implemented (all shipped configs enable it)")
         if len(self.frame_ids) != 3 or "s" in self.frame_ids:
             raise NotImplementedError("the HIP loss chain handles frame_ids=[0, a, b] (two temporal source frames)")
 
@@ -116,7 +114,8 @@ class MonoDepth2Decoder(nn.Module):
             # the warped images only reach HBM when somebody looks at them (logging; output_dict entries below)
             self._pl = ops.PhotometricLoss(B, H, W, self.scales, device, self.min_depth, self.max_depth,
                                            want_pred=bool(getattr(self, "is_log_image", True)
-                                                          or getattr(self, "keep_warped_images", False)))
+                                                          or getattr(self, "keep_warped_images", False)),
+                                           overlapped_mask=bool(getattr(self, "overlapped_mask", False)))
             self._pl_key = key
         return self._pl
 
@@ -184,7 +183,8 @@ class MonoDepth2Decoder(nn.Module):
             for k, s in enumerate(self.scales):
                 for j, f in enumerate((fa, fb)):
                     output_dict[("original_image", f, s)] = self._pl.pred[k, j]
-                    output_dict[("overlapped_mask", f, s)] = self._pl.ov[k, j].view(torch.bool)   # 0/1 bytes: no kernel
+                    if self._pl.overlapped_mask:      # (the reference only produces it when the option is on)
+                        output_dict[("overlapped_mask", f, s)] = self._pl.ov[k, j].view(torch.bool)   # 0/1 bytes
         hm = {}
         if getattr(self, "is_log_image", True) and self._pl.pred is not None:
             hm["original_image"] = img0[0:1]

@@ -419,6 +419,11 @@ typedef struct FsPhotoArgs {
    * per-pixel minimum runs over the two reprojection terms alone (no identity auto-mask) and the gradient of a pixel
    * is scaled by (1 - motion_mask): to_optimise.detach() * m + to_optimise * (1 - m). */
   const float* motion_mask;
+  /* overlapped_mask=False (monodepth2_decoder.py:110-116, 230-235; configs/multi_dataset_example, nusc_wpose_example):
+   * a reprojection term is used wherever it is, with border-clamped samples — no 100.0 substitution where the sample
+   * left the source frame.  0 = the masked behaviour of the KITTI configs. */
+  int32_t no_overlap_mask;
+  int32_t reserved0;
 } FsPhotoArgs;
 int fs_photo_setup(const float* P2, const float* T0, const float* T1, float* geo, int B, int* seed_counter,
                    int fisheye, void* stream);   /* seed_counter (or NULL): device int bumped by one — the noise seed of

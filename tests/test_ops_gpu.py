@@ -401,3 +401,50 @@ def test_motion_mask_and_pose_term_vs_reference_golden(dev):
         for got, key in ((pose[tag][0].grad, "gaa_" + tag), (pose[tag][1].grad, "gtr_" + tag)):
             ref = torch.from_numpy(g[key])
             assert (got.cpu() - ref).abs().max() < 1e-2 * ref.abs().max() + 1e-9, key
+
+
+def test_overlapped_mask_off_vs_reference_golden(dev):
+    """MonoDepth2Decoder.loss with overlapped_mask=False (configs/multi_dataset_example, nusc_wpose_example) on the
+    fused kernels against the REAL decoder: loss per scale, depth and pose gradients — 14.6 % of the samples of this
+    case leave the source frames, which is where the option acts"""
+    from fsnet_amd.configs import meta_arch_cfg
+    from fsnet_amd.engine.runtime import RT
+    from fsnet_amd.monodepth.networks.utils.monodepth_utils import transformation_from_parameters
+    from fsnet_amd.vision_base.utils.builder import build
+    from tests.test_oracle_golden import no_overlap_case
+    g = np.load(os.path.join(GOLD, "no_overlap_mask.npz"))
+    H, W = int(g["H"]), int(g["W"])
+    RT.tie_noise = False
+    try:
+        cfg = meta_arch_cfg(H, W, with_pose=True)
+        cfg.head_cfg.overlapped_mask = False
+        head = build(**cfg).head.to(dev)
+        data, depths, poses = no_overlap_case(H, W)
+        data = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in data.items()}
+        outputs, leaves, pl = {}, {}, {}
+        for s in range(4):
+            d = depths[s].to(dev).requires_grad_(True)
+            leaves[s] = d
+            outputs[("depth", s, s)] = d
+            outputs[("disp", s)] = O.depth_to_disp(d, 0.5, 100.0)
+        for f, tag in ((1, "p"), (-1, "m")):
+            aa, tr = poses[f][0].to(dev).requires_grad_(True), poses[f][1].to(dev).requires_grad_(True)
+            pl[tag] = (aa, tr)
+            outputs[("cam_T_cam", f)] = transformation_from_parameters(aa, tr, invert=(f < 0))
+        res = head.loss(outputs, data)
+        res["loss"].backward()
+        torch.cuda.synchronize()
+        assert not any(k[0] == "overlapped_mask" for k in outputs if isinstance(k, tuple))
+        assert abs(float(res["loss"].detach()) - float(g["total_loss"])) < 5e-6 * float(g["total_loss"])
+        assert abs(float(res["loss"].detach()) - float(g["total_loss_masked"])) > 1e-3      # not the masked value
+        for s in range(4):
+            assert abs(float(res["loss_dict"]["loss/%d" % s]) - float(g["ld_loss_%d" % s])) < 5e-6 * float(g["ld_loss_%d" % s])
+            ref = torch.from_numpy(g["gdepth_%d" % s])
+            assert float((leaves[s].grad.cpu() - ref).norm() / ref.norm()) < 1e-2, s
+            assert int((head._pl.sel[s] == 4).sum()) == 0                  # no constant-100 selections without the mask
+        for tag in ("p", "m"):
+            for got, key in ((pl[tag][0].grad, "gaa_" + tag), (pl[tag][1].grad, "gtr_" + tag)):
+                ref = torch.from_numpy(g[key])
+                assert (got.cpu() - ref).abs().max() < 1e-2 * ref.abs().max() + 1e-9, key
+    finally:
+        RT.tie_noise = True

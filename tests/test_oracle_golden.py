@@ -342,3 +342,48 @@ def test_frozen_stages_and_norm_eval_match_reference(tag, fs, ne):
     nbt = np.array([int(trn.sd[k]) for k in trn.sd if k.endswith("num_batches_tracked")])
     assert np.array_equal(nbt, g[tag + "_nbt_final"])
     assert (nbt == 0).sum() == {"fs1": 5, "ne": 20}[tag]        # the eval-mode BatchNorms never count a batch
+
+
+def no_overlap_case(H=64, W=96, B=2, seed=43):
+    """inputs of tests/golden/no_overlap_mask.npz (as tools/gen_golden.py::no_overlap_case builds them)"""
+    data = O.synthetic_batch(B, H, W, seed=seed)
+    g = torch.Generator().manual_seed(18)
+    depths = []
+    for s in range(4):
+        h, w = H >> s, W >> s
+        ys = torch.linspace(0, 1, h).view(1, 1, h, 1)
+        depths.append(4 + 25 * (1 - ys) + 3 * torch.rand(B, 1, h, w, generator=g))
+    poses = {}
+    for f in (1, -1):
+        aa = 0.03 * torch.randn(B, 1, 3, generator=g)
+        tr = torch.tensor([[[0.9 if f > 0 else -0.9, -0.05, -0.8 if f > 0 else 0.8]]]).repeat(B, 1, 1) + 0.02 * torch.randn(B, 1, 3, generator=g)
+        poses[f] = (aa, tr)
+    return data, depths, poses
+
+
+def test_overlapped_mask_off_oracle_matches_reference_golden():
+    """overlapped_mask=False (multi_dataset / nusc configs): every reprojection sample counts, border-clamped, also
+    where it left the source frame (14.6 % of this case's samples) — against the REAL decoder (no_overlap_mask.npz)"""
+    g = np.load(os.path.join(GOLD, "no_overlap_mask.npz"))
+    data, depths, poses = no_overlap_case(int(g["H"]), int(g["W"]))
+    outputs, leaves, pl = {}, {}, {}
+    for s in range(4):
+        d = depths[s].clone().requires_grad_(True)
+        leaves[s] = d
+        outputs[("depth", s, s)] = d
+        outputs[("disp", s)] = O.depth_to_disp(d, 0.5, 100.0)
+    for f, tag in ((1, "p"), (-1, "m")):
+        aa, tr = poses[f][0].clone().requires_grad_(True), poses[f][1].clone().requires_grad_(True)
+        pl[tag] = (aa, tr)
+        outputs[("cam_T_cam", f)] = O.transformation_from_parameters(aa, tr, invert=(f < 0))
+    total, ld = O.photometric_loss(outputs, data, overlapped_mask=False)
+    total.backward()
+    assert float(g["outside_frac"]) > 0.1 and abs(float(g["total_loss"]) - float(g["total_loss_masked"])) > 1e-3
+    assert abs(float(total.detach()) - float(g["total_loss"])) < 2e-6 * float(g["total_loss"])
+    for s in range(4):
+        ref = T(g["gdepth_%d" % s])
+        assert float((leaves[s].grad - ref).norm() / ref.norm()) < 1e-2, s       # (the reference's tie-break randn)
+    for tag in ("p", "m"):
+        for got, key in ((pl[tag][0].grad, "gaa_" + tag), (pl[tag][1].grad, "gtr_" + tag)):
+            ref = T(g[key])
+            assert maxdev(got, ref) < 1e-2 * float(ref.abs().max()) + 1e-9, key

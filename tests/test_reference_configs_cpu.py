@@ -133,6 +133,7 @@ def test_multi_dataset_config_meta_arch_builds(tmp_path):
     dec = m.head.depth_decoder
     assert type(m).__name__ == "MonoDepthWPose" and dec.num_output_channels == 64 and dec.base_fx is not None
     assert sum(p.numel() for p in m.depth_backbone.parameters()) > 23e6            # ResNet-50
+    assert m.head.overlapped_mask is False          # this config trains without the overlap mask (FsPhotoArgs.no_overlap_mask)
     assert type(build(**cfg.trainer.training_hook)).__name__ == "BaseTrainingHook"
     assert cfg.train_dataset.name.endswith("ConcatDataset")
     # its Resize-based training augmentation (Resize, colour Shuffle, RandomMirror, Normalize x2) plans device work

@@ -734,6 +734,74 @@ def gen_loss_options():
     np.savez_compressed(os.path.join(GOLD, "loss_options.npz"), **out)
 
 
+def no_overlap_case(H=64, W=96, B=2, seed=43):
+    """inputs of the overlapped_mask=False golden: large translations, so that a good part of the samples leaves the
+    source frames (those are exactly the pixels the option changes)"""
+    data = O.synthetic_batch(B, H, W, seed=seed)
+    g = torch.Generator().manual_seed(18)
+    depths = []
+    for s in range(4):
+        h, w = H >> s, W >> s
+        ys = torch.linspace(0, 1, h).view(1, 1, h, 1)
+        depths.append(4 + 25 * (1 - ys) + 3 * torch.rand(B, 1, h, w, generator=g))
+    poses = {}
+    for f in (1, -1):
+        aa = 0.03 * torch.randn(B, 1, 3, generator=g)
+        tr = torch.tensor([[[0.9 if f > 0 else -0.9, -0.05, -0.8 if f > 0 else 0.8]]]).repeat(B, 1, 1) + 0.02 * torch.randn(B, 1, 3, generator=g)
+        poses[f] = (aa, tr)
+    return data, depths, poses
+
+
+def gen_no_overlap_mask():
+    """MonoDepth2Decoder.loss with overlapped_mask=False (configs/multi_dataset_example, nusc_wpose_example;
+    monodepth2_decoder.py:110-116, 230-235) from the REAL decoder: totals, depth and pose gradients"""
+    H, W = 64, 96
+    data, depths, poses = no_overlap_case(H, W)
+    dec = ref_model(H, W, True).head
+    dec.overlapped_mask = False
+    outputs, leaves = {}, {}
+    for s in range(4):
+        d = depths[s].clone().requires_grad_(True)
+        leaves[("depth", s)] = d
+        outputs[("depth", s, s)] = d
+        outputs[("disp", s)] = mu.depth_to_disp(d, 0.5, 100.0)
+    for f in (1, -1):
+        aa, tr = poses[f][0].clone().requires_grad_(True), poses[f][1].clone().requires_grad_(True)
+        leaves[("aa", f)], leaves[("tr", f)] = aa, tr
+        outputs[("cam_T_cam", f)] = mu.transformation_from_parameters(aa, tr, invert=(f < 0))
+    torch.manual_seed(0)
+    res = dec.loss(outputs, data)
+    res['loss'].backward()
+    assert not any(k[0] == "overlapped_mask" for k in outputs)
+    out = {"H": H, "W": W, "total_loss": npy(res['loss'])}
+    for k, v in res['loss_dict'].items():
+        out["ld_" + k.replace('/', '_')] = npy(v)
+    for s in range(4):
+        out["gdepth_%d" % s] = npy(leaves[("depth", s)].grad)
+    for f in (1, -1):
+        tag = "p" if f > 0 else "m"
+        out["gaa_" + tag], out["gtr_" + tag] = npy(leaves[("aa", f)].grad), npy(leaves[("tr", f)].grad)
+    # how much the option matters on this case: the same inputs with the mask on
+    dec.overlapped_mask = True
+    o_on = {k: v.detach() for k, v in outputs.items() if k[0] in ("depth", "disp", "cam_T_cam")}
+    torch.manual_seed(0)
+    on = dec.loss(o_on, data)
+    out["total_loss_masked"] = npy(on['loss'])
+    out["outside_frac"] = np.float64(1.0 - float(torch.stack([o_on[("overlapped_mask", f, 0)].float().mean() for f in (1, -1)]).mean()))
+    o2, lv = {}, {}
+    for s in range(4):
+        d = depths[s].clone().requires_grad_(True); lv[s] = d
+        o2[("depth", s, s)] = d; o2[("disp", s)] = O.depth_to_disp(d, 0.5, 100.0)
+    for f in (1, -1):
+        o2[("cam_T_cam", f)] = outputs[("cam_T_cam", f)].detach()
+    tot, ld = O.photometric_loss(o2, data, overlapped_mask=False)
+    tot.backward()
+    print("no overlap mask: ref total %.9f (masked %.9f, %.1f %% of the samples outside) oracle %.9f | gdepth0 rel dev %.2e" % (
+        float(res['loss']), float(on['loss']), 100 * float(out["outside_frac"]), float(tot),
+        dev(lv[0].grad, leaves[("depth", 0)].grad) / float(leaves[("depth", 0)].grad.abs().max())))
+    np.savez_compressed(os.path.join(GOLD, "no_overlap_mask.npz"), **out)
+
+
 def thin(t, limit=4096):
     """every k-th element of the flattened tensor (k = the smallest stride that leaves <= `limit` values), float32;
     tests apply the same rule to what they compare"""
@@ -865,6 +933,9 @@ def gen_teacher_keys():
 
 
 if __name__ == "__main__":
+    if "--only-noov" in sys.argv:
+        gen_no_overlap_mask()
+        sys.exit(0)
     if "--only-concat" in sys.argv:
         gen_concat()
         sys.exit(0)
@@ -911,5 +982,6 @@ if __name__ == "__main__":
     gen_frozen()
     gen_concat()
     gen_augment_resize()
+    gen_no_overlap_mask()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")
