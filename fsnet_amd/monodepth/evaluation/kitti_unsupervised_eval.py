@@ -21,10 +21,23 @@ class KittiEigenEvaluator(object):
         elif gt_saved_file is not None and os.path.isfile(gt_saved_file):
             self.gt_depths = np.load(gt_saved_file, fix_imports=True, encoding='latin1', allow_pickle=True)["data"]
         else:
-            raise NotImplementedError(
-                "ground-truth export from raw KITTI velodyne scans is not part of fsnet_amd; run the reference's "
-                "KittiEigenEvaluator once to write %r and point gt_saved_file at it" % (gt_saved_file,))
+            print("Start exporting ground truth depths specified by %s to %s" % (split_file, gt_saved_file))
+            self._precompute(data_path, split_file, gt_saved_file)
         self._gt_dev = {}
+
+    def _precompute(self, data_path, split_file, gt_saved_file):
+        """ground truth of a split from the raw velodyne scans, cached as <gt_saved_file> (reference :27-46)"""
+        from fsnet_amd.monodepth.networks.utils.monodepth_utils import generate_depth_map
+        gts = []
+        with open(split_file, "r") as f:
+            for line in f:
+                if not line.strip():
+                    continue
+                folder, frame_id, _ = line.split()
+                scan = os.path.join(data_path, folder, "velodyne_points/data", "{:010d}.bin".format(int(frame_id)))
+                gts.append(generate_depth_map(os.path.join(data_path, folder.split("/")[0]), scan, 2, True).astype(np.float32))
+        np.savez_compressed(gt_saved_file, data=np.array(gts))
+        self.gt_depths = gts
 
     def _gt(self, index, device):
         g = self._gt_dev.get(index)

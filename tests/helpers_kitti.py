@@ -69,3 +69,45 @@ def dataset_cfg(raw, split, prefix):
                     dict(name=aug + '.ConvertToTensor')],
                     image_keys=[('image', i) for i in frame_idxs] + [('original_image', i) for i in frame_idxs],
                     calib_keys=['P2'], gt_image_keys=['patched_mask']))
+
+
+def add_velodyne(raw, seed=9, H=H, W=W, npts=5000):
+    """velodyne scans + the calibration entries the ground-truth export reads (S_rect_02, R_rect_00) for the frames of
+    make_tree's drive.  Points are drawn in the image (a margin outside included) and carried back to the velodyne
+    frame, so that many share a pixel of the tiny image — duplicates and the export's index collisions — and a
+    tenth of them sit behind the sensor."""
+    from scipy.spatial.transform import Rotation as R
+    rng = np.random.RandomState(seed)
+    date = os.path.join(raw, DATE)
+    Rr = R.from_euler("xyz", [0.003, -0.002, 0.001]).as_matrix()
+    # (this tree's own calibration: a camera that looks along the velodyne's forward axis and sees the tiny frame)
+    P2 = np.array([[60.0, 0, W / 2.0, 3.0], [0, 60.0, H / 2.0, 0.1], [0, 0, 1, 0.002]])
+    with open(os.path.join(date, "calib_cam_to_cam.txt"), "w") as f:
+        f.write("calib_time: 09-Jan-2012 13:57:47\n")
+        f.write("S_rect_02: %.6e %.6e\n" % (W, H))
+        f.write("R_rect_00: " + " ".join("%.6e" % v for v in Rr.flatten()) + "\n")
+        f.write("P_rect_02: " + " ".join("%.6e" % v for v in P2.flatten()) + "\n")
+    Rv = np.array([[0.0, -1, 0], [0, 0, -1], [1, 0, 0]]) @ R.from_euler("xyz", [0.01, -0.02, 0.015]).as_matrix()
+    with open(os.path.join(date, "calib_velo_to_cam.txt"), "w") as f:
+        f.write("calib_time: 15-Mar-2012 11:37:16\n")
+        f.write("R: " + " ".join("%.6e" % v for v in Rv.flatten()) + "\n")
+        f.write("T: -4.069766e-03 -7.631618e-02 -2.717806e-01\n")
+    from fsnet_amd.monodepth.networks.utils.monodepth_utils import read_calib_file
+    c2c = read_calib_file(os.path.join(date, "calib_cam_to_cam.txt"))
+    v2c = read_calib_file(os.path.join(date, "calib_velo_to_cam.txt"))
+    P = c2c["P_rect_02"].reshape(3, 4)
+    T = np.eye(4); T[:3, :3] = v2c["R"].reshape(3, 3); T[:3, 3] = v2c["T"]
+    R4 = np.eye(4); R4[:3, :3] = c2c["R_rect_00"].reshape(3, 3)
+    to_velo = np.linalg.inv(R4 @ T)
+    d = os.path.join(date, DRIVE, "velodyne_points", "data")
+    os.makedirs(d, exist_ok=True)
+    for i in range(NFRAMES):
+        u = rng.uniform(-4, W + 6, npts); v = rng.uniform(-4, H + 6, npts); z = rng.uniform(2, 60, npts)
+        X = (u * (z + P[2, 3]) - P[0, 2] * z - P[0, 3]) / P[0, 0]
+        Y = (v * (z + P[2, 3]) - P[1, 2] * z - P[1, 3]) / P[1, 1]
+        cam = np.stack([X, Y, z, np.ones(npts)], 1)
+        pts = (to_velo @ cam.T).T.astype(np.float32)
+        back = rng.rand(npts) < 0.1
+        pts[back, 0] = -np.abs(pts[back, 0])
+        pts[:, 3] = rng.uniform(0, 1, npts).astype(np.float32)
+        pts.tofile(os.path.join(d, "%010d.bin" % i))

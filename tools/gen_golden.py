@@ -912,6 +912,29 @@ def gen_concat():
     print("concat dataset: %d items" % len(ds))
 
 
+def gen_velo_gt():
+    """KITTI ground-truth export (monodepth_utils.py:368-420 generate_depth_map, with its sub2ind quirk) over the seeded
+    on-disk tree of tests/helpers_kitti.py: the reference's depth maps for the split's frames"""
+    import tempfile
+    if not hasattr(np, "int"):
+        np.int = int
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers_kitti as HK
+    from monodepth.networks.utils.monodepth_utils import generate_depth_map
+    with tempfile.TemporaryDirectory() as d:
+        raw, split = HK.make_tree(d)
+        HK.add_velodyne(raw)
+        gts = []
+        for line in open(split):
+            folder, frame_id, _ = line.split()
+            gts.append(generate_depth_map(os.path.join(raw, folder.split("/")[0]),
+                                          os.path.join(raw, folder, "velodyne_points/data", "%010d.bin" % int(frame_id)), 2, True))
+    gts = np.array(gts)
+    print("velodyne gt: %s, %.1f %% of the pixels hit, depth range %.2f..%.2f" % (
+        gts.shape, 100 * float((gts > 0).mean()), float(gts[gts > 0].min()), float(gts.max())))
+    np.savez_compressed(os.path.join(GOLD, "velo_gt.npz"), gt=gts)
+
+
 def gen_teacher_keys():
     """monodepth/transform_teacher.py on a checkpoint of the reference depth+pose meta-arch: the key list of the
     teacher state_dict (order included) and a checksum per kept tensor."""
@@ -933,6 +956,9 @@ def gen_teacher_keys():
 
 
 if __name__ == "__main__":
+    if "--only-velo" in sys.argv:
+        gen_velo_gt()
+        sys.exit(0)
     if "--only-noov" in sys.argv:
         gen_no_overlap_mask()
         sys.exit(0)
@@ -983,5 +1009,6 @@ if __name__ == "__main__":
     gen_concat()
     gen_augment_resize()
     gen_no_overlap_mask()
+    gen_velo_gt()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")
