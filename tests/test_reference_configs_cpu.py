@@ -189,3 +189,20 @@ def test_fisheye_config_of_the_reference_does_not_load_as_shipped(tmp_path):
     fisheye meta-arch itself is covered by tests/test_fisheye_gpu.py with the config's values."""
     with pytest.raises(NameError):
         _load_cfg(tmp_path, "kitti360_fisheye_example")
+
+
+@pytest.mark.parametrize("name", ["kitti360_wpose_example", "nusc_wpose_example", "distill_nusc_example"])
+def test_other_shipped_configs_build_model_hooks_and_augmentations(tmp_path, name):
+    """the KITTI-360 / nuScenes configs: meta-arch, training hook and both augmentation chains build with repointed
+    names (their dataset readers and evaluators are out of scope)"""
+    from fsnet_amd.vision_base.utils.builder import build
+    cfg = _load_cfg(tmp_path, name)
+    _no_download(cfg)
+    if "teacher_net_path" in cfg.meta_arch:
+        teacher = build(**cfg.meta_arch.teacher_net_cfg)
+        torch.save(teacher.state_dict(), cfg.meta_arch.teacher_net_path)
+    m = build(**cfg.meta_arch)
+    assert type(m).__name__ in ("MonoDepthWPose", "DistillWPoseMeta")
+    assert type(build(**cfg.trainer.training_hook)).__name__ == "BaseTrainingHook"
+    for sec in ("train_dataset", "val_dataset"):
+        assert callable(build(**cfg[sec].augmentation))
