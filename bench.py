@@ -177,6 +177,11 @@ def main():
         extra["conv_wgrad"] = {"achieved_tflops": round(tf(wg), 2), "launches_per_step": wg[0] // nprof,
                                "avg_launch_us": round(wg[2] / wg[0] * 1e6, 2)}
         allc = [ch, cg, wg]
+        if "conv1x1" in agg:        # 1x1 forward / stride-1 data gradient on the row-streaming GEMM (ResNet-50 configs)
+            c1 = agg["conv1x1"]
+            extra["conv1x1"] = {"achieved_tflops": round(tf(c1), 2), "launches_per_step": c1[0] // nprof,
+                                "avg_launch_us": round(c1[2] / c1[0] * 1e6, 2)}
+            allc.append(c1)
         if "conv_stem" in agg:      # 7x7 stems (forward) have their own kernel
             cs = agg["conv_stem"]
             extra["conv_stem"] = {"achieved_tflops": round(tf(cs), 2), "launches_per_step": cs[0] // nprof,

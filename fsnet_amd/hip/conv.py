@@ -91,6 +91,7 @@ def _nhwc_strides(t):
 
 import os
 
+USE_1X1 = os.environ.get("FSNET_AMD_CONV1X1", "1") != "0"
 USE_HALO = os.environ.get("FSNET_AMD_HALO", "1") != "0"   # 3x3/s1 LDS-halo kernel (conv3x3_halo.hip)
 USE_STEM_LDS = os.environ.get("FSNET_AMD_STEM_LDS", "1") != "0"   # 7x7/s2 stem kernel (conv_stem.hip)
 _WGRAD_WS = {}
@@ -229,6 +230,8 @@ class ConvOp:
         if grp_imgs:
             a.stat_group_rows, a.grp_imgs, a.M = 0, grp_imgs, grp_imgs * Ho * Wo
         fn = lib.fs_conv3x3_halo if halo else lib.fs_conv_igemm
+        if self._try_1x1(a, flops, lambda: "fwd  %s x[%d,%d,%d,%d]" % (self.describe(), N, x.shape[1], x.shape[2], x.shape[3])):
+            return out
         if stem:
             _timed("conv_stem", flops, lambda: check(lib.fs_conv_stem(C.byref(a), self.code, stream_ptr()), "conv_stem"),
                    tag=lambda: "fwd  %s x[%d,%d,%d,%d]" % (self.describe(), N, x.shape[1], x.shape[2], x.shape[3]))
@@ -236,6 +239,27 @@ class ConvOp:
         _timed("conv3x3_halo" if halo else "conv_igemm", flops, lambda: check(fn(C.byref(a), self.code, stream_ptr()), "conv_fwd"),
                tag=lambda: "fwd  %s x[%d,%d,%d,%d]" % (self.describe(), N, x.shape[1], x.shape[2], x.shape[3]))
         return out
+
+    def _try_1x1(self, a, flops, tag):
+        """1x1 convolutions (forward, stride-1 data gradient) on the row-streaming GEMM kernel (conv1x1.hip); False =
+        not a case for it (the kernel said FS_EINVAL, or FSNET_AMD_CONV1X1=0): the caller goes on to fs_conv_igemm"""
+        if not (USE_1X1 and self.R == 1 and self.S == 1 and self.pad == 0 and self.dtype == torch.bfloat16):
+            return False
+        status = [0]
+
+        def run():
+            status[0] = lib.fs_conv1x1(C.byref(a), self.code, stream_ptr())
+            if status[0] != 1:            # FS_EINVAL = "not mine"; anything else non-zero is an error
+                check(status[0], "conv1x1")
+        if a.stat_group_rows and a.stat_group_rows % 128 != 0:
+            return False
+        # measured per shape at ResNet-50 / 320x1024 / B=8 (tools/probes/conv1x1_shapes.py): the streaming kernel wins
+        # while the K walk is one or two chunks (forward 64->256 49.5 -> 40.8 us, data gradient 256<-64 43.7 -> 33.9),
+        # the implicit GEMM with its deeper K pipeline from there on (forward 256->128 44 vs 52 us, K = 1024: 25.5 vs 29.5)
+        if a.Cs > (128 if a.sgn > 0 else 256) or a.hb_mul != 1:
+            return False
+        _timed("conv1x1", flops, run, tag=tag)
+        return status[0] == 0
 
     def can_fuse_bn_bwd(self, N, H, W, groups):
         """whether dgrad(..., bn_fuse=) may carry the BatchNorm-backward sums of a [N,H,W,Ci_p] gradient"""
@@ -365,6 +389,8 @@ class ConvOp:
         flops = 2.0 * N * Ho * Wo * self.Co * self.R * self.S * self.Ci
         halo = self.halo_d and USE_HALO
         fn = lib.fs_conv3x3_halo if halo else lib.fs_conv_igemm
+        if self._try_1x1(a, flops, lambda: "dgrd %s dy[%d,%d,%d,%d]" % (self.describe(), N, Ho, Wo, Cd)):
+            return out
         _timed("conv3x3_halo" if halo else "conv_igemm", flops, lambda: check(fn(C.byref(a), self.code, stream_ptr()), "conv_dgrad"),
                tag=lambda: "dgrd %s dy[%d,%d,%d,%d]" % (self.describe(), N, Ho, Wo, Cd))
         return out

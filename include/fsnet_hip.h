@@ -104,6 +104,11 @@ typedef struct FsConvArgs {
                               images and, for fs_conv_igemm, stat_group_rows % 256 == 0 (no tile straddles). */
 } FsConvArgs;
 int fs_conv_igemm(const FsConvArgs* args, int dtype, void* stream);
+/* 1x1 convolutions (forward; data gradient at stride 1) as a row-streaming GEMM: same FsConvArgs and epilogue semantics
+ * as fs_conv_igemm (ktab unused), bf16 only.  Returns FS_EINVAL for anything it does not take (fp32, padding, a
+ * stride-2 data gradient, a K extent that is not whole 64-byte steps): the caller then uses fs_conv_igemm.
+ * Replaces the Bottleneck 1x1 convolutions and downsample projections, resnet.py:52-89, 119. */
+int fs_conv1x1(const FsConvArgs* args, int dtype, void* stream);
 
 /* 3x3 / stride-1 specialisation (forward: hb_mul=1, hb_add=-pad, sgn=+1; dgrad: hb_add=+pad, sgn=-1) with an
  * LDS-resident input halo tile reused by all nine taps.  Same arguments, packed weights and epilogue as

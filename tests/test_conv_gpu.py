@@ -28,6 +28,13 @@ CASES = [
     (128, 128, 3, 1, 1, 12, 48, 160), # big M -> 128x128 tiles
     (512, 512, 3, 1, 1, 4, 2, 3),     # layer4 of a 64x96 input: feature map narrower than the smallest tile
     (64, 64, 3, 1, 1, 3, 1, 2),
+    # Bottleneck 1x1s on the row-streaming GEMM (conv1x1.hip; bf16) / implicit GEMM (fp32)
+    (64, 256, 1, 1, 0, 2, 20, 24),    # expand, K = 64 (one 64-channel chunk)
+    (256, 64, 1, 1, 0, 2, 20, 24),    # reduce, K = 256
+    (128, 512, 1, 1, 0, 3, 9, 13),    # K = 128, ragged M (351 rows)
+    (2048, 512, 1, 1, 0, 2, 5, 8),    # eight K chunks
+    (256, 512, 1, 2, 0, 2, 20, 24),   # strided projection (downsample)
+    (512, 96, 1, 1, 0, 2, 6, 10),     # Co_p = 96: 32-channel tiles
 ]
 
 
@@ -123,7 +130,8 @@ def test_conv_addend_relu_strided(dev):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", [(64, 64, 3, 1, 1, 4, 16, 32, 1), (64, 128, 3, 2, 1, 4, 16, 32, 1),
                                   (128, 128, 3, 1, 1, 4, 12, 20, 2), (256, 256, 3, 1, 1, 12, 6, 20, 1),
-                                  (64, 128, 3, 2, 1, 4, 32, 64, 2)])
+                                  (64, 128, 3, 2, 1, 4, 32, 64, 2), (64, 256, 1, 1, 0, 4, 16, 32, 1),
+                                  (512, 128, 1, 1, 0, 4, 8, 16, 2)])
 def test_dgrad_epilogue_carries_bn_backward_sums(dev, case, dtype):
     """ConvOp.dgrad(mask=, addend=, bn_fuse=): masked gradient and BatchNorm-backward sums (sum g, sum g*xhat)
     == unfused dgrad followed by fs_bn_bwd_reduce (batch_norm backward's first pass, ATen via
