@@ -387,10 +387,8 @@ int dispatch(const FsConvArgs& a, hipStream_t st) {
       static const int cfg = [] { const char* e = getenv("FSNET_AMD_HALO_CFG"); return e ? atoi(e) : 0; }();
       if (cfg == 1) return launch_halo<T, 128, 32, 4, 1>(a, st);
       if (cfg == 2) return launch_halo<T, 128, 32, 4, 2>(a, st);
-      if (cfg == 3 && cop % 64 == 0) return launch_halo<T, 128, 64, 4, 2>(a, st);
-      if (cfg == 4 && cop % 64 == 0) return launch_halo<T, 128, 64, 2, 2>(a, st);
-      if (cfg == 5 && cop % 64 == 0) return launch_halo<T, 128, 64, 4, 1>(a, st);
-      if (cfg == 6 && cop % 64 == 0) return launch_halo<T, 128, 64, 4, 0>(a, st);
+      // (128x64 tiles with 2x4 / 4x2 MFMA tiles per wave were measured too, at every prefetch depth: 10-20 % slower at
+      // two blocks per CU, also on ResNet-50's 164 k-pixel launches — DESIGN section 7)
     }
     return launch_halo<T, 128, 32, 4>(a, st);
   }

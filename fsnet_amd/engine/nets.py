@@ -95,7 +95,7 @@ def _defer_param_grads(cur, item):
         # synchronises the streams it used with the caller's stream
         torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
         _CALLBACK_QUEUED[0] = True
-    if RT.wgrad_streams not in (3, 4) and len(ent[1]) >= RT.wgrad_flush:
+    if RT.wgrad_streams != 3 and len(ent[1]) >= RT.wgrad_flush:
         flush_deferred(cur)
 
 
@@ -110,16 +110,6 @@ def flush_deferred(cur=None, spread=False):
         if RT.wgrad_streams == 3:
             # the pose chain's stream: shorter than the depth chain's, so its tail is idle GPU time
             targets = [RT.side_stream(chain.device)]
-            tail = int(os.environ.get("FSNET_AMD_WGRAD_TAIL", "1"))
-            if tail >= 2:
-                targets.append(chain)
-            if tail >= 3:
-                targets.append(RT.companion_stream(chain.device, chain)[1])
-        elif RT.wgrad_streams == 4:
-            # everything the depth chain collected, once, when that chain has run out of other work: on the chain
-            # itself and on two companions, next to the rest of the pose chain
-            targets = [chain, RT.companion_stream(chain.device, chain)[1],
-                       RT.companion_stream(chain.device, RT.side_stream(chain.device))[1]]
         else:
             targets = [RT.companion_stream(chain.device, chain)[1]]
             if spread and (RT.wgrad_spread == 2 or (RT.wgrad_spread == 1 and RT.is_side(chain))):
@@ -132,11 +122,6 @@ def flush_deferred(cur=None, spread=False):
         for k, ws in enumerate(targets):
             mine = items[k::len(targets)]
             if not mine:
-                continue
-            if ws is chain or ws.cuda_stream == chain.cuda_stream:
-                with torch.cuda.stream(chain):
-                    for it in mine:
-                        _run_param_grads(*it)
                 continue
             ws.wait_stream(chain)                   # one cross-stream edge per batch
             with torch.cuda.stream(ws):
@@ -308,10 +293,6 @@ class ConvLayer:
                 # only while the budget lasts: hand over about as much as balances the two chains
                 ent = _DEFERRED.get(cur.cuda_stream)
                 if not RT.is_side(cur) and (ent is None or len(ent[1]) < RT.wgrad_side_budget):
-                    _defer_param_grads(cur, item)
-                    return
-            elif mode == 4:
-                if not RT.is_side(cur):
                     _defer_param_grads(cur, item)
                     return
             elif mode == 2 or not RT.is_side(cur):
@@ -737,7 +718,7 @@ class DepthDecoderRunner:
             else:
                 gfeats[4] = op0.dgrad(dc0, h, w)
         RT.mark("ddec.bwd.end")
-        if RT.wgrad_streams not in (3, 4):
+        if RT.wgrad_streams != 3:
             flush_deferred(_current_stream())
         return gfeats
 
