@@ -60,7 +60,7 @@ def test_depth_eval_edge_cases(dev):
     ev = KittiEigenEvaluator(gt_depths=[gt], device=dev)
     r = ev.single_call(torch.full((H, W), 5.0, device=dev), 0)
     assert abs(float(r["ratio"]) - 2.0) < 1e-6 and r["error"][0] < 1e-6 and abs(r["abs_error"][0] - 0.5) < 1e-6
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(FileNotFoundError):      # no cache: the export starts and finds no split file (like the reference)
         KittiEigenEvaluator(data_path="/nonexistent", split_file="x", gt_saved_file="/nonexistent/gt.npz")
 
 
