@@ -470,7 +470,42 @@ class ResNetRunner:
         k = len(units)
         inp, c, y, st = bctx["u"][k - 1]
         Ho, Wo = y.shape[1], y.shape[2]
-        if dout_sums is not None:
+        joint = (ds is not None and RT.dp is not None and st.count != float("inf")
+                 and bctx["ds"][1].count != float("inf"))
+        if joint:
+            # data parallel: the block's last BatchNorm and its downsample BatchNorm take the same gradient — both
+            # first passes run before ONE exchange of their (adjacent) sums, then both second passes
+            c_ds, st2 = bctx["ds"]
+            dop = ds[0].ready(x.dtype, x.device)
+            bn_m, bn_d = units[k - 1][1], ds[1]
+            fused_in = dout_sums is not None
+            pool = _BWD_POOLS[(c.device, raw_stream(c.device.index))]
+            s_m = dout_sums if fused_in else _bwd_sums(c, st)
+            s_d = _bwd_sums(c_ds, st2)
+            dc, dc_ds = torch.empty_like(c), torch.empty_like(c_ds)
+            g = dout if fused_in else torch.empty_like(c)
+            if not fused_in:
+                ops.bn_backward(dout, y, c, bn_m.weight.data, st, dc, None, None, Ho, Wo, relu=True, sums=s_m,
+                                sums_zeroed=True, phase="reduce")
+            # (the downsample branch's sums need the masked gradient: dout with this block's ReLU mask, or the
+            # already masked gradient of a fused producer)
+            ops.bn_backward(dout, None if fused_in else y, c_ds, bn_d.weight.data, st2, dc_ds, None, None, Ho, Wo,
+                            relu=not fused_in, sums=s_d, sums_zeroed=True, phase="reduce")
+            both = pool.span(s_m, s_d)
+            if both is not None:
+                glob = torch.empty_like(both)
+                RT.dp.allreduce_small(both, out=glob)
+                g_m, g_d = glob[: s_m.numel()].view(s_m.shape), glob[s_m.numel():].view(s_d.shape)
+            else:
+                g_m, g_d = torch.empty_like(s_m), torch.empty_like(s_d)
+                RT.dp.allreduce_small(s_m, out=g_m)
+                RT.dp.allreduce_small(s_d, out=g_d)
+            ops.bn_backward(dout, None if fused_in else y, c, bn_m.weight.data, st, dc, grad_of(bn_m.weight),
+                            grad_of(bn_m.bias), Ho, Wo, relu=not fused_in, g_out=(None if fused_in else g), sums=s_m,
+                            sums_zeroed=True, reduced=fused_in, phase="apply", glob=g_m)
+            ops.bn_backward(g, None, c_ds, bn_d.weight.data, st2, dc_ds, grad_of(bn_d.weight), grad_of(bn_d.bias), Ho, Wo,
+                            relu=False, sums=s_d, sums_zeroed=True, phase="apply", glob=g_d)
+        elif dout_sums is not None:
             g = dout
             dc = _bn_bwd(dout, None, c, units[k - 1][1], st, Ho, Wo, sums=dout_sums)
         else:
@@ -479,7 +514,8 @@ class ResNetRunner:
         if ds is not None:
             c_ds, st2 = bctx["ds"]
             dop = ds[0].ready(x.dtype, x.device)
-            dc_ds = _bn_bwd(g, None, c_ds, ds[1], st2, Ho, Wo, relu=False)
+            if not joint:
+                dc_ds = _bn_bwd(g, None, c_ds, ds[1], st2, Ho, Wo, relu=False)
             ds[0].accumulate_param_grads(dop, dc_ds, x)
             dres = dop.dgrad(dc_ds, H, W, addend=extra)
         else:

@@ -81,7 +81,7 @@ def bn_apply(x, stats, bn, st, y, H, W, count, relu=True, pad_out=False, res=Non
 
 
 def bn_backward(dout, y, x, gamma, st, dx, dgamma, dbeta, H, W, relu=True, fold=False, g_out=None, sums=None,
-                allreduce=None, sums_zeroed=False, reduced=False):
+                allreduce=None, sums_zeroed=False, reduced=False, phase="all", glob=None):
     """Two-pass BN backward.  dout: grad w.r.t. the block output (strided view, or the padded buffer
     when fold=True); y: saved output activation (interior view) for the ReLU mask.
     reduced=True: the first pass already happened in the epilogue of the convolution that produced dout
@@ -109,10 +109,16 @@ def bn_backward(dout, y, x, gamma, st, dx, dgamma, dbeta, H, W, relu=True, fold=
     code = dtype_code(x.dtype)
     nb = x.numel() * x.element_size()
     shp = lambda: "[%d,%d,%d,%d]%s" % (x.shape[0], H, W, Cc, " fold" if fold else "")
-    if not reduced:
+    # phase "reduce": only the first pass (the caller exchanges the sums of several BatchNorms in one collective and
+    # comes back with phase "apply", glob = the exchanged sums; `sums` then holds the local ones)
+    if not reduced and phase != "apply":
         _timed("bn_bwd_reduce", nb * (2 + (y is not None)),
                lambda: check(lib.fs_bn_bwd_reduce(C.byref(a), code, stream_ptr()), "bn_bwd_reduce"), tag=shp)
-    if allreduce is not None:
+    if phase == "reduce":
+        return None
+    if glob is not None:
+        a.sums_local, a.sums = sums.data_ptr(), glob.data_ptr()
+    elif allreduce is not None:
         # SyncBN: dgamma / dbeta come from the local sums, dx from the global ones — reduce out of place instead
         # of cloning the local copy first (one device copy per BatchNorm and step)
         glob = torch.empty_like(sums)
