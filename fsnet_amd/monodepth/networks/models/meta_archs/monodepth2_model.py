@@ -51,6 +51,10 @@ class _HipMetaArch(BaseMetaArch):
             fn(data)
 
     def dummy_forward(self, image):
+        if torch.onnx.is_in_onnx_export():
+            # scripts/onnx_export.py traces this method: hand the tracer the graph description (export/onnx_graph.py)
+            from fsnet_amd.export.onnx_graph import describe_depth_network
+            return describe_depth_network(self, image)
         features = self.depth_backbone(image)
         outputs = self.head.forward_depth(features)
         return self.head.get_prediction(None, outputs)

@@ -955,7 +955,49 @@ def gen_teacher_keys():
     print("teacher keys: %d of %d kept" % (len(rec["dst_keys"]), len(rec["src_keys"])))
 
 
+def gen_onnx():
+    """scripts/onnx_export.py:39-52 on the real MonoDepthWPose (CPU, eval mode): `dummy_forward(image)` and the
+    reference's own `torch.onnx.export(..., opset_version=11)` of it — operator histogram, graph input / output
+    signature and initializer shapes of the file the reference writes (read back with the wire-format reader; the
+    `onnx` package is absent, so the exporter's onnxscript splice is skipped — see fsnet_amd/export/onnx_graph.py)."""
+    import collections
+    import io
+    import json
+    import warnings
+    from fsnet_amd.export import onnx_graph as G
+    from tests.helpers_onnx import case as onnx_case
+    sd0, image = onnx_case()
+    m = ref_model(64, 128, False)
+    m.load_state_dict({k: v.clone() for k, v in sd0.items()}, strict=True)
+    m.eval()
+    with torch.no_grad():
+        pred = m.dummy_forward(image)
+    assert list(pred.keys()) == ["depth"]
+    m.forward = m.dummy_forward
+    f = io.BytesIO()
+    with warnings.catch_warnings(), G._without_onnx_package():
+        warnings.simplefilter("ignore")
+        torch.onnx.export(m, torch.zeros(1, 3, 64, 128), f, input_names=['input'], output_names=['output'],
+                          opset_version=11, dynamo=False)
+    model = G.read_model(f)
+    G.check_model(model)
+    g = model["graph"]
+    rec = {"ir_version": model["ir_version"], "opsets": model["opsets"],
+           "ops": dict(collections.Counter(n["op_type"] for n in g["nodes"])),
+           "inputs": [v for v in g["inputs"] if v["name"] not in g["initializers"]],
+           "outputs": [dict(name=v["name"], elem_type=v["elem_type"], rank=len(v["shape"])) for v in g["outputs"]],
+           "initializer_shapes": sorted([list(a.shape) for a in g["initializers"].values()]),
+           "n_bytes": len(f.getvalue())}
+    json.dump(rec, open(os.path.join(GOLD, "onnx_graph.json"), "w"), indent=1, sort_keys=True)
+    np.savez_compressed(os.path.join(GOLD, "onnx_dummy_forward.npz"), depth=npy(pred["depth"]))
+    print("onnx: %d nodes, %d initializers, depth range %.3f..%.3f" % (
+        len(g["nodes"]), len(g["initializers"]), float(pred["depth"].min()), float(pred["depth"].max())))
+
+
 if __name__ == "__main__":
+    if "--only-onnx" in sys.argv:
+        gen_onnx()
+        sys.exit(0)
     if "--only-velo" in sys.argv:
         gen_velo_gt()
         sys.exit(0)
