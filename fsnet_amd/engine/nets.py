@@ -60,7 +60,7 @@ _PENDING_JOIN = set()   # (chain stream, companion stream) pairs with weight-gra
 _PENDING_KEEP = []      # tensors the companion kernels still read: kept alive until the join (no record_stream
                         # bookkeeping in the allocator, and safe inside a hipGraph capture's private pool)
 _DEFERRED = {}          # chain stream id -> (chain stream, [weight-gradient work items not yet handed over])
-_CALLBACK_QUEUED = [False]
+_CALLBACK_QUEUED = [None]     # id of the backward pass whose end-of-backward callback is queued
 _ACTIVE_CHAINS = set()  # chain stream ids that deferred work during the running backward pass
 
 
@@ -85,16 +85,22 @@ def _run_param_grads(op, dc, x, gw, gb, nb):
 
 
 def _defer_param_grads(cur, item):
+    if _CALLBACK_QUEUED[0] is not None and _CALLBACK_QUEUED[0] != torch._C._current_graph_task_id():
+        for stale in _DEFERRED.values():       # leftovers of a backward pass that raised: not this pass's gradients
+            stale[1].clear()
+        _ACTIVE_CHAINS.clear()
     ent = _DEFERRED.get(cur.cuda_stream)
     if ent is None:
         ent = _DEFERRED[cur.cuda_stream] = (cur, [])
     ent[1].append(item)
     _ACTIVE_CHAINS.add(cur.cuda_stream)
-    if not _CALLBACK_QUEUED[0]:
+    task = torch._C._current_graph_task_id()
+    if _CALLBACK_QUEUED[0] != task:
         # runs once, when the autograd engine has executed every node of this backward pass and before it
-        # synchronises the streams it used with the caller's stream
+        # synchronises the streams it used with the caller's stream.  (Keyed by the pass: a backward that died in an
+        # exception never ran its callback, and must not keep the next one from queueing its own.)
         torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
-        _CALLBACK_QUEUED[0] = True
+        _CALLBACK_QUEUED[0] = task
     if RT.wgrad_streams != 3 and len(ent[1]) >= RT.wgrad_flush:
         flush_deferred(cur)
 
@@ -133,7 +139,7 @@ def flush_deferred(cur=None, spread=False):
 
 
 def _end_of_backward():
-    _CALLBACK_QUEUED[0] = False
+    _CALLBACK_QUEUED[0] = None
     flush_deferred()
     _ACTIVE_CHAINS.clear()
     join_companions()
@@ -193,7 +199,11 @@ def pack_all(key, arena=None):
               and (arena is None or arena.owns(l.m.weight))]
     if not layers:
         return
-    sig = tuple((l.m.weight.data_ptr(), l._op.w_f.data_ptr()) for l in layers)
+    # everything a descriptor encodes: a freed model's successor can land on the same master-weight and forward-
+    # operand addresses with its dgrad operand elsewhere (seen as a rare wrong feature gradient in a long test run:
+    # the stale table packed into the old model's freed dgrad buffers and left the new ones unpacked)
+    sig = tuple((l.m.weight.data_ptr(), l._op.w_f.data_ptr(), l._op.w_d.data_ptr() if l._op.need_dgrad else 0,
+                 l._op.Co, l._op.Ci, l._op.R, l._op.S, l._op.stride) for l in layers)
     ent = _PACK_TABLES.get((key, sig))
     if ent is None:
         arr = (FsPackDesc * len(layers))()

@@ -224,3 +224,23 @@ def test_stem_lds_kernel(dev, Ci, N, H, W, groups):
     y2 = op2.forward(xd)
     torch.cuda.synchronize()
     assert (y2.float() - y.float()).abs().max().item() <= 1.6e-2 * scale
+
+
+@pytest.mark.gpu
+def test_pack_table_follows_every_operand_buffer(dev):
+    """the cached descriptor table of the one-launch weight re-pack is keyed by everything it encodes: a layer whose
+    dgrad operand moved (a dropped model's successor at the same master-weight addresses) must get a fresh table —
+    the stale one packed into freed memory and left the new operand empty (a rare wrong feature gradient)"""
+    from fsnet_amd.engine.nets import ConvLayer
+    from fsnet_amd.engine.runtime import RT
+    conv = torch.nn.Conv2d(16, 32, 3, padding=1, bias=False).to(dev)
+    cl = ConvLayer(conv)
+    op = cl.ready(torch.bfloat16, dev)
+    torch.cuda.synchronize()
+    ref_d, ref_f = op.w_d.clone(), op.w_f.clone()
+    assert float(ref_d.float().abs().sum()) > 0
+    op.w_d = torch.zeros_like(op.w_d)
+    RT.bump_weights()
+    assert cl.ready(torch.bfloat16, dev) is op
+    torch.cuda.synchronize()
+    assert torch.equal(op.w_d, ref_d) and torch.equal(op.w_f, ref_f)
