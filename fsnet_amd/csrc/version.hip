@@ -1,6 +1,6 @@
 #include "common.h"
 #include "fsnet_hip_internal.h"
-extern "C" int fs_abi_version(void) { return 3; }
+extern "C" int fs_abi_version(void) { return FS_ABI_VERSION; }
 extern "C" const char* fs_target_arch(void) { return "gfx950"; }
 
 // Debugging aid (FSNET_AMD_MARKS=1): one thread writes the constant-rate (100 MHz) device clock into *slot — a node

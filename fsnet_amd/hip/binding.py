@@ -139,6 +139,7 @@ class FsSmoothArgs(C.Structure):
     ]
 
 
+ABI_VERSION = 3      # FS_ABI_VERSION of include/fsnet_hip.h (tests/test_abi.py holds the two together)
 _lib = None
 
 
@@ -154,9 +155,14 @@ def load_library(path=None):
         raise FsError(
             "libfsnet_hip.so not found at %s — the HIP kernel library is required (no CPU fallback). "
             "Build it with `python fsnet_amd/csrc/build.py` or __graft_entry__.build()." % path)
-    _lib = C.CDLL(path)
+    handle = C.CDLL(path)
     from . import signatures
-    signatures.declare(_lib)
+    signatures.declare(handle)
+    got = int(handle.fs_abi_version())
+    if got != ABI_VERSION:
+        raise FsError("libfsnet_hip.so at %s reports ABI %d, this binding is written against ABI %d (FS_ABI_VERSION "
+                      "in include/fsnet_hip.h): rebuild it with `python fsnet_amd/csrc/build.py`" % (path, got, ABI_VERSION))
+    _lib = handle
     return _lib
 
 

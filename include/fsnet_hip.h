@@ -31,7 +31,9 @@ extern "C" {
  * address slots: layout [FS_STAT_SLOTS][2][C]; consumers add the slots up. */
 #define FS_STAT_SLOTS 8
 
-/* library/ABI version and the ISA the kernels were compiled for ("gfx950") */
+/* library/ABI version and the ISA the kernels were compiled for ("gfx950").  FS_ABI_VERSION changes whenever an
+ * argument struct or a signature below does; a host binding refuses a library that reports another number. */
+#define FS_ABI_VERSION 3
 int fs_abi_version(void);
 const char* fs_target_arch(void);
 /* debugging aid: writes the device's constant-rate clock (wall_clock64, 100 MHz) into *slot (u64) on `stream`;

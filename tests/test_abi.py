@@ -65,7 +65,10 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, name), "libfsnet_hip.so does not export %s" % name
     lib.fs_abi_version.restype = C.c_int
     lib.fs_target_arch.restype = C.c_char_p
-    assert lib.fs_abi_version() == 3
+    from fsnet_amd.hip import binding
+    header = open(HEADER).read()
+    declared = int(re.search(r"#define FS_ABI_VERSION (\d+)", header).group(1))
+    assert lib.fs_abi_version() == declared == binding.ABI_VERSION
     assert lib.fs_target_arch() == b"gfx950"
 
 
@@ -118,3 +121,12 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.delenv("FSNET_HIP_LIB")
     monkeypatch.setattr(L, "_lib", None)
     L.load_library()
+
+
+def test_graft_entry_build_passes():
+    """the driver's "does it build" check, run the way the driver runs it (incremental: seconds)"""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    entry = importlib.import_module("__graft_entry__")
+    entry.build()
