@@ -16,7 +16,8 @@ streams).  torch.distributed's communicator is then only used at set-up and for 
 the direct one (two communicators executing collectives on one device at the same time can deadlock when the
 device-side order differs across ranks).  No c10d work objects exist during a step, so the step can be captured
 into a hipGraph: RCCL's launches become graph nodes, RCCL itself orders the launches of one communicator across the
-chain streams.  With gloo (CPU tests, shared-device rigs), or if the direct path fails its start-up self-test, the
+chain streams — in issue order, which at N > 1 couples the depth and the pose chain wherever they exchange (DESIGN.md 6;
+FSNET_AMD_DP_COMMS=3 opens one communicator per role instead).  With gloo (CPU tests, shared-device rigs), or if the direct path fails its start-up self-test, the
 collectives fall back to torch.distributed and the step is issued eagerly.
 """
 import os
@@ -41,6 +42,18 @@ class DataParallelContext:
         self._sum.reduceOp = dist.ReduceOp.SUM
         from .rccl_direct import DirectComm
         self._direct = DirectComm.create(group)
+        # FSNET_AMD_DP_COMMS=3: the pose chain's SyncBN exchanges and the gradient buckets get communicators of their
+        # own (see the module docstring: one communicator serialises every collective of a step in issue order)
+        self._direct_side, self._direct_grad = self._direct, self._direct
+        if self._direct is not None and os.environ.get("FSNET_AMD_DP_COMMS", "1") == "3":
+            side, grad = DirectComm.create(group), DirectComm.create(group)
+            if side is not None and grad is not None:
+                self._direct_side, self._direct_grad = side, grad
+                self._direct.capture_ok = self._direct.capture_ok and side.capture_ok and grad.capture_ok
+            else:
+                for c in (side, grad):
+                    if c is not None:
+                        c.close()
         self._comm_stream = None
         self._graph_owners = []    # weak references to hooks whose captured step contains this communicator's nodes
         self.capturable = False
@@ -57,7 +70,12 @@ class DataParallelContext:
     def allreduce_small(self, t, out=None):
         """SUM over the ranks, in place or into `out` (t then keeps the local values)"""
         if self._direct is not None:
-            self._direct.all_reduce_sum(t, out)          # current stream; a graph node under capture
+            comm = self._direct
+            if self._direct_side is not comm:
+                from .runtime import RT
+                if RT.is_side(torch.cuda.current_stream(t.device)):
+                    comm = self._direct_side
+            comm.all_reduce_sum(t, out)                  # current stream; a graph node under capture
             return
         if out is not None:
             out.copy_(t)
@@ -106,7 +124,7 @@ class DataParallelContext:
             cur = torch.cuda.current_stream(g.device)
             self._comm_stream.wait_stream(cur)
             with torch.cuda.stream(self._comm_stream):
-                self._direct.all_reduce_sum(g)
+                self._direct_grad.all_reduce_sum(g)
             return
         from .nets import flush_deferred, join_companions
         if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
@@ -159,9 +177,9 @@ class DataParallelContext:
             if owner is not None:
                 owner.reset_graph()
         self._graph_owners = []
-        if self._direct is not None:
-            self._direct.close()
-            self._direct = None
+        for c in {id(c): c for c in (self._direct, self._direct_side, self._direct_grad) if c is not None}.values():
+            c.close()
+        self._direct = self._direct_side = self._direct_grad = None
         if self._comm_stream is not None:
             from .runtime import RT
             RT.release_stream(self._comm_stream.cuda_stream)

@@ -128,6 +128,7 @@ class DirectComm(object):
         a = (torch.arange(37, dtype=torch.float64, device=self.device) + 1.0) * (self.rank + 1)
         b = a.clone()
         self.all_reduce_sum(a)
+        torch.cuda.synchronize(self.device)     # never two communicators' collectives in flight at once (start-up only)
         dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
         torch.cuda.synchronize(self.device)
         ok = torch.tensor([1 if torch.equal(a, b) else 0], dtype=torch.int32, device=self.device)

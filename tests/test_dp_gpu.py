@@ -104,7 +104,8 @@ def test_direct_rccl_communicator(dev):
         dist.destroy_process_group()
 
 
-def test_dp_step_replayed_from_a_hipgraph_on_rccl(dev):
+@pytest.mark.parametrize("comms", ["1", "3"])
+def test_dp_step_replayed_from_a_hipgraph_on_rccl(dev, comms):
     """the data-parallel step — SyncBN exchanges on both chain streams and the gradient buckets on the communication
     stream, all on the direct RCCL communicator — captured into a hipGraph and replayed; three independent captures
     (the round-1 capture raced the process group's watchdog once in ~15 runs: no torch.distributed work object exists
@@ -115,10 +116,11 @@ def test_dp_step_replayed_from_a_hipgraph_on_rccl(dev):
     from fsnet_amd.vision_base.networks.optimizers.optimizers import build_optimizer
     from fsnet_amd.vision_base.utils.builder import build
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["FSNET_AMD_DP_COMMS"] = comms      # 3: one communicator per role (depth chain, pose chain, buckets)
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
     all_losses = []
     try:
-        for rep in range(3):
+        for rep in range(3 if comms == "1" else 1):
             RT.set_compute_dtype(torch.float32)
             RT.tie_noise = False
             m = build(**meta_arch_cfg(64, 128, with_pose=True))
@@ -130,6 +132,7 @@ def test_dp_step_replayed_from_a_hipgraph_on_rccl(dev):
             m.ensure_arena()
             RT.dp = DataParallelContext(m)
             assert RT.dp.direct and RT.dp.capturable
+            assert (RT.dp._direct_side is not RT.dp._direct) == (comms == "3")
             losses = []
             for it in range(6):
                 out = hook(dict(O.synthetic_batch(2, 64, 128, seed=50 + it)), m, opt)
@@ -141,6 +144,7 @@ def test_dp_step_replayed_from_a_hipgraph_on_rccl(dev):
             RT.dp = None
     finally:
         RT.dp = None
+        del os.environ["FSNET_AMD_DP_COMMS"]
         dist.destroy_process_group()
     l_ref, _, _ = _run_steps(dev, False)
     for losses in all_losses:
