@@ -145,6 +145,9 @@ class DataParallelContext:
             return
         lo, hi = arena.slice_of(params)
         assert sl[0] <= lo and hi <= sl[1]
+        if any(a < hi and lo < b for a, b in self._done.get(id(module), [])):
+            raise RuntimeError("gradient range [%d, %d) of %s was already reduced in this step" %
+                               (lo, hi, type(module).__name__))
         self._done.setdefault(id(module), []).append((lo, hi))
         self._reduce_range(arena, lo, hi)
 

@@ -580,7 +580,10 @@ class ResNetRunner:
                     # feature gradient still has to be added to it first (stage boundary without downsample)
                     prev = (pu[2], pu[1], pu[3])
                 dout, dsums = self._block_bwd(units, ds, ctx["blocks"][bi], dout, extra, dout_sums=dsums, prev=prev)
-            if RT.dp is not None and si >= 2:
+            if RT.dp is not None and si >= 2 and self.m._pending == 1:
+                # (only the module's LAST pending backward of the step: an encoder that ran several training forwards —
+                # the pose encoder with FSNET_AMD_BATCH_POSE=0 — accumulates every call's gradients first; a slice
+                # reduced after the first backward would be reduced again with the second one's local sums on top)
                 # gradient bucket of this stage (reverse parameter order, like DDP): layer4 and layer3 carry 94 % of
                 # the encoder's parameters and finish first
                 RT.dp.partial_ready(self.m, [getattr(self.m, "layer%d" % (si + 1))])

@@ -21,6 +21,9 @@ class KittiEigenEvaluator(object):
         elif gt_saved_file is not None and os.path.isfile(gt_saved_file):
             self.gt_depths = np.load(gt_saved_file, fix_imports=True, encoding='latin1', allow_pickle=True)["data"]
         else:
+            if data_path is None or split_file is None:
+                raise ValueError("KittiEigenEvaluator: no cached ground truth (gt_saved_file=%r) and no data_path / "
+                                 "split_file to export it from" % (gt_saved_file,))
             print("Start exporting ground truth depths specified by %s to %s" % (split_file, gt_saved_file))
             self._precompute(data_path, split_file, gt_saved_file)
         self._gt_dev = {}
@@ -36,7 +39,17 @@ class KittiEigenEvaluator(object):
                 folder, frame_id, _ = line.split()
                 scan = os.path.join(data_path, folder, "velodyne_points/data", "{:010d}.bin".format(int(frame_id)))
                 gts.append(generate_depth_map(os.path.join(data_path, folder.split("/")[0]), scan, 2, True).astype(np.float32))
-        np.savez_compressed(gt_saved_file, data=np.array(gts))
+        # the Eigen split mixes recording dates whose rectified image sizes differ (375x1242, 370x1224, 376x1241 ...):
+        # a ragged list only becomes an array as dtype=object (the reference's np.array(gts) relied on an older NumPy
+        # doing that implicitly; NumPy >= 1.24 raises).  The loader above passes allow_pickle=True.
+        if gt_saved_file is not None:
+            if len({g.shape for g in gts}) <= 1:
+                arr = np.array(gts)
+            else:
+                arr = np.empty(len(gts), dtype=object)
+                for k, g in enumerate(gts):
+                    arr[k] = g
+            np.savez_compressed(gt_saved_file, data=arr)
         self.gt_depths = gts
 
     def _gt(self, index, device):

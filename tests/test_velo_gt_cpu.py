@@ -35,3 +35,36 @@ def test_evaluator_exports_and_caches_ground_truth(tmp_path):
     assert len(ev.gt_depths) == gt.shape[0] and all(np.array_equal(a, b) for a, b in zip(ev.gt_depths, gt))
     again = KittiEigenEvaluator(data_path="/nonexistent", split_file="/nonexistent", gt_saved_file=cache)   # from the cache
     assert np.array_equal(np.asarray(again.gt_depths), gt)
+
+
+def test_export_with_ragged_image_sizes_and_without_cache_file(tmp_path, monkeypatch):
+    """recording dates of the Eigen split have different rectified sizes: the cache must hold a ragged list; and
+    gt_saved_file=None keeps the export in memory instead of crashing at the save"""
+    from fsnet_amd.monodepth.evaluation.kitti_unsupervised_eval import KittiEigenEvaluator
+    from fsnet_amd.monodepth.networks.utils import monodepth_utils as MU
+    raw, split = HK.make_tree(str(tmp_path))
+    sizes = [(7, 11), (6, 12), (7, 11), (8, 10)]
+    calls = []
+
+    def fake(calib_dir, scan, cam, vel_depth):
+        h, w = sizes[len(calls) % len(sizes)]
+        calls.append(scan)
+        return np.full((h, w), float(len(calls)))
+    monkeypatch.setattr(MU, "generate_depth_map", fake)
+    cache = str(tmp_path / "ragged.npz")
+    ev = KittiEigenEvaluator(data_path=raw, split_file=split, gt_saved_file=cache)
+    n = len(ev.gt_depths)
+    assert n == len(calls) and n >= 2
+    again = KittiEigenEvaluator(gt_saved_file=cache)
+    assert len(again.gt_depths) == n
+    for a, b in zip(ev.gt_depths, again.gt_depths):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    calls.clear()
+    mem = KittiEigenEvaluator(data_path=raw, split_file=split, gt_saved_file=None)
+    assert len(mem.gt_depths) == n
+    try:
+        KittiEigenEvaluator(gt_saved_file=None)
+    except ValueError:
+        pass
+    else:
+        raise AssertionError("expected a ValueError without a cache file and without a data path")
