@@ -401,6 +401,8 @@ int dispatch(const FsConvArgs& a, hipStream_t st) {
 
 }  // namespace
 
+int fs_conv3x3_t32(const FsConvArgs& a, int dtype, hipStream_t st);      // conv3x3_t32.hip
+
 extern "C" int fs_conv3x3_halo(const FsConvArgs* args, int dtype, void* stream) {
   if (!args || !args->src || !args->wgt || !args->dst) return FS_EINVAL;
   const int es = dtype == FS_DTYPE_BF16 ? 2 : 4;
@@ -412,6 +414,15 @@ extern "C" int fs_conv3x3_halo(const FsConvArgs* args, int dtype, void* stream) 
       args->wgt_bytes > 0x7fffffffLL)
     return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // 32x32-tile kernel for whole 64-byte channel chunks and >= 32 output channels; the 16x16-tile kernel below keeps
+  // the 16-channel decoder layers
+  const char* te = getenv("FSNET_AMD_T32");
+  const bool use_t32 = !(te && te[0] == '0');
+  if (use_t32) {
+    const int r = fs_conv3x3_t32(*args, dtype, st);
+    if (r != FS_EINVAL) return r;
+  }
+  if (args->pro_mode != 0 || args->wgt2 || args->bnb_scale) return FS_EINVAL;   // only the 32x32-tile kernel has these
   if (dtype == FS_DTYPE_BF16) return dispatch<bf16>(*args, st);
   if (dtype == FS_DTYPE_F32) return dispatch<float>(*args, st);
   return FS_EINVAL;

@@ -33,7 +33,7 @@ extern "C" {
 
 /* library/ABI version and the ISA the kernels were compiled for ("gfx950").  FS_ABI_VERSION changes whenever an
  * argument struct or a signature below does; a host binding refuses a library that reports another number. */
-#define FS_ABI_VERSION 3
+#define FS_ABI_VERSION 4
 int fs_abi_version(void);
 const char* fs_target_arch(void);
 /* debugging aid: writes the device's constant-rate clock (wall_clock64, 100 MHz) into *slot (u64) on `stream`;
@@ -104,6 +104,28 @@ typedef struct FsConvArgs {
   int32_t stat_group_rows; /* 0: one statistics group.  >0: rows (pixels) per BatchNorm statistics group; row m
                               adds to stats + (m / stat_group_rows) * FS_STAT_SLOTS*2*Co.  Groups are whole
                               images and, for fs_conv_igemm, stat_group_rows % 256 == 0 (no tile straddles). */
+  /* ---- fs_conv3x3_halo only (ABI 4) ----
+   * Operand prologue: the BatchNorm (+ ReLU) that precedes this convolution in the reference
+   * (resnet.py:33-50 conv1 -> bn1 -> relu -> conv2; blocks.py:41-54) — or, in a data-gradient launch, the second pass
+   * of that BatchNorm's backward — is applied to the source operand while it is staged into LDS, so the normalised
+   * activation / the BatchNorm input gradient never exists in HBM.  Coefficients are fp32 [groups][Cs], group =
+   * image / pro_group_imgs (0: one group).  Out-of-image taps stay zero (the padding applies to the transformed
+   * tensor).
+   *   pro_mode 1: x' = a[c]*x + b[c], then max(x', 0) if pro_relu          (forward: a = gamma*invstd, b = beta - mean*a)
+   *   pro_mode 2: x' = a[c]*x + b[c]*pro_src2 + c[c]                        (backward: x = masked gradient g, pro_src2 =
+   *               the raw convolution output the BatchNorm normalised (same layout and strides as src):
+   *               dx = (g - mean_g - xhat*mean_gx) * gamma*invstd written as one affine form) */
+  const float* pro_a; const float* pro_b; const float* pro_c;
+  const void* pro_src2;
+  int32_t pro_mode, pro_relu, pro_group_imgs;
+  /* ReLU-backward mask derived instead of read: with bnb_x set and bnb_scale != NULL the mask is
+   * bnb_scale[c]*bnb_x + bnb_shift[c] > 0 (the folded forward's own expression; [groups][Co]) and `mask` must be NULL */
+  int32_t reserved1;
+  const float* bnb_scale; const float* bnb_shift;
+  /* second packed weight operand (same geometry as wgt): images n >= wgt2_from_n multiply with it — one launch for two
+   * networks of identical shapes (depth and pose encoder, monodepth2_model.py:24-46).  NULL: one operand. */
+  const void* wgt2;
+  int32_t wgt2_from_n, reserved2;
 } FsConvArgs;
 int fs_conv_igemm(const FsConvArgs* args, int dtype, void* stream);
 /* 1x1 convolutions (forward; data gradient at stride 1) as a row-streaming GEMM: same FsConvArgs and epilogue semantics
