@@ -213,7 +213,10 @@ def main():
                        "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(loss, 6),
                        "hipgraph_replays": hook.graph_replays, "frames_per_s": round(3 * B * world * args.steps / elapsed, 1),
                        "dp_collectives": (None if RT.dp is None else ("rccl-direct" + ("+hipgraph" if RT.dp.capturable else "")
-                                                                        if RT.dp.direct else "torch.distributed"))},
+                                                                        if RT.dp.direct else "torch.distributed")),
+                       "dp_world": (None if RT.dp is None else RT.dp.world),
+                       "syncbn_exchanges_per_step": (None if RT.dp is None else RT.dp.n_small),
+                       "gradient_buckets_per_step": (None if RT.dp is None else RT.dp.n_bucket)},
             "roofline": roofline, "kernels": extra,
         }
         if world == 1 and not args.no_cpu_baseline:

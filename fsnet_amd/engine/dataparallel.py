@@ -16,8 +16,8 @@ streams).  torch.distributed's communicator is then only used at set-up and for 
 the direct one (two communicators executing collectives on one device at the same time can deadlock when the
 device-side order differs across ranks).  No c10d work objects exist during a step, so the step can be captured
 into a hipGraph: RCCL's launches become graph nodes, RCCL itself orders the launches of one communicator across the
-chain streams — in issue order, which at N > 1 couples the depth and the pose chain wherever they exchange (DESIGN.md 6;
-FSNET_AMD_DP_COMMS=3 opens one communicator per role instead).  With gloo (CPU tests, shared-device rigs), or if the direct path fails its start-up self-test, the
+chain streams — in issue order, which at N > 1 couples the depth and the pose chain wherever they exchange.
+With gloo (CPU tests, shared-device rigs), or if the direct path fails its start-up self-test, the
 collectives fall back to torch.distributed and the step is issued eagerly.
 """
 import os
@@ -37,23 +37,12 @@ class DataParallelContext:
         self._done = {}            # id(module) -> [(lo, hi)] reduced in this step
         self._expected = {}        # id(module) -> module: ran a training forward in this step
         self._synced = False
+        self.n_small = self.n_bucket = 0   # collectives issued in the current step (bench.py reports them at N > 1)
         self._pg = group if group is not None else dist.distributed_c10d._get_default_group()
         self._sum = dist.AllreduceOptions()
         self._sum.reduceOp = dist.ReduceOp.SUM
         from .rccl_direct import DirectComm
         self._direct = DirectComm.create(group)
-        # FSNET_AMD_DP_COMMS=3: the pose chain's SyncBN exchanges and the gradient buckets get communicators of their
-        # own (see the module docstring: one communicator serialises every collective of a step in issue order)
-        self._direct_side, self._direct_grad = self._direct, self._direct
-        if self._direct is not None and os.environ.get("FSNET_AMD_DP_COMMS", "1") == "3":
-            side, grad = DirectComm.create(group), DirectComm.create(group)
-            if side is not None and grad is not None:
-                self._direct_side, self._direct_grad = side, grad
-                self._direct.capture_ok = self._direct.capture_ok and side.capture_ok and grad.capture_ok
-            else:
-                for c in (side, grad):
-                    if c is not None:
-                        c.close()
         self._comm_stream = None
         self._graph_owners = []    # weak references to hooks whose captured step contains this communicator's nodes
         self.capturable = False
@@ -69,13 +58,9 @@ class DataParallelContext:
     # ---- small latency-bound exchanges (BN) ------------------------------------------------
     def allreduce_small(self, t, out=None):
         """SUM over the ranks, in place or into `out` (t then keeps the local values)"""
+        self.n_small += 1
         if self._direct is not None:
-            comm = self._direct
-            if self._direct_side is not comm:
-                from .runtime import RT
-                if RT.is_side(torch.cuda.current_stream(t.device)):
-                    comm = self._direct_side
-            comm.all_reduce_sum(t, out)                  # current stream; a graph node under capture
+            self._direct.all_reduce_sum(t, out)          # current stream; a graph node under capture
             return
         if out is not None:
             out.copy_(t)
@@ -102,6 +87,7 @@ class DataParallelContext:
         self.handles = []
         self._done = {}
         self._expected = {}
+        self.n_small = self.n_bucket = 0
 
     def note_forward(self, module):
         """a network ran a training forward: its gradients must be reduced before finish()"""
@@ -117,6 +103,7 @@ class DataParallelContext:
     def _reduce_range(self, arena, lo, hi):
         if hi <= lo:
             return
+        self.n_bucket += 1
         g = arena.grad[lo:hi]
         if self._direct is not None:
             # the bucket's weight gradients were issued on the current (chain) stream: the communication stream
@@ -124,7 +111,7 @@ class DataParallelContext:
             cur = torch.cuda.current_stream(g.device)
             self._comm_stream.wait_stream(cur)
             with torch.cuda.stream(self._comm_stream):
-                self._direct_grad.all_reduce_sum(g)
+                self._direct.all_reduce_sum(g)
             return
         from .nets import flush_deferred, join_companions
         if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
@@ -166,6 +153,18 @@ class DataParallelContext:
         self._reduce_range(arena, pos, sl[1])
         self._done[id(module)] = [(sl[0], sl[1])]
 
+    def all_agree(self, ok):
+        """True on every rank iff `ok` on every rank (MIN all-reduce on the process group; never inside a capture).
+        Used after a rank-local decision that changes WHICH collectives a rank will issue — a rank that fell back to
+        eager launches while the others replay a captured step would hang them."""
+        dev = self._direct.device if self._direct is not None else torch.device("cpu")
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if dev.type == "cuda":
+            from .rccl_direct import quiesce_watchdog
+            quiesce_watchdog(dev)        # the process group's watchdog has reaped this collective before the next capture
+        return bool(int(flag.item()))
+
     def note_graph_owner(self, owner):
         """`owner.reset_graph()` drops a hipGraph captured with this context's collectives"""
         import weakref
@@ -180,9 +179,9 @@ class DataParallelContext:
             if owner is not None:
                 owner.reset_graph()
         self._graph_owners = []
-        for c in {id(c): c for c in (self._direct, self._direct_side, self._direct_grad) if c is not None}.values():
+        for c in ([self._direct] if self._direct is not None else []):
             c.close()
-        self._direct = self._direct_side = self._direct_grad = None
+        self._direct = None
         if self._comm_stream is not None:
             from .runtime import RT
             RT.release_stream(self._comm_stream.cuda_stream)

@@ -134,6 +134,11 @@ class BaseTrainingHook(object):
                        stage_meta=stage)
         if RT.dp is not None:
             RT.dp.note_graph_owner(self)     # the graph holds RCCL nodes: it must go before the communicator does
+            return output                    # data parallel: the ranks agree first (__call__), then _first_replay()
+        return self._first_replay()
+
+    def _first_replay(self):
+        graph, output = self._g["graph"], self._g["output"]
         graph.replay()
         RT.bump_weights()
         return output
@@ -202,13 +207,25 @@ class BaseTrainingHook(object):
         with torch.cuda.stream(self._g_stream):
             if self._g is None:
                 steps_before = optimizer._step_count_fused
+                failure = None
                 try:
                     output = self._capture(data, meta_arch, optimizer, arena, meta, sig)
-                    self.graph_captures += 1
                 except Exception as e:      # something in the step is not capturable here: stay eager, loudly
+                    failure = "%s: %s" % (type(e).__name__, e)
+                if RT.dp is not None:
+                    # Every rank replays or none does: a rank that fell back to eager launches would issue its
+                    # collectives from the host while the others replay theirs from a graph, and a rank whose capture
+                    # died would not issue them at all.  (MIN all-reduce over torch.distributed, outside any capture.)
+                    if not RT.dp.all_agree(failure is None) and failure is None:
+                        failure = "the capture failed on another rank"
+                    if failure is None:
+                        output = self._first_replay()
+                if failure is None:
+                    self.graph_captures += 1
+                else:
                     import warnings
-                    warnings.warn("fsnet_amd: hipGraph capture of the training step failed (%s: %s); "
-                                  "continuing with eager launches" % (type(e).__name__, e))
+                    warnings.warn("fsnet_amd: hipGraph capture of the training step failed (%s); "
+                                  "continuing with eager launches" % failure)
                     self.use_graph = False
                     self._g = None
                     optimizer._step_count_fused = steps_before

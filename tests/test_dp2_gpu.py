@@ -99,3 +99,29 @@ def test_two_ranks_equal_one_process_on_the_full_batch(dev, tmp_path):
     agree, rel = same_update(r0["params"] - p_init, params - p_init)
     assert agree > 0.97 and rel < 0.2, (agree, rel)
     assert float(((r0["running"] - running).abs() / running.abs().clamp_min(1.0)).max()) < 1e-3
+
+
+def test_bench_script_runs_with_two_ranks(tmp_path):
+    """bench.py's multi-rank path — rendezvous from the torchrun environment, barrier + synchronize around the timed
+    steps, MAX-reduce of the elapsed time, RT.dp.close(), ONE JSON line on rank 0 — exercised once before the driver
+    runs it on a multi-GPU node: two ranks launched like the driver does (python -m torch.distributed.run), sharing
+    the test box's single device over gloo (FSNET_AMD_BENCH_SHARED_DEVICE=1)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FSNET_AMD_BENCH_SHARED_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+           "--batch", "2", "--height", "64", "--width", "128"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                 # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2" and d["config"]["dp_world"] == 2
+    assert d["config"]["dp_collectives"] == "torch.distributed"          # gloo rig: no direct RCCL communicator
+    assert d["config"]["syncbn_exchanges_per_step"] > 40 and d["config"]["gradient_buckets_per_step"] >= 4
+    assert d["value"] > 0 and abs(d["value"] - 4 * 3 / (d["ms_per_step"] * 3e-3)) < 0.02 * d["value"]
+    assert "cpu_baseline" not in d                           # rank 0 at N = 1 only
