@@ -56,6 +56,38 @@ __device__ inline void bn_channel_coeffs(const double* stats, const float* rmean
   shift = beta - mean * scale;
 }
 
+// BatchNorm statistics -> per-channel coefficients, without touching the activation: the normalisation itself is
+// applied by the convolution that consumes the tensor (FsConvArgs.pro_mode = 1, FsWgradArgs.pro_a) — "BatchNorm
+// folded into the operand staging".  Same arithmetic and running-statistics update as bn_apply_kernel's preamble.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const FsBnApplyArgs p, float* __restrict__ scale,
+                                                          float* __restrict__ shift) {
+  const int C = p.C;
+  const int G = p.groups > 1 ? p.groups : 1;
+  const int z = blockIdx.y;
+  const long gstat = (long)FS_STAT_SLOTS * 2 * C;
+  const double* stats_z = p.stats ? p.stats + z * gstat : nullptr;
+  const bool train = p.stats != nullptr;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < C) {
+    float mean, invstd, varb, sc, sh;
+    bn_channel_coeffs(stats_z, p.running_mean, p.running_var, C, c, p.count, p.eps, p.gamma[c], p.beta[c], mean, invstd, varb, sc, sh);
+    p.save_mean[z * C + c] = mean; p.save_invstd[z * C + c] = invstd;
+    scale[z * C + c] = sc; shift[z * C + c] = sh;
+    if (z == 0 && train && p.running_mean) {
+      float rm = p.running_mean[c], rv = p.running_var[c];
+      for (int g = 0; g < G; ++g) {
+        float mg = mean, vg = varb, t0, t1, t2;
+        if (g > 0) bn_channel_coeffs(p.stats + g * gstat, nullptr, nullptr, C, c, p.count, p.eps, 1.f, 0.f, mg, t0, vg, t1, t2);
+        double unb = p.count > 1.0 ? (double)vg * p.count / (p.count - 1.0) : (double)vg;
+        rm = (1.f - p.momentum) * rm + p.momentum * mg;
+        rv = (1.f - p.momentum) * rv + p.momentum * (float)unb;
+      }
+      p.running_mean[c] = rm; p.running_var[c] = rv;
+    }
+  }
+  if (z == 0 && blockIdx.x == 0 && threadIdx.x == 0 && train && p.num_batches_tracked) *p.num_batches_tracked += G;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const FsBnApplyArgs p) {
   // per-channel coefficients in dynamic LDS (4*C floats): a fixed MAXC-sized array would cap the occupancy of
@@ -348,6 +380,17 @@ int grid_for(long items) {
 }
 
 }  // namespace
+
+extern "C" int fs_bn_finalize(const FsBnApplyArgs* a, float* scale, float* shift, void* stream) {
+  if (!a || !a->gamma || !a->beta || !a->save_mean || !a->save_invstd || !scale || !shift) return FS_EINVAL;
+  if (!a->stats && (!a->running_mean || !a->running_var)) return FS_EINVAL;
+  if (a->C <= 0 || a->C > MAXC || a->gamma2) return FS_EINVAL;
+  const int G = a->groups > 1 ? a->groups : 1;
+  if (G > 1 && !a->stats) return FS_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((a->C + 255) / 256, G), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     *a, scale, shift);
+  return fs_launch_status();
+}
 
 extern "C" int fs_bn_apply(const FsBnApplyArgs* a, int dtype, void* stream) {
   if (!a || !a->x || !a->y || !a->gamma || !a->beta || !a->save_mean || !a->save_invstd) return FS_EINVAL;

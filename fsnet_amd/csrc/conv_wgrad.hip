@@ -398,8 +398,24 @@ __global__ __launch_bounds__(256 * KG) void wgrad3x3_halo_kernel(const FsWgradAr
   for (int i = 0; i < LB; ++i)
     brel[i] = (int)(((long)bhy[i] * p.sH + (long)bhx[i] * p.sW + ci0 + ((t + i * 256) % UB) * 8) * 2);
   uint4 ra[LA], rb[LB];
+  // operand prologue (BatchNorm + ReLU folded into the staging of x): this thread's 16-byte units all hold the same 8
+  // input channels (256 % UB == 0), coefficients per statistics group of the tile's image
+  static_assert(256 % UB == 0, "a thread's x units must share their channel slot");
+  const bool has_pro = p.pro_a != nullptr;
+  float ka[8], kb[8];
+  unsigned bok = 0u;                       // which of the thread's x units lie inside the image (padding stays zero)
   auto load_regs = [&](int pt) {
     int q = fs_div(pt, g.dTX); int tx_i = pt - q * g.tiles_x; int n = fs_div(q, g.dTY); int ty_i = q - n * g.tiles_y;
+    if (has_pro) {
+      const int pg = p.pro_group_imgs > 0 ? n / p.pro_group_imgs : 0;
+      const float* pa = p.pro_a + (long)pg * g.Cs + ci0 + (t % UB) * 8;
+      const float* pb = p.pro_b + (long)pg * g.Cs + ci0 + (t % UB) * 8;
+      const float4 a0 = reinterpret_cast<const float4*>(pa)[0], a1 = reinterpret_cast<const float4*>(pa)[1];
+      const float4 b0 = reinterpret_cast<const float4*>(pb)[0], b1 = reinterpret_cast<const float4*>(pb)[1];
+      ka[0] = a0.x; ka[1] = a0.y; ka[2] = a0.z; ka[3] = a0.w; ka[4] = a1.x; ka[5] = a1.y; ka[6] = a1.z; ka[7] = a1.w;
+      kb[0] = b0.x; kb[1] = b0.y; kb[2] = b0.z; kb[3] = b0.w; kb[4] = b1.x; kb[5] = b1.y; kb[6] = b1.z; kb[7] = b1.w;
+      bok = 0u;
+    }
     int y0 = ty_i * g.TH, x0 = tx_i * g.TW;
     // tile origin as 32-bit byte offsets (both tensors are below 2 GiB: the buffer descriptors require it)
     const int abase = (((n * p.Hd + y0) * p.Wd + x0) * p.Cd) * 2;
@@ -414,7 +430,20 @@ __global__ __launch_bounds__(256 * KG) void wgrad3x3_halo_kernel(const FsWgradAr
       const int sy = y0 - p.pad + bhy[i], sx = x0 - p.pad + bhx[i];
       const bool ok = bhy[i] >= 0 && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
       rb[i] = wg_buf_load16(rs_x, ok ? bbase + brel[i] : OOB);
+      if (has_pro && ok) bok |= 1u << i;
     }
+  };
+  auto pro_unit = [&](uint4 u) {
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+    unsigned o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float lo = bf16_bits_to_f(w[j] & 0xffffu) * ka[2 * j] + kb[2 * j];
+      float hi = __uint_as_float(w[j] & 0xffff0000u) * ka[2 * j + 1] + kb[2 * j + 1];
+      if (p.pro_relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+      o[j] = pack_bf16x2(lo, hi);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
   };
   auto store_lds = [&]() {
 #pragma unroll
@@ -425,7 +454,9 @@ __global__ __launch_bounds__(256 * KG) void wgrad3x3_halo_kernel(const FsWgradAr
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
       int idx = t + i * 256; int hp = idx / UB, u = idx % UB;
-      if (hp < HMAX) *reinterpret_cast<uint4*>(&lds_b[hp * SB + u * 8]) = rb[i];
+      uint4 v = rb[i];
+      if (has_pro) v = ((bok >> i) & 1u) ? pro_unit(v) : make_uint4(0u, 0u, 0u, 0u);
+      if (hp < HMAX) *reinterpret_cast<uint4*>(&lds_b[hp * SB + u * 8]) = v;
     }
   };
 
@@ -595,8 +626,24 @@ __global__ __launch_bounds__(256) void wgrad3x3_narrow_kernel(const FsWgradArgs 
   for (int i = 0; i < LB; ++i)
     brel[i] = (int)(((long)bhy[i] * p.sH + (long)bhx[i] * p.sW + ci0 + ((t + i * 256) % UB) * 8) * 2);
   uint4 ra[LA], rb[LB];
+  // operand prologue (BatchNorm + ReLU folded into the staging of x): this thread's 16-byte units all hold the same 8
+  // input channels (256 % UB == 0), coefficients per statistics group of the tile's image
+  static_assert(256 % UB == 0, "a thread's x units must share their channel slot");
+  const bool has_pro = p.pro_a != nullptr;
+  float ka[8], kb[8];
+  unsigned bok = 0u;                       // which of the thread's x units lie inside the image (padding stays zero)
   auto load_regs = [&](int pt) {
     int q = fs_div(pt, g.dTX); int tx_i = pt - q * g.tiles_x; int n = fs_div(q, g.dTY); int ty_i = q - n * g.tiles_y;
+    if (has_pro) {
+      const int pg = p.pro_group_imgs > 0 ? n / p.pro_group_imgs : 0;
+      const float* pa = p.pro_a + (long)pg * g.Cs + ci0 + (t % UB) * 8;
+      const float* pb = p.pro_b + (long)pg * g.Cs + ci0 + (t % UB) * 8;
+      const float4 a0 = reinterpret_cast<const float4*>(pa)[0], a1 = reinterpret_cast<const float4*>(pa)[1];
+      const float4 b0 = reinterpret_cast<const float4*>(pb)[0], b1 = reinterpret_cast<const float4*>(pb)[1];
+      ka[0] = a0.x; ka[1] = a0.y; ka[2] = a0.z; ka[3] = a0.w; ka[4] = a1.x; ka[5] = a1.y; ka[6] = a1.z; ka[7] = a1.w;
+      kb[0] = b0.x; kb[1] = b0.y; kb[2] = b0.z; kb[3] = b0.w; kb[4] = b1.x; kb[5] = b1.y; kb[6] = b1.z; kb[7] = b1.w;
+      bok = 0u;
+    }
     int y0 = ty_i * g.TH, x0 = tx_i * g.TW;
     const int abase = (((n * p.Hd + y0) * p.Wd + x0) * p.Cd) * 2;
     const int bbase = (int)(((long)n * p.sN + (long)(y0 - p.pad) * p.sH + (long)(x0 - p.pad) * p.sW) * 2);
@@ -951,8 +998,9 @@ int launch_wgrad(const FsWgradArgs& a, hipStream_t st) {
         a.M >= 4096 && a.M % (a.Hd * a.Wd) == 0)
       return launch_wgrad_stem(a, st);
     if (a.use_halo && a.R == 3 && a.S == 3 && a.stride == 1 && a.Cd % 64 == 0 && Cs % 32 == 0 && a.x_bytes > 0 &&
-        a.x_bytes <= 0x7fffffffLL && (long)a.M * a.Cd * 2 <= 0x7fffffffLL && a.M >= 1024)
+        a.x_bytes <= 0x7fffffffLL && (long)a.M * a.Cd * 2 <= 0x7fffffffLL && (a.M >= 1024 || a.pro_a))
       return launch_wgrad_halo(a, st);   // (tiny pixel counts: too few tiles to split, the generic kernel wins)
+    if (a.pro_a) return FS_EINVAL;       // only the halo kernel stages x through the prologue
     if (a.use_halo && a.R == 3 && a.S == 3 && a.stride == 1 && ((a.Cd == 16 && Cs % 16 == 0) || (a.Cd == 32 && Cs % 32 == 0)) &&
         a.x_bytes > 0 && a.x_bytes <= 0x7fffffffLL && (long)a.M * a.Cd * 2 <= 0x7fffffffLL && a.M >= 4096)
       return launch_wgrad_narrow(a, st);
@@ -979,6 +1027,7 @@ int launch_wgrad(const FsWgradArgs& a, hipStream_t st) {
 extern "C" int fs_conv_wgrad(const FsWgradArgs* args, int dtype, void* stream) {
   if (!args || !args->dy || !args->x || !args->dw || !args->ktab) return FS_EINVAL;
   if (args->M <= 0 || args->ncolgroups <= 0) return FS_EINVAL;
+  if (args->pro_a && (!args->pro_b || dtype != FS_DTYPE_BF16)) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == FS_DTYPE_BF16) return launch_wgrad<bf16>(*args, st);
   if (dtype == FS_DTYPE_F32) return launch_wgrad<float>(*args, st);

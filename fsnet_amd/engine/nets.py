@@ -21,6 +21,9 @@ from .runtime import RT, grad_of
 STAT_SLOTS = ops.STAT_SLOTS
 # BatchNorm-backward reduction pass fused into the epilogue of the data-gradient convolution that feeds it
 FUSE_BN_BWD = os.environ.get("FSNET_AMD_FUSE_BN_BWD", "1") != "0"
+# BatchNorm + ReLU between two convolutions of a residual block applied by the SECOND convolution while it stages its
+# operand (and by its weight gradient), instead of a pass of its own: the normalised activation never reaches HBM
+FOLD_BN = os.environ.get("FSNET_AMD_BN_FOLD", "1") != "0"
 
 
 class StatsPool:
@@ -78,8 +81,8 @@ def _current_stream(device=None):
     return s
 
 
-def _run_param_grads(op, dc, x, gw, gb, nb):
-    op.wgrad(dc, x, gw)
+def _run_param_grads(op, dc, x, gw, gb, nb, pro=None):
+    op.wgrad(dc, x, gw, pro=pro)
     if gb is not None:
         ops.channel_sum(dc, gb, nb)
 
@@ -284,16 +287,17 @@ class ConvLayer:
     def bias(self):
         return self._bias
 
-    def accumulate_param_grads(self, op, dc, x):
+    def accumulate_param_grads(self, op, dc, x, pro=None):
         """wgrad + bias grad into the parameters' gradient buffers.  They feed nothing downstream in the
-        backward pass, so they run on a companion stream while the chain continues with the dgrad."""
+        backward pass, so they run on a companion stream while the chain continues with the dgrad.
+        pro: x is a raw convolution output whose BatchNorm (+ ReLU) the weight gradient applies itself."""
         gw = grad_of(self.m.weight)
         gb = grad_of(self.m.bias) if self.m.bias is not None else None
         if gw is None:                       # frozen layer: nothing to accumulate (a lone trainable bias: its sum)
             if gb is not None:
                 ops.channel_sum(dc, gb, self.m.bias.numel())
             return
-        item = (op, dc, x, gw, gb, self.m.bias.numel() if gb is not None else 0)
+        item = (op, dc, x, gw, gb, self.m.bias.numel() if gb is not None else 0, pro)
         # (data parallel: inline on the chain stream, so that one event after a stage's last weight gradient covers
         # the arena slice its gradient bucket reduces — also inside a captured step)
         mode = RT.wgrad_streams if (dc.is_cuda and RT.overlap and RT.dp is None) else 0
@@ -394,7 +398,30 @@ class ResNetRunner:
         self.pool = None
 
     # ------------------------------------------------------------------ forward
-    def _unit_fwd(self, cl, bn, x, train, relu=True, res=None, ds_c=None, ds_stats=None, ds_bn=None):
+    def _unit_fwd_fold(self, cl, bn, x, pro=None):
+        """convolution + the statistics half of its BatchNorm only (training mode): returns (raw output, BnState with
+        the affine form) — the consumer applies scale * c + shift and the ReLU itself"""
+        op = cl.ready(x.dtype, x.device)
+        N, H, W, _ = x.shape
+        Ho, Wo = op.out_hw(H, W)
+        G = self.groups
+        stats = self.pool.take(op.Co_p, G)
+        c = op.forward(x, stats=stats, stat_groups=G, pro=pro)
+        world = _dp_stats(stats)
+        st = ops.BnState(op.Co_p, x.device, G, affine=True)
+        ops.bn_finalize(stats, bn_tensors(bn), st, op.Co_p, (N // G) * Ho * Wo * world, track=True, groups=G)
+        return c, st
+
+    def _can_fold(self, bn, nxt_cl, c_shape, dtype, device, train):
+        """unit -> next unit of a block: may the BatchNorm + ReLU in between be folded into the next convolution?"""
+        if not (FOLD_BN and FUSE_BN_BWD and train and bn.training):
+            return False
+        N, H, W = c_shape
+        nop = nxt_cl.ready(dtype, device)
+        return (nop.can_fold_input(N, H, W) and nop.can_fuse_bn_bwd(N, H, W, self.groups)
+                and N * H * W >= 1)
+
+    def _unit_fwd(self, cl, bn, x, train, relu=True, res=None, ds_c=None, ds_stats=None, ds_bn=None, pro=None):
         op = cl.ready(x.dtype, x.device)
         N, H, W, _ = x.shape
         Ho, Wo = op.out_hw(H, W)
@@ -405,7 +432,7 @@ class ResNetRunner:
         assert ds_bn is None or (train and ds_bn.training) == bt, "main and downsample BatchNorm modes differ"
         G = self.groups if bt else 1
         stats = self.pool.take(op.Co_p, G) if bt else None
-        c = op.forward(x, stats=stats, stat_groups=G)
+        c = op.forward(x, stats=stats, stat_groups=G, pro=pro)
         if bt and ds_stats is not None and RT.dp is not None:
             # block end with a downsample branch: its statistics sit right before this conv's in the pool (taken
             # back to back) and are consumed by the same bn_apply — one exchange for both
@@ -446,12 +473,19 @@ class ResNetRunner:
         for blocks in self.stages:
             for units, ds in blocks:
                 bctx = {"x": cur, "u": []}
-                inp = cur
+                inp, pro = cur, None             # pro: inp is a raw conv output, (BnState, relu) still to be applied
                 for j, (cl, bn) in enumerate(units):
                     if j < len(units) - 1:
-                        c, y, st, _ = self._unit_fwd(cl, bn, inp, train)
-                        bctx["u"].append((inp, c, y, st))
-                        inp = y
+                        op = cl.ready(inp.dtype, inp.device)
+                        Ho, Wo = op.out_hw(inp.shape[1], inp.shape[2])
+                        if self._can_fold(bn, units[j + 1][0], (inp.shape[0], Ho, Wo), inp.dtype, inp.device, train):
+                            c, st = self._unit_fwd_fold(cl, bn, inp, pro=pro)
+                            bctx["u"].append((inp, c, None, st, pro))
+                            inp, pro = c, (st, True)
+                        else:
+                            c, y, st, _ = self._unit_fwd(cl, bn, inp, train, pro=pro)
+                            bctx["u"].append((inp, c, y, st, pro))
+                            inp, pro = y, None
                     else:
                         if ds is not None:
                             dop = ds[0].ready(cur.dtype, cur.device)
@@ -459,12 +493,12 @@ class ResNetRunner:
                             dstats = self.pool.take(dop.Co_p, self.groups) if dbt else None
                             c_ds = dop.forward(cur, stats=dstats, stat_groups=(self.groups if dbt else 1))
                             # (data parallel: exchanged together with the main branch's statistics in _unit_fwd)
-                            c, y, st, st2 = self._unit_fwd(cl, bn, inp, train, ds_c=c_ds, ds_stats=dstats, ds_bn=ds[1])
+                            c, y, st, st2 = self._unit_fwd(cl, bn, inp, train, ds_c=c_ds, ds_stats=dstats, ds_bn=ds[1], pro=pro)
                             bctx["ds"] = (c_ds, st2)
                         else:
-                            c, y, st, _ = self._unit_fwd(cl, bn, inp, train, res=cur)
-                        bctx["u"].append((inp, c, y, st))
-                        inp = y
+                            c, y, st, _ = self._unit_fwd(cl, bn, inp, train, res=cur, pro=pro)
+                        bctx["u"].append((inp, c, y, st, pro))
+                        inp, pro = y, None
                 ctx["blocks"].append(bctx)
                 cur = inp
             feats.append(cur)
@@ -478,7 +512,7 @@ class ResNetRunner:
         x = bctx["x"]
         N, H, W, _ = x.shape
         k = len(units)
-        inp, c, y, st = bctx["u"][k - 1]
+        inp, c, y, st, pro_in = bctx["u"][k - 1]
         Ho, Wo = y.shape[1], y.shape[2]
         joint = (ds is not None and RT.dp is not None and st.count != float("inf")
                  and bctx["ds"][1].count != float("inf"))
@@ -534,10 +568,16 @@ class ResNetRunner:
         for j in range(k - 1, 0, -1):
             cl = units[j][0]
             op = cl.ready(x.dtype, x.device)
-            cl.accumulate_param_grads(op, dc, inp)
+            cl.accumulate_param_grads(op, dc, inp, pro=pro_in)
             xin = inp
-            inp, c, y, st = bctx["u"][j - 1]
-            if FUSE_BN_BWD and op.can_fuse_bn_bwd(N, xin.shape[1], xin.shape[2], st.groups):
+            inp, c, y, st, pro_in = bctx["u"][j - 1]
+            if y is None:
+                # folded BatchNorm: the activation was never stored — the ReLU mask is the sign of scale * c + shift,
+                # evaluated (with the BatchNorm-backward sums) in the data gradient's epilogue from c
+                sums = _bwd_sums(c, st)
+                dy_prev = op.dgrad(dc, xin.shape[1], xin.shape[2], bn_fuse=(c, st, sums), mask_bn=True)
+                dc = _bn_bwd(dy_prev, None, c, units[j - 1][1], st, c.shape[1], c.shape[2], sums=sums)
+            elif FUSE_BN_BWD and op.can_fuse_bn_bwd(N, xin.shape[1], xin.shape[2], st.groups):
                 sums = _bwd_sums(c, st)
                 dy_prev = op.dgrad(dc, xin.shape[1], xin.shape[2], mask=y, bn_fuse=(c, st, sums))
                 dc = _bn_bwd(dy_prev, None, c, units[j - 1][1], st, y.shape[1], y.shape[2], sums=sums)

@@ -48,6 +48,7 @@ class FsWgradArgs(C.Structure):
         ("stride", C.c_int32), ("pad", C.c_int32), ("ncolgroups", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_elems", C.c_int64), ("x_bytes", C.c_int64), ("use_halo", C.c_int32),
         ("pix_per_split", C.c_int32), ("nsplit", C.c_int32), ("ws_rows", C.c_int32), ("ws_cols", C.c_int32),
+        ("pro_a", C.c_void_p), ("pro_b", C.c_void_p), ("pro_relu", C.c_int32), ("pro_group_imgs", C.c_int32),
     ]
 
 

@@ -190,8 +190,10 @@ class ConvOp:
         return Ho, Wo
 
     # ------------------------------------------------------------------
-    def forward(self, x, out=None, bias=None, addend=None, stats=None, relu=False, out_f32=False, stat_groups=1):
-        """stat_groups G > 1: the batch is G stacked BatchNorm invocations; stats is [G][SLOTS][2][Co]."""
+    def forward(self, x, out=None, bias=None, addend=None, stats=None, relu=False, out_f32=False, stat_groups=1, pro=None):
+        """stat_groups G > 1: the batch is G stacked BatchNorm invocations; stats is [G][SLOTS][2][Co].
+        pro = (BnState with scale / shift, relu): x is the RAW output of the convolution in front of a BatchNorm (+ ReLU)
+        that is applied while the operand is staged (fs_conv3x3_halo prologue; can_fold_input())."""
         N, H, W, Cs = x.shape
         assert Cs == self.Ci_p and x.dtype == self.dtype, (x.shape, self.Ci_p, x.dtype)
         Ho, Wo = self.out_hw(H, W)
@@ -226,6 +228,12 @@ class ConvOp:
         a.relu, a.out_f32 = int(relu), int(out_f32)
         a.N, a.Cs = N, self.Ci_p
         a.stat_group_rows = group_rows
+        if pro is not None:
+            pst, prelu = pro
+            assert halo and pst.scale is not None and N % pst.groups == 0
+            a.pro_mode, a.pro_relu = 1, int(prelu)
+            a.pro_a, a.pro_b = pst.scale.data_ptr(), pst.shift.data_ptr()
+            a.pro_group_imgs = N // pst.groups if pst.groups > 1 else 0
         flops = 2.0 * a.M * self.Co * self.R * self.S * self.Ci
         if grp_imgs:
             a.stat_group_rows, a.grp_imgs, a.M = 0, grp_imgs, grp_imgs * Ho * Wo
@@ -263,6 +271,15 @@ class ConvOp:
         if status[0] != 0:
             del LaunchProfile.records[n0:]      # "not mine": the implicit GEMM runs (and is timed) instead
         return status[0] == 0
+
+    def can_fold_input(self, N, H, W):
+        """whether this convolution can take its input as (raw convolution output, BatchNorm affine form, ReLU) — forward
+        AND weight gradient apply the normalisation while staging the operand (the 32x32-tile forward kernel and the
+        LDS-halo weight-gradient kernel: bf16, 3x3 / stride 1, whole 64-byte channel chunks, >= 64 output channels)"""
+        eb = 2 if self.dtype == torch.bfloat16 else 4
+        return (USE_HALO and self.dtype == torch.bfloat16 and self.R == 3 and self.S == 3 and self.stride == 1
+                and self.Ci == self.Ci_p and (self.Ci_p * eb) % 64 == 0 and self.Co_p % 64 == 0 and self.Co % 8 == 0
+                and self.need_dgrad and N * H * W * self.Co_p * eb < 0x7fffffff)
 
     def can_fuse_bn_bwd(self, N, H, W, groups):
         """whether dgrad(..., bn_fuse=) may carry the BatchNorm-backward sums of a [N,H,W,Ci_p] gradient"""
@@ -348,7 +365,7 @@ class ConvOp:
                tag=lambda: "dgrd %s dy[%d,%d,%d,%d]" % (self.describe(), N, Ho, Wo, Cd))
         return out
 
-    def dgrad(self, dy, H, W, out=None, addend=None, mask=None, bn_fuse=None):
+    def dgrad(self, dy, H, W, out=None, addend=None, mask=None, bn_fuse=None, mask_bn=False):
         """dy: [N,Ho,Wo,Co_p] -> dx [N,H,W,Ci_p] (out may be a strided view; addend is summed in).
         bn_fuse = (c, BnState, sums): dx is the gradient w.r.t. relu(BN(c)) (+ residual): the epilogue also
         accumulates the BatchNorm-backward sums (sum g, sum g*xhat) of that BatchNorm into `sums` (zeroed f64
@@ -389,6 +406,13 @@ class ConvOp:
             a.bnb_x, a.bnb_mean, a.bnb_invstd = c.data_ptr(), st.mean.data_ptr(), st.invstd.data_ptr()
             a.stats = sums.data_ptr()
             a.stat_group_rows = (N // st.groups) * H * W if st.groups > 1 else 0
+            if mask_bn:
+                # the ReLU mask of a folded BatchNorm: sign of scale * c + shift, evaluated in the epilogue from the
+                # tensor it reads anyway (the normalised activation was never stored)
+                assert mask is None and st.scale is not None and self.halo_d and USE_HALO
+                a.bnb_scale, a.bnb_shift = st.scale.data_ptr(), st.shift.data_ptr()
+        else:
+            assert not mask_bn
         flops = 2.0 * N * Ho * Wo * self.Co * self.R * self.S * self.Ci
         halo = self.halo_d and USE_HALO
         fn = lib.fs_conv3x3_halo if halo else lib.fs_conv_igemm
@@ -401,8 +425,8 @@ class ConvOp:
     def describe(self):
         return "%dx%d/s%d p%d %d->%d" % (self.R, self.S, self.stride, self.pad, self.Ci, self.Co)
 
-    def wgrad(self, dy, x, dw):
-        """accumulates into dw (fp32 OIHW [Co,Ci,R,S]); dy must be dense [N,Ho,Wo,Co_p]."""
+    def wgrad(self, dy, x, dw, pro=None):
+        """accumulates into dw (fp32 OIHW [Co,Ci,R,S]); dy must be dense [N,Ho,Wo,Co_p].  pro as in forward()."""
         N, Ho, Wo, Cd = dy.shape
         assert dy.is_contiguous() and Cd == self.Co_p and x.shape[3] == self.Ci_p
         assert dw.dtype == torch.float32 and dw.is_contiguous()
@@ -416,6 +440,10 @@ class ConvOp:
         ws = wgrad_workspace(dy.device)
         a.workspace, a.workspace_elems = ws.data_ptr(), ws.numel()
         a.x_bytes, a.use_halo = _span_bytes(x), int(USE_HALO)
+        if pro is not None:
+            pst, prelu = pro
+            a.pro_a, a.pro_b, a.pro_relu = pst.scale.data_ptr(), pst.shift.data_ptr(), int(prelu)
+            a.pro_group_imgs = N // pst.groups if pst.groups > 1 else 0
         flops = 2.0 * a.M * self.Co * self.R * self.S * self.Ci
         _timed("conv_wgrad", flops, lambda: check(lib.fs_conv_wgrad(C.byref(a), self.code, stream_ptr()), "conv_wgrad"),
                tag=lambda: "wgrd %s dy[%d,%d,%d,%d]" % (self.describe(), N, Ho, Wo, Cd))

@@ -35,13 +35,35 @@ def nchw_to_nhwc(a, b, cp, dtype, out=None):
 
 class BnState:
     """Device-side state of one BatchNorm invocation (saved for backward)."""
-    __slots__ = ("mean", "invstd", "count", "groups")
+    __slots__ = ("mean", "invstd", "count", "groups", "scale", "shift")
 
-    def __init__(self, C, device, groups=1):
+    def __init__(self, C, device, groups=1, affine=False):
         self.mean = torch.empty(groups * C, dtype=torch.float32, device=device)
         self.invstd = torch.empty(groups * C, dtype=torch.float32, device=device)
         self.count = 0.0          # rows per statistics group (x world size)
         self.groups = groups
+        # folded BatchNorm (bn_finalize): y = scale * x + shift per (group, channel), applied by the consumer
+        self.scale = torch.empty(groups * C, dtype=torch.float32, device=device) if affine else None
+        self.shift = torch.empty(groups * C, dtype=torch.float32, device=device) if affine else None
+
+
+def bn_finalize(stats, bn, st, Cc, count, track=True, groups=1):
+    """the statistics half of bn_apply (fs_bn_finalize): fills st.mean / invstd / scale / shift ([groups][C]) and
+    updates the running statistics; the activation is normalised by the kernels that read it."""
+    a = FsBnApplyArgs()
+    a.groups = groups
+    assert st.groups == groups and st.scale is not None
+    a.stats = _p(stats)
+    a.gamma, a.beta = bn["weight"].data_ptr(), bn["bias"].data_ptr()
+    if track or stats is None:
+        a.running_mean, a.running_var = bn["running_mean"].data_ptr(), bn["running_var"].data_ptr()
+        a.num_batches_tracked = bn["num_batches_tracked"].data_ptr() if track else None
+    a.save_mean, a.save_invstd = st.mean.data_ptr(), st.invstd.data_ptr()
+    st.count = float(count)
+    a.count, a.eps, a.momentum = float(count), BN_EPS, BN_MOMENTUM
+    a.C = Cc
+    check(lib.fs_bn_finalize(C.byref(a), st.scale.data_ptr(), st.shift.data_ptr(), stream_ptr()), "bn_finalize")
+    return st
 
 
 def bn_apply(x, stats, bn, st, y, H, W, count, relu=True, pad_out=False, res=None, stats2=None, bn2=None, st2=None,

@@ -29,6 +29,7 @@ SIGNATURES = {
     "fs_pack_weights_multi": (C.c_int, [P, I, L, I, P]),
     "fs_nchw_to_nhwc": (C.c_int, [P, P, P, I, I, I, I, I, I, I, P]),
     "fs_bn_apply": (C.c_int, [P, I, P]),
+    "fs_bn_finalize": (C.c_int, [P, P, P, P]),
     "fs_bn_bwd_reduce": (C.c_int, [P, I, P]),
     "fs_bn_bwd_apply": (C.c_int, [P, I, P]),
     "fs_maxpool_fwd": (C.c_int, [P, P, P, I, I, I, I, I, P]),

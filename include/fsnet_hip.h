@@ -169,6 +169,12 @@ typedef struct FsWgradArgs {
   int64_t x_bytes;      /* addressable span from x (< 2 GiB) — enables the 3x3/s1 LDS-halo path */
   int32_t use_halo;     /* 1: allow the 3x3/s1 LDS-halo kernel (bf16) */
   int32_t pix_per_split, nsplit, ws_rows, ws_cols;  /* filled by the library */
+  /* (ABI 4) operand prologue of the 3x3/s1 LDS-halo kernel: x' = max(pro_a[c]*x + pro_b[c], 0 if pro_relu) for pixels
+   * inside the image, 0 for the padding — x is then the RAW output of the convolution in front of the BatchNorm + ReLU
+   * whose result this weight gradient multiplies (fs_bn_finalize).  [groups][Ci] fp32, group = image / pro_group_imgs
+   * (0: one group).  fs_conv_wgrad returns FS_EINVAL if the shape is not one the halo kernel takes. */
+  const float* pro_a; const float* pro_b;
+  int32_t pro_relu, pro_group_imgs;
 } FsWgradArgs;
 int fs_conv_wgrad(const FsWgradArgs* args, int dtype, void* stream);
 
@@ -317,6 +323,12 @@ typedef struct FsBnApplyArgs {
                            in group order. */
 } FsBnApplyArgs;
 int fs_bn_apply(const FsBnApplyArgs* args, int dtype, void* stream);
+/* The statistics part of fs_bn_apply alone: save_mean / save_invstd, the affine form scale = gamma*invstd, shift =
+ * beta - mean*scale ([groups][C] each) and the running-statistics update (x, res, y and the second BatchNorm's fields
+ * are ignored).  The activation is then normalised by whoever reads it: FsConvArgs.pro_mode = 1 in the consuming
+ * convolution (resnet.py:33-50: conv1 -> bn1 -> relu -> conv2), FsWgradArgs.pro_a in the weight gradient that takes
+ * it as its input operand, bnb_scale / bnb_shift for the ReLU mask of the data gradient that flows back into it. */
+int fs_bn_finalize(const FsBnApplyArgs* args, float* scale, float* shift, void* stream);
 
 /* BatchNorm backward, two passes (the data-parallel host all-reduces `sums` in between):
  *   reduce: sums[slot][0][c] += sum g, sums[slot][1][c] += sum g*xhat, g = dout * (y > 0 if relu)
