@@ -338,7 +338,7 @@ int launch_tile(const FsWgradArgs& a, hipStream_t st) {
 // reads at shifted halo rows), i.e. 9x fewer input fetches and 72 MFMAs per wave between barriers; the
 // generic kernel above re-gathers the input per tap and synchronises every 4 MFMAs.
 // ---------------------------------------------------------------------------------------------
-struct WGeom { int TH, TW, tiles_x, tiles_y, N, Cs, nsplit; unsigned mTW, mHW; FsDiv dTX, dTY; };
+struct WGeom { int TH, TW, tiles_x, tiles_y, N, Cs, nsplit; unsigned mTW, mHW; FsDiv dTX, dTY; int abl; };
 
 __device__ __forceinline__ uint4 wg_buf_load16(__amdgpu_buffer_rsrc_t rsrc, int voff) {
   return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
@@ -494,6 +494,7 @@ __global__ __launch_bounds__(256 * KG) void wgrad3x3_halo_kernel(const FsWgradAr
     __syncthreads();
     if (pt >= npix) continue;
     if (pt + step < npix) load_regs(pt + step);
+    if (g.abl & 1) continue;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       bf16x8 fa[TA];
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(256 * KG) void wgrad3x3_halo_kernel(const FsWgradAr
           bf16x8 fb = __builtin_bit_cast(bf16x8, make_uint4(l2.x, l2.y, h2.x, h2.y));
 #pragma unroll
           for (int a = 0; a < TA; ++a)
-            acc[tp][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb, acc[tp][a][b], 0, 0, 0);
+            acc[tp][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[a], acc[tp][a][b], 0, 0, 0);   // D[ci][co]
         }
       }
     }
@@ -548,34 +549,31 @@ __global__ __launch_bounds__(256 * KG) void wgrad3x3_halo_kernel(const FsWgradAr
 #pragma unroll
           for (int j = 0; j < 4; ++j, ++q) acc[tp][a][b][j] += red[q * 256 + t];
   }
-  // ---- epilogue: D rows = co (lg*4 + j), cols = ci (li) ----
+  if ((g.abl & 2) && acc[0][0][0][0] != 123.456f) return;
+  // ---- epilogue: the MFMA ran with the input-channel fragment as its row operand, D rows = ci (lg*4 + j), cols = co
+  // (li): a lane holds four consecutive input channels of one output channel, i.e. one 16-byte run of the slab row
+  // [co][tap][ci] (the other orientation stored 288 single floats per lane: a sixth of the kernel) ----
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
     for (int b = 0; b < TB; ++b) {
-      int ci = ci0 + wcn * (CIT / 2) + b * 16 + li;
+      const int ci = ci0 + wcn * (CIT / 2) + b * 16 + lg * 4;
 #pragma unroll
-      for (int a = 0; a < TA; ++a)
+      for (int a = 0; a < TA; ++a) {
+        const int co = co0 + wr * (COT / 2) + a * 16 + li;
+        const f32x4 v = acc[tp][a][b];
+        if (g.nsplit > 1) {
+          *reinterpret_cast<float4*>(&p.workspace[((long)blockIdx.z * p.ws_rows + co) * p.ws_cols + tp * g.Cs + ci]) =
+              make_float4(v[0], v[1], v[2], v[3]);
+        } else if (co < p.Co) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          int co = co0 + wr * (COT / 2) + a * 16 + lg * 4 + j;
-          float v = acc[tp][a][b][j];
-          if (g.nsplit > 1) {
-            p.workspace[((long)blockIdx.z * p.ws_rows + co) * p.ws_cols + tp * g.Cs + ci] = v;
-          } else if (co < p.Co && ci < p.Ci) {
-            p.dw[(((long)co * p.Ci + ci) * 3 + tp / 3) * 3 + tp % 3] += v;
-          }
+          for (int j = 0; j < 4; ++j)
+            if (ci + j < p.Ci) p.dw[(((long)co * p.Ci + ci + j) * 3 + tp / 3) * 3 + tp % 3] += v[j];
         }
+      }
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Narrow variant for the 16-channel decoder layers (Cd = 16: dY rows are 32 bytes, dW is a few KB, the pixel
-// count is up to 1.5 M): the block owns ALL 16 output channels x 9 taps x CIT input channels, its four waves
-// split the 128-pixel tile along the reduction axis (32 pixels = one MFMA K step each) and add their partial
-// accumulators through LDS once, after the last tile.  The generic kernel spends a 16x256 tile on 144 useful
-// columns and re-gathers the input per tap: 124 us for the 192x640 16->16 layer against ~15 us of HBM time.
-// ---------------------------------------------------------------------------------------------
 template <int COT, int CIT>
 __global__ __launch_bounds__(256) void wgrad3x3_narrow_kernel(const FsWgradArgs p, const WGeom g) {
   typedef bf16 T;
@@ -916,6 +914,7 @@ int launch_wgrad_halo_t(const FsWgradArgs& a, hipStream_t st) {
   if (!a.workspace) splits = 1;
   else splits = std::min<long>(splits, std::max<long>(1, a.workspace_elems / slab));
   g.nsplit = (int)splits; b.nsplit = g.nsplit;
+  { const char* ae = getenv("FSNET_AMD_WGRAD_ABL"); g.abl = ae ? atoi(ae) : 0; }
   dim3 grid(Cs / CIT, a.Cd / COT, g.nsplit);
   // Measured (B=12 bench shapes): KG = 2 makes the kernel itself 6-11 % faster (33.5 vs 35.5 us on the ResNet stages,
   // 45 vs 50 us on the decoder's), but the step 1.5 % SLOWER (6.11 / 6.15 vs 5.99 / 6.05 ms, same box, alternating):

@@ -11,7 +11,7 @@ acc = collections.defaultdict(list)
 for f in glob.glob("$OUT/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if "conv3x3" in n or "copy" in n.lower() or "elementwise" in n:
+        if "conv3x3" in n or "wgrad" in n or "copy" in n.lower():
             acc[n[:110]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 for k, v in acc.items():
     w = sorted(v[2:]) if len(v) > 4 else sorted(v)
