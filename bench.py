@@ -26,12 +26,12 @@ PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, /opt/skills/
 PEAK_HBM_GBS = 8000.0
 
 
-def synthetic_device_batches(B, H, W, dev, rank, n=4):
+def synthetic_device_batches(B, H, W, dev, rank, n=4, fisheye=False):
     """SURVEY §8(d) synthetic triplets from the package's own SyntheticTripletDataset through its collate_fn,
     generated once and kept resident in HBM (the timed region contains no host-to-device transfer)."""
     from fsnet_amd.vision_base.data.datasets.dataset_utils import collate_fn
     from fsnet_amd.vision_base.data.datasets.synthetic import SyntheticTripletDataset
-    ds = SyntheticTripletDataset(size=n * B, height=H, width=W, seed=1000 + rank)
+    ds = SyntheticTripletDataset(size=n * B, height=H, width=W, seed=1000 + rank, fisheye=fisheye)
     out = []
     for i in range(n):
         d = collate_fn([ds[i * B + j] for j in range(B)])
@@ -90,9 +90,19 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--depth", type=int, default=18)
+    ap.add_argument("--workload", default="kitti", choices=["kitti", "fisheye"],
+                    help="kitti: BASELINE configs[1] (default, the headline metric); fisheye: BASELINE configs[3] at the "
+                         "reference's own size — KITTI-360 fisheye, ResNet-18 + FishEyeDecoder (Mei camera model), 64 depth "
+                         "bins, 384x384, batch 16, max depth 150, weight decay 1e-5 (configs/kitti360_fisheye_example:72,"
+                         "83-86,198-207), dataset poses")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     args = ap.parse_args()
+    fisheye = args.workload == "fisheye"
+    if fisheye:
+        defaults = ap.parse_args([])
+        if (args.batch, args.height, args.width) == (defaults.batch, defaults.height, defaults.width):
+            args.batch, args.height, args.width = 16, 384, 384
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -120,11 +130,16 @@ def main():
     set_random_seed(123)
     RT.set_compute_dtype(args.dtype)
     B, H, W = args.batch, args.height, args.width
-    model = build(**meta_arch_cfg(H, W, with_pose=True, depth=args.depth)).to(dev).train()
-    tc = training_cfg(clip_gradients=35.0, lr=1e-4)
+    if fisheye:
+        model = build(**meta_arch_cfg(H, W, with_pose=False, depth=args.depth, num_output_channels=64, max_depth=150.0,
+                                      fisheye=True)).to(dev).train()
+        tc = training_cfg(clip_gradients=35.0, lr=1e-4, weight_decay=1e-5)
+    else:
+        model = build(**meta_arch_cfg(H, W, with_pose=True, depth=args.depth)).to(dev).train()
+        tc = training_cfg(clip_gradients=35.0, lr=1e-4)
     optimizer = build_optimizer(model, **tc.optimizer)
     hook = build(**tc.training_hook)
-    batches = synthetic_device_batches(B, H, W, dev, rank)
+    batches = synthetic_device_batches(B, H, W, dev, rank, fisheye=fisheye)
 
     def run_steps(n, start):
         for i in range(n):
@@ -165,7 +180,7 @@ def main():
         def tf(a):
             return a[1] / a[2] / 1e12
         # (the committed PMC passes were taken on the default workload: no figure for any other)
-        default_workload = (args.depth, args.height, args.width, args.batch, args.dtype) == (18, 192, 640, 12, "bf16")
+        default_workload = (args.depth, args.height, args.width, args.batch, args.dtype, fisheye) == (18, 192, 640, 12, "bf16", False)
         ch = agg["conv3x3_halo"]            # dominant kernel family by time: 3x3/s1 fwd+dgrad (LDS halo kernel)
         ach = tf(ch)
         roofline = {"kernel": "conv3x3_halo_kernel (3x3/s1 fwd+dgrad, %d launches/step)" % (ch[0] // nprof),
@@ -203,13 +218,18 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         line = {
-            "metric": "training samples/sec (3-frame triplets) at %dx%d, ResNet-%d depth+pose" % (H, W, args.depth),
+            "metric": ("training samples/sec (3-frame triplets) at %dx%d, ResNet-%d depth+pose" % (H, W, args.depth) if not fisheye
+                       else "training samples/sec (3-frame fisheye triplets) at %dx%d, ResNet-%d + FishEyeDecoder" % (H, W, args.depth)),
             "value": round(B * world * args.steps / elapsed, 2), "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "KITTI Eigen-Zhou-shaped synthetic triplets, ResNet-%d depth+pose, %dx%d, %s, "
-                                   "batch %d/GPU, full step (fwd+loss+bwd+clip35+Adam); inputs HBM-resident, no H2D in "
-                                   "the timed region" % (args.depth, H, W, args.dtype, B),
+            "config": {"workload": ("KITTI Eigen-Zhou-shaped synthetic triplets, ResNet-%d depth+pose, %dx%d, %s, "
+                                    "batch %d/GPU, full step (fwd+loss+bwd+clip35+Adam); inputs HBM-resident, no H2D in "
+                                    "the timed region" % (args.depth, H, W, args.dtype, B)) if not fisheye else
+                                   ("KITTI-360-fisheye-shaped synthetic triplets (Mei camera model, two calibrations per batch), "
+                                    "ResNet-%d + FishEyeDecoder, 64 bins, max depth 150, dataset poses, %dx%d, %s, batch %d/GPU, "
+                                    "full step (fwd+loss+bwd+clip35+Adam, weight decay 1e-5); inputs HBM-resident"
+                                    % (args.depth, H, W, args.dtype, B)),
                        "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(loss, 6),
                        "hipgraph_replays": hook.graph_replays, "frames_per_s": round(3 * B * world * args.steps / elapsed, 1),
                        "dp_collectives": (None if RT.dp is None else ("rccl-direct" + ("+hipgraph" if RT.dp.capturable else "")

@@ -38,9 +38,9 @@ def meta_arch_cfg(height=192, width=640, with_pose=True, depth=18, num_output_ch
     return EasyDict(cfg)
 
 
-def training_cfg(clip_gradients=35.0, lr=1e-4):
+def training_cfg(clip_gradients=35.0, lr=1e-4, weight_decay=0):
     return EasyDict(
         training_hook=dict(name=P + 'vision_base.pipeline_hooks.train_val_hooks.base_training_hooks.BaseTrainingHook',
                            clip_gradients=clip_gradients),
-        optimizer=dict(name='adam', lr=lr, weight_decay=0),
+        optimizer=dict(name='adam', lr=lr, weight_decay=weight_decay),
         scheduler=dict(name='StepLR', step_size=15))

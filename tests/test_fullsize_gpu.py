@@ -6,6 +6,7 @@
   * identical source and target frames under the identity pose reproject onto themselves: zero photometric loss
     and zero pose gradient;
   * a few full-size training steps stay finite, replay from the hipGraph, and keep every parameter finite."""
+import numpy as np
 import pytest
 import torch
 
@@ -181,4 +182,76 @@ def test_r50_full_size_training_steps_320x1024(dev, with_pose, base_fx, bins):
     assert max(losses) < 1.5 * losses[0], losses
     assert float(opt.grad_norm()) > 0
     assert bool(torch.isfinite(torch.cat([p.detach().flatten() for p in m.parameters()])).all())
+    RT.tie_noise = False
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3]: KITTI-360 fisheye at the reference's size (configs/kitti360_fisheye_example:72,83-86,198-207:
+# ResNet-18 + FishEyeDecoder, 64 bins, 384x384, batch 16, max depth 150, weight decay 1e-5)
+# ---------------------------------------------------------------------------------------------------------------
+def _fisheye_batches(n, Bf, Hf, Wf, dev, seed):
+    from fsnet_amd.vision_base.data.datasets.dataset_utils import collate_fn
+    from fsnet_amd.vision_base.data.datasets.synthetic import SyntheticTripletDataset
+    ds = SyntheticTripletDataset(size=n * Bf, height=Hf, width=Wf, seed=seed, fisheye=True)
+    out = []
+    for i in range(n):
+        d = collate_fn([ds[i * Bf + j] for j in range(Bf)])
+        out.append({k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in d.items()})
+    return out
+
+
+def test_fisheye_identical_frames_reproject_onto_themselves_at_384(dev):
+    """size-independent property of the Mei chain at full size: ray table x norm -> identity pose -> cam2image lands on
+    the pixel it started from, so with source == target the photometric term and the pose gradient vanish for every
+    depth (monodepth2_decoder.py:355-411, mei_fisheye_utils.py:14-187) — for both calibrations of the batch"""
+    from fsnet_amd.hip import ops
+    from fsnet_amd.monodepth.networks.utils.mei_fisheye_utils import MeiCameraProjection
+    from fsnet_amd.vision_base.data.datasets.synthetic import synthetic_mei_calib
+    Bf, Hf, Wf, S = 4, 384, 384, 4
+    pl = ops.PhotometricLoss(Bf, Hf, Wf, [0, 1, 2, 3], dev, 0.5, 150.0)
+    g = torch.Generator().manual_seed(5)
+    img = torch.rand(Bf, 3, Hf, Wf, generator=g).to(dev)
+    Ps, calibs = zip(*[synthetic_mei_calib(Hf, Wf, b % 2) for b in range(Bf)])
+    P2 = torch.from_numpy(np.stack(Ps, 0))
+    tabs, rows = MeiCameraProjection().tables(Hf, Wf, P2, list(calibs), dev)
+    pl.stage_fisheye(tabs, rows)
+    P2 = P2.to(dev)
+    T = torch.eye(4).repeat(Bf, 1, 1).to(dev)
+    norms = [(torch.rand(Bf, 1, Hf >> s, Wf >> s, generator=g) * 20 + 2).to(dev) for s in range(S)]
+    disps = [1.0 / d for d in norms]
+    out = pl.forward(img, [img.clone(), img.clone()], P2, [T, T.clone()], None, norms, disps, noise_seed=-1)
+    torch.cuda.synchronize()
+    photo, smooth = out[:S].cpu(), out[S:2 * S].cpu()
+    assert float((photo - smooth).abs().max()) < 2e-5, (photo, smooth)
+    d_depth, d_disp, dT = pl.backward(None)
+    torch.cuda.synchronize()
+    assert float(dT[0].abs().max()) < 1e-5 and float(dT[1].abs().max()) < 1e-5
+
+
+def test_fisheye_full_size_training_steps_384(dev):
+    from fsnet_amd.configs import meta_arch_cfg, training_cfg
+    from fsnet_amd.engine.runtime import RT
+    from fsnet_amd.vision_base.networks.optimizers.optimizers import build_optimizer
+    from fsnet_amd.vision_base.utils.builder import build
+    RT.set_compute_dtype(torch.bfloat16)
+    RT.tie_noise = True
+    torch.manual_seed(0)
+    Bf, Hf, Wf = 16, 384, 384
+    m = build(**meta_arch_cfg(Hf, Wf, with_pose=False, num_output_channels=64, max_depth=150.0, fisheye=True)).to(dev).train()
+    tc = training_cfg(clip_gradients=35.0, lr=1e-4, weight_decay=1e-5)
+    opt = build_optimizer(m, **tc.optimizer)
+    hook = build(graph_warmup=2, **tc.training_hook)
+    batches = _fisheye_batches(2, Bf, Hf, Wf, dev, seed=9)
+    batches[1]["calib_meta"] = batches[1]["calib_meta"][1:] + batches[1]["calib_meta"][:1]    # the cameras change places:
+    batches[1]["P2"] = torch.cat([batches[1]["P2"][1:], batches[1]["P2"][:1]], 0)             # staged per step, also on replay
+    losses = []
+    for it in range(8):
+        out = hook(dict(batches[it % 2]), m, opt)
+        losses.append(float(out["loss"].detach()))
+    torch.cuda.synchronize()
+    assert hook.graph_captures == 1 and hook.graph_replays == 5
+    assert all(l == l and 0 < l < 10 for l in losses), losses
+    assert min(losses[-2:]) < max(losses[:2]), losses
+    flat = torch.cat([p.detach().flatten() for p in m.parameters()])
+    assert bool(torch.isfinite(flat).all())
     RT.tie_noise = False
