@@ -447,8 +447,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_d32_kernel(const FsConvArgs p,
   if ((g.abl & 2) && acc[0][0][0] == 123.456f) p.stats[0] = 1.0;
 }
 
-static const bool kNoPixMajorD = [] { const char* e = getenv("FSNET_AMD_HALO_PIXMAJOR"); return e && e[0] == '0'; }();
-
 template <typename T, int PIX, int CO, int EP, int PRO>
 int d32_launch(const FsConvArgs& a, hipStream_t st) {
   T32Geom g = t32_pick_geom(a.Hd, a.Wd, PIX, t32_hmax(PIX));
@@ -464,7 +462,7 @@ int d32_launch(const FsConvArgs& a, hipStream_t st) {
   if (a.pro_group_imgs > 0) g.dPRG = fs_make_div(a.pro_group_imgs);
   const int npix = a.N * g.tiles_x * g.tiles_y, nco = a.Co_p / CO;
   int items = npix * nco;
-  g.pix_major = (nco > 1 && a.src_bytes > 2 * a.wgt_bytes && !kNoPixMajorD) ? 1 : 0;
+  g.pix_major = (nco > 1 && a.src_bytes > 2 * a.wgt_bytes) ? 1 : 0;
   if (g.pix_major) items = 8 * ((npix + 7) / 8) * nco;
   else if (nco % 8 != 0 && 8 % nco == 0) { const int q = 8 / nco; items = 8 * ((npix + q - 1) / q); }
   g.nitems = items;

@@ -47,18 +47,7 @@ struct HaloGeom {
   int pix_major;     // block -> tile mapping keeps a pixel tile's channel tiles on one XCD (else: a channel tile's)
 };
 
-// scheduling groups of one pipelined tap: NR fragment reads spread evenly between its NM MFMAs
-template <int NR, int NM, int K = 0>
-__device__ __forceinline__ void sched_tap() {
-  if constexpr (K < NR) {
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    constexpr int m = (NM * (K + 1)) / NR - (NM * K) / NR;
-    if constexpr (m > 0) __builtin_amdgcn_sched_group_barrier(0x008, m, 0);
-    sched_tap<NR, NM, K + 1>();
-  }
-}
-
-template <typename T, int PIX, int CO, int WP, int DEPTH>
+template <typename T, int PIX, int CO, int WP>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, const HaloGeom g) {
   constexpr int WC = 4 / WP;
   constexpr int WPIX = PIX / WP, WCO = CO / WC;
@@ -182,55 +171,35 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
     store_lds();
     lds_barrier();
     if (cc + 1 < nchunk) load_regs(cc + 1);
-    // The tap walk is software-pipelined by hand: the fragments of tap t+DEPTH are requested before the MFMAs of tap t
-    // issue (the compiler's own schedule sinks every ds_read next to its use: ~100 cycles of LDS latency per 64 cycles
-    // of MFMA, hidden only by the other waves of the SIMD).  The ring is indexed statically (full unroll) and the
-    // sched_group_barriers pin the read / MFMA interleave.
-    uint4 fa[DEPTH + 1][TC], fb[DEPTH + 1][TP];
-    auto frags = [&](int tap, int slot) {
+    // (the compiler's own schedule of this tap walk — every fragment read next to its use — is as fast as a hand-
+    // pipelined one with the reads one or two taps ahead: measured)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
       const int r = tap / 3, s = tap - r * 3;
       const int hoff = (fwd ? (r * HW + s) : ((2 - r) * HW + (2 - s))) * HS;
+      uint4 fa[TC], fb[TP];
 #pragma unroll
       for (int a = 0; a < TC; ++a) {
         int row = tap * CO + wc * WCO + a * 16 + li;
-        fa[slot][a] = lds_w[row * 4 + (lg ^ swz64(row))];
+        fa[a] = lds_w[row * 4 + (lg ^ swz64(row))];
       }
 #pragma unroll
-      for (int b = 0; b < TP; ++b) fb[slot][b] = lds_h[hbase[b] + hoff];
-    };
-#pragma unroll
-    for (int tap = 0; tap < DEPTH; ++tap) frags(tap, tap);
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int slot = tap % (DEPTH + 1);
-      if (tap + DEPTH < 9) frags(tap + DEPTH, (tap + DEPTH) % (DEPTH + 1));
+      for (int b = 0; b < TP; ++b) fb[b] = lds_h[hbase[b] + hoff];
 #pragma unroll
       for (int a = 0; a < TC; ++a)
 #pragma unroll
         for (int b = 0; b < TP; ++b) {
           if constexpr (sizeof(T) == 2) {
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                __builtin_bit_cast(bf16x8, fa[slot][a]), __builtin_bit_cast(bf16x8, fb[slot][b]), acc[a][b], 0, 0, 0);
+                __builtin_bit_cast(bf16x8, fa[a]), __builtin_bit_cast(bf16x8, fb[b]), acc[a][b], 0, 0, 0);
           } else {
-            f32x4 va = __builtin_bit_cast(f32x4, fa[slot][a]);
-            f32x4 vb = __builtin_bit_cast(f32x4, fb[slot][b]);
+            f32x4 va = __builtin_bit_cast(f32x4, fa[a]);
+            f32x4 vb = __builtin_bit_cast(f32x4, fb[b]);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
               acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[j], vb[j], acc[a][b], 0, 0, 0);
           }
         }
-    }
-    if constexpr (sizeof(T) == 2 && DEPTH > 0) {
-      __builtin_amdgcn_sched_group_barrier(0x100, DEPTH * (TC + TP), 0);      // prologue reads
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        if (tap + DEPTH < 9) {
-          // one read, then MFMAs, alternating: the LDS queue and the matrix pipe both stay fed
-          sched_tap<TC + TP, TC * TP>();
-        } else {
-          __builtin_amdgcn_sched_group_barrier(0x008, TC * TP, 0);
-        }
-      }
     }
   }
 
@@ -327,8 +296,6 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
   }
 }
 
-static const bool kNoPixMajor = [] { const char* e = getenv("FSNET_AMD_HALO_PIXMAJOR"); return e && e[0] == '0'; }();
-
 // pick the pixel tile (TH x TW <= PIX, halo <= hmax) that wastes the fewest lanes, preferring wide tiles
 HaloGeom pick_geom(int Hd, int Wd, int PIX, int hmax) {
   HaloGeom best{0, 0, 0, 0, 0u, 0u, FsDiv{0u, 0u}, FsDiv{0u, 0u}, FsDiv{0u, 0u}, 0};
@@ -349,7 +316,7 @@ HaloGeom pick_geom(int Hd, int Wd, int PIX, int hmax) {
   return best;
 }
 
-template <typename T, int PIX, int CO, int WP, int DEPTH = 0>
+template <typename T, int PIX, int CO, int WP>
 int launch_halo(const FsConvArgs& a, hipStream_t st) {
   HaloGeom g = pick_geom(a.Hd, a.Wd, PIX, PIX == 256 ? 360 : (PIX == 128 ? 208 : 120));
   if (g.TH == 0) return FS_EINVAL;
@@ -361,10 +328,10 @@ int launch_halo(const FsConvArgs& a, hipStream_t st) {
   const int npix = a.N * g.tiles_x * g.tiles_y, nco = a.Co_p / CO;
   int blocks = npix * nco;
   // which operand is worth keeping XCD-local: the input activation (fetched once per channel tile) or the weights
-  g.pix_major = (nco > 1 && a.src_bytes > 2 * a.wgt_bytes && !kNoPixMajor) ? 1 : 0;
+  g.pix_major = (nco > 1 && a.src_bytes > 2 * a.wgt_bytes) ? 1 : 0;
   if (g.pix_major) blocks = 8 * ((npix + 7) / 8) * nco;
   else if (nco % 8 != 0 && 8 % nco == 0) { const int q = 8 / nco; blocks = 8 * ((npix + q - 1) / q); }
-  hipLaunchKernelGGL((conv3x3_halo_kernel<T, PIX, CO, WP, DEPTH>), dim3(blocks), dim3(256), 0, st, a, g);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<T, PIX, CO, WP>), dim3(blocks), dim3(256), 0, st, a, g);
   return fs_launch_status();
 }
 
@@ -383,13 +350,9 @@ int dispatch(const FsConvArgs& a, hipStream_t st) {
     // chip short of blocks (layer 4 at batch 12: 192 -> 384 blocks, 33 -> 25 us).  Measured the other way too:
     // 256-pixel tiles, which halve the weight fill per pixel, are 20-30 % slower.
     if (blocks_for(128, 32) < 256) return launch_halo<T, 128, 16, 4>(a, st);
-    if constexpr (sizeof(T) == 2) {
-      static const int cfg = [] { const char* e = getenv("FSNET_AMD_HALO_CFG"); return e ? atoi(e) : 0; }();
-      if (cfg == 1) return launch_halo<T, 128, 32, 4, 1>(a, st);
-      if (cfg == 2) return launch_halo<T, 128, 32, 4, 2>(a, st);
-      // (128x64 tiles with 2x4 / 4x2 MFMA tiles per wave were measured too, at every prefetch depth: 10-20 % slower at
-      // two blocks per CU, also on ResNet-50's 164 k-pixel launches — DESIGN section 7)
-    }
+    // (measured and removed: fragment reads pipelined one / two taps ahead of the MFMAs — within 5 % either way —,
+    // 128x64 tiles with 2x4 / 4x2 MFMA tiles per wave at every prefetch depth: 10-20 % slower at two blocks per CU, also
+    // on ResNet-50's 164 k-pixel launches — DESIGN section 7)
     return launch_halo<T, 128, 32, 4>(a, st);
   }
   if (cop % 16 == 0) {   // 16-channel decoder layers at 96x320 / 192x640: memory-bound, large pixel tiles

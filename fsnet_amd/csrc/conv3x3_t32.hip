@@ -344,8 +344,6 @@ __global__ __launch_bounds__(256, t32_minwaves(PIX, CO, EP, PRO)) void conv3x3_t
   }
 }
 
-static const bool kNoPixMajor = [] { const char* e = getenv("FSNET_AMD_HALO_PIXMAJOR"); return e && e[0] == '0'; }();
-
 template <typename T, int PIX, int CO, int EP, int PRO>
 int t32_launch(const FsConvArgs& a, hipStream_t st) {
   T32Geom g = t32_pick_geom(a.Hd, a.Wd, PIX, t32_hmax(PIX));
@@ -359,7 +357,7 @@ int t32_launch(const FsConvArgs& a, hipStream_t st) {
   if (a.pro_group_imgs > 0) g.dPRG = fs_make_div(a.pro_group_imgs);
   const int npix = a.N * g.tiles_x * g.tiles_y, nco = a.Co_p / CO;
   int blocks = npix * nco;
-  g.pix_major = (nco > 1 && a.src_bytes > 2 * a.wgt_bytes && !kNoPixMajor) ? 1 : 0;
+  g.pix_major = (nco > 1 && a.src_bytes > 2 * a.wgt_bytes) ? 1 : 0;
   if (g.pix_major) blocks = 8 * ((npix + 7) / 8) * nco;
   else if (nco % 8 != 0 && 8 % nco == 0) { const int q = 8 / nco; blocks = 8 * ((npix + q - 1) / q); }
   hipLaunchKernelGGL((conv3x3_t32_kernel<T, PIX, CO, EP, PRO>), dim3(blocks), dim3(256), 0, st, a, g);

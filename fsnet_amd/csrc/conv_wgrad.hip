@@ -338,7 +338,7 @@ int launch_tile(const FsWgradArgs& a, hipStream_t st) {
 // reads at shifted halo rows), i.e. 9x fewer input fetches and 72 MFMAs per wave between barriers; the
 // generic kernel above re-gathers the input per tap and synchronises every 4 MFMAs.
 // ---------------------------------------------------------------------------------------------
-struct WGeom { int TH, TW, tiles_x, tiles_y, N, Cs, nsplit; unsigned mTW, mHW; FsDiv dTX, dTY; int abl; };
+struct WGeom { int TH, TW, tiles_x, tiles_y, N, Cs, nsplit; unsigned mTW, mHW; FsDiv dTX, dTY; };
 
 __device__ __forceinline__ uint4 wg_buf_load16(__amdgpu_buffer_rsrc_t rsrc, int voff) {
   return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
@@ -494,7 +494,6 @@ __global__ __launch_bounds__(256 * KG) void wgrad3x3_halo_kernel(const FsWgradAr
     __syncthreads();
     if (pt >= npix) continue;
     if (pt + step < npix) load_regs(pt + step);
-    if (g.abl & 1) continue;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       bf16x8 fa[TA];
@@ -549,7 +548,6 @@ __global__ __launch_bounds__(256 * KG) void wgrad3x3_halo_kernel(const FsWgradAr
 #pragma unroll
           for (int j = 0; j < 4; ++j, ++q) acc[tp][a][b][j] += red[q * 256 + t];
   }
-  if ((g.abl & 2) && acc[0][0][0][0] != 123.456f) return;
   // ---- epilogue: the MFMA ran with the input-channel fragment as its row operand, D rows = ci (lg*4 + j), cols = co
   // (li): a lane holds four consecutive input channels of one output channel, i.e. one 16-byte run of the slab row
   // [co][tap][ci] (the other orientation stored 288 single floats per lane: a sixth of the kernel) ----
@@ -914,18 +912,11 @@ int launch_wgrad_halo_t(const FsWgradArgs& a, hipStream_t st) {
   if (!a.workspace) splits = 1;
   else splits = std::min<long>(splits, std::max<long>(1, a.workspace_elems / slab));
   g.nsplit = (int)splits; b.nsplit = g.nsplit;
-  { const char* ae = getenv("FSNET_AMD_WGRAD_ABL"); g.abl = ae ? atoi(ae) : 0; }
   dim3 grid(Cs / CIT, a.Cd / COT, g.nsplit);
-  // Measured (B=12 bench shapes): KG = 2 makes the kernel itself 6-11 % faster (33.5 vs 35.5 us on the ResNet stages,
-  // 45 vs 50 us on the decoder's), but the step 1.5 % SLOWER (6.11 / 6.15 vs 5.99 / 6.05 ms, same box, alternating):
-  // on its companion stream the fatter kernel takes CU time from the data-gradient chain, which is the critical
-  // path; with the weight gradients inline (the data-parallel placement) the two are equal (6.31 vs 6.34 ms).
-  static const int kg = [] { const char* e = getenv("FSNET_AMD_WGRAD_KG"); return e ? atoi(e) : 1; }();
-  // (two wave groups need at least two pixel tiles per block to split)
-  if (kg == 2 && npix >= 2 * g.nsplit)
-    hipLaunchKernelGGL((wgrad3x3_halo_kernel<COT, CIT, 2>), grid, dim3(512), 0, st, b, g);
-  else
-    hipLaunchKernelGGL((wgrad3x3_halo_kernel<COT, CIT, 1>), grid, dim3(256), 0, st, b, g);
+  // (a second wave group per block — the block's pixel tiles split between two groups of four waves, partial sums added
+  // through LDS — made the kernel itself 6-11 % faster and the step 1.5 % slower: on its companion stream the fatter
+  // kernel takes CU time from the data-gradient chain, which is the critical path; measured and removed)
+  hipLaunchKernelGGL((wgrad3x3_halo_kernel<COT, CIT, 1>), grid, dim3(256), 0, st, b, g);
   if (b.nsplit > 1) {
     const int ncols = 9 * Cs;
     launch_reduce(b, a.Co, ncols, 8, st);

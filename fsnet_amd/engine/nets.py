@@ -104,7 +104,7 @@ def _defer_param_grads(cur, item):
         # exception never ran its callback, and must not keep the next one from queueing its own.)
         torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
         _CALLBACK_QUEUED[0] = task
-    if RT.wgrad_streams != 3 and len(ent[1]) >= RT.wgrad_flush:
+    if len(ent[1]) >= RT.wgrad_flush:
         flush_deferred(cur)
 
 
@@ -116,18 +116,14 @@ def flush_deferred(cur=None, spread=False):
         if ent is None or not ent[1]:
             continue
         chain, items = ent
-        if RT.wgrad_streams == 3:
-            # the pose chain's stream: shorter than the depth chain's, so its tail is idle GPU time
-            targets = [RT.side_stream(chain.device)]
-        else:
-            targets = [RT.companion_stream(chain.device, chain)[1]]
-            if spread and (RT.wgrad_spread == 2 or (RT.wgrad_spread == 1 and RT.is_side(chain))):
-                # the last batch of a chain (its largest layers) otherwise runs serially after everything else has
-                # finished: the other chains' companions are idle by then and take every other layer
-                for key2 in _ACTIVE_CHAINS:         # chains of THIS backward pass only
-                    if key2 != key:
-                        chain2 = _DEFERRED[key2][0]
-                        targets.append(RT.companion_stream(chain2.device, chain2)[1])
+        targets = [RT.companion_stream(chain.device, chain)[1]]
+        if spread and RT.wgrad_spread and RT.is_side(chain):
+            # the pose chain's last batch (its largest layers) otherwise runs serially after everything else has
+            # finished: the other chains' companions are idle by then and take every other layer
+            for key2 in _ACTIVE_CHAINS:         # chains of THIS backward pass only
+                if key2 != key:
+                    chain2 = _DEFERRED[key2][0]
+                    targets.append(RT.companion_stream(chain2.device, chain2)[1])
         for k, ws in enumerate(targets):
             mine = items[k::len(targets)]
             if not mine:
@@ -302,16 +298,8 @@ class ConvLayer:
         # the arena slice its gradient bucket reduces — also inside a captured step)
         mode = RT.wgrad_streams if (dc.is_cuda and RT.overlap and RT.dp is None) else 0
         if mode:
-            cur = _current_stream(dc.device)
-            if mode == 3:
-                # only while the budget lasts: hand over about as much as balances the two chains
-                ent = _DEFERRED.get(cur.cuda_stream)
-                if not RT.is_side(cur) and (ent is None or len(ent[1]) < RT.wgrad_side_budget):
-                    _defer_param_grads(cur, item)
-                    return
-            elif mode == 2 or not RT.is_side(cur):
-                _defer_param_grads(cur, item)
-                return
+            _defer_param_grads(_current_stream(dc.device), item)
+            return
         _run_param_grads(*item)
 
 
@@ -633,8 +621,7 @@ class ResNetRunner:
         op = self.stem.ready(y0.dtype, y0.device)
         self.stem.accumulate_param_grads(op, dc0, ctx["x"])
         RT.mark(tag + ".bwd.end")
-        if RT.wgrad_streams != 3:
-            flush_deferred(_current_stream(), spread=True)
+        flush_deferred(_current_stream(), spread=True)
 
 
 # ==============================================================================================
@@ -807,8 +794,7 @@ class DepthDecoderRunner:
             else:
                 gfeats[4] = op0.dgrad(dc0, h, w)
         RT.mark("ddec.bwd.end")
-        if RT.wgrad_streams != 3:
-            flush_deferred(_current_stream())
+        flush_deferred(_current_stream())
         return gfeats
 
 
@@ -862,6 +848,5 @@ class PoseDecoderRunner:
             self.cl[j].accumulate_param_grads(op, d, xin)
             # gradient w.r.t. the input activation, masked by the producing ReLU (none for the encoder feature)
             d = op.dgrad(d, xin.shape[1], xin.shape[2], mask=(xin if j > 0 else None))
-        if RT.wgrad_streams != 3:
-            flush_deferred(_current_stream())
+        flush_deferred(_current_stream())
         return d

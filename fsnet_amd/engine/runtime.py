@@ -17,20 +17,15 @@ class _Runtime:
         # run the pose chain on a second HIP stream next to the depth chain (they are independent until the
         # loss): measured, ~40 % of the GPU idles in kernel boundaries / tails of the many small launches
         self.overlap = os.environ.get("FSNET_AMD_OVERLAP", "1") != "0"
-        # weight gradients feed nothing downstream in the backward pass: 0 = inline on the chain stream,
-        # 1 = the main (depth) chain hands them to a companion stream in batches of `wgrad_flush` layers,
-        # 2 = every chain does.  Cross-stream edges are not free (host time eagerly, barrier packets in a
-        # hipGraph), hence batches rather than one fork per layer.
-        # Default 2 / batches of 8: +1.8 % on the reference workload (1618 vs 1589 samples/s, three runs each) once the
-        # conv kernels were light enough on LDS to co-reside with another stream's blocks; before that change every
-        # variant was slower than inline.  The gain is sensitive to the batch size (6: -4 %, 16: -3 %).
-        self.wgrad_streams = int(os.environ.get("FSNET_AMD_WGRAD_STREAMS", "2"))
-        self.wgrad_flush = int(os.environ.get("FSNET_AMD_WGRAD_FLUSH", "8"))
-        # 1: the pose chain's last batch (it ends the backward) also uses the depth chain's idle companion; 2: both
-        self.wgrad_spread = int(os.environ.get("FSNET_AMD_WGRAD_SPREAD", "1"))
-        # 3 = the first `wgrad_side_budget` weight gradients of the main chain's backward (the decoder's, then
-        # the encoder's deepest stages) run at the tail of the pose chain's stream, which finishes earlier
-        self.wgrad_side_budget = int(os.environ.get("FSNET_AMD_WGRAD_SIDE_BUDGET", "12"))
+        # Weight gradients feed nothing downstream in the backward pass: every chain hands them to a companion stream in
+        # batches of `wgrad_flush` layers (cross-stream edges are not free — host time eagerly, barrier packets in a
+        # hipGraph — hence batches rather than one fork per layer), and the pose chain's last batch, which ends the
+        # backward, also uses the depth chain's by then idle companion.  Measured on the replayed step:
+        # inline 6.13 ms, main chain only 6.1, onto the pose stream's tail 6.15, this placement 5.93; batches of 6 / 16
+        # are 3-4 % slower than 8.  wgrad_streams = 0 (inline) is what data parallelism uses and what tests may set.
+        self.wgrad_streams = 2
+        self.wgrad_flush = 8
+        self.wgrad_spread = 1
         # the pose encoder's image pairs as one stacked pass with per-pair BatchNorm statistics
         self.batch_pose_pairs = os.environ.get("FSNET_AMD_BATCH_POSE", "1") != "0"
         self._side = {}

@@ -485,7 +485,7 @@ class PhotometricLoss:
     def _fork(device):
         """(current stream, pose stream) when the smoothness kernels may run beside the photometric ones"""
         from ..engine.runtime import RT
-        if not (RT.overlap and device.type == "cuda") or os.environ.get("FSNET_AMD_SMOOTH_SIDE", "1") == "0":
+        if not (RT.overlap and device.type == "cuda"):
             return None
         cur, side = torch.cuda.current_stream(device), RT.side_stream(device)
         return None if cur.cuda_stream == side.cuda_stream else (cur, side)

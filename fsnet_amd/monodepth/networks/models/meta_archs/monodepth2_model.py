@@ -1,7 +1,6 @@
 """Meta-archs with the reference's constructor contract (monodepth2_model.py:8-148):
 MonoDepthMeta (learned pose, "depth+pose") and MonoDepthWPose (dataset pose).  Sub-networks are built
 through build(**cfg) exactly like the reference, so configs only change `name=` strings."""
-import os
 
 import torch
 
@@ -103,46 +102,28 @@ class MonoDepthMeta(_HipMetaArch):
         pose_out = {}
         overlap = RT.overlap and image_0.is_cuda
         if overlap:
-            # fork: pose chain (2 encoder passes + pose decoder) on the side stream, depth chain on the main one;
-            # autograd replays each chain's backward on the stream its forward ran on, so the backward overlaps too.
-            # FSNET_AMD_POSE_FIRST=0 issues the depth chain first (the fork is an event, so the captured topology is
-            # the same): autograd then issues the POSE backward first.
+            # fork: pose chain (encoder pass over both pairs + pose decoder) on the side stream, depth chain on the main
+            # one; autograd replays each chain's backward on the stream its forward ran on, so the backward overlaps too.
+            # The pose chain is issued first (issued second it starts ~0.2 ms late in the replayed step), and the loss
+            # chain's image-only inputs (colour pyramid, identity reprojection terms) follow it on its stream: they need
+            # only the batch and are first read by the loss, so they fill the pose stream's idle tail beside the depth
+            # decoder instead of delaying both encoders at the head of the step (measured both ways).
             main = torch.cuda.current_stream(image_0.device)
             side = RT.side_stream(image_0.device)
-            pose_first = os.environ.get("FSNET_AMD_POSE_FIRST", "1") != "0"
-            fork = None
-            if not pose_first:
-                fork = torch.cuda.Event()
-                fork.record(main)
-
-            def pose_side():
-                if fork is None:
-                    side.wait_stream(main)
-                else:
-                    side.wait_event(fork)
-                with torch.cuda.stream(side):
-                    RT.mark("side.fork")
-                    late = os.environ.get("FSNET_AMD_LOSS_INPUTS_LATE", "1") != "0"
-                    if not late and hasattr(self.head, "prefetch_loss_inputs"):
-                        self.head.prefetch_loss_inputs(data)
-                    RT.mark("pose.fwd.start")
-                    self._pose_chain(data, image_0, pose_out)
-                    RT.mark("pose.fwd.end")
-                    if late and hasattr(self.head, "prefetch_loss_inputs"):
-                        # the loss chain's image-only inputs (colour pyramid, identity reprojection terms) need only
-                        # the batch and are first read by the loss: they fill the pose stream's idle tail beside the
-                        # depth decoder instead of delaying both encoders at the head of the step
-                        self.head.prefetch_loss_inputs(data)
-            if pose_first:
-                pose_side()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                RT.mark("side.fork")
+                RT.mark("pose.fwd.start")
+                self._pose_chain(data, image_0, pose_out)
+                RT.mark("pose.fwd.end")
+                if hasattr(self.head, "prefetch_loss_inputs"):
+                    self.head.prefetch_loss_inputs(data)
         RT.mark("depth.fwd.start")
         features = self.depth_backbone(image_0)
         RT.mark("denc.fwd.end")
         outputs = self.head.forward_depth(features)
         RT.mark("ddec.fwd.end")
         if overlap:
-            if not pose_first:
-                pose_side()
             main.wait_stream(side)            # join before the loss consumes cam_T_cam
             RT.mark("join")
             for v in pose_out.values():
