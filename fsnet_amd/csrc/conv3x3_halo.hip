@@ -365,7 +365,6 @@ int dispatch(const FsConvArgs& a, hipStream_t st) {
 }  // namespace
 
 int fs_conv3x3_t32(const FsConvArgs& a, int dtype, hipStream_t st);      // conv3x3_t32.hip
-int fs_conv3x3_d32(const FsConvArgs& a, int dtype, hipStream_t st);      // conv3x3_d32.hip
 
 extern "C" int fs_conv3x3_halo(const FsConvArgs* args, int dtype, void* stream) {
   if (!args || !args->src || !args->wgt || !args->dst) return FS_EINVAL;
@@ -382,11 +381,6 @@ extern "C" int fs_conv3x3_halo(const FsConvArgs* args, int dtype, void* stream) 
   // the 16-channel decoder layers
   const char* te = getenv("FSNET_AMD_T32");
   const bool use_t32 = !(te && te[0] == '0');
-  const char* de = getenv("FSNET_AMD_D32");
-  if (de && de[0] == '1' && use_t32) {             // two-wave-group experiment (conv3x3_d32.hip): opt-in
-    const int r = fs_conv3x3_d32(*args, dtype, st);
-    if (r != FS_EINVAL) return r;
-  }
   if (use_t32) {
     const int r = fs_conv3x3_t32(*args, dtype, st);
     if (r != FS_EINVAL) return r;

@@ -22,7 +22,7 @@
 // 14.0 / 16.4 (16x16 kernel 18.8 / 23.9), B=36 33.0 / 39.8 (40.9 / 61.5); 128->128 @24x80 B=36 30.5 / 34.0 (32.3 /
 // 40.6); 256->256 @12x40 B=36 30.3 / 32.9 (33.4 / 36.3); 64->64 @80x256 B=8 20.7 / 25.4 (25.5 / 34.5).  Variants that
 // lost on the same shapes (persistent blocks with cross-item prefetch and an LDS-free permlane epilogue; two LDS stage
-// buffers at one block per CU) are not kept; conv3x3_d32.hip holds the two-wave-group experiment.
+// buffers at one block per CU; two wave groups per block alternating compute and memory roles) are not kept: DESIGN 7.
 // Reference call sites: vision_base/networks/models/backbone/resnet.py:21-50 (BasicBlock), blocks.py:41-54,
 // monodepth/networks/models/heads/depth_encoder.py:45-63, pose_decoder.py:17-37.
 #include "t32_common.h"

@@ -1,4 +1,4 @@
-// Shared pieces of the 32x32-MFMA-tile 3x3 convolution kernels (conv3x3_t32.hip, conv3x3_d32.hip): operand units,
+// Pieces of the 32x32-MFMA-tile 3x3 convolution kernel (conv3x3_t32.hip): operand units,
 // 16-byte epilogue accessors, the v_permlane32_swap accumulator transposition and the halving statistics reduction.
 #pragma once
 #include "common.h"
@@ -30,11 +30,6 @@ struct T32Geom {
   FsDiv dIPG;      // images per BatchNorm statistics group
   FsDiv dPRG;      // images per prologue coefficient group
   int pix_major;
-  int map_mode, map_div, map_shift;   // conv3x3_d32: item id -> (pixel tile, channel tile) map, see d32_launch
-  FsDiv dMap;
-  int nitems;      // item ids to walk (pixel tiles x channel tiles, padded by the XCD mapping)
-  unsigned long long* dbg;   // development: cycle stamps of block 0 (FSNET_AMD_T32_DBG = device address)
-  int abl;         // development: ablation bits (1 no MFMA loop, 2 no epilogue, 4 no global operand loads, 8 no weight loads)
 };
 
 enum : int { EP_BIAS = 1, EP_ADDEND = 2, EP_RELU = 4, EP_MASK = 8, EP_STATS = 16, EP_BNB = 32, EP_F32 = 64,

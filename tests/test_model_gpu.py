@@ -136,7 +136,8 @@ def test_fp32_gradients_match_oracle(dev):
 def test_bf16_training_step_close_to_fp32_oracle(dev):
     """bf16 policy: conv operands / activations bf16, fp32 accumulate, fp32 BN statistics, fp32 depth head,
     geometry and loss.  Stated tolerances vs the fp32 oracle on the same batch (DESIGN.md "bf16"):
-    loss 2e-2 rel; disparity 4e-2 mean-rel / 0.35 max-rel; parameter gradients cosine > 0.8.
+    loss 5e-3 rel (measured 7.5e-4); disparity 4e-2 mean-rel / 0.3 max-rel (measured 1.3-2.8e-2 / 0.10-0.21);
+    convolution weight gradients cosine > 0.85 (measured >= 0.89), norm within 0.9 .. 1.2 of the oracle's (1.00 .. 1.09).
     (Per-parameter gradient L2 deviations of 0.05 (un-rectified heads) .. 0.45 (encoder) are expected: the
     ~3 % forward perturbation flips ~1-2 % of the BN-centred ReLU masks per layer, and each flipped mask
     is an O(1) change of that element's gradient.  fp32 compute matches the oracle to 2e-3.)"""
@@ -153,23 +154,28 @@ def test_bf16_training_step_close_to_fp32_oracle(dev):
     for s in range(4):
         ref = oo[("disp", s)].detach()
         rel = (outs[("disp", s)].detach().cpu() - ref).abs() / ref.abs()
-        assert float(rel.mean()) < 4e-2 and float(rel.max()) < 0.35, (s, float(rel.mean()), float(rel.max()))
+        print("bf16 disparity scale %d: mean rel %.4f max rel %.4f" % (s, float(rel.mean()), float(rel.max())))
+        assert float(rel.mean()) < 4e-2 and float(rel.max()) < 0.3, (s, float(rel.mean()), float(rel.max()))
     m2 = build_model(True, H, W, dev, torch.bfloat16, sd0)
     out = m2(to_dev(data, dev), dict(is_training=True))
     out["loss"].backward()
     torch.cuda.synchronize()
     tr = O.OracleTrainer(sd0, with_pose=True, clip=None)
     total, ld, _, raw, _ = tr.step(data)
-    assert abs(float(out["loss"].detach()) - float(total)) < 2e-2 * abs(float(total))
+    assert abs(float(out["loss"].detach()) - float(total)) < 5e-3 * abs(float(total))
+    print("bf16 loss rel dev %.5f" % (abs(float(out["loss"].detach()) - float(total)) / abs(float(total))))
     gmax = max(float(r.norm()) for r in raw.values())
+    mincos, ratios = 1.0, []
     for k, p in m2.named_parameters():
         ref = raw[k]
         if float(ref.norm()) < 1e-3 * gmax or ref.dim() != 4:
             continue
         g = p.grad.cpu()
         cos = float((g * ref).sum() / (g.norm() * ref.norm()))
-        assert cos > 0.8, (k, cos)
-        assert 0.6 < float(g.norm() / ref.norm()) < 1.6, k
+        mincos = min(mincos, cos); ratios.append(float(g.norm() / ref.norm()))
+        assert cos > 0.85, (k, cos)
+        assert 0.9 < float(g.norm() / ref.norm()) < 1.2, k
+    print("bf16 conv gradients: min cosine %.4f, norm ratio %.3f .. %.3f" % (mincos, min(ratios), max(ratios)))
 
 
 @gpu
@@ -334,7 +340,7 @@ def test_bf16_training_run_tracks_fp32_over_50_steps(dev):
     print("bf16 vs fp32 loss curves: max rel dev %.4f, mean %.4f; fp32 %.5f -> %.5f, bf16 %.5f -> %.5f" % (
         rel.max(), rel.mean(), f[:8].mean(), f[-8:].mean(), b[:8].mean(), b[-8:].mean()))
     assert np.isfinite(b).all() and np.isfinite(f).all()
-    assert rel.max() < 2e-2 and rel.mean() < 2e-3, (rel.max(), rel.mean())      # run-to-run: 1e-3 .. 5e-3 max
+    assert rel.max() < 6e-3 and rel.mean() < 1e-3, (rel.max(), rel.mean())      # measured 1e-3 max, 2e-4 mean
     df, db = curves[(torch.float32, "dp")], curves[(torch.bfloat16, "dp")]
     d2 = curves[("fp32-again", "dp")]
     cos = float((df * db).sum() / (df.norm() * db.norm()))
@@ -343,7 +349,8 @@ def test_bf16_training_run_tracks_fp32_over_50_steps(dev):
         cos, cos_ref, float(db.norm() / df.norm())))
     # Adam moves every weight by ~lr per step whatever the gradient's size, so weights with noise-level gradients
     # random-walk: two fp32 runs (atomic ordering) are the yardstick for what "the same update" means here
-    assert cos > 0.6 * cos_ref and 0.8 < float(db.norm() / df.norm()) < 1.25, (cos, cos_ref)
+    # (measured round 3: 0.70 against 0.93 for the two fp32 runs, norm ratio 0.998)
+    assert cos > 0.68 * cos_ref and 0.9 < float(db.norm() / df.norm()) < 1.1, (cos, cos_ref)
 
 
 @gpu

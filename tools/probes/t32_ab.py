@@ -1,22 +1,18 @@
 """same-process A/B of conv kernel variants: rounds interleave the variants (median over rounds).
-variants: old | <cfg>:<persist>"""
+variants: old (16x16-tile kernel) | 1 | 2 | 3 (32x32-tile kernel, tile configuration)"""
 import os, sys
 sys.path.insert(0, '.')
 import torch
 from fsnet_amd.hip.conv import ConvOp
 dev = torch.device('cuda:0'); dt = torch.bfloat16
-VARS = sys.argv[1].split(",") if len(sys.argv) > 1 else ["old", "3:0", "1:0", "d0", "d1", "d2", "d3"]
+VARS = sys.argv[1].split(",") if len(sys.argv) > 1 else ["old", "3", "1", "2"]
 SHAPES = [(64, 64, 48, 160, 12), (64, 64, 48, 160, 36), (128, 128, 24, 80, 36), (256, 256, 12, 40, 36), (512, 512, 6, 20, 36)]
 reps, rounds = 20, 5
 def setv(v):
-    os.environ["FSNET_AMD_D32"] = "0"
     if v == "old":
         os.environ["FSNET_AMD_T32"] = "0"
-    elif v[0] == "d":                      # dual-group kernel, tile configuration v[1:]
-        os.environ["FSNET_AMD_T32"] = "1"; os.environ["FSNET_AMD_D32"] = "1"; os.environ["FSNET_AMD_D32_CFG"] = v[1:]
     else:
-        c, pz = v.split(":")
-        os.environ["FSNET_AMD_T32"] = "1"; os.environ["FSNET_AMD_T32_CFG"] = c; os.environ["FSNET_AMD_T32_PERSIST"] = pz
+        os.environ["FSNET_AMD_T32"] = "1"; os.environ["FSNET_AMD_T32_CFG"] = v
 def timed(fn):
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

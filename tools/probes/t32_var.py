@@ -1,21 +1,15 @@
 """one conv shape, one kernel variant (see t32_ab.py), forward + dgrad launches, plus a same-size copy as a yardstick.
-args: Ci Co H W B variant [abl]"""
+args: Ci Co H W B variant (old | 1 | 2 | 3)"""
 import os, sys
 sys.path.insert(0, '.')
 import torch
 from fsnet_amd.hip.conv import ConvOp
 Ci, Co, H, W, B = (int(v) for v in sys.argv[1:6])
 v = sys.argv[6]
-os.environ["FSNET_AMD_D32"] = "0"
 if v == "old":
     os.environ["FSNET_AMD_T32"] = "0"
-elif v[0] == "d":
-    os.environ["FSNET_AMD_T32"] = "1"; os.environ["FSNET_AMD_D32"] = "1"; os.environ["FSNET_AMD_D32_CFG"] = v[1:]
 else:
-    c, pz = v.split(":")
-    os.environ["FSNET_AMD_T32"] = "1"; os.environ["FSNET_AMD_T32_CFG"] = c; os.environ["FSNET_AMD_T32_PERSIST"] = pz
-if len(sys.argv) > 7:
-    os.environ["FSNET_AMD_T32_ABL"] = sys.argv[7]
+    os.environ["FSNET_AMD_T32"] = "1"; os.environ["FSNET_AMD_T32_CFG"] = v
 dev = torch.device('cuda:0'); dt = torch.bfloat16
 op = ConvOp(Ci, Co, 3, 3, 1, 1, dt, dev)
 op.pack(torch.randn(Co, Ci, 3, 3, device=dev) * 0.05)

@@ -1,11 +1,9 @@
-"""one weight-gradient shape, a few launches (kernel-trace runs).  args: Ci Co H W B [abl]"""
+"""one weight-gradient shape, a few launches (kernel-trace runs).  args: Ci Co H W B"""
 import os, sys
 sys.path.insert(0, '.')
 import torch
 from fsnet_amd.hip.conv import ConvOp
 Ci, Co, H, W, B = (int(v) for v in sys.argv[1:6])
-if len(sys.argv) > 6:
-    os.environ["FSNET_AMD_WGRAD_ABL"] = sys.argv[6]
 dev = torch.device('cuda:0'); dt = torch.bfloat16
 op = ConvOp(Ci, Co, 3, 3, 1, 1, dt, dev)
 x = torch.randn(B, H, W, op.Ci_p, device=dev).to(dt)
