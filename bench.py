@@ -183,7 +183,7 @@ def main():
         default_workload = (args.depth, args.height, args.width, args.batch, args.dtype, fisheye) == (18, 192, 640, 12, "bf16", False)
         ch = agg["conv3x3_halo"]            # dominant kernel family by time: 3x3/s1 fwd+dgrad (LDS halo kernel)
         ach = tf(ch)
-        roofline = {"kernel": "conv3x3_halo_kernel (3x3/s1 fwd+dgrad, %d launches/step)" % (ch[0] // nprof),
+        roofline = {"kernel": "conv3x3_t32_kernel + conv3x3_halo_kernel (3x3/s1 fwd+dgrad LDS-halo family, %d launches/step)" % (ch[0] // nprof),
                     "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": pmc_traffic("conv3x3_halo") if default_workload else None,
                     "avg_launch_us": round(ch[2] / ch[0] * 1e6, 2),

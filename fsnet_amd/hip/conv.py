@@ -106,6 +106,33 @@ def wgrad_workspace(device, elems=1 << 23):
     return ws
 
 
+def _t32_geom(Hd, Wd, PIX, hmax):
+    """the 32x32-tile kernel's pixel tile choice (t32_pick_geom in csrc/t32_common.h): (tiles per image, wasted-lane factor)"""
+    best, best_cost = None, 1e30
+    for tw in range(min(4, Wd), min(Wd, 64) + 1):
+        th = min(PIX // tw, Hd)
+        if th < 1 or (th + 2) * (tw + 2) > hmax:
+            continue
+        tx, ty = -(-Wd // tw), -(-Hd // th)
+        waste = tx * ty * PIX / float(Hd * Wd)
+        cost = waste * (1.0 + 0.15 * (th + 2) * (tw + 2) / float(th * tw))
+        if tw % 32 != 0 and tw != Wd:
+            cost *= 1.02
+        if cost < best_cost - 1e-9:
+            best, best_cost = (tx * ty, waste), cost
+    return best
+
+
+def t32_takes(N, Hd, Wd, rows_p):
+    """whether fs_conv3x3_halo runs a launch of this size on the 32x32-tile kernel by its own choice (t32_pick_cfg in
+    csrc/conv3x3_t32.hip: 256-pixel tiles that waste no lanes, >= 512 blocks); smaller launches are faster on the
+    16x16-tile kernel, which has no operand prologue — BatchNorm folding is only worth it where this is true"""
+    g256, g128 = _t32_geom(Hd, Wd, 256, 360), _t32_geom(Hd, Wd, 128, 208)
+    if g256 is None or g128 is None:
+        return False
+    return g256[1] <= 1.15 * g128[1] and N * g256[0] * (rows_p // 32) >= 512
+
+
 class ConvOp:
     def __init__(self, Ci, Co, R, S, stride, pad, dtype, device, need_dgrad=True):
         assert stride in (1, 2)
@@ -279,7 +306,8 @@ class ConvOp:
         eb = 2 if self.dtype == torch.bfloat16 else 4
         return (USE_HALO and self.dtype == torch.bfloat16 and self.R == 3 and self.S == 3 and self.stride == 1
                 and self.Ci == self.Ci_p and (self.Ci_p * eb) % 64 == 0 and self.Co_p % 64 == 0 and self.Co % 8 == 0
-                and self.need_dgrad and N * H * W * self.Co_p * eb < 0x7fffffff)
+                and self.need_dgrad and N * H * W * self.Co_p * eb < 0x7fffffff
+                and t32_takes(N, H, W, self.Co_p) and t32_takes(N, H, W, roundup(self.Ci_p, 16)))
 
     def can_fuse_bn_bwd(self, N, H, W, groups):
         """whether dgrad(..., bn_fuse=) may carry the BatchNorm-backward sums of a [N,H,W,Ci_p] gradient"""

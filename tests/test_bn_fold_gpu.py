@@ -44,12 +44,14 @@ def _step(dev, fold, H, W, B, groups_pose=True):
         RT.set_compute_dtype(torch.float32)
 
 
-@pytest.mark.parametrize("H,W,B", [(64, 128, 2), (96, 192, 3)])
-def test_folded_batchnorm_step_equals_separate_pass(dev, H, W, B):
+@pytest.mark.parametrize("H,W,B,folded", [(192, 640, 12, 6), (192, 640, 24, 10)])
+def test_folded_batchnorm_step_equals_separate_pass(dev, H, W, B, folded):
     l0, g0, b0, k0 = _step(dev, False, H, W, B)
     l1, g1, b1, k1 = _step(dev, True, H, W, B)
-    # the fold removed BatchNorm passes: 8 interior BatchNorms per ResNet-18 encoder invocation (depth + stacked pose)
-    assert k0.count("bn_apply") - k1.count("bn_apply") == 16, (k0.count("bn_apply"), k1.count("bn_apply"))
+    # the fold removed BatchNorm passes where the consuming convolution's launch is large enough for the 32x32-tile
+    # kernel (ConvOp.can_fold_input): at the benchmark batch 12 the two layer-1 BatchNorms of the depth encoder and the four of
+    # layers 1 + 2 of the stacked pose pass (24 images); at batch 24 layers 1 + 2 and layers 1 - 3
+    assert k0.count("bn_apply") - k1.count("bn_apply") == folded, (k0.count("bn_apply"), k1.count("bn_apply"))
     assert abs(l1 - l0) <= 2e-3 * abs(l0), (l0, l1)
     gmax = max(v.norm().item() for v in g0.values())
     worst, dots = 0.0, [0.0, 0.0, 0.0]
@@ -68,7 +70,7 @@ def test_folded_batchnorm_step_equals_separate_pass(dev, H, W, B):
         # elements (DESIGN section 3, bf16 policy) — per parameter the two steps stay far closer to each other than
         # either is to the fp32 oracle (cosine > 0.8 there)
         assert cos > 0.95 and rel < 0.35, (k, cos, rel)
-    assert dots[0] / (dots[1] ** 0.5 * dots[2] ** 0.5) > 0.96         # the whole gradient (0.977 at 64x128, B=2: BatchNorm over 16 samples in layer 4)
+    assert dots[0] / (dots[1] ** 0.5 * dots[2] ** 0.5) > 0.98         # the whole gradient
     # running statistics follow the same batch statistics
     for k in b0:
         # (deep layers see inputs that differ by the flipped roundings upstream: 2 % of the buffer's scale)
