@@ -344,27 +344,29 @@ __device__ __forceinline__ uint4 wg_buf_load16(__amdgpu_buffer_rsrc_t rsrc, int 
   return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
 }
 
-// KG = 2: two groups of four waves share the block's output tile and split its pixel tiles between them (each group
-// stages its own tile); the second group's accumulators are added through LDS before the slab is written.  The grid
-// — and with it the slab traffic — stays what it was, but a CU holds two waves per SIMD instead of one: with one, a
-// wave's LDS -> MFMA chain (88 transposing reads and 116 waits around 72 MFMAs per tile) had nobody to overlap with.
-template <int COT, int CIT, int KG>
-__global__ __launch_bounds__(256 * KG) void wgrad3x3_halo_kernel(const FsWgradArgs p, const WGeom g) {
+// NG tap groups: NG x 4 waves share the staged tile, group g multiplies only its taps [tap0(g), tap0(g+1)) — the CU
+// holds NG waves per SIMD on ONE stage buffer and ONE output slab (the nine taps are disjoint slices of it, nothing is
+// added across groups), each wave's LDS -> MFMA chain is 9/NG taps long and the tile is staged by NG x 256 threads.
+// (With one group a wave's chain per tile — 88 transposing reads, 72 MFMAs, 16 LDS stores, two barriers — ran alone on
+// its SIMD: ds_read_b64_tr_b16 reaches its rate only from several waves per SIMD, MI355X_MICROARCH.md / LDS.)
+template <int COT, int CIT, int NG>
+__global__ __launch_bounds__(256 * NG) void wgrad3x3_halo_kernel(const FsWgradArgs p, const WGeom g) {
   typedef bf16 T;
+  constexpr int NT = 256 * NG;
+  constexpr int TPG = (9 + NG - 1) / NG;               // taps per group (the last groups may hold one fewer)
   constexpr int PIXT = 128, HMAX = 208, OOB = 0x7fffffff;
   constexpr int SA = COT + 8, SB = CIT + 8;
   constexpr int TA = COT / 32, TB = CIT / 32;          // per-wave 16x16 sub-tiles (2 x 2 waves)
   constexpr int UA = COT / 8, UB = CIT / 8;            // 16-byte units per pixel row
-  constexpr int LA = (PIXT * UA + 255) / 256, LB = (HMAX * UB + 255) / 256;
-  constexpr int STAGE_BYTES = (PIXT * SA + HMAX * SB) * 2;
-  constexpr int RED_BYTES = KG > 1 ? 9 * TA * TB * 4 * 256 * 4 : 0;
-  constexpr int LDS_BYTES = STAGE_BYTES * KG > RED_BYTES ? STAGE_BYTES * KG : RED_BYTES;
+  constexpr int LA = (PIXT * UA + NT - 1) / NT, LB = (HMAX * UB + NT - 1) / NT;
+  constexpr int LDS_BYTES = (PIXT * SA + HMAX * SB) * 2;
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
-  const int grp = KG > 1 ? (int)(threadIdx.x >> 8) : 0;
-  T* lds_a = reinterpret_cast<T*>(lds_raw + grp * STAGE_BYTES);
+  T* lds_a = reinterpret_cast<T*>(lds_raw);
   T* lds_b = lds_a + PIXT * SA;
 
-  const int t = threadIdx.x & 255, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63, wave = (t >> 6) & 3;
+  const int grp = NG > 1 ? __builtin_amdgcn_readfirstlane(t >> 8) : 0;
+  const int tap0 = (grp * 9 + NG - 1) / NG, ntap = ((grp + 1) * 9 + NG - 1) / NG - tap0;
   const int wr = wave & 1, wcn = wave >> 1;
   const int li = lane & 15, lg = lane >> 4;
   const int HW = g.TW + 2, nhalo = (g.TH + 2) * HW, ntile = g.TH * g.TW;
@@ -380,27 +382,27 @@ __global__ __launch_bounds__(256 * KG) void wgrad3x3_halo_kernel(const FsWgradAr
   int aty[LA], atx[LA], bhy[LB], bhx[LB];
 #pragma unroll
   for (int i = 0; i < LA; ++i) {
-    int pix = (t + i * 256) / UA;
+    int pix = (t + i * NT) / UA;
     const int aq = fs_fastdiv(min(pix, 4095), g.mTW);
     aty[i] = pix < ntile ? aq : -1; atx[i] = pix < ntile ? pix - aq * g.TW : 0;
   }
 #pragma unroll
   for (int i = 0; i < LB; ++i) {
-    int hp = (t + i * 256) / UB;
+    int hp = (t + i * NT) / UB;
     const int bq = fs_fastdiv(min(hp, 4095), g.mHW);
     bhy[i] = hp < nhalo ? bq : -1; bhx[i] = hp < nhalo ? hp - bq * HW : 0;
   }
   // byte offsets of the units relative to the tile origin (fixed over the tiles)
   int arel[LA], brel[LB];
 #pragma unroll
-  for (int i = 0; i < LA; ++i) arel[i] = ((aty[i] * p.Wd + atx[i]) * p.Cd + co0 + ((t + i * 256) % UA) * 8) * 2;
+  for (int i = 0; i < LA; ++i) arel[i] = ((aty[i] * p.Wd + atx[i]) * p.Cd + co0 + ((t + i * NT) % UA) * 8) * 2;
 #pragma unroll
   for (int i = 0; i < LB; ++i)
-    brel[i] = (int)(((long)bhy[i] * p.sH + (long)bhx[i] * p.sW + ci0 + ((t + i * 256) % UB) * 8) * 2);
+    brel[i] = (int)(((long)bhy[i] * p.sH + (long)bhx[i] * p.sW + ci0 + ((t + i * NT) % UB) * 8) * 2);
   uint4 ra[LA], rb[LB];
   // operand prologue (BatchNorm + ReLU folded into the staging of x): this thread's 16-byte units all hold the same 8
-  // input channels (256 % UB == 0), coefficients per statistics group of the tile's image
-  static_assert(256 % UB == 0, "a thread's x units must share their channel slot");
+  // input channels (NT % UB == 0), coefficients per statistics group of the tile's image
+  static_assert(NT % UB == 0, "a thread's x units must share their channel slot");
   const bool has_pro = p.pro_a != nullptr;
   float ka[8], kb[8];
   unsigned bok = 0u;                       // which of the thread's x units lie inside the image (padding stays zero)
@@ -448,51 +450,58 @@ __global__ __launch_bounds__(256 * KG) void wgrad3x3_halo_kernel(const FsWgradAr
   auto store_lds = [&]() {
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-      int idx = t + i * 256; int pix = idx / UA, u = idx % UA;
+      int idx = t + i * NT; int pix = idx / UA, u = idx % UA;
       if (pix < PIXT) *reinterpret_cast<uint4*>(&lds_a[pix * SA + u * 8]) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
-      int idx = t + i * 256; int hp = idx / UB, u = idx % UB;
+      int idx = t + i * NT; int hp = idx / UB, u = idx % UB;
       uint4 v = rb[i];
       if (has_pro) v = ((bok >> i) & 1u) ? pro_unit(v) : make_uint4(0u, 0u, 0u, 0u);
       if (hp < HMAX) *reinterpret_cast<uint4*>(&lds_b[hp * SB + u * 8]) = v;
     }
   };
 
-  // transposed-fragment row offsets: lane (li, lg) supplies pixel k = ks*32 + lg*8 + (li>>2) (+4)
+  // transposed-fragment row offsets.  A ds_read_b64_tr_b16 hands lane (li, lg) four consecutive pixels' values of
+  // channel li from the four rows its 16-lane group addresses; which 8 of the K step's 32 pixels a lane group takes is
+  // free as long as dY and x agree.  The 32 lanes served in one LDS cycle take same-parity pixels of a 16-pixel span:
+  // with row strides of 36 (dY) and 20 (x) dwords those eight 32-byte rows tile the 64 banks (consecutive pixels
+  // collide two-way) — pixel k = ks*32 + (lg>>1)*16 + 2*((lg&1)*4 + (li>>2)) + half
   int arow[4][2], brow[4][2];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
-      int pk = ks * 32 + lg * 8 + (li >> 2) + hf * 4;
+      int pk = ks * 32 + (lg >> 1) * 16 + 2 * ((lg & 1) * 4 + (li >> 2)) + hf;
       arow[ks][hf] = pk * SA + wr * (COT / 2) + (li & 3) * 4;
       int pv = pk < ntile ? pk : 0;
       const int pq = fs_fastdiv(pv, g.mTW);
       brow[ks][hf] = (pq * HW + (pv - pq * g.TW)) * SB + wcn * (CIT / 2) + (li & 3) * 4;
     }
-
-  f32x4 acc[9][TA][TB];
+  // the group's tap offsets (halo elements), wave-uniform
+  int toff[TPG];
 #pragma unroll
-  for (int tp = 0; tp < 9; ++tp)
+  for (int tp = 0; tp < TPG; ++tp) {
+    const int tap = tap0 + (tp < ntap ? tp : 0);
+    toff[tp] = ((tap / 3) * HW + (tap % 3)) * SB;
+  }
+
+  f32x4 acc[TPG][TA][TB];
+#pragma unroll
+  for (int tp = 0; tp < TPG; ++tp)
 #pragma unroll
     for (int a = 0; a < TA; ++a)
 #pragma unroll
       for (int b = 0; b < TB; ++b) acc[tp][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // the block's pixel tiles z, z + nsplit, ...: group `grp` takes every KG-th of them; the barrier count is the
-  // block's (the group with one tile fewer idles through its last round)
-  const int step = g.nsplit * KG;
-  int pt = blockIdx.z + grp * g.nsplit;
-  const int ntz = (npix - (int)blockIdx.z + g.nsplit - 1) / g.nsplit;
-  const int rounds = (ntz + KG - 1) / KG;
+  // the block's pixel tiles z, z + nsplit, ...
+  const int step = g.nsplit;
+  int pt = blockIdx.z;
   if (pt < npix) load_regs(pt);
-  for (int rd = 0; rd < rounds; ++rd, pt += step) {
+  for (; pt < npix; pt += step) {
     __syncthreads();
-    if (pt < npix) store_lds();
+    store_lds();
     __syncthreads();
-    if (pt >= npix) continue;
     if (pt + step < npix) load_regs(pt + step);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -505,12 +514,12 @@ __global__ __launch_bounds__(256 * KG) void wgrad3x3_halo_kernel(const FsWgradAr
         fa[a] = __builtin_bit_cast(bf16x8, make_uint4(l2.x, l2.y, h2.x, h2.y));
       }
 #pragma unroll
-      for (int tp = 0; tp < 9; ++tp) {
-        const int toff = ((tp / 3) * HW + (tp % 3)) * SB;
+      for (int tp = 0; tp < TPG; ++tp) {
+        if (NG > 1 && tp >= ntap) break;
 #pragma unroll
         for (int b = 0; b < TB; ++b) {
-          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(&lds_b[brow[ks][0] + toff + b * 16]));
-          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(&lds_b[brow[ks][1] + toff + b * 16]));
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(&lds_b[brow[ks][0] + toff[tp] + b * 16]));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(&lds_b[brow[ks][1] + toff[tp] + b * 16]));
           uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
           bf16x8 fb = __builtin_bit_cast(bf16x8, make_uint4(l2.x, l2.y, h2.x, h2.y));
 #pragma unroll
@@ -521,38 +530,13 @@ __global__ __launch_bounds__(256 * KG) void wgrad3x3_halo_kernel(const FsWgradAr
     }
   }
 
-  if constexpr (KG > 1) {
-    // second group's partial sums -> LDS ([value][thread]: conflict-free), first group adds them
-    float* red = reinterpret_cast<float*>(lds_raw);
-    __syncthreads();                       // every wave is done with the staging buffers
-    if (grp == 1) {
-      int q = 0;
-#pragma unroll
-      for (int tp = 0; tp < 9; ++tp)
-#pragma unroll
-        for (int a = 0; a < TA; ++a)
-#pragma unroll
-          for (int b = 0; b < TB; ++b)
-#pragma unroll
-            for (int j = 0; j < 4; ++j, ++q) red[q * 256 + t] = acc[tp][a][b][j];
-    }
-    __syncthreads();
-    if (grp != 0) return;
-    int q = 0;
-#pragma unroll
-    for (int tp = 0; tp < 9; ++tp)
-#pragma unroll
-      for (int a = 0; a < TA; ++a)
-#pragma unroll
-        for (int b = 0; b < TB; ++b)
-#pragma unroll
-          for (int j = 0; j < 4; ++j, ++q) acc[tp][a][b][j] += red[q * 256 + t];
-  }
   // ---- epilogue: the MFMA ran with the input-channel fragment as its row operand, D rows = ci (lg*4 + j), cols = co
   // (li): a lane holds four consecutive input channels of one output channel, i.e. one 16-byte run of the slab row
   // [co][tap][ci] (the other orientation stored 288 single floats per lane: a sixth of the kernel) ----
 #pragma unroll
-  for (int tp = 0; tp < 9; ++tp)
+  for (int tp = 0; tp < TPG; ++tp) {
+    if (NG > 1 && tp >= ntap) break;
+    const int tap = tap0 + tp;
 #pragma unroll
     for (int b = 0; b < TB; ++b) {
       const int ci = ci0 + wcn * (CIT / 2) + b * 16 + lg * 4;
@@ -561,15 +545,16 @@ __global__ __launch_bounds__(256 * KG) void wgrad3x3_halo_kernel(const FsWgradAr
         const int co = co0 + wr * (COT / 2) + a * 16 + li;
         const f32x4 v = acc[tp][a][b];
         if (g.nsplit > 1) {
-          *reinterpret_cast<float4*>(&p.workspace[((long)blockIdx.z * p.ws_rows + co) * p.ws_cols + tp * g.Cs + ci]) =
+          *reinterpret_cast<float4*>(&p.workspace[((long)blockIdx.z * p.ws_rows + co) * p.ws_cols + tap * g.Cs + ci]) =
               make_float4(v[0], v[1], v[2], v[3]);
         } else if (co < p.Co) {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            if (ci + j < p.Ci) p.dw[(((long)co * p.Ci + ci + j) * 3 + tp / 3) * 3 + tp % 3] += v[j];
+            if (ci + j < p.Ci) p.dw[(((long)co * p.Ci + ci + j) * 3 + tap / 3) * 3 + tap % 3] += v[j];
         }
       }
     }
+  }
 }
 
 template <int COT, int CIT>
@@ -895,6 +880,19 @@ WGeom wgrad_pick_geom(int Hd, int Wd) {
   return best;
 }
 
+// resident blocks of a kernel on the whole device (occupancy x CUs).  A split-K grid a little larger than this runs
+// as TWO rounds — 288 blocks of a one-block-per-CU kernel took twice the time of 256 (measured).
+template <typename K>
+int wg_resident_blocks(K kernel, int threads) {
+  int dev = 0, cus = 256, per_cu = 1;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+  }
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+  return cus * per_cu;
+}
+
 template <int COT, int CIT>
 int launch_wgrad_halo_t(const FsWgradArgs& a, hipStream_t st) {
   FsWgradArgs b = a;
@@ -906,17 +904,17 @@ int launch_wgrad_halo_t(const FsWgradArgs& a, hipStream_t st) {
   const int npix = g.N * g.tiles_x * g.tiles_y;
   b.ws_rows = a.Cd; b.ws_cols = 9 * Cs;
   const long slab = (long)b.ws_rows * b.ws_cols;
-  // ~256-320 blocks: every extra split adds a Cd x 9Cs fp32 slab to write and re-read
-  // (re-measured with 512 / 768 / 1024 blocks after the reduce kernels got cheaper: 288 is still the fastest)
-  long splits = std::max<long>(1, std::min<long>(npix / 2 > 0 ? npix / 2 : 1, (288 + out_tiles - 1) / out_tiles));
+  // one round of resident blocks: every split adds a Cd x 9Cs fp32 slab to write and re-read, every block beyond the
+  // resident ones waits for a whole block to finish
+  static const int slots = wg_resident_blocks(wgrad3x3_halo_kernel<COT, CIT, 2>, 512);
+  long splits = std::max<long>(1, std::min<long>(npix / 2 > 0 ? npix / 2 : 1, std::max(1, slots / out_tiles)));
   if (!a.workspace) splits = 1;
   else splits = std::min<long>(splits, std::max<long>(1, a.workspace_elems / slab));
   g.nsplit = (int)splits; b.nsplit = g.nsplit;
   dim3 grid(Cs / CIT, a.Cd / COT, g.nsplit);
-  // (a second wave group per block — the block's pixel tiles split between two groups of four waves, partial sums added
-  // through LDS — made the kernel itself 6-11 % faster and the step 1.5 % slower: on its companion stream the fatter
-  // kernel takes CU time from the data-gradient chain, which is the critical path; measured and removed)
-  hipLaunchKernelGGL((wgrad3x3_halo_kernel<COT, CIT, 1>), grid, dim3(256), 0, st, b, g);
+  // two tap groups: one, three and four measured — 35.0 / 30.3 / 30.3 / 30.1 us at 288 blocks, 25.0 / 22.9 / - / 22.5 us
+  // at 256 (64 -> 64 @48x160 B=12, with the reduce); in the step four groups (1024-thread blocks) lose to two
+  hipLaunchKernelGGL((wgrad3x3_halo_kernel<COT, CIT, 2>), grid, dim3(512), 0, st, b, g);
   if (b.nsplit > 1) {
     const int ncols = 9 * Cs;
     launch_reduce(b, a.Co, ncols, 8, st);
@@ -941,9 +939,13 @@ int launch_wgrad_narrow(const FsWgradArgs& a, hipStream_t st) {
   const int npix = g.N * g.tiles_x * g.tiles_y;
   b.ws_rows = COT; b.ws_cols = 9 * Cs;
   const long slab = (long)b.ws_rows * b.ws_cols;
-  // every tile step waits one global-load latency: ~1024 short chains keep 4 blocks per CU in flight; the slabs
-  // are tiny (16 x 9Cs floats)
-  long splits = std::max<long>(1, std::min<long>(npix / 4 > 0 ? npix / 4 : 1, (1024 + out_tiles - 1) / out_tiles));
+  // every tile step waits one global-load latency: as many short chains as the device holds at once (2-4 blocks per
+  // CU by the instantiation's registers) — one round, see wg_resident_blocks; the slabs are tiny (16 x 9Cs floats)
+  static const int slots_32_32 = wg_resident_blocks(wgrad3x3_narrow_kernel<32, 32>, 256);
+  static const int slots_16_32 = wg_resident_blocks(wgrad3x3_narrow_kernel<16, 32>, 256);
+  static const int slots_16_16 = wg_resident_blocks(wgrad3x3_narrow_kernel<16, 16>, 256);
+  const int slots = COT == 32 ? slots_32_32 : CIT == 32 ? slots_16_32 : slots_16_16;
+  long splits = std::max<long>(1, std::min<long>(npix / 4 > 0 ? npix / 4 : 1, std::max(1, slots / out_tiles)));
   if (!a.workspace) splits = 1;
   else splits = std::min<long>(splits, std::max<long>(1, a.workspace_elems / slab));
   g.nsplit = (int)splits; b.nsplit = g.nsplit;
@@ -965,9 +967,9 @@ int launch_wgrad_stem(const FsWgradArgs& a, hipStream_t st) {
   const long ntiles = (long)(a.M / (a.Hd * a.Wd)) * tiles_x * tiles_y;
   b.ws_rows = 64; b.ws_cols = 49 * 8;
   const long slab = (long)b.ws_rows * b.ws_cols;
-  // one slab per persistent block: ~1.25 blocks per CU keeps the slab traffic (100 KB each, written and re-read)
-  // well below the operand traffic
-  const long max_blocks = std::min<long>(320, a.workspace_elems / slab);
+  // one slab per persistent block (100 KB each, written and re-read), as many blocks as the device holds at once
+  static const int slots = wg_resident_blocks(wgrad_stem_kernel, 256);   // (320 blocks of this one-block-per-CU kernel ran as two rounds)
+  const long max_blocks = std::min<long>(slots, a.workspace_elems / slab);
   if (max_blocks < 1 || ntiles < 1) return FS_EINVAL;
   const int per = (int)((ntiles + max_blocks - 1) / max_blocks);
   const int blocks = (int)((ntiles + per - 1) / per);

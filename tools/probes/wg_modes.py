@@ -1,0 +1,33 @@
+"""weight gradient under development switches: values against the first mode, time of each.  args: NAME=V[,NAME=V] ... (FSNET_DEV_<NAME>)"""
+import os, sys
+sys.path.insert(0, '.')
+import torch
+from fsnet_amd.hip.conv import ConvOp
+MODES = sys.argv[1:]
+dev = torch.device('cuda:0'); dt = torch.bfloat16
+shapes = [(64, 64, 48, 160, 12), (64, 64, 48, 160, 24), (128, 128, 24, 80, 12), (128, 128, 24, 80, 24), (256, 256, 12, 40, 24),
+          (512, 512, 6, 20, 24), (64, 64, 96, 320, 12), (128, 64, 24, 80, 12)]
+for Ci, Co, H, W, B in shapes:
+    op = ConvOp(Ci, Co, 3, 3, 1, 1, dt, dev)
+    x = torch.randn(B, H, W, op.Ci_p, device=dev).to(dt)
+    gy = torch.randn(B, H, W, op.Co_p, device=dev).to(dt)
+    res = {}
+    for mode in MODES:
+        for k in list(os.environ):
+            if k.startswith("FSNET_DEV_"): del os.environ[k]
+        for kv in mode.split(","):
+            if "=" in kv: os.environ["FSNET_DEV_" + kv.split("=")[0]] = kv.split("=")[1]
+        dw = torch.zeros(Co, Ci, 3, 3, device=dev)
+        op.wgrad(gy, x, dw)
+        torch.cuda.synchronize()
+        ref = dw.clone()
+        for _ in range(5):
+            op.wgrad(gy, x, dw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            op.wgrad(gy, x, dw)
+        e1.record(); torch.cuda.synchronize()
+        res[mode] = (ref, e0.elapsed_time(e1) / 50 * 1e3)
+    ref = res[MODES[0]][0]
+    print("%-24s" % ((Ci, Co, H, W, B),), "  ".join("%s %.1f us (d %.2g)" % (m, res[m][1], (res[m][0] - ref).abs().max().item() / ref.abs().max().item()) for m in MODES))
