@@ -16,6 +16,15 @@
 
 namespace {
 
+// fs_conv_wgrad_plan: the launch functions below report (kernel, blocks, threads, resident blocks) instead of launching
+thread_local int32_t* g_plan = nullptr;
+inline bool wg_plan(int kind, long blocks, int threads, int resident) {
+  if (!g_plan) return false;
+  g_plan[0] = kind; g_plan[1] = (int32_t)blocks; g_plan[2] = threads; g_plan[3] = resident;
+  return true;
+}
+
+
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 template <typename T, int COT, int CLT, int WR, int CH>
@@ -299,6 +308,19 @@ void launch_reduce(const FsWgradArgs& b, int Co, int ncols, int eg, hipStream_t 
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(Co * ((ncols + 63) / 64))), dim3(256), 0, st, b, eg);
 }
 
+// resident blocks of a kernel on the whole device (occupancy x CUs).  A split-K grid a little larger than this runs
+// as TWO rounds — 288 blocks of a one-block-per-CU kernel took twice the time of 256 (measured, DESIGN section 14).
+template <typename K>
+int wg_resident_blocks(K kernel, int threads) {
+  int dev = 0, cus = 256, per_cu = 1;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+  }
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+  return cus * per_cu;
+}
+
 template <typename T, int COT, int CLT, int WR>
 int launch_tile(const FsWgradArgs& a, hipStream_t st) {
   constexpr int EG = ElemTraits<T>::EG;
@@ -323,6 +345,7 @@ int launch_tile(const FsWgradArgs& a, hipStream_t st) {
   b.pix_per_split = (int)(cps * CH);
   b.nsplit = (int)((chunks + cps - 1) / cps);
   dim3 grid(ct, rt, b.nsplit);
+  if (g_plan) return wg_plan(0, (long)ct * rt * b.nsplit, 256, wg_resident_blocks(conv_wgrad_kernel<T, COT, CLT, WR, CH>, 256)) ? 0 : FS_EINVAL;
   hipLaunchKernelGGL((conv_wgrad_kernel<T, COT, CLT, WR, CH>), grid, dim3(256), 0, st, b, fs_make_div(a.Wd),
                      fs_make_div(a.Hd));
   if (b.nsplit > 1) {
@@ -880,19 +903,6 @@ WGeom wgrad_pick_geom(int Hd, int Wd) {
   return best;
 }
 
-// resident blocks of a kernel on the whole device (occupancy x CUs).  A split-K grid a little larger than this runs
-// as TWO rounds — 288 blocks of a one-block-per-CU kernel took twice the time of 256 (measured, DESIGN section 14).
-template <typename K>
-int wg_resident_blocks(K kernel, int threads) {
-  int dev = 0, cus = 256, per_cu = 1;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    hipDeviceProp_t pr;
-    if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
-  }
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-  return cus * per_cu;
-}
-
 template <int COT, int CIT>
 int launch_wgrad_halo_t(const FsWgradArgs& a, hipStream_t st) {
   FsWgradArgs b = a;
@@ -914,6 +924,7 @@ int launch_wgrad_halo_t(const FsWgradArgs& a, hipStream_t st) {
   dim3 grid(Cs / CIT, a.Cd / COT, g.nsplit);
   // two tap groups: one, three and four measured — 35.0 / 30.3 / 30.3 / 30.1 us at 288 blocks, 25.0 / 22.9 / - / 22.5 us
   // at 256 (64 -> 64 @48x160 B=12, with the reduce); in the step four groups (1024-thread blocks) lose to two
+  if (wg_plan(1, (long)grid.x * grid.y * grid.z, 512, slots)) return 0;
   hipLaunchKernelGGL((wgrad3x3_halo_kernel<COT, CIT, 2>), grid, dim3(512), 0, st, b, g);
   if (b.nsplit > 1) {
     const int ncols = 9 * Cs;
@@ -950,6 +961,7 @@ int launch_wgrad_narrow(const FsWgradArgs& a, hipStream_t st) {
   else splits = std::min<long>(splits, std::max<long>(1, a.workspace_elems / slab));
   g.nsplit = (int)splits; b.nsplit = g.nsplit;
   dim3 grid(out_tiles, 1, g.nsplit);
+  if (wg_plan(2, (long)grid.x * grid.z, 256, slots)) return (COT == 32 && CIT == 32) || (COT == 16 && (CIT == 32 || CIT == 16)) ? 0 : FS_EINVAL;
   if (COT == 32 && CIT == 32) hipLaunchKernelGGL((wgrad3x3_narrow_kernel<32, 32>), grid, dim3(256), 0, st, b, g);
   else if (COT == 16 && CIT == 32) hipLaunchKernelGGL((wgrad3x3_narrow_kernel<16, 32>), grid, dim3(256), 0, st, b, g);
   else if (COT == 16 && CIT == 16) hipLaunchKernelGGL((wgrad3x3_narrow_kernel<16, 16>), grid, dim3(256), 0, st, b, g);
@@ -974,6 +986,7 @@ int launch_wgrad_stem(const FsWgradArgs& a, hipStream_t st) {
   const int per = (int)((ntiles + max_blocks - 1) / max_blocks);
   const int blocks = (int)((ntiles + per - 1) / per);
   b.nsplit = blocks;
+  if (wg_plan(3, blocks, 256, slots)) return 0;
   hipLaunchKernelGGL(wgrad_stem_kernel, dim3(blocks), dim3(256), 0, st, b, tiles_x, tiles_y, (int)ntiles, per,
                      fs_make_div(tiles_x), fs_make_div(tiles_y));
   launch_reduce(b, a.Co, 49 * 8, 8, st);
@@ -1024,4 +1037,15 @@ extern "C" int fs_conv_wgrad(const FsWgradArgs* args, int dtype, void* stream) {
   if (dtype == FS_DTYPE_BF16) return launch_wgrad<bf16>(*args, st);
   if (dtype == FS_DTYPE_F32) return launch_wgrad<float>(*args, st);
   return FS_EINVAL;
+}
+
+extern "C" int fs_conv_wgrad_plan(const FsWgradArgs* args, int dtype, int32_t* plan) {
+  if (!args || !plan || args->M <= 0 || args->ncolgroups <= 0) return FS_EINVAL;
+  if (args->pro_a && (!args->pro_b || dtype != FS_DTYPE_BF16)) return FS_EINVAL;
+  g_plan = plan;
+  int r = FS_EINVAL;
+  if (dtype == FS_DTYPE_BF16) r = launch_wgrad<bf16>(*args, nullptr);
+  else if (dtype == FS_DTYPE_F32) r = launch_wgrad<float>(*args, nullptr);
+  g_plan = nullptr;
+  return r;
 }

@@ -17,6 +17,7 @@ SIGNATURES = {
     "fs_conv1x1": (C.c_int, [P, I, P]),
     "fs_conv_stem": (C.c_int, [P, I, P]),
     "fs_conv_wgrad": (C.c_int, [P, I, P]),
+    "fs_conv_wgrad_plan": (C.c_int, [P, I, P]),
     "fs_pack_weights": (C.c_int, [P, P, I, I, I, I, I, I, L, I, I, P]),
     "fs_sigmoid_head_fwd": (C.c_int, [P, P, L, I, P]),
     "fs_sigmoid_head_bwd": (C.c_int, [P, P, P, L, I, I, P]),

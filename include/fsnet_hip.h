@@ -33,7 +33,7 @@ extern "C" {
 
 /* library/ABI version and the ISA the kernels were compiled for ("gfx950").  FS_ABI_VERSION changes whenever an
  * argument struct or a signature below does; a host binding refuses a library that reports another number. */
-#define FS_ABI_VERSION 4
+#define FS_ABI_VERSION 5
 int fs_abi_version(void);
 const char* fs_target_arch(void);
 /* debugging aid: writes the device's constant-rate clock (wall_clock64, 100 MHz) into *slot (u64) on `stream`;
@@ -177,6 +177,10 @@ typedef struct FsWgradArgs {
   int32_t pro_relu, pro_group_imgs;
 } FsWgradArgs;
 int fs_conv_wgrad(const FsWgradArgs* args, int dtype, void* stream);
+/* the launch fs_conv_wgrad would make for these arguments, nothing launched: plan = {kernel (0 generic tile, 1 3x3 LDS-halo,
+ * 2 narrow 16/32-channel, 3 7x7 stem), blocks, threads per block, blocks of that kernel the device holds at once}.
+ * A split-K grid a little above the resident count runs as two rounds; tests hold the grids to one. */
+int fs_conv_wgrad_plan(const FsWgradArgs* args, int dtype, int32_t* plan);
 
 /* Weight packing.  OIHW fp32 master weights (the reference's state_dict layout,
  * e.g. depth_backbone.conv1.weight (64,3,7,7)) -> [rows_p][ktot_p] K-contiguous
