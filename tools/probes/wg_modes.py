@@ -1,9 +1,12 @@
-"""weight gradient under development switches: values against the first mode, time of each.  args: NAME=V[,NAME=V] ... (FSNET_DEV_<NAME>)"""
+"""3x3 weight gradient (kernel + reduce) under sets of environment variables: values against the first set, time of each.
+args: one set per argument, NAME=V[,NAME=V] (`none` = nothing set).  The shipped library reads no development switch;
+this is the harness the round-3 experiments (tap groups, block counts, atomic epilogue) were timed with."""
 import os, sys
 sys.path.insert(0, '.')
 import torch
 from fsnet_amd.hip.conv import ConvOp
 MODES = sys.argv[1:]
+SET = []
 dev = torch.device('cuda:0'); dt = torch.bfloat16
 shapes = [(64, 64, 48, 160, 12), (64, 64, 48, 160, 24), (128, 128, 24, 80, 12), (128, 128, 24, 80, 24), (256, 256, 12, 40, 24),
           (512, 512, 6, 20, 24), (64, 64, 96, 320, 12), (128, 64, 24, 80, 12)]
@@ -13,10 +16,13 @@ for Ci, Co, H, W, B in shapes:
     gy = torch.randn(B, H, W, op.Co_p, device=dev).to(dt)
     res = {}
     for mode in MODES:
-        for k in list(os.environ):
-            if k.startswith("FSNET_DEV_"): del os.environ[k]
+        for k in SET:
+            os.environ.pop(k, None)
+        SET.clear()
         for kv in mode.split(","):
-            if "=" in kv: os.environ["FSNET_DEV_" + kv.split("=")[0]] = kv.split("=")[1]
+            if "=" in kv:
+                os.environ[kv.split("=")[0]] = kv.split("=")[1]
+                SET.append(kv.split("=")[0])
         dw = torch.zeros(Co, Ci, 3, 3, device=dev)
         op.wgrad(gy, x, dw)
         torch.cuda.synchronize()
