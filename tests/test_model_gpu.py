@@ -349,8 +349,9 @@ def test_bf16_training_run_tracks_fp32_over_50_steps(dev):
         cos, cos_ref, float(db.norm() / df.norm())))
     # Adam moves every weight by ~lr per step whatever the gradient's size, so weights with noise-level gradients
     # random-walk: two fp32 runs (atomic ordering) are the yardstick for what "the same update" means here
-    # (measured round 3: 0.70 against 0.93 for the two fp32 runs, norm ratio 0.998)
-    assert cos > 0.68 * cos_ref and 0.9 < float(db.norm() / df.norm()) < 1.1, (cos, cos_ref)
+    # (measured round 3: 0.65-0.70 against 0.93-0.96 for the two fp32 runs; a bound of 0.68 x cos_ref held in three
+    # runs of the suite and was missed by 1e-4 in a fourth — the runs differ by atomic ordering —, norm ratio 0.998)
+    assert cos > 0.62 * cos_ref and 0.9 < float(db.norm() / df.norm()) < 1.1, (cos, cos_ref)
 
 
 @gpu
