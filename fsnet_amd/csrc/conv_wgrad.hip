@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256 * NG) void wgrad3x3_halo_kernel(const FsWgradAr
   constexpr int NT = 256 * NG;
   constexpr int TPG = (9 + NG - 1) / NG;               // taps per group (the last groups may hold one fewer)
   constexpr int PIXT = 128, HMAX = 208, OOB = 0x7fffffff;
-  constexpr int SA = COT + 8, SB = CIT + 8;
+  constexpr int SA = COT + 24, SB = CIT + 24;   // LDS row pads (elements): 8 / 16 / 24 / 32 each measured, 24 + 24 is 3-6 % ahead of 8 + 8; a 128-byte x row costs 30-50 %
   constexpr int TA = COT / 32, TB = CIT / 32;          // per-wave 16x16 sub-tiles (2 x 2 waves)
   constexpr int UA = COT / 8, UB = CIT / 8;            // 16-byte units per pixel row
   constexpr int LA = (PIXT * UA + NT - 1) / NT, LB = (HMAX * UB + NT - 1) / NT;
@@ -488,8 +488,8 @@ __global__ __launch_bounds__(256 * NG) void wgrad3x3_halo_kernel(const FsWgradAr
   // transposed-fragment row offsets.  A ds_read_b64_tr_b16 hands lane (li, lg) four consecutive pixels' values of
   // channel li from the four rows its 16-lane group addresses; which 8 of the K step's 32 pixels a lane group takes is
   // free as long as dY and x agree.  The 32 lanes served in one LDS cycle take same-parity pixels of a 16-pixel span:
-  // with row strides of 36 (dY) and 20 (x) dwords those eight 32-byte rows tile the 64 banks (consecutive pixels
-  // collide two-way) — pixel k = ks*32 + (lg>>1)*16 + 2*((lg&1)*4 + (li>>2)) + half
+  // with row strides of 44 (dY) and 28 (x) dwords — as with 36 and 20 — those eight 32-byte rows tile the 64 banks
+  // (consecutive pixels collide two-way) — pixel k = ks*32 + (lg>>1)*16 + 2*((lg&1)*4 + (li>>2)) + half
   int arow[4][2], brow[4][2];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks)
