@@ -15,8 +15,13 @@
 // dispatch(): occupancy, not reuse, decides the tile on the monodepth shapes.
 // Dgrad = same kernel on dY with Wt[ci][r][s][co] and the taps mirrored (sgn = -1).
 // The epilogue (bias / addend / ReLU / ReLU-mask / fp32 out / fused BN statistics) matches conv_igemm.hip.
+// Round 4: the operand prologues of conv3x3_t32.hip (conv_pro.h: BatchNorm + ReLU in front of the convolution, the
+// second pass of a BatchNorm backward in front of a data gradient, coefficients derived in the kernel) and the derived
+// ReLU mask (bnb_scale) exist here too, so that every BasicBlock of every stage folds, not only the launches large
+// enough for the 32x32-tile kernel.
 #include "common.h"
 #include "fsnet_hip_internal.h"
+#include "conv_pro.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -44,11 +49,16 @@ struct HaloGeom {
   unsigned mTW, mHW; // fs_div_magic(TW), fs_div_magic(TW + 2)
   FsDiv dTX, dTY;    // tiles_x, tiles_y
   FsDiv dIPG;        // images per BatchNorm statistics group (stat_group_rows / (Hd*Wd)); unused when 0 groups
+  FsDiv dPRG;        // images per prologue coefficient group
   int pix_major;     // block -> tile mapping keeps a pixel tile's channel tiles on one XCD (else: a channel tile's)
 };
 
-template <typename T, int PIX, int CO, int WP>
-__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, const HaloGeom g) {
+// waves per SIMD the register allocation is held to: the forward prologue must not cost the 128x32 tile its fourth block
+// per CU (132 registers without the bound: measured +6 us on a 22 us launch, more than the BatchNorm pass it replaces saves)
+constexpr int halo_minwaves(int PIX, int CO, int PRO) { return (PRO == 1 && PIX == 128) ? 4 : 1; }
+
+template <typename T, int PIX, int CO, int WP, int PRO>
+__global__ __launch_bounds__(256, halo_minwaves(PIX, CO, PRO)) void conv3x3_halo_kernel(const FsConvArgs p, const HaloGeom g) {
   constexpr int WC = 4 / WP;
   constexpr int WPIX = PIX / WP, WCO = CO / WC;
   constexpr int TP = WPIX / 16, TC = WCO / 16;
@@ -66,6 +76,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
   constexpr int HS = 6;
   __shared__ uint4 lds_h[HMAX * HS];
   __shared__ uint4 lds_w[9 * CO * 4];
+  extern __shared__ float halo_pro_tab[];            // [pro_ncoef<PRO>()][Cs] (PRO != 0 launches only)
+  constexpr int UN = 16 / (int)sizeof(T);            // elements per 16-byte unit
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wp = wave % WP, wc = wave / WP;
@@ -101,10 +113,17 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, (int)p.src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wgt =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, (int)p.wgt_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_src2 =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(PRO == 2 ? p.pro_src2 : p.src), 0, (int)p.src_bytes, 0x00020000);
+
+  // the prologue's coefficient table first: its f64 sums are the oldest loads in flight when the halo arrives, and
+  // none of the walk's scalar state is live yet (the table is complete at the loop's first barrier)
+  if constexpr (PRO != 0) pro_build_table<PRO>(p, halo_pro_tab, (p.pro_group_imgs > 0) ? fs_div(n, g.dPRG) : 0, t, 256);
 
   // ---- per-thread load units (fixed over the channel walk) ----
   const int row_bytes = p.Cs * (int)sizeof(T);     // real bytes per pixel / per tap
   int hvoff[LH], wvoff[LW];
+  unsigned interior = 0u;        // PRO == 2 with pro_dst: the units this thread writes out (its tile's own pixels)
 #pragma unroll
   for (int i = 0; i < LH; ++i) {
     int idx = t + i * 256;
@@ -114,7 +133,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
     // (a 16-channel bf16 layer fills half a 64-byte chunk: the upper units stay zero, as do their weights)
     bool ok = hp < nhalo && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws && q * 16 < row_bytes;
     hvoff[i] = ok ? (int)(((long)n * p.sN + (long)sy * p.sH + (long)sx * p.sW) * (long)sizeof(T)) + q * 16 : OOB;
+    if (PRO == 2 && ok && hy >= 1 && hy <= g.TH && hx >= 1 && hx <= g.TW) interior |= 1u << i;
   }
+  if (PRO != 2 || p.pro_dst == nullptr || cy != 0) interior = 0u;
+
   const int wrow_bytes = p.nchunks * p.kg * 16;    // packed weight row stride (as packed for conv_igemm)
   const int tap_bytes = p.Cs * (int)sizeof(T);
 #pragma unroll
@@ -126,19 +148,66 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
   }
 
   uint4 rh[LH], rw[LW];
+  uint4 rh2[PRO == 2 ? LH : 1];
   auto load_regs = [&](int cc) {
     const int coff = cc * 64;
 #pragma unroll
     for (int i = 0; i < LH; ++i) rh[i] = buf_load16(rs_src, hvoff[i] == OOB ? OOB : hvoff[i] + coff);
+    if constexpr (PRO == 2) {
+#pragma unroll
+      for (int i = 0; i < LH; ++i) rh2[i] = buf_load16(rs_src2, hvoff[i] == OOB ? OOB : hvoff[i] + coff);
+    }
 #pragma unroll
     for (int i = 0; i < LW; ++i) rw[i] = buf_load16(rs_wgt, wvoff[i] == OOB ? OOB : wvoff[i] + coff);
   };
-  auto store_lds = [&]() {
+  auto store_lds = [&](int cc) {
+    float ka[PRO != 0 ? UN : 1], kb[PRO != 0 ? UN : 1], kc[PRO == 2 ? UN : 1], km[PRO == 2 ? UN : 1];
+    if constexpr (PRO != 0) {
+      // this thread's channels of the chunk: 256 % 4 == 0, so slot q = t & 3 of every pixel it stages
+      const int c0r = cc * (64 / (int)sizeof(T)) + (t & 3) * UN;
+      const int c0 = c0r < p.Cs ? c0r : 0;
+#pragma unroll
+      for (int j = 0; j < UN; j += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(halo_pro_tab + c0 + j);
+        const float4 b = *reinterpret_cast<const float4*>(halo_pro_tab + p.Cs + c0 + j);
+        ka[j] = a.x; ka[j + 1] = a.y; ka[j + 2] = a.z; ka[j + 3] = a.w;
+        kb[j] = b.x; kb[j + 1] = b.y; kb[j + 2] = b.z; kb[j + 3] = b.w;
+        if constexpr (PRO == 2) {
+          const float4 c = *reinterpret_cast<const float4*>(halo_pro_tab + 2 * p.Cs + c0 + j);
+          const float4 m = *reinterpret_cast<const float4*>(halo_pro_tab + 3 * p.Cs + c0 + j);
+          kc[j] = c.x; kc[j + 1] = c.y; kc[j + 2] = c.z; kc[j + 3] = c.w;
+          km[j] = m.x; km[j + 1] = m.y; km[j + 2] = m.z; km[j + 3] = m.w;
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < LH; ++i) {
       int idx = t + i * 256;
       int hp = idx >> 2, q = idx & 3;
-      if (hp < HMAX) lds_h[hp * HS + q] = rh[i];
+      uint4 u = rh[i];
+      if constexpr (PRO == 1) {
+        float v[UN];
+        Unit<T>::unpack(u, v);
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+          v[j] = v[j] * ka[j] + kb[j];
+          if (p.pro_relu) v[j] = fmaxf(v[j], 0.f);
+        }
+        u = Unit<T>::pack(v);
+        if (hvoff[i] == OOB) u = make_uint4(0u, 0u, 0u, 0u);     // padding applies to the transformed tensor
+      }
+      if constexpr (PRO == 2) {
+        float v[UN], w[UN];
+        Unit<T>::unpack(u, v);
+        Unit<T>::unpack(rh2[i], w);
+#pragma unroll
+        for (int j = 0; j < UN; ++j) v[j] = v[j] * ka[j] + ((w[j] - km[j]) * kb[j] + kc[j]);
+        u = Unit<T>::pack(v);
+        if (hvoff[i] == OOB) u = make_uint4(0u, 0u, 0u, 0u);
+        if ((interior >> i) & 1u)
+          *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.pro_dst) + (long)hvoff[i] + cc * 64) = u;
+      }
+      if (hp < HMAX) lds_h[hp * HS + q] = u;
     }
 #pragma unroll
     for (int i = 0; i < LW; ++i) {
@@ -167,8 +236,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
   const int nchunk = (p.Cs * (int)sizeof(T) + 63) / 64;
   load_regs(0);
   for (int cc = 0; cc < nchunk; ++cc) {
-    lds_barrier();                 // previous chunk fully multiplied
-    store_lds();
+    lds_barrier();                 // previous chunk fully multiplied (first pass: the coefficient table is complete)
+    store_lds(cc);
     lds_barrier();
     if (cc + 1 < nchunk) load_regs(cc + 1);
     // (the compiler's own schedule of this tap walk — every fragment read next to its use — is as fast as a hand-
@@ -227,11 +296,15 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
   for (int a = 0; a < TC; ++a) {
     const int co = co0 + wc * WCO + a * 16 + lg * 4;
     if (co >= p.Co) continue;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), mu = bv, is = bv;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), mu = bv, is = bv, msc = bv, msh = bv;
     if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + co);
     if (p.bnb_x) {
       mu = *reinterpret_cast<const float4*>(p.bnb_mean + sgoff + co);
       is = *reinterpret_cast<const float4*>(p.bnb_invstd + sgoff + co);
+      if (p.bnb_scale) {
+        msc = *reinterpret_cast<const float4*>(p.bnb_scale + sgoff + co);
+        msh = *reinterpret_cast<const float4*>(p.bnb_shift + sgoff + co);
+      }
     }
 #pragma unroll
     for (int b = 0; b < TP; ++b) {
@@ -255,6 +328,11 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
       if (p.bnb_x) {   // BatchNorm-backward sums of the layer this gradient flows into: (sum g, sum g*xhat)
         float cv[4];
         load4<T>(reinterpret_cast<const T*>(p.bnb_x) + doff[b] + co, cv);   // same layout as dst
+        if (p.bnb_scale) {
+          // ReLU mask of a folded BatchNorm: the sign of the forward prologue's own expression
+          v[0] = (cv[0] * msc.x + msh.x) > 0.f ? v[0] : 0.f; v[1] = (cv[1] * msc.y + msh.y) > 0.f ? v[1] : 0.f;
+          v[2] = (cv[2] * msc.z + msh.z) > 0.f ? v[2] : 0.f; v[3] = (cv[3] * msc.w + msh.w) > 0.f ? v[3] : 0.f;
+        }
         s1[a][0] += v[0]; s1[a][1] += v[1]; s1[a][2] += v[2]; s1[a][3] += v[3];
         s2[a][0] += v[0] * (cv[0] - mu.x) * is.x; s2[a][1] += v[1] * (cv[1] - mu.y) * is.y;
         s2[a][2] += v[2] * (cv[2] - mu.z) * is.z; s2[a][3] += v[3] * (cv[3] - mu.w) * is.w;
@@ -294,11 +372,13 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const FsConvArgs p, c
       }
     }
   }
+  // (last, so that its arguments are not live across the walk: saved statistics / running statistics / dgamma, dbeta)
+  if constexpr (PRO != 0) { if (blockIdx.x == 0) pro_block0<PRO>(p, t, 256); }
 }
 
 // pick the pixel tile (TH x TW <= PIX, halo <= hmax) that wastes the fewest lanes, preferring wide tiles
 HaloGeom pick_geom(int Hd, int Wd, int PIX, int hmax) {
-  HaloGeom best{0, 0, 0, 0, 0u, 0u, FsDiv{0u, 0u}, FsDiv{0u, 0u}, FsDiv{0u, 0u}, 0};
+  HaloGeom best{0, 0, 0, 0, 0u, 0u, FsDiv{0u, 0u}, FsDiv{0u, 0u}, FsDiv{0u, 0u}, FsDiv{0u, 0u}, 0};
   double best_cost = 1e30;
   for (int tw = std::min(4, Wd); tw <= std::min(Wd, 64); ++tw) {
     int th = std::min(PIX / tw, Hd);
@@ -307,7 +387,7 @@ HaloGeom pick_geom(int Hd, int Wd, int PIX, int hmax) {
     double waste = (double)tx * ty * PIX / ((double)Hd * Wd);          // MFMA lanes spent per useful pixel
     double halo = (double)(th + 2) * (tw + 2) / ((double)th * tw);     // fetch overhead
     double cost = waste * (1.0 + 0.15 * halo);
-    if (cost < best_cost - 1e-9) { best_cost = cost; best = HaloGeom{th, tw, tx, ty}; }
+    if (cost < best_cost - 1e-9) { best_cost = cost; best.TH = th; best.TW = tw; best.tiles_x = tx; best.tiles_y = ty; }
   }
   if (best.TW > 0) {
     best.mTW = fs_div_magic(best.TW); best.mHW = fs_div_magic(best.TW + 2);
@@ -316,8 +396,8 @@ HaloGeom pick_geom(int Hd, int Wd, int PIX, int hmax) {
   return best;
 }
 
-template <typename T, int PIX, int CO, int WP>
-int launch_halo(const FsConvArgs& a, hipStream_t st) {
+template <typename T, int PIX, int CO, int WP, int PRO>
+int launch_halo_pro(const FsConvArgs& a, hipStream_t st) {
   HaloGeom g = pick_geom(a.Hd, a.Wd, PIX, PIX == 256 ? 360 : (PIX == 128 ? 208 : 120));
   if (g.TH == 0) return FS_EINVAL;
   if (a.stat_group_rows > 0) {
@@ -325,14 +405,29 @@ int launch_halo(const FsConvArgs& a, hipStream_t st) {
     if (a.stat_group_rows % hw != 0) return FS_EINVAL;          // statistics groups are whole images
     g.dIPG = fs_make_div((int)(a.stat_group_rows / hw));
   }
+  if (a.pro_group_imgs > 0) g.dPRG = fs_make_div(a.pro_group_imgs);
   const int npix = a.N * g.tiles_x * g.tiles_y, nco = a.Co_p / CO;
   int blocks = npix * nco;
   // which operand is worth keeping XCD-local: the input activation (fetched once per channel tile) or the weights
   g.pix_major = (nco > 1 && a.src_bytes > 2 * a.wgt_bytes) ? 1 : 0;
   if (g.pix_major) blocks = 8 * ((npix + 7) / 8) * nco;
   else if (nco % 8 != 0 && 8 % nco == 0) { const int q = 8 / nco; blocks = 8 * ((npix + q - 1) / q); }
-  hipLaunchKernelGGL((conv3x3_halo_kernel<T, PIX, CO, WP>), dim3(blocks), dim3(256), 0, st, a, g);
+  if (fs_conv3x3_plan_slot) {
+    fs_conv3x3_plan_slot[0] = 0; fs_conv3x3_plan_slot[1] = blocks; fs_conv3x3_plan_slot[2] = PIX; fs_conv3x3_plan_slot[3] = CO;
+    return FS_OK;
+  }
+  hipLaunchKernelGGL((conv3x3_halo_kernel<T, PIX, CO, WP, PRO>), dim3(blocks), dim3(256), pro_lds_bytes<PRO>(a), st, a, g);
   return fs_launch_status();
+}
+
+template <typename T, int PIX, int CO, int WP>
+int launch_halo(const FsConvArgs& a, hipStream_t st) {
+  switch (a.pro_mode) {
+    case 0: return launch_halo_pro<T, PIX, CO, WP, 0>(a, st);
+    case 1: return launch_halo_pro<T, PIX, CO, WP, 1>(a, st);
+    case 2: return launch_halo_pro<T, PIX, CO, WP, 2>(a, st);
+    default: return FS_EINVAL;
+  }
 }
 
 template <typename T>
@@ -366,7 +461,8 @@ int dispatch(const FsConvArgs& a, hipStream_t st) {
 
 int fs_conv3x3_t32(const FsConvArgs& a, int dtype, hipStream_t st);      // conv3x3_t32.hip
 
-extern "C" int fs_conv3x3_halo(const FsConvArgs* args, int dtype, void* stream) {
+namespace {
+int conv3x3_entry(const FsConvArgs* args, int dtype, hipStream_t st) {
   if (!args || !args->src || !args->wgt || !args->dst) return FS_EINVAL;
   const int es = dtype == FS_DTYPE_BF16 ? 2 : 4;
   if (args->Cs <= 0 || (args->Cs * es) % 32 != 0 || ((args->Cs * es) % 64 != 0 && args->Cs * es != 32) ||
@@ -376,17 +472,33 @@ extern "C" int fs_conv3x3_halo(const FsConvArgs* args, int dtype, void* stream) 
   if (args->src_bytes <= 0 || args->src_bytes > 0x7fffffffLL || args->wgt_bytes <= 0 ||
       args->wgt_bytes > 0x7fffffffLL)
     return FS_EINVAL;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  // 32x32-tile kernel for whole 64-byte channel chunks and >= 32 output channels; the 16x16-tile kernel below keeps
-  // the 16-channel decoder layers
+  if (!pro_args_ok(*args)) return FS_EINVAL;
+  if (args->pro_mode != 0 && (args->Cs * es) % 64 != 0) return FS_EINVAL;   // whole 64-byte chunks with a prologue
+  if (args->bnb_scale && (!args->bnb_x || !args->bnb_shift || args->mask)) return FS_EINVAL;
+  if (args->bnb_x && (!args->stats || !args->bnb_mean || !args->bnb_invstd)) return FS_EINVAL;
+  // 32x32-tile kernel for the launches it wants (whole 64-byte channel chunks, >= 32 output channels, enough 256-pixel
+  // tiles); the 16x16-tile kernel below takes everything else, with the same prologues and epilogues
   const char* te = getenv("FSNET_AMD_T32");
   const bool use_t32 = !(te && te[0] == '0');
   if (use_t32) {
     const int r = fs_conv3x3_t32(*args, dtype, st);
     if (r != FS_EINVAL) return r;
   }
-  if (args->pro_mode != 0 || args->wgt2 || args->bnb_scale) return FS_EINVAL;   // only the 32x32-tile kernel has these
   if (dtype == FS_DTYPE_BF16) return dispatch<bf16>(*args, st);
   if (dtype == FS_DTYPE_F32) return dispatch<float>(*args, st);
   return FS_EINVAL;
+}
+}  // namespace
+
+extern "C" int fs_conv3x3_halo(const FsConvArgs* args, int dtype, void* stream) {
+  return conv3x3_entry(args, dtype, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int fs_conv3x3_halo_plan(const FsConvArgs* args, int dtype, int32_t* plan) {
+  if (!plan) return FS_EINVAL;
+  plan[0] = -1; plan[1] = plan[2] = plan[3] = 0;
+  fs_conv3x3_plan_slot = plan;
+  const int r = conv3x3_entry(args, dtype, nullptr);
+  fs_conv3x3_plan_slot = nullptr;
+  return r;
 }

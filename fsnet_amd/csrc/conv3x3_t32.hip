@@ -17,7 +17,9 @@
 //   * epilogue options are template flags for the combinations the networks use (EP >= 0), run-time tests otherwise.
 //   * operand prologue (FsConvArgs.pro_mode): the BatchNorm + ReLU in front of the convolution, or the second pass of
 //     its backward in front of a data gradient, is applied while the halo is staged — see fsnet_hip.h.
-//   * a second weight operand for the images from wgt2_from_n on (depth + pose encoder in one launch).
+//   * round 4: the prologue's coefficients come from an LDS table every block fills itself from the f64 sums of the
+//     producing kernel's epilogue (conv_pro.h: no fs_bn_finalize launch); in a data-gradient launch the transformed
+//     operand — the BatchNorm input gradient — is also written out for the weight gradient (pro_dst).
 // Measured alone (HIP events, bf16, fwd + statistics / dgrad + BatchNorm-backward sums, us): 64->64 @48x160 B=12
 // 14.0 / 16.4 (16x16 kernel 18.8 / 23.9), B=36 33.0 / 39.8 (40.9 / 61.5); 128->128 @24x80 B=36 30.5 / 34.0 (32.3 /
 // 40.6); 256->256 @12x40 B=36 30.3 / 32.9 (33.4 / 36.3); 64->64 @80x256 B=8 20.7 / 25.4 (25.5 / 34.5).  Variants that
@@ -26,6 +28,7 @@
 // Reference call sites: vision_base/networks/models/backbone/resnet.py:21-50 (BasicBlock), blocks.py:41-54,
 // monodepth/networks/models/heads/depth_encoder.py:45-63, pose_decoder.py:17-37.
 #include "t32_common.h"
+#include "conv_pro.h"
 
 namespace {
 
@@ -58,6 +61,7 @@ __global__ __launch_bounds__(256, t32_minwaves(PIX, CO, EP, PRO)) void conv3x3_t
   // 256-byte bank row — differ in (row >> 2) & 3 within a group.
   __shared__ uint4 lds[BUFU];
   uint4* const lds_w = lds + HMAX * HS;
+  extern __shared__ float t32_pro_tab[];             // [pro_ncoef<PRO>()][Cs] (PRO != 0 launches only)
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, hk = lane >> 5;
@@ -83,19 +87,19 @@ __global__ __launch_bounds__(256, t32_minwaves(PIX, CO, EP, PRO)) void conv3x3_t
   const int fwd = p.sgn > 0;
   const int oy = y0 + p.hb_add + (fwd ? 0 : -2), ox = x0 + p.hb_add + (fwd ? 0 : -2);
 
-  const void* wsel = (p.wgt2 != nullptr && n >= p.wgt2_from_n) ? p.wgt2 : p.wgt;
   const __amdgpu_buffer_rsrc_t rs_src =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, (int)p.src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_src2 =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(PRO == 2 ? p.pro_src2 : p.src), 0, (int)p.src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wgt =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wsel), 0, (int)p.wgt_bytes, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, (int)p.wgt_bytes, 0x00020000);
 
   // ---- per-thread load units (fixed over the channel walk): thread t always holds 16-byte slot q = t & 3; the chunk
   // offset is the scalar offset operand of the buffer loads ----
   const int row_bytes = p.Cs * (int)sizeof(T);
   const int q4 = t & 3;
   int hvoff[LH], wvoff[LW];
+  unsigned interior = 0u;        // PRO == 2 with pro_dst: the units this thread writes out (its tile's own pixels)
 #pragma unroll
   for (int i = 0; i < LH; ++i) {
     const int hp = (t >> 2) + i * 64;
@@ -103,7 +107,9 @@ __global__ __launch_bounds__(256, t32_minwaves(PIX, CO, EP, PRO)) void conv3x3_t
     const int sy = oy + hy, sx = ox + hx;
     const bool ok = hp < nhalo && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws && q4 * 16 < row_bytes;
     hvoff[i] = ok ? (int)(((long)n * p.sN + (long)sy * p.sH + (long)sx * p.sW) * (long)sizeof(T)) + q4 * 16 : OOB;
+    if (PRO == 2 && ok && hy >= 1 && hy <= g.TH && hx >= 1 && hx <= g.TW) interior |= 1u << i;
   }
+  if (PRO != 2 || p.pro_dst == nullptr || cy != 0) interior = 0u;
   const int wrow_bytes = p.nchunks * p.kg * 16;
 #pragma unroll
   for (int i = 0; i < LW; ++i) {
@@ -111,11 +117,10 @@ __global__ __launch_bounds__(256, t32_minwaves(PIX, CO, EP, PRO)) void conv3x3_t
     const int tap = rt / CO, row = rt - tap * CO;
     wvoff[i] = (rt < 9 * CO && q4 * 16 < row_bytes) ? (co0 + row) * wrow_bytes + tap * row_bytes + q4 * 16 : OOB;
   }
-  const int pgo = (PRO != 0 && p.pro_group_imgs > 0) ? fs_div(n, g.dPRG) * p.Cs : 0;
+  const int pgrp = (PRO != 0 && p.pro_group_imgs > 0) ? fs_div(n, g.dPRG) : 0;
 
   uint4 rh[LH], rw[LW];
   uint4 rh2[PRO == 2 ? LH : 1];
-  float ka[PRO != 0 ? UN : 1], kb[PRO != 0 ? UN : 1], kc[PRO == 2 ? UN : 1];
   auto load_regs = [&](int cc) {
     const int coff = cc * 64;
 #pragma unroll
@@ -129,24 +134,27 @@ __global__ __launch_bounds__(256, t32_minwaves(PIX, CO, EP, PRO)) void conv3x3_t
 #pragma unroll
     for (int i = 0; i < LW; ++i)
       rw[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_wgt, wvoff[i], coff, 0));
+  };
+  auto store_lds = [&](int cc) {
+    float ka[PRO != 0 ? UN : 1], kb[PRO != 0 ? UN : 1], kc[PRO == 2 ? UN : 1], km[PRO == 2 ? UN : 1];
     if constexpr (PRO != 0) {
+      // this thread's channels of the chunk (the same 16-byte slot q4 of every pixel it stages), from the block's table
       const int c0r = cc * (64 / (int)sizeof(T)) + q4 * UN;
-      const bool cok = c0r < p.Cs;
-      const int c0 = cok ? c0r : 0;                  // (always a valid address: the select happens on the values)
+      const int c0 = c0r < p.Cs ? c0r : 0;
 #pragma unroll
       for (int j = 0; j < UN; j += 4) {
-        const float4 a = *reinterpret_cast<const float4*>(p.pro_a + pgo + c0 + j);
-        const float4 b = *reinterpret_cast<const float4*>(p.pro_b + pgo + c0 + j);
-        ka[j] = cok ? a.x : 0.f; ka[j + 1] = cok ? a.y : 0.f; ka[j + 2] = cok ? a.z : 0.f; ka[j + 3] = cok ? a.w : 0.f;
-        kb[j] = cok ? b.x : 0.f; kb[j + 1] = cok ? b.y : 0.f; kb[j + 2] = cok ? b.z : 0.f; kb[j + 3] = cok ? b.w : 0.f;
+        const float4 a = *reinterpret_cast<const float4*>(t32_pro_tab + c0 + j);
+        const float4 b = *reinterpret_cast<const float4*>(t32_pro_tab + p.Cs + c0 + j);
+        ka[j] = a.x; ka[j + 1] = a.y; ka[j + 2] = a.z; ka[j + 3] = a.w;
+        kb[j] = b.x; kb[j + 1] = b.y; kb[j + 2] = b.z; kb[j + 3] = b.w;
         if constexpr (PRO == 2) {
-          const float4 c = *reinterpret_cast<const float4*>(p.pro_c + pgo + c0 + j);
-          kc[j] = cok ? c.x : 0.f; kc[j + 1] = cok ? c.y : 0.f; kc[j + 2] = cok ? c.z : 0.f; kc[j + 3] = cok ? c.w : 0.f;
+          const float4 c = *reinterpret_cast<const float4*>(t32_pro_tab + 2 * p.Cs + c0 + j);
+          const float4 m = *reinterpret_cast<const float4*>(t32_pro_tab + 3 * p.Cs + c0 + j);
+          kc[j] = c.x; kc[j + 1] = c.y; kc[j + 2] = c.z; kc[j + 3] = c.w;
+          km[j] = m.x; km[j + 1] = m.y; km[j + 2] = m.z; km[j + 3] = m.w;
         }
       }
     }
-  };
-  auto store_lds = [&]() {
 #pragma unroll
     for (int i = 0; i < LH; ++i) {
       const int hp = (t >> 2) + i * 64;
@@ -167,9 +175,11 @@ __global__ __launch_bounds__(256, t32_minwaves(PIX, CO, EP, PRO)) void conv3x3_t
         Unit<T>::unpack(u, v);
         Unit<T>::unpack(rh2[i], w);
 #pragma unroll
-        for (int j = 0; j < UN; ++j) v[j] = v[j] * ka[j] + (w[j] * kb[j] + kc[j]);
+        for (int j = 0; j < UN; ++j) v[j] = v[j] * ka[j] + ((w[j] - km[j]) * kb[j] + kc[j]);
         u = Unit<T>::pack(v);
         if (hvoff[i] == OOB) u = make_uint4(0u, 0u, 0u, 0u);
+        if ((interior >> i) & 1u)
+          *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.pro_dst) + (long)hvoff[i] + cc * 64) = u;
       }
       if (64 * (i + 1) <= HMAX || hp < HMAX) lds[hp * HS + q4] = u;
     }
@@ -202,9 +212,13 @@ __global__ __launch_bounds__(256, t32_minwaves(PIX, CO, EP, PRO)) void conv3x3_t
 
   const int nchunk = (row_bytes + 63) / 64;
   load_regs(0);
+  if constexpr (PRO != 0) {
+    // (behind the first chunk's loads, in front of the loop's first barrier)
+    pro_build_table<PRO>(p, t32_pro_tab, pgrp, t, 256);
+  }
   for (int cc = 0; cc < nchunk; ++cc) {
-    t32_barrier();                 // previous chunk fully multiplied
-    store_lds();
+    t32_barrier();                 // previous chunk fully multiplied (first pass: the coefficient table is complete)
+    store_lds(cc);
     t32_barrier();
     if (cc + 1 < nchunk) load_regs(cc + 1);
 #pragma unroll
@@ -342,6 +356,8 @@ __global__ __launch_bounds__(256, t32_minwaves(PIX, CO, EP, PRO)) void conv3x3_t
       }
     }
   }
+  // (last, so that its arguments are not live across the walk: saved statistics / running statistics / dgamma, dbeta)
+  if constexpr (PRO != 0) { if (blockIdx.x == 0) pro_block0<PRO>(p, t, 256); }
 }
 
 template <typename T, int PIX, int CO, int EP, int PRO>
@@ -360,7 +376,11 @@ int t32_launch(const FsConvArgs& a, hipStream_t st) {
   g.pix_major = (nco > 1 && a.src_bytes > 2 * a.wgt_bytes) ? 1 : 0;
   if (g.pix_major) blocks = 8 * ((npix + 7) / 8) * nco;
   else if (nco % 8 != 0 && 8 % nco == 0) { const int q = 8 / nco; blocks = 8 * ((npix + q - 1) / q); }
-  hipLaunchKernelGGL((conv3x3_t32_kernel<T, PIX, CO, EP, PRO>), dim3(blocks), dim3(256), 0, st, a, g);
+  if (fs_conv3x3_plan_slot) {
+    fs_conv3x3_plan_slot[0] = 1; fs_conv3x3_plan_slot[1] = blocks; fs_conv3x3_plan_slot[2] = PIX; fs_conv3x3_plan_slot[3] = CO;
+    return FS_OK;
+  }
+  hipLaunchKernelGGL((conv3x3_t32_kernel<T, PIX, CO, EP, PRO>), dim3(blocks), dim3(256), pro_lds_bytes<PRO>(a), st, a, g);
   return fs_launch_status();
 }
 
@@ -391,12 +411,10 @@ int t32_pick_cfg(const FsConvArgs& a) {
   const char* fe = getenv("FSNET_AMD_T32_CFG");        // development knob (tools/probes/t32_ab.py)
   if (fe) { const int c = atoi(fe); return (a.Co_p % 64 != 0 && c == 1) ? 2 : c; }
   // 256-pixel tiles where they do not waste lanes and the launch still fills the chip's three block slots per CU a
-  // few times over; the prologue / second-operand launches have no other kernel
-  const bool must = a.pro_mode != 0 || a.wgt2 != nullptr || a.bnb_scale != nullptr;
+  // few times over; everything else is faster on the 16x16-tile kernel (same prologues and epilogues there)
   const bool big = t32_waste(a, 256) <= 1.15 * t32_waste(a, 128);
   if (big && t32_blocks(a, 256, 32) >= 512) return 3;
-  if (!must) return -1;
-  return big ? 3 : 2;
+  return -1;
 }
 
 template <typename T, int PRO>
@@ -439,8 +457,20 @@ int fs_conv3x3_t32(const FsConvArgs& a, int dtype, hipStream_t st) {
   const int es = dtype == FS_DTYPE_BF16 ? 2 : 4;
   if ((a.Cs * es) % 64 != 0 || a.Co_p % 32 != 0 || a.Co % 8 != 0) return FS_EINVAL;
   if (a.src_bytes >= 0x7ffff000LL) return FS_EINVAL;
-  if (a.pro_mode != 0 && (!a.pro_a || !a.pro_b || (a.pro_mode == 2 && (!a.pro_c || !a.pro_src2)))) return FS_EINVAL;
   if (a.bnb_scale && (!a.bnb_x || !a.bnb_shift || a.mask)) return FS_EINVAL;
+  if (a.bnb_x && !a.stats) return FS_EINVAL;
+  // the epilogue moves 16 bytes per lane with 32-bit element offsets: every tensor it touches must keep pixels on
+  // 16-byte boundaries and the destination must span fewer than 2^31 elements (strided views that do not: the 16x16-tile
+  // kernel, whose pieces are 8 bytes)
+  auto al16 = [&](const void* ptr, int64_t sn, int64_t sh, int64_t sw, int esz) {
+    return ptr == nullptr || (((uintptr_t)ptr & 15u) == 0 && (sn * esz) % 16 == 0 && (sh * esz) % 16 == 0 && (sw * esz) % 16 == 0);
+  };
+  const int dsz = a.out_f32 ? 4 : es;
+  if (!al16(a.dst, a.dN, a.dH, a.dW, dsz) || !al16(a.addend, a.aN, a.aH, a.aW, es) || !al16(a.mask, a.mN, a.mH, a.mW, es) ||
+      !al16(a.bnb_x, a.dN, a.dH, a.dW, es))
+    return FS_EINVAL;
+  const int64_t span = (int64_t)(a.N - 1) * a.dN + (int64_t)(a.Hd - 1) * a.dH + (int64_t)(a.Wd - 1) * a.dW + a.Co;
+  if (a.dN < 0 || a.dH < 0 || a.dW < 0 || span >= 0x7fffffffLL) return FS_EINVAL;
   if (dtype == FS_DTYPE_BF16) return t32_dispatch<bf16>(a, st);
   if (dtype == FS_DTYPE_F32) return t32_dispatch<float>(a, st);
   return FS_EINVAL;

@@ -1,0 +1,142 @@
+// Operand prologue of the 3x3 / stride-1 LDS-halo convolution kernels (conv3x3_t32.hip, conv3x3_halo.hip): the
+// BatchNorm in front of a convolution (mode 1) or the second pass of the backward of the BatchNorm behind it (mode 2),
+// applied to 16-byte units while they travel from the load registers to LDS.  FsConvArgs documents the two modes
+// (include/fsnet_hip.h).  The per-channel coefficients live in a small LDS table that every block fills itself — from
+// the f64 sums the producing kernel's epilogue left (bn_apply_kernel's / bn_bwd_apply_kernel's preamble, bn.hip, same
+// arithmetic: no fs_bn_finalize launch and no BatchNorm pass between two convolutions), or from coefficient arrays
+// handed in.  Reference: nn.BatchNorm2d in train mode between conv1 and conv2 of a BasicBlock and its autograd
+// backward, vision_base/networks/models/backbone/resnet.py:33-50.
+#pragma once
+#include "common.h"
+#include "fsnet_hip_internal.h"
+
+namespace {
+
+template <int PRO> constexpr int pro_ncoef() { return PRO == 1 ? 2 : (PRO == 2 ? 4 : 0); }
+// dynamic LDS a launch with this prologue needs
+template <int PRO> inline unsigned pro_lds_bytes(const FsConvArgs& a) { return (unsigned)(pro_ncoef<PRO>() * a.Cs * sizeof(float)); }
+
+__device__ inline void pro_sum_slots(const double* st, int C, int c, double& s1, double& s2) {
+  s1 = 0.0; s2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < FS_STAT_SLOTS; ++k) { s1 += st[(long)k * 2 * C + c]; s2 += st[(long)k * 2 * C + C + c]; }
+}
+
+// mode 1, channel c of statistics group g: bn_channel_coeffs of bn.hip
+__device__ inline void pro1_channel(const FsConvArgs& p, int g, int c, float& mean, float& invstd, float& varb,
+                                    float& sc, float& sh) {
+  const int C = p.Cs;
+  double s1, s2;
+  pro_sum_slots(p.pro_stats + (long)g * FS_STAT_SLOTS * 2 * C, C, c, s1, s2);
+  double m = s1 / p.pro_count, v = s2 / p.pro_count - m * m;
+  if (v < 0) v = 0;
+  mean = (float)m;
+  varb = (float)v;
+  invstd = (float)(1.0 / sqrt(v + (double)p.pro_eps));
+  sc = p.pro_gamma[c] * invstd;
+  sh = p.pro_beta[c] - mean * sc;
+}
+
+// mode 2: dx = k*(g - a - xhat*b), k = gamma*invstd, a = sum g / count, b = sum g*xhat / count (bn_bwd_apply_kernel)
+// as g*ka + ((x - m)*kb + kc)
+__device__ inline void pro2_channel(const FsConvArgs& p, int g, int c, float& ka, float& kb, float& kc, float& km) {
+  const int C = p.Cs;
+  double sg, sgx;
+  pro_sum_slots(p.pro_stats + (long)g * FS_STAT_SLOTS * 2 * C, C, c, sg, sgx);
+  const float istd = p.pro_invstd[g * C + c];
+  const float k = p.pro_gamma[c] * istd;
+  const float a = (float)(sg / p.pro_count), b = (float)(sgx / p.pro_count);
+  ka = k; kb = -(k * b) * istd; kc = -(k * a); km = p.pro_mean[g * C + c];
+}
+
+// fills tab[ncoef][Cs] for statistics group grp (all threads of the block; a barrier must follow before it is read)
+template <int PRO>
+__device__ inline void pro_build_table(const FsConvArgs& p, float* tab, int grp, int t, int nt) {
+  const int C = p.Cs;
+  if (p.pro_stats) {
+    for (int c = t; c < C; c += nt) {
+      if constexpr (PRO == 1) {
+        float mean, istd, varb, sc, sh;
+        pro1_channel(p, grp, c, mean, istd, varb, sc, sh);
+        tab[c] = sc; tab[C + c] = sh;
+      } else {
+        float ka, kb, kc, km;
+        pro2_channel(p, grp, c, ka, kb, kc, km);
+        tab[c] = ka; tab[C + c] = kb; tab[2 * C + c] = kc; tab[3 * C + c] = km;
+      }
+    }
+  } else {
+    for (int c = t; c < C; c += nt) {
+      tab[c] = p.pro_a[grp * C + c]; tab[C + c] = p.pro_b[grp * C + c];
+      if constexpr (PRO == 2) { tab[2 * C + c] = p.pro_c[grp * C + c]; tab[3 * C + c] = p.pro_m[grp * C + c]; }
+    }
+  }
+}
+
+// what ONE block of the launch does besides its tile when the coefficients are derived in the kernel: mode 1 — saved
+// statistics, the affine form for the backward's consumers, running statistics (one momentum update per group, in
+// group order, like bn_finalize_kernel); mode 2 — dgamma / dbeta of the local shard
+template <int PRO>
+__device__ inline void pro_block0(const FsConvArgs& p, int t, int nt) {
+  if (!p.pro_stats) return;
+  const int C = p.Cs;
+  const int G = p.pro_group_imgs > 0 ? p.N / p.pro_group_imgs : 1;
+  if constexpr (PRO == 1) {
+    const bool track = p.pro_running_mean != nullptr;
+    for (int c = t; c < C; c += nt) {
+      float rm = track ? p.pro_running_mean[c] : 0.f, rv = track ? p.pro_running_var[c] : 0.f;
+      for (int g = 0; g < G; ++g) {
+        float mean, istd, varb, sc, sh;
+        pro1_channel(p, g, c, mean, istd, varb, sc, sh);
+        if (p.pro_mean) { p.pro_mean[g * C + c] = mean; p.pro_invstd[g * C + c] = istd; }
+        if (p.pro_save_a) { p.pro_save_a[g * C + c] = sc; p.pro_save_b[g * C + c] = sh; }
+        const double unb = p.pro_count > 1.0 ? (double)varb * p.pro_count / (p.pro_count - 1.0) : (double)varb;
+        rm = (1.f - p.pro_momentum) * rm + p.pro_momentum * mean;
+        rv = (1.f - p.pro_momentum) * rv + p.pro_momentum * (float)unb;
+      }
+      if (track) { p.pro_running_mean[c] = rm; p.pro_running_var[c] = rv; }
+    }
+    if (t == 0 && p.pro_nbt) *p.pro_nbt += G;
+  } else if constexpr (PRO == 2) {
+    const double* src = p.pro_stats_local ? p.pro_stats_local : p.pro_stats;
+    for (int c = t; c < C; c += nt) {
+      double lg = 0.0, lgx = 0.0;
+      for (int g = 0; g < G; ++g) {
+        double a, b;
+        pro_sum_slots(src + (long)g * FS_STAT_SLOTS * 2 * C, C, c, a, b);
+        lg += a; lgx += b;
+      }
+      if (p.pro_dgamma) p.pro_dgamma[c] += (float)lgx;
+      if (p.pro_dbeta) p.pro_dbeta[c] += (float)lg;
+    }
+  }
+}
+
+// argument checks shared by the two kernels' entry points
+inline bool pro_args_ok(const FsConvArgs& a) {
+  if (a.pro_mode == 0) return a.pro_dst == nullptr;
+  if (a.pro_mode != 1 && a.pro_mode != 2) return false;
+  if (a.Cs % 4 != 0 || a.Cs > 2048) return false;
+  if (a.pro_group_imgs < 0 || (a.pro_group_imgs > 0 && a.N % a.pro_group_imgs != 0)) return false;
+  if (a.pro_mode == 2 && !a.pro_src2) return false;
+  if (a.pro_mode == 1 && a.pro_dst) return false;
+  if (a.pro_stats) {
+    if (!a.pro_gamma || !(a.pro_count > 0.0)) return false;
+    if (a.pro_mode == 1 && !a.pro_beta) return false;
+    if (a.pro_mode == 1 && ((a.pro_mean == nullptr) != (a.pro_invstd == nullptr) || (a.pro_save_a == nullptr) != (a.pro_save_b == nullptr))) return false;
+    if (a.pro_mode == 1 && (a.pro_running_mean == nullptr) != (a.pro_running_var == nullptr)) return false;
+    if (a.pro_mode == 2 && (!a.pro_mean || !a.pro_invstd)) return false;
+  } else {
+    if (!a.pro_a || !a.pro_b) return false;
+    if (a.pro_mode == 2 && (!a.pro_c || !a.pro_m)) return false;
+  }
+  if (a.pro_dst) {
+    // the copy is written at src's offsets: src must be a dense [N][Hs][Ws][Cs] tensor and the halo origin the pad-1
+    // data gradient's (tile interiors then partition src)
+    if (a.sW != a.Cs || a.sH != (int64_t)a.Ws * a.Cs || a.sN != (int64_t)a.Hs * a.Ws * a.Cs) return false;
+    if (a.sgn > 0 || a.hb_add != 1 || a.Hs != a.Hd || a.Ws != a.Wd) return false;
+  }
+  return true;
+}
+
+}  // namespace

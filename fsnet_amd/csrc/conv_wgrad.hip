@@ -630,24 +630,9 @@ __global__ __launch_bounds__(256) void wgrad3x3_narrow_kernel(const FsWgradArgs 
   for (int i = 0; i < LB; ++i)
     brel[i] = (int)(((long)bhy[i] * p.sH + (long)bhx[i] * p.sW + ci0 + ((t + i * 256) % UB) * 8) * 2);
   uint4 ra[LA], rb[LB];
-  // operand prologue (BatchNorm + ReLU folded into the staging of x): this thread's 16-byte units all hold the same 8
-  // input channels (256 % UB == 0), coefficients per statistics group of the tile's image
-  static_assert(256 % UB == 0, "a thread's x units must share their channel slot");
-  const bool has_pro = p.pro_a != nullptr;
-  float ka[8], kb[8];
-  unsigned bok = 0u;                       // which of the thread's x units lie inside the image (padding stays zero)
+  // (no operand prologue here: launch_wgrad sends every launch that carries one to the halo kernel above)
   auto load_regs = [&](int pt) {
     int q = fs_div(pt, g.dTX); int tx_i = pt - q * g.tiles_x; int n = fs_div(q, g.dTY); int ty_i = q - n * g.tiles_y;
-    if (has_pro) {
-      const int pg = p.pro_group_imgs > 0 ? n / p.pro_group_imgs : 0;
-      const float* pa = p.pro_a + (long)pg * g.Cs + ci0 + (t % UB) * 8;
-      const float* pb = p.pro_b + (long)pg * g.Cs + ci0 + (t % UB) * 8;
-      const float4 a0 = reinterpret_cast<const float4*>(pa)[0], a1 = reinterpret_cast<const float4*>(pa)[1];
-      const float4 b0 = reinterpret_cast<const float4*>(pb)[0], b1 = reinterpret_cast<const float4*>(pb)[1];
-      ka[0] = a0.x; ka[1] = a0.y; ka[2] = a0.z; ka[3] = a0.w; ka[4] = a1.x; ka[5] = a1.y; ka[6] = a1.z; ka[7] = a1.w;
-      kb[0] = b0.x; kb[1] = b0.y; kb[2] = b0.z; kb[3] = b0.w; kb[4] = b1.x; kb[5] = b1.y; kb[6] = b1.z; kb[7] = b1.w;
-      bok = 0u;
-    }
     int y0 = ty_i * g.TH, x0 = tx_i * g.TW;
     const int abase = (((n * p.Hd + y0) * p.Wd + x0) * p.Cd) * 2;
     const int bbase = (int)(((long)n * p.sN + (long)(y0 - p.pad) * p.sH + (long)(x0 - p.pad) * p.sW) * 2);

@@ -49,30 +49,6 @@ template <> struct Mma32<float> {
   }
 };
 
-// ---- 16-byte operand units as floats and back ----
-template <typename T> struct Unit;
-template <> struct Unit<bf16> {
-  static constexpr int N = 8;
-  static __device__ __forceinline__ void unpack(const uint4& u, float* v) {
-    v[0] = bf16_bits_to_f(u.x & 0xffffu); v[1] = __uint_as_float(u.x & 0xffff0000u);
-    v[2] = bf16_bits_to_f(u.y & 0xffffu); v[3] = __uint_as_float(u.y & 0xffff0000u);
-    v[4] = bf16_bits_to_f(u.z & 0xffffu); v[5] = __uint_as_float(u.z & 0xffff0000u);
-    v[6] = bf16_bits_to_f(u.w & 0xffffu); v[7] = __uint_as_float(u.w & 0xffff0000u);
-  }
-  static __device__ __forceinline__ uint4 pack(const float* v) {
-    return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
-  }
-};
-template <> struct Unit<float> {
-  static constexpr int N = 4;
-  static __device__ __forceinline__ void unpack(const uint4& u, float* v) {
-    v[0] = __uint_as_float(u.x); v[1] = __uint_as_float(u.y); v[2] = __uint_as_float(u.z); v[3] = __uint_as_float(u.w);
-  }
-  static __device__ __forceinline__ uint4 pack(const float* v) {
-    return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
-  }
-};
-
 // 8 consecutive channels of one pixel <-> floats (epilogue side)
 template <typename T> __device__ __forceinline__ void load8(const T* p, float* v);
 template <> __device__ __forceinline__ void load8<bf16>(const bf16* p, float* v) {

@@ -23,7 +23,13 @@ STAT_SLOTS = ops.STAT_SLOTS
 FUSE_BN_BWD = os.environ.get("FSNET_AMD_FUSE_BN_BWD", "1") != "0"
 # BatchNorm + ReLU between two convolutions of a residual block applied by the SECOND convolution while it stages its
 # operand (and by its weight gradient), instead of a pass of its own: the normalised activation never reaches HBM
-FOLD_BN = os.environ.get("FSNET_AMD_BN_FOLD", "1") != "0"
+# (0: never; 1: wherever the kernels can; 2: only launches the 32x32-tile kernel takes)
+FOLD_BN = int(os.environ.get("FSNET_AMD_BN_FOLD", "1"))
+# the second pass of a BatchNorm's backward applied by the data gradient of the convolution in front of it while it stages
+# dY (coefficients from the sums the previous data gradient's epilogue left; written out once for the weight gradient).
+# Built, tested against the oracle and MEASURED slower (the data gradient stages two tensors, holds
+# half the blocks per CU and takes +19 us where the pass it replaces took 15): off by default, same values as FOLD_BN.
+FOLD_BN_BWD = int(os.environ.get("FSNET_AMD_BN_FOLD_BWD", "0"))
 
 
 class StatsPool:
@@ -387,8 +393,10 @@ class ResNetRunner:
 
     # ------------------------------------------------------------------ forward
     def _unit_fwd_fold(self, cl, bn, x, pro=None):
-        """convolution + the statistics half of its BatchNorm only (training mode): returns (raw output, BnState with
-        the affine form) — the consumer applies scale * c + shift and the ReLU itself"""
+        """convolution + the batch statistics of its BatchNorm only (training mode): returns (raw output, BnState, what
+        the consumer needs to finalise it) — the consuming convolution derives scale / shift from the sums in its own
+        prologue, applies scale * c + shift and the ReLU while staging, and its block 0 fills the BnState (mean, invstd,
+        scale, shift: read by the backward) and updates the running statistics: no launch between the two convolutions"""
         op = cl.ready(x.dtype, x.device)
         N, H, W, _ = x.shape
         Ho, Wo = op.out_hw(H, W)
@@ -397,8 +405,8 @@ class ResNetRunner:
         c = op.forward(x, stats=stats, stat_groups=G, pro=pro)
         world = _dp_stats(stats)
         st = ops.BnState(op.Co_p, x.device, G, affine=True)
-        ops.bn_finalize(stats, bn_tensors(bn), st, op.Co_p, (N // G) * Ho * Wo * world, track=True, groups=G)
-        return c, st
+        st.count = float((N // G) * Ho * Wo * world)
+        return c, st, (stats, bn_tensors(bn), st.count, True)
 
     def _can_fold(self, bn, nxt_cl, c_shape, dtype, device, train):
         """unit -> next unit of a block: may the BatchNorm + ReLU in between be folded into the next convolution?"""
@@ -406,8 +414,9 @@ class ResNetRunner:
             return False
         N, H, W = c_shape
         nop = nxt_cl.ready(dtype, device)
-        return (nop.can_fold_input(N, H, W) and nop.can_fuse_bn_bwd(N, H, W, self.groups)
-                and N * H * W >= 1)
+        if not (nop.can_fold_input(N, H, W) and nop.can_fuse_bn_bwd(N, H, W, self.groups) and N * H * W >= 1):
+            return False
+        return int(FOLD_BN) != 2 or nop.plan_3x3(N, H, W, forward=True, pro_mode=1)["kernel"] == "t32"
 
     def _unit_fwd(self, cl, bn, x, train, relu=True, res=None, ds_c=None, ds_stats=None, ds_bn=None, pro=None):
         op = cl.ready(x.dtype, x.device)
@@ -461,19 +470,22 @@ class ResNetRunner:
         for blocks in self.stages:
             for units, ds in blocks:
                 bctx = {"x": cur, "u": []}
-                inp, pro = cur, None             # pro: inp is a raw conv output, (BnState, relu) still to be applied
+                # pro: inp is a raw conv output, (BnState, relu) still to be applied — what the weight gradient and the
+                # saved context carry; fin: + (sums, BatchNorm tensors, count, track) for the forward launch that
+                # finalises the statistics itself
+                inp, pro, fin = cur, None, None
                 for j, (cl, bn) in enumerate(units):
                     if j < len(units) - 1:
                         op = cl.ready(inp.dtype, inp.device)
                         Ho, Wo = op.out_hw(inp.shape[1], inp.shape[2])
                         if self._can_fold(bn, units[j + 1][0], (inp.shape[0], Ho, Wo), inp.dtype, inp.device, train):
-                            c, st = self._unit_fwd_fold(cl, bn, inp, pro=pro)
+                            c, st, fnext = self._unit_fwd_fold(cl, bn, inp, pro=fin)
                             bctx["u"].append((inp, c, None, st, pro))
-                            inp, pro = c, (st, True)
+                            inp, pro, fin = c, (st, True), (st, True) + fnext
                         else:
-                            c, y, st, _ = self._unit_fwd(cl, bn, inp, train, pro=pro)
+                            c, y, st, _ = self._unit_fwd(cl, bn, inp, train, pro=fin)
                             bctx["u"].append((inp, c, y, st, pro))
-                            inp, pro = y, None
+                            inp, pro, fin = y, None, None
                     else:
                         if ds is not None:
                             dop = ds[0].ready(cur.dtype, cur.device)
@@ -481,27 +493,63 @@ class ResNetRunner:
                             dstats = self.pool.take(dop.Co_p, self.groups) if dbt else None
                             c_ds = dop.forward(cur, stats=dstats, stat_groups=(self.groups if dbt else 1))
                             # (data parallel: exchanged together with the main branch's statistics in _unit_fwd)
-                            c, y, st, st2 = self._unit_fwd(cl, bn, inp, train, ds_c=c_ds, ds_stats=dstats, ds_bn=ds[1], pro=pro)
+                            c, y, st, st2 = self._unit_fwd(cl, bn, inp, train, ds_c=c_ds, ds_stats=dstats, ds_bn=ds[1], pro=fin)
                             bctx["ds"] = (c_ds, st2)
                         else:
-                            c, y, st, _ = self._unit_fwd(cl, bn, inp, train, res=cur, pro=pro)
+                            c, y, st, _ = self._unit_fwd(cl, bn, inp, train, res=cur, pro=fin)
                         bctx["u"].append((inp, c, y, st, pro))
-                        inp, pro = y, None
+                        inp, pro, fin = y, None, None
                 ctx["blocks"].append(bctx)
                 cur = inp
             feats.append(cur)
         return feats, ctx
 
     # ------------------------------------------------------------------ backward
+    def _pend(self, g, c, st, bn, sums):
+        """a BatchNorm backward whose second pass is left to the data gradient of the convolution in front of it: g = the
+        masked gradient w.r.t. the BatchNorm output, sums = (sum g, sum g*xhat) of the local shard.  Data parallel: the
+        global sums are exchanged here, dgamma / dbeta come from the local ones."""
+        glob, local = sums, None
+        if RT.dp is not None and st.count != float("inf"):
+            glob = torch.empty_like(sums)
+            RT.dp.allreduce_small(sums, out=glob)
+            local = sums
+        return dict(g=g, c=c, st=st, bn=bn, sums=glob, sums_local=local)
+
+    @staticmethod
+    def _pend_kw(pend):
+        """ConvOp.dgrad arguments of a pending BatchNorm backward: (source gradient, kwargs, the tensor that receives
+        the BatchNorm input gradient)"""
+        dc = torch.empty_like(pend["c"])
+        bn = pend["bn"]
+        return pend["g"], dict(pro_bwd=dict(c=pend["c"], st=pend["st"], gamma=bn.weight.data, sums=pend["sums"],
+                                            sums_local=pend["sums_local"], dgamma=grad_of(bn.weight),
+                                            dbeta=grad_of(bn.bias), dc_out=dc)), dc
+
+    def _can_fold_bwd(self, op, bn, st, c):
+        if not (FOLD_BN_BWD and FUSE_BN_BWD and st.count != float("inf")
+                and op.can_fold_bn_bwd(c.shape[0], c.shape[1], c.shape[2])):
+            return False
+        return int(FOLD_BN_BWD) != 2 or op.plan_3x3(c.shape[0], c.shape[1], c.shape[2], forward=False, pro_mode=2)["kernel"] == "t32"
+
     def _block_bwd(self, units, ds, bctx, dout, extra, dout_sums=None, prev=None):
         """dout: gradient w.r.t. the block output.  dout_sums: set when dout came out of a data-gradient epilogue
         that already masked it with this block's output ReLU and accumulated the BatchNorm-backward sums.
-        prev = (y, c, BnState) of the block that consumes the returned gradient (fused the same way)."""
+        prev = (y, c, BnState) of the block that consumes the returned gradient (fused the same way).
+
+        A BatchNorm whose masked output gradient and backward sums exist (they come out of the epilogue of the data
+        gradient behind it) does not get a second pass of its own where the convolution in front of it is a 3x3 /
+        stride-1 one: that convolution's data gradient applies dx = gamma*invstd*(g - mean_g - xhat*mean_gx) to dY while it
+        stages it (`pend`), writes it out once, and the weight gradient reads that."""
         x = bctx["x"]
         N, H, W, _ = x.shape
         k = len(units)
         inp, c, y, st, pro_in = bctx["u"][k - 1]
         Ho, Wo = y.shape[1], y.shape[2]
+        op_last = units[k - 1][0].ready(x.dtype, x.device)
+        bn_last = units[k - 1][1]
+        fold_last = dout_sums is not None and self._can_fold_bwd(op_last, bn_last, st, c)
+        pend, dc = None, None
         joint = (ds is not None and RT.dp is not None and st.count != float("inf")
                  and bctx["ds"][1].count != float("inf"))
         if joint:
@@ -509,12 +557,14 @@ class ResNetRunner:
             # first passes run before ONE exchange of their (adjacent) sums, then both second passes
             c_ds, st2 = bctx["ds"]
             dop = ds[0].ready(x.dtype, x.device)
-            bn_m, bn_d = units[k - 1][1], ds[1]
+            bn_m, bn_d = bn_last, ds[1]
             fused_in = dout_sums is not None
             pool = _BWD_POOLS[(c.device, raw_stream(c.device.index))]
             s_m = dout_sums if fused_in else _bwd_sums(c, st)
             s_d = _bwd_sums(c_ds, st2)
-            dc, dc_ds = torch.empty_like(c), torch.empty_like(c_ds)
+            dc_ds = torch.empty_like(c_ds)
+            if not fold_last:
+                dc = torch.empty_like(c)
             g = dout if fused_in else torch.empty_like(c)
             if not fused_in:
                 ops.bn_backward(dout, y, c, bn_m.weight.data, st, dc, None, None, Ho, Wo, relu=True, sums=s_m,
@@ -532,17 +582,23 @@ class ResNetRunner:
                 g_m, g_d = torch.empty_like(s_m), torch.empty_like(s_d)
                 RT.dp.allreduce_small(s_m, out=g_m)
                 RT.dp.allreduce_small(s_d, out=g_d)
-            ops.bn_backward(dout, None if fused_in else y, c, bn_m.weight.data, st, dc, grad_of(bn_m.weight),
-                            grad_of(bn_m.bias), Ho, Wo, relu=not fused_in, g_out=(None if fused_in else g), sums=s_m,
-                            sums_zeroed=True, reduced=fused_in, phase="apply", glob=g_m)
+            if fold_last:
+                pend = dict(g=g, c=c, st=st, bn=bn_m, sums=g_m, sums_local=s_m)
+            else:
+                ops.bn_backward(dout, None if fused_in else y, c, bn_m.weight.data, st, dc, grad_of(bn_m.weight),
+                                grad_of(bn_m.bias), Ho, Wo, relu=not fused_in, g_out=(None if fused_in else g), sums=s_m,
+                                sums_zeroed=True, reduced=fused_in, phase="apply", glob=g_m)
             ops.bn_backward(g, None, c_ds, bn_d.weight.data, st2, dc_ds, grad_of(bn_d.weight), grad_of(bn_d.bias), Ho, Wo,
                             relu=False, sums=s_d, sums_zeroed=True, phase="apply", glob=g_d)
         elif dout_sums is not None:
             g = dout
-            dc = _bn_bwd(dout, None, c, units[k - 1][1], st, Ho, Wo, sums=dout_sums)
+            if fold_last:
+                pend = self._pend(g, c, st, bn_last, dout_sums)
+            else:
+                dc = _bn_bwd(dout, None, c, bn_last, st, Ho, Wo, sums=dout_sums)
         else:
             g = torch.empty_like(c)
-            dc = _bn_bwd(dout, y, c, units[k - 1][1], st, Ho, Wo, relu=True, g_out=g)
+            dc = _bn_bwd(dout, y, c, bn_last, st, Ho, Wo, relu=True, g_out=g)
         if ds is not None:
             c_ds, st2 = bctx["ds"]
             dop = ds[0].ready(x.dtype, x.device)
@@ -556,30 +612,45 @@ class ResNetRunner:
         for j in range(k - 1, 0, -1):
             cl = units[j][0]
             op = cl.ready(x.dtype, x.device)
-            cl.accumulate_param_grads(op, dc, inp, pro=pro_in)
-            xin = inp
+            xin, pro_x = inp, pro_in                 # the input of convolution j (raw + prologue where the forward folded)
             inp, c, y, st, pro_in = bctx["u"][j - 1]
+            src, kw = dc, {}
+            if pend is not None:
+                src, kw, dc = self._pend_kw(pend)
+            sums = None
             if y is None:
                 # folded BatchNorm: the activation was never stored — the ReLU mask is the sign of scale * c + shift,
                 # evaluated (with the BatchNorm-backward sums) in the data gradient's epilogue from c
                 sums = _bwd_sums(c, st)
-                dy_prev = op.dgrad(dc, xin.shape[1], xin.shape[2], bn_fuse=(c, st, sums), mask_bn=True)
-                dc = _bn_bwd(dy_prev, None, c, units[j - 1][1], st, c.shape[1], c.shape[2], sums=sums)
+                dy_prev = op.dgrad(src, xin.shape[1], xin.shape[2], bn_fuse=(c, st, sums), mask_bn=True, **kw)
             elif FUSE_BN_BWD and op.can_fuse_bn_bwd(N, xin.shape[1], xin.shape[2], st.groups):
                 sums = _bwd_sums(c, st)
-                dy_prev = op.dgrad(dc, xin.shape[1], xin.shape[2], mask=y, bn_fuse=(c, st, sums))
-                dc = _bn_bwd(dy_prev, None, c, units[j - 1][1], st, y.shape[1], y.shape[2], sums=sums)
+                dy_prev = op.dgrad(src, xin.shape[1], xin.shape[2], mask=y, bn_fuse=(c, st, sums), **kw)
             else:
-                dy_prev = op.dgrad(dc, xin.shape[1], xin.shape[2])
-                dc = _bn_bwd(dy_prev, y, c, units[j - 1][1], st, y.shape[1], y.shape[2], relu=True)
+                dy_prev = op.dgrad(src, xin.shape[1], xin.shape[2], **kw)
+            # (after the data gradient: with a pending BatchNorm backward, dc is its side output)
+            cl.accumulate_param_grads(op, dc, xin, pro=pro_x)
+            bn_prev = units[j - 1][1]
+            pend = None
+            if sums is not None and self._can_fold_bwd(units[j - 1][0].ready(x.dtype, x.device), bn_prev, st, c):
+                pend = self._pend(dy_prev, c, st, bn_prev, sums)
+            elif sums is not None:
+                dc = _bn_bwd(dy_prev, None, c, bn_prev, st, c.shape[1], c.shape[2], sums=sums)
+            else:
+                dc = _bn_bwd(dy_prev, y, c, bn_prev, st, y.shape[1], y.shape[2], relu=True)
         cl = units[0][0]
         op = cl.ready(x.dtype, x.device)
-        cl.accumulate_param_grads(op, dc, x)
+        src, kw = dc, {}
+        if pend is not None:
+            src, kw, dc = self._pend_kw(pend)
         if prev is not None and FUSE_BN_BWD and op.can_fuse_bn_bwd(N, H, W, prev[2].groups):
             py, pc, pst = prev
             sums = _bwd_sums(pc, pst)
-            return op.dgrad(dc, H, W, addend=dres, mask=py, bn_fuse=(pc, pst, sums)), sums
-        return op.dgrad(dc, H, W, addend=dres), None
+            out = op.dgrad(src, H, W, addend=dres, mask=py, bn_fuse=(pc, pst, sums), **kw), sums
+        else:
+            out = op.dgrad(src, H, W, addend=dres, **kw), None
+        cl.accumulate_param_grads(op, dc, x)
+        return out
 
     def backward(self, ctx, gfeats):
         """gfeats: list of 5 NHWC dense gradients (or None).  Accumulates parameter gradients."""

@@ -31,10 +31,18 @@ class FsConvArgs(C.Structure):
         ("grp_imgs", C.c_int32), ("ncls", C.c_int32), ("cls_nch", C.c_int32 * 4), ("cls_ktab_off", C.c_int32 * 4), ("cls_wgt_off", C.c_int64 * 4),
         ("bnb_x", C.c_void_p), ("bnb_mean", C.c_void_p), ("bnb_invstd", C.c_void_p),
         ("stat_group_rows", C.c_int32),
-        ("pro_a", C.c_void_p), ("pro_b", C.c_void_p), ("pro_c", C.c_void_p), ("pro_src2", C.c_void_p),
+        ("pro_a", C.c_void_p), ("pro_b", C.c_void_p), ("pro_c", C.c_void_p), ("pro_m", C.c_void_p), ("pro_src2", C.c_void_p),
         ("pro_mode", C.c_int32), ("pro_relu", C.c_int32), ("pro_group_imgs", C.c_int32), ("reserved1", C.c_int32),
         ("bnb_scale", C.c_void_p), ("bnb_shift", C.c_void_p),
-        ("wgt2", C.c_void_p), ("wgt2_from_n", C.c_int32), ("reserved2", C.c_int32),
+        ("pro_stats", C.c_void_p), ("pro_stats_local", C.c_void_p),
+        ("pro_gamma", C.c_void_p), ("pro_beta", C.c_void_p),
+        ("pro_mean", C.c_void_p), ("pro_invstd", C.c_void_p),
+        ("pro_save_a", C.c_void_p), ("pro_save_b", C.c_void_p),
+        ("pro_running_mean", C.c_void_p), ("pro_running_var", C.c_void_p),
+        ("pro_nbt", C.c_void_p),
+        ("pro_dgamma", C.c_void_p), ("pro_dbeta", C.c_void_p),
+        ("pro_dst", C.c_void_p),
+        ("pro_count", C.c_double), ("pro_eps", C.c_float), ("pro_momentum", C.c_float),
     ]
 
 
@@ -144,7 +152,7 @@ class FsSmoothArgs(C.Structure):
     ]
 
 
-ABI_VERSION = 5      # FS_ABI_VERSION of include/fsnet_hip.h (tests/test_abi.py holds the two together)
+ABI_VERSION = 6      # FS_ABI_VERSION of include/fsnet_hip.h (tests/test_abi.py holds the two together)
 _lib = None
 
 

@@ -91,6 +91,9 @@ def _nhwc_strides(t):
 
 import os
 
+BN_EPS = 1e-5            # nn.BatchNorm2d defaults (resnet.py:17-19, blocks.py:46)
+BN_MOMENTUM = 0.1
+
 USE_1X1 = os.environ.get("FSNET_AMD_CONV1X1", "1") != "0"
 USE_HALO = os.environ.get("FSNET_AMD_HALO", "1") != "0"   # 3x3/s1 LDS-halo kernel (conv3x3_halo.hip)
 USE_STEM_LDS = os.environ.get("FSNET_AMD_STEM_LDS", "1") != "0"   # 7x7/s2 stem kernel (conv_stem.hip)
@@ -104,33 +107,6 @@ def wgrad_workspace(device, elems=1 << 23):
     if ws is None or ws.numel() < elems:
         ws = _WGRAD_WS[key] = torch.empty(elems, dtype=torch.float32, device=device)
     return ws
-
-
-def _t32_geom(Hd, Wd, PIX, hmax):
-    """the 32x32-tile kernel's pixel tile choice (t32_pick_geom in csrc/t32_common.h): (tiles per image, wasted-lane factor)"""
-    best, best_cost = None, 1e30
-    for tw in range(min(4, Wd), min(Wd, 64) + 1):
-        th = min(PIX // tw, Hd)
-        if th < 1 or (th + 2) * (tw + 2) > hmax:
-            continue
-        tx, ty = -(-Wd // tw), -(-Hd // th)
-        waste = tx * ty * PIX / float(Hd * Wd)
-        cost = waste * (1.0 + 0.15 * (th + 2) * (tw + 2) / float(th * tw))
-        if tw % 32 != 0 and tw != Wd:
-            cost *= 1.02
-        if cost < best_cost - 1e-9:
-            best, best_cost = (tx * ty, waste), cost
-    return best
-
-
-def t32_takes(N, Hd, Wd, rows_p):
-    """whether fs_conv3x3_halo runs a launch of this size on the 32x32-tile kernel by its own choice (t32_pick_cfg in
-    csrc/conv3x3_t32.hip: 256-pixel tiles that waste no lanes, >= 512 blocks); smaller launches are faster on the
-    16x16-tile kernel, which has no operand prologue — BatchNorm folding is only worth it where this is true"""
-    g256, g128 = _t32_geom(Hd, Wd, 256, 360), _t32_geom(Hd, Wd, 128, 208)
-    if g256 is None or g128 is None:
-        return False
-    return g256[1] <= 1.15 * g128[1] and N * g256[0] * (rows_p // 32) >= 512
 
 
 class ConvOp:
@@ -256,11 +232,26 @@ class ConvOp:
         a.N, a.Cs = N, self.Ci_p
         a.stat_group_rows = group_rows
         if pro is not None:
-            pst, prelu = pro
+            pst, prelu = pro[0], pro[1]
             assert halo and pst.scale is not None and N % pst.groups == 0
             a.pro_mode, a.pro_relu = 1, int(prelu)
-            a.pro_a, a.pro_b = pst.scale.data_ptr(), pst.shift.data_ptr()
             a.pro_group_imgs = N // pst.groups if pst.groups > 1 else 0
+            if len(pro) > 2:
+                # the consumer finalises the statistics itself (no fs_bn_finalize launch): every block derives scale /
+                # shift from the f64 sums, block 0 saves them with mean / invstd for the backward and updates the
+                # running statistics
+                pstats, pbn, pcount, ptrack = pro[2:]
+                a.pro_stats = pstats.data_ptr()
+                a.pro_gamma, a.pro_beta = pbn["weight"].data_ptr(), pbn["bias"].data_ptr()
+                a.pro_mean, a.pro_invstd = pst.mean.data_ptr(), pst.invstd.data_ptr()
+                a.pro_save_a, a.pro_save_b = pst.scale.data_ptr(), pst.shift.data_ptr()
+                if ptrack:
+                    a.pro_running_mean, a.pro_running_var = pbn["running_mean"].data_ptr(), pbn["running_var"].data_ptr()
+                    a.pro_nbt = pbn["num_batches_tracked"].data_ptr()
+                pst.count = float(pcount)
+                a.pro_count, a.pro_eps, a.pro_momentum = float(pcount), BN_EPS, BN_MOMENTUM
+            else:
+                a.pro_a, a.pro_b = pst.scale.data_ptr(), pst.shift.data_ptr()
         flops = 2.0 * a.M * self.Co * self.R * self.S * self.Ci
         if grp_imgs:
             a.stat_group_rows, a.grp_imgs, a.M = 0, grp_imgs, grp_imgs * Ho * Wo
@@ -271,9 +262,40 @@ class ConvOp:
             _timed("conv_stem", flops, lambda: check(lib.fs_conv_stem(C.byref(a), self.code, stream_ptr()), "conv_stem"),
                    tag=lambda: "fwd  %s x[%d,%d,%d,%d]" % (self.describe(), N, x.shape[1], x.shape[2], x.shape[3]))
             return out
-        _timed("conv3x3_halo" if halo else "conv_igemm", flops, lambda: check(fn(C.byref(a), self.code, stream_ptr()), "conv_fwd"),
+        _timed(self._kind3x3(a) if halo else "conv_igemm", flops, lambda: check(fn(C.byref(a), self.code, stream_ptr()), "conv_fwd"),
                tag=lambda: "fwd  %s x[%d,%d,%d,%d]" % (self.describe(), N, x.shape[1], x.shape[2], x.shape[3]))
         return out
+
+    def _kind3x3(self, a):
+        """launch-profile kind of a 3x3 / stride-1 launch: which of the two kernels fs_conv3x3_halo runs it on"""
+        if not LaunchProfile.active:
+            return "conv3x3_halo"
+        plan = (C.c_int32 * 4)()
+        check(lib.fs_conv3x3_halo_plan(C.byref(a), self.code, plan), "conv3x3_plan")
+        return "conv3x3_t32" if plan[0] == 1 else "conv3x3_halo"
+
+    def plan_3x3(self, N, H, W, forward=True, pro_mode=0, Co_out=None):
+        """the launch fs_conv3x3_halo makes for a forward (x [N,H,W,Ci_p]) or data-gradient (dy [N,H,W,Co_p]) call of this
+        3x3 / stride-1 layer on dense tensors: {"kernel": "t32" | "halo", "blocks", "pix", "co"} — nothing is launched"""
+        assert self.R == 3 and self.S == 3 and self.stride == 1
+        eb = 2 if self.dtype == torch.bfloat16 else 4
+        a = FsConvArgs()
+        a.src, a.wgt, a.dst = 16, 16, 16             # only tested against NULL
+        Cs, rows = (self.Ci_p, self.Co_p) if forward else (self.Co_p, self.rows_d)
+        a.sN, a.sH, a.sW = H * W * Cs, W * Cs, Cs
+        a.dN, a.dH, a.dW = H * W * rows, W * rows, rows
+        a.src_bytes = N * H * W * Cs * eb
+        a.wgt_bytes = (self.w_f if forward else self.w_d).numel() * eb
+        a.Hs, a.Ws, a.Hd, a.Wd, a.M = H, W, H, W, N * H * W
+        a.Co = Co_out if Co_out is not None else (self.Co_p if forward else self.Ci_p)
+        a.Co_p, a.nchunks, a.kg = rows, (self.nch_f if forward else self.nch_d), (self.kg_f if forward else self.kg_d)
+        a.hb_mul, a.hb_add, a.sgn = 1, (-self.pad if forward else self.pad), (1 if forward else -1)
+        a.N, a.Cs = N, Cs
+        if pro_mode:
+            a.pro_mode, a.pro_a, a.pro_b, a.pro_c, a.pro_m, a.pro_src2 = pro_mode, 16, 16, 16, 16, 16
+        plan = (C.c_int32 * 4)()
+        check(lib.fs_conv3x3_halo_plan(C.byref(a), self.code, plan), "conv3x3_plan")
+        return {"kernel": "t32" if plan[0] == 1 else "halo", "blocks": int(plan[1]), "pix": int(plan[2]), "co": int(plan[3])}
 
     def _try_1x1(self, a, flops, tag):
         """1x1 convolutions (forward, stride-1 data gradient) on the row-streaming GEMM kernel (conv1x1.hip); False =
@@ -300,14 +322,23 @@ class ConvOp:
         return status[0] == 0
 
     def can_fold_input(self, N, H, W):
-        """whether this convolution can take its input as (raw convolution output, BatchNorm affine form, ReLU) — forward
-        AND weight gradient apply the normalisation while staging the operand (the 32x32-tile forward kernel and the
-        LDS-halo weight-gradient kernel: bf16, 3x3 / stride 1, whole 64-byte channel chunks, >= 64 output channels)"""
+        """whether this convolution can take its input as (raw convolution output, BatchNorm statistics, ReLU) — forward
+        AND weight gradient apply the normalisation while staging the operand (both 3x3 LDS-halo forward kernels and the
+        LDS-halo weight-gradient kernel: bf16, 3x3 / stride 1, whole 64-byte channel chunks, >= 64 output channels),
+        and the data gradient derives the ReLU mask in its epilogue"""
         eb = 2 if self.dtype == torch.bfloat16 else 4
         return (USE_HALO and self.dtype == torch.bfloat16 and self.R == 3 and self.S == 3 and self.stride == 1
-                and self.Ci == self.Ci_p and (self.Ci_p * eb) % 64 == 0 and self.Co_p % 64 == 0 and self.Co % 8 == 0
-                and self.need_dgrad and N * H * W * self.Co_p * eb < 0x7fffffff
-                and t32_takes(N, H, W, self.Co_p) and t32_takes(N, H, W, roundup(self.Ci_p, 16)))
+                and self.Ci == self.Ci_p and (self.Ci_p * eb) % 64 == 0 and self.Co_p % 64 == 0 and self.Co % 4 == 0
+                and self.need_dgrad and N * H * W * max(self.Co_p, self.Ci_p) * eb < 0x7fffffff)
+
+    def can_fold_bn_bwd(self, N, Ho, Wo):
+        """whether this convolution's data gradient can take (masked gradient g, raw convolution output c, BatchNorm-backward
+        sums) instead of the BatchNorm input gradient: the second pass of the backward of the BatchNorm BEHIND the
+        convolution is applied while dY is staged (FsConvArgs.pro_mode = 2) and written out once for the weight gradient.
+        Both 3x3 LDS-halo kernels, either dtype, whole 64-byte channel chunks of dY."""
+        eb = 2 if self.dtype == torch.bfloat16 else 4
+        return (USE_HALO and self.halo_d and self.pad == 1 and self.Co == self.Co_p and (self.Co_p * eb) % 64 == 0
+                and N * Ho * Wo * self.Co_p * eb < 0x7fffffff)
 
     def can_fuse_bn_bwd(self, N, H, W, groups):
         """whether dgrad(..., bn_fuse=) may carry the BatchNorm-backward sums of a [N,H,W,Ci_p] gradient"""
@@ -393,7 +424,7 @@ class ConvOp:
                tag=lambda: "dgrd %s dy[%d,%d,%d,%d]" % (self.describe(), N, Ho, Wo, Cd))
         return out
 
-    def dgrad(self, dy, H, W, out=None, addend=None, mask=None, bn_fuse=None, mask_bn=False):
+    def dgrad(self, dy, H, W, out=None, addend=None, mask=None, bn_fuse=None, mask_bn=False, pro_bwd=None):
         """dy: [N,Ho,Wo,Co_p] -> dx [N,H,W,Ci_p] (out may be a strided view; addend is summed in).
         bn_fuse = (c, BnState, sums): dx is the gradient w.r.t. relu(BN(c)) (+ residual): the epilogue also
         accumulates the BatchNorm-backward sums (sum g, sum g*xhat) of that BatchNorm into `sums` (zeroed f64
@@ -402,6 +433,13 @@ class ConvOp:
         assert Cd == self.Co_p and dy.dtype == self.dtype and self.need_dgrad
         if out is None:
             out = torch.empty(N, H, W, self.Ci_p, dtype=self.dtype, device=dy.device)
+        if pro_bwd is not None:
+            # dy is the masked gradient g w.r.t. the OUTPUT of the BatchNorm behind this convolution; pro_bwd = dict(c= raw
+            # output of this convolution, st= that BatchNorm's BnState, gamma=, sums= (sum g, sum g*xhat) [global under
+            # data parallelism], sums_local=, dgamma=, dbeta=, dc_out= dense tensor that receives the BatchNorm input
+            # gradient for the weight gradient)
+            assert self.can_fold_bn_bwd(N, Ho, Wo) and dy.is_contiguous() and pro_bwd["c"].is_contiguous()
+            assert pro_bwd["c"].shape == dy.shape and pro_bwd["dc_out"].shape == dy.shape and pro_bwd["dc_out"].is_contiguous()
         if bn_fuse is not None:
             c, st, _ = bn_fuse
             assert c.is_contiguous() and out.is_contiguous() and c.shape == out.shape and c.dtype == self.dtype
@@ -441,12 +479,24 @@ class ConvOp:
                 a.bnb_scale, a.bnb_shift = st.scale.data_ptr(), st.shift.data_ptr()
         else:
             assert not mask_bn
+        if pro_bwd is not None:
+            pst = pro_bwd["st"]
+            a.pro_mode, a.pro_src2 = 2, pro_bwd["c"].data_ptr()
+            a.pro_stats = pro_bwd["sums"].data_ptr()
+            a.pro_stats_local = pro_bwd["sums_local"].data_ptr() if pro_bwd.get("sums_local") is not None else None
+            a.pro_gamma = pro_bwd["gamma"].data_ptr()
+            a.pro_mean, a.pro_invstd = pst.mean.data_ptr(), pst.invstd.data_ptr()
+            a.pro_count = float(pst.count)
+            a.pro_dgamma = pro_bwd["dgamma"].data_ptr() if pro_bwd.get("dgamma") is not None else None
+            a.pro_dbeta = pro_bwd["dbeta"].data_ptr() if pro_bwd.get("dbeta") is not None else None
+            a.pro_dst = pro_bwd["dc_out"].data_ptr()
+            a.pro_group_imgs = N // pst.groups if pst.groups > 1 else 0
         flops = 2.0 * N * Ho * Wo * self.Co * self.R * self.S * self.Ci
         halo = self.halo_d and USE_HALO
         fn = lib.fs_conv3x3_halo if halo else lib.fs_conv_igemm
         if self._try_1x1(a, flops, lambda: "dgrd %s dy[%d,%d,%d,%d]" % (self.describe(), N, Ho, Wo, Cd)):
             return out
-        _timed("conv3x3_halo" if halo else "conv_igemm", flops, lambda: check(fn(C.byref(a), self.code, stream_ptr()), "conv_dgrad"),
+        _timed(self._kind3x3(a) if halo else "conv_igemm", flops, lambda: check(fn(C.byref(a), self.code, stream_ptr()), "conv_dgrad"),
                tag=lambda: "dgrd %s dy[%d,%d,%d,%d]" % (self.describe(), N, Ho, Wo, Cd))
         return out
 

@@ -6,11 +6,9 @@ import os
 import torch
 
 from .binding import (lib, check, stream_ptr, FsBnApplyArgs, FsBnBwdArgs, FsPhotoArgs, FsSmoothArgs)
-from .conv import dtype_code, _timed
+from .conv import dtype_code, _timed, BN_EPS, BN_MOMENTUM
 
-BN_EPS = 1e-5
 STAT_SLOTS = 8   # FS_STAT_SLOTS in include/fsnet_hip.h
-BN_MOMENTUM = 0.1
 
 
 def _p(t):

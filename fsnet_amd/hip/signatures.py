@@ -14,6 +14,7 @@ SIGNATURES = {
     "fs_debug_timestamp": (C.c_int, [P, P]),
     "fs_conv_igemm": (C.c_int, [P, I, P]),
     "fs_conv3x3_halo": (C.c_int, [P, I, P]),
+    "fs_conv3x3_halo_plan": (C.c_int, [P, I, P]),
     "fs_conv1x1": (C.c_int, [P, I, P]),
     "fs_conv_stem": (C.c_int, [P, I, P]),
     "fs_conv_wgrad": (C.c_int, [P, I, P]),

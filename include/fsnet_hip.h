@@ -33,7 +33,7 @@ extern "C" {
 
 /* library/ABI version and the ISA the kernels were compiled for ("gfx950").  FS_ABI_VERSION changes whenever an
  * argument struct or a signature below does; a host binding refuses a library that reports another number. */
-#define FS_ABI_VERSION 5
+#define FS_ABI_VERSION 6
 int fs_abi_version(void);
 const char* fs_target_arch(void);
 /* debugging aid: writes the device's constant-rate clock (wall_clock64, 100 MHz) into *slot (u64) on `stream`;
@@ -104,28 +104,46 @@ typedef struct FsConvArgs {
   int32_t stat_group_rows; /* 0: one statistics group.  >0: rows (pixels) per BatchNorm statistics group; row m
                               adds to stats + (m / stat_group_rows) * FS_STAT_SLOTS*2*Co.  Groups are whole
                               images and, for fs_conv_igemm, stat_group_rows % 256 == 0 (no tile straddles). */
-  /* ---- fs_conv3x3_halo only (ABI 4) ----
+  /* ---- fs_conv3x3_halo only ----
    * Operand prologue: the BatchNorm (+ ReLU) that precedes this convolution in the reference
    * (resnet.py:33-50 conv1 -> bn1 -> relu -> conv2; blocks.py:41-54) — or, in a data-gradient launch, the second pass
-   * of that BatchNorm's backward — is applied to the source operand while it is staged into LDS, so the normalised
-   * activation / the BatchNorm input gradient never exists in HBM.  Coefficients are fp32 [groups][Cs], group =
-   * image / pro_group_imgs (0: one group).  Out-of-image taps stay zero (the padding applies to the transformed
-   * tensor).
+   * of the backward of the BatchNorm that FOLLOWS the convolution — is applied to the source operand while it is staged
+   * into LDS, so the normalised activation / the BatchNorm input gradient is not produced by a pass of its own.
+   * Coefficients are fp32 [groups][Cs], group = image / pro_group_imgs (0: one group).  Out-of-image taps stay zero (the
+   * padding applies to the transformed tensor).
    *   pro_mode 1: x' = a[c]*x + b[c], then max(x', 0) if pro_relu          (forward: a = gamma*invstd, b = beta - mean*a)
-   *   pro_mode 2: x' = a[c]*x + b[c]*pro_src2 + c[c]                        (backward: x = masked gradient g, pro_src2 =
-   *               the raw convolution output the BatchNorm normalised (same layout and strides as src):
-   *               dx = (g - mean_g - xhat*mean_gx) * gamma*invstd written as one affine form) */
-  const float* pro_a; const float* pro_b; const float* pro_c;
+   *   pro_mode 2: x' = a[c]*x + (b[c]*(pro_src2 - m[c]) + c[c])            (data gradient: x = masked gradient g,
+   *               pro_src2 = the raw convolution output the BatchNorm normalised (same layout and strides as src),
+   *               a = gamma*invstd, b = -a*invstd*sum(g*xhat)/count, c = -a*sum(g)/count, m = mean:
+   *               dx = gamma*invstd*(g - mean_g - xhat*mean_gx), fs_bn_bwd_apply's expression)
+   * Coefficients come from one of two places:
+   *   pro_stats == NULL: pro_a / pro_b (/ pro_c / pro_m) are read as given (fs_bn_finalize made them).
+   *   pro_stats != NULL (ABI 6): every block derives them itself from the f64 sums [groups][FS_STAT_SLOTS][2][Cs] — mode 1:
+   *     (sum x, sum x^2) of src as the producing convolution's epilogue left them (after the data-parallel exchange),
+   *     with pro_gamma / pro_beta / pro_count / pro_eps: bn_apply's preamble, no fs_bn_finalize launch; block 0 also writes
+   *     pro_mean / pro_invstd / pro_save_a / pro_save_b ([groups][Cs]: saved for the backward) and updates
+   *     pro_running_mean / pro_running_var / pro_nbt (momentum pro_momentum, once per group in group order).
+   *     Mode 2: (sum g, sum g*xhat) with pro_gamma, pro_mean, pro_invstd (inputs) and pro_count; block 0 adds
+   *     dgamma += sum g*xhat, dbeta += sum g from pro_stats_local (NULL: from pro_stats) into pro_dgamma / pro_dbeta.
+   * pro_dst (mode 2): the transformed operand is also written out, dense, at src's offsets — the BatchNorm input
+   * gradient that the weight gradient of the same convolution reads (src must then be dense, as dY always is). */
+  const float* pro_a; const float* pro_b; const float* pro_c; const float* pro_m;
   const void* pro_src2;
   int32_t pro_mode, pro_relu, pro_group_imgs;
+  int32_t reserved1;
   /* ReLU-backward mask derived instead of read: with bnb_x set and bnb_scale != NULL the mask is
    * bnb_scale[c]*bnb_x + bnb_shift[c] > 0 (the folded forward's own expression; [groups][Co]) and `mask` must be NULL */
-  int32_t reserved1;
   const float* bnb_scale; const float* bnb_shift;
-  /* second packed weight operand (same geometry as wgt): images n >= wgt2_from_n multiply with it — one launch for two
-   * networks of identical shapes (depth and pose encoder, monodepth2_model.py:24-46).  NULL: one operand. */
-  const void* wgt2;
-  int32_t wgt2_from_n, reserved2;
+  const double* pro_stats; const double* pro_stats_local;
+  const float* pro_gamma; const float* pro_beta;
+  float* pro_mean; float* pro_invstd;
+  float* pro_save_a; float* pro_save_b;
+  float* pro_running_mean; float* pro_running_var;
+  int64_t* pro_nbt;
+  float* pro_dgamma; float* pro_dbeta;
+  void* pro_dst;
+  double pro_count;
+  float pro_eps, pro_momentum;
 } FsConvArgs;
 int fs_conv_igemm(const FsConvArgs* args, int dtype, void* stream);
 /* 1x1 convolutions (forward; data gradient at stride 1) as a row-streaming GEMM: same FsConvArgs and epilogue semantics
@@ -139,6 +157,11 @@ int fs_conv1x1(const FsConvArgs* args, int dtype, void* stream);
  * fs_conv_igemm (ktab is not used); requires Cs*sizeof(T) % 64 == 0 and Co_p % 32 == 0.
  */
 int fs_conv3x3_halo(const FsConvArgs* args, int dtype, void* stream);
+/* the launch fs_conv3x3_halo would make for these arguments, nothing launched (pointers are only tested against NULL):
+ * plan = {kernel (0: 16x16-MFMA-tile kernel, 1: 32x32-MFMA-tile kernel), blocks, pixels per block tile, output channels per
+ * block tile}.  bench.py splits the family's time by kernel with it; tests check that a forced configuration is the one that
+ * runs. */
+int fs_conv3x3_halo_plan(const FsConvArgs* args, int dtype, int32_t* plan);
 
 /* 7x7 / stride-2 / pad-3 stem (resnet.py:118-121: conv1 of both encoders) over 8-channel bf16 pixels, forward only:
  * weights resident in LDS, im2col from an LDS input patch, persistent blocks.  Same arguments and packed forward

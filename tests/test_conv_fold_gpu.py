@@ -1,0 +1,471 @@
+"""Value-level parity of the BatchNorm-fold paths and of every tile configuration of the 32x32-tile kernel against
+torch's fp32 conv2d / autograd on the CPU (the ATen ops the reference calls:
+vision_base/networks/models/backbone/resnet.py:33-50, conv1 -> bn1 -> relu -> conv2 and its backward).
+
+  * forward with the operand prologue (FsConvArgs.pro_mode = 1): reference = conv2d(round_bf16(relu(scale*x + shift)), w)
+    with the zero padding applied AFTER the transform;
+  * weight gradient with the same prologue on its input operand (FsWgradArgs.pro_a);
+  * data gradient whose epilogue derives the ReLU mask from scale*c + shift (bnb_scale) and accumulates the
+    BatchNorm-backward sums;
+at sizes where the benchmark step runs them (the launches the 32x32-tile kernel takes by its own choice), and the
+32x32-tile kernel's three tile configurations x {fp32, bf16} x the epilogue combinations the networks use, forced through
+FSNET_AMD_T32_CFG (read per launch)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(x):
+    return x.bfloat16().float()
+
+
+def _affine(x_nhwc, scale, shift, G, relu=True):
+    """per-group scale * x + shift (+ ReLU), rounded once to bf16 — fp32 multiply, then add, as the kernels do
+    (the library is built with -ffp-contract=off)"""
+    N = x_nhwc.shape[0]
+    C = x_nhwc.shape[-1]
+    out = torch.empty_like(x_nhwc)
+    n = N // G
+    for g in range(G):
+        v = x_nhwc[g * n:(g + 1) * n] * scale[g * C:(g + 1) * C] + shift[g * C:(g + 1) * C]
+        out[g * n:(g + 1) * n] = torch.relu(v) if relu else v
+    return _bf(out)
+
+
+FOLD_CASES = [
+    # Ci, Co, N, H, W, groups — shapes whose launch the 32x32-tile kernel takes by its own choice (ConvOp.can_fold_input)
+    (64, 64, 12, 48, 160, 1),      # layer 1 of the depth encoder at the benchmark batch
+    (128, 128, 24, 24, 80, 2),     # layer 2 of the stacked pose pass: two statistics groups
+]
+
+
+@pytest.mark.parametrize("case", FOLD_CASES)
+def test_forward_with_batchnorm_prologue_matches_conv_of_normalised_input(dev, case):
+    from fsnet_amd.hip import ops
+    from fsnet_amd.hip.conv import ConvOp
+    Ci, Co, N, H, W, G = case
+    g = torch.Generator().manual_seed(100 + Ci + N)
+    x = _bf(torch.randn(N, H, W, Ci, generator=g))                  # the RAW output of conv1
+    w = _bf(torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5)
+    scale = torch.rand(G * Ci, generator=g) + 0.5
+    shift = torch.randn(G * Ci, generator=g) * 0.3
+    xn = _affine(x, scale, shift, G)
+    ref = F.conv2d(xn.permute(0, 3, 1, 2), w, None, padding=1)     # zero padding of the normalised tensor
+    op = ConvOp(Ci, Co, 3, 3, 1, 1, torch.bfloat16, dev)
+    assert op.can_fold_input(N, H, W), "the case must be one the benchmark folds"
+    op.pack(w.to(dev).contiguous())
+    st = ops.BnState(Ci, dev, G, affine=True)
+    st.scale.copy_(scale); st.shift.copy_(shift)
+    xd = x.to(dev).bfloat16()
+    scale_y = ref.abs().max().item()
+    n = N // G
+    for out_f32, tol in ((False, 6e-3), (True, 2e-3)):            # templated EP_STATS epilogue / run-time flags
+        stats = torch.zeros(G, 8, 2, Co, dtype=torch.float64, device=dev)
+        y = op.forward(xd, stats=stats, stat_groups=G, pro=(st, True), out_f32=out_f32)
+        torch.cuda.synchronize()
+        got = y.float().permute(0, 3, 1, 2).cpu()
+        assert (got - ref).abs().max().item() <= tol * scale_y, (out_f32, (got - ref).abs().max().item() / scale_y)
+        for gi in range(G):
+            r = ref[gi * n:(gi + 1) * n].double()
+            s = stats[gi].sum(0).cpu()
+            assert torch.allclose(s[0], r.sum(dim=(0, 2, 3)), rtol=2e-3, atol=2e-3 * (r ** 2).sum(dim=(0, 2, 3)).max().sqrt().item())
+            assert torch.allclose(s[1], (r ** 2).sum(dim=(0, 2, 3)), rtol=3e-3)
+    # without the ReLU flag the prologue is the affine map alone
+    xn2 = _affine(x, scale, shift, G, relu=False)
+    ref2 = F.conv2d(xn2.permute(0, 3, 1, 2), w, None, padding=1)
+    stats = torch.zeros(G, 8, 2, Co, dtype=torch.float64, device=dev)
+    y2 = op.forward(xd, stats=stats, stat_groups=G, pro=(st, False), out_f32=True)
+    torch.cuda.synchronize()
+    assert (y2.permute(0, 3, 1, 2).cpu() - ref2).abs().max().item() <= 2e-3 * ref2.abs().max().item()
+
+
+@pytest.mark.parametrize("case", FOLD_CASES)
+def test_weight_gradient_with_batchnorm_prologue_matches_autograd(dev, case):
+    from fsnet_amd.hip import ops
+    from fsnet_amd.hip.conv import ConvOp
+    Ci, Co, N, H, W, G = case
+    g = torch.Generator().manual_seed(200 + Ci + N)
+    x = _bf(torch.randn(N, H, W, Ci, generator=g))
+    scale = torch.rand(G * Ci, generator=g) + 0.5
+    shift = torch.randn(G * Ci, generator=g) * 0.3
+    xn = _affine(x, scale, shift, G)
+    gy = _bf(torch.randn(N, H, W, Co, generator=g))
+    w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    F.conv2d(xn.permute(0, 3, 1, 2), w, None, padding=1).backward(gy.permute(0, 3, 1, 2))
+    op = ConvOp(Ci, Co, 3, 3, 1, 1, torch.bfloat16, dev)
+    st = ops.BnState(Ci, dev, G, affine=True)
+    st.scale.copy_(scale); st.shift.copy_(shift)
+    dw = torch.zeros(Co, Ci, 3, 3, device=dev)
+    op.wgrad(gy.to(dev).bfloat16(), x.to(dev).bfloat16(), dw, pro=(st, True))
+    torch.cuda.synchronize()
+    wscale = w.grad.abs().max().item()
+    assert (dw.cpu() - w.grad).abs().max().item() <= 2e-3 * wscale
+    # and it accumulates
+    op.wgrad(gy.to(dev).bfloat16(), x.to(dev).bfloat16(), dw, pro=(st, True))
+    torch.cuda.synchronize()
+    assert (dw.cpu() - 2 * w.grad).abs().max().item() <= 4e-3 * wscale
+
+
+@pytest.mark.parametrize("case", FOLD_CASES)
+def test_data_gradient_with_derived_relu_mask_matches_autograd(dev, case):
+    """dgrad(bn_fuse=(c, st, sums), mask_bn=True): dx = conv_transpose(dy) where scale*c + shift > 0, else 0, and
+    sums = (sum dx, sum dx * xhat), xhat = (c - mean) * invstd, per statistics group"""
+    from fsnet_amd.hip import ops
+    from fsnet_amd.hip.conv import ConvOp
+    Ci, Co, N, H, W, G = case
+    g = torch.Generator().manual_seed(300 + Ci + N)
+    w = _bf(torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5)
+    dy = _bf(torch.randn(N, H, W, Co, generator=g))
+    c = _bf(torch.randn(N, H, W, Ci, generator=g))                  # raw output of the convolution in front of the BatchNorm
+    scale = torch.rand(G * Ci, generator=g) + 0.5
+    shift = torch.randn(G * Ci, generator=g) * 0.3
+    mean = torch.randn(G * Ci, generator=g) * 0.1
+    invstd = torch.rand(G * Ci, generator=g) + 0.5
+    dx_ref = F.conv_transpose2d(dy.permute(0, 3, 1, 2), w, None, padding=1).permute(0, 2, 3, 1)   # [N,H,W,Ci] fp32
+    n = N // G
+    keep = torch.empty(N, H, W, Ci, dtype=torch.bool)
+    xhat = torch.empty(N, H, W, Ci)
+    for gi in range(G):
+        sl = slice(gi * n, (gi + 1) * n)
+        keep[sl] = (c[sl] * scale[gi * Ci:(gi + 1) * Ci] + shift[gi * Ci:(gi + 1) * Ci]) > 0
+        xhat[sl] = (c[sl] - mean[gi * Ci:(gi + 1) * Ci]) * invstd[gi * Ci:(gi + 1) * Ci]
+    g_ref = torch.where(keep, dx_ref, torch.zeros(()))
+    op = ConvOp(Ci, Co, 3, 3, 1, 1, torch.bfloat16, dev)
+    op.pack(w.to(dev).contiguous())
+    st = ops.BnState(Ci, dev, G, affine=True)
+    st.scale.copy_(scale); st.shift.copy_(shift); st.mean.copy_(mean); st.invstd.copy_(invstd)
+    st.count = float(n * H * W)
+    sums = torch.zeros(G, 8, 2, Ci, dtype=torch.float64, device=dev)
+    got = op.dgrad(dy.to(dev).bfloat16(), H, W, bn_fuse=(c.to(dev).bfloat16(), st, sums), mask_bn=True)
+    torch.cuda.synchronize()
+    gscale = dx_ref.abs().max().item()
+    assert (got.float().cpu() - g_ref).abs().max().item() <= 1e-2 * gscale
+    assert ((got.float().cpu() != 0) <= keep).all()                # nothing leaks through the mask
+    for gi in range(G):
+        sl = slice(gi * n, (gi + 1) * n)
+        s = sums[gi].sum(0).cpu()
+        r0 = g_ref[sl].double().sum(dim=(0, 1, 2))
+        r1 = (g_ref[sl].double() * xhat[sl].double()).sum(dim=(0, 1, 2))
+        big = max(r0.abs().max().item(), r1.abs().max().item())
+        # (the kernel's sums come from the fp32 accumulators before the bf16 store)
+        assert (s[0] - r0).abs().max().item() <= 2e-3 * big + 1e-3 * (g_ref[sl].double() ** 2).sum().sqrt().item() / Ci ** 0.5
+        assert (s[1] - r1).abs().max().item() <= 2e-3 * big + 1e-3 * (g_ref[sl].double() ** 2).sum().sqrt().item() / Ci ** 0.5
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# every tile configuration of the 32x32-tile kernel, both element types, the epilogues the networks use
+# ---------------------------------------------------------------------------------------------------------------
+T32_SHAPES = [
+    # Ci, Co, N, H, W
+    (64, 64, 2, 16, 32),
+    (128, 64, 3, 12, 20),      # ragged pixel tiles
+    (64, 128, 2, 9, 33),       # odd sizes: partial tiles in both directions
+]
+
+
+def _nhwc(x, dev, dtype):
+    return x.permute(0, 2, 3, 1).contiguous().to(dev).to(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("cfg", [1, 2, 3])
+@pytest.mark.parametrize("shape", T32_SHAPES)
+def test_t32_tile_configurations_against_conv2d(dev, monkeypatch, shape, cfg, dtype):
+    from fsnet_amd.hip import ops
+    from fsnet_amd.hip.conv import ConvOp
+    monkeypatch.setenv("FSNET_AMD_T32_CFG", str(cfg))
+    Ci, Co, N, H, W = shape
+    lo = dtype == torch.bfloat16
+    g = torch.Generator().manual_seed(17 * cfg + Ci + Co + H)
+    rnd = (lambda t: _bf(t)) if lo else (lambda t: t)
+    x = rnd(torch.randn(N, Ci, H, W, generator=g))
+    w = rnd(torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5)
+    b = torch.randn(Co, generator=g)
+    gy = rnd(torch.randn(N, Co, H, W, generator=g))
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, None, padding=1)
+    y_ref.backward(gy)
+    op = ConvOp(Ci, Co, 3, 3, 1, 1, dtype, dev)
+    op.pack(w.to(dev).contiguous())
+    plan = op.plan_3x3(N, H, W, forward=True)
+    assert plan["kernel"] == "t32", plan                            # the forced configuration is what runs
+    assert (plan["pix"], plan["co"]) == {1: (128, 64), 2: (128, 32), 3: (256, 32)}[cfg], plan
+    xd, gyd = _nhwc(x, dev, dtype), _nhwc(gy, dev, dtype)
+    tol = 2e-5 if not lo else 2e-3
+    ys = y_ref.detach().abs().max().item()
+    bias = b.to(dev)
+
+    # forward: statistics only (encoder), bias + statistics (decoder), bias + ReLU (pose decoder), fp32 output
+    stats = torch.zeros(8, 2, Co, dtype=torch.float64, device=dev)
+    y = op.forward(xd, stats=stats, out_f32=True)
+    torch.cuda.synchronize()
+    assert (y.permute(0, 3, 1, 2).cpu() - y_ref.detach()).abs().max().item() <= tol * ys
+    s = stats.sum(0).cpu()
+    assert torch.allclose(s[0], y_ref.detach().double().sum(dim=(0, 2, 3)), rtol=1e-3, atol=1e-3 * ys * (N * H * W) ** 0.5)
+    assert torch.allclose(s[1], (y_ref.detach().double() ** 2).sum(dim=(0, 2, 3)), rtol=2e-3)
+    stats.zero_()
+    y = op.forward(xd, stats=stats)                                 # templated EP_STATS, output in the compute dtype
+    torch.cuda.synchronize()
+    assert (y.float().permute(0, 3, 1, 2).cpu() - y_ref.detach()).abs().max().item() <= (tol if not lo else 6e-3) * ys
+    stats.zero_()
+    yb = op.forward(xd, bias=bias, stats=stats, out_f32=True)
+    yr = op.forward(xd, bias=bias, relu=True, out_f32=True)
+    torch.cuda.synchronize()
+    ref_b = y_ref.detach() + b.view(1, -1, 1, 1)
+    assert (yb.permute(0, 3, 1, 2).cpu() - ref_b).abs().max().item() <= tol * ref_b.abs().max().item()
+    assert (yr.permute(0, 3, 1, 2).cpu() - ref_b.clamp_min(0)).abs().max().item() <= tol * ref_b.abs().max().item()
+    assert torch.allclose(stats.sum(0)[0].cpu(), ref_b.double().sum(dim=(0, 2, 3)), rtol=1e-3, atol=1e-3 * ys * (N * H * W) ** 0.5)
+
+    # data gradient: plain, + addend, ReLU mask, mask + BatchNorm-backward sums, addend + mask + sums, derived mask + sums
+    tg = 2e-5 if not lo else 1e-2
+    dx_ref = xr.grad
+    gs = dx_ref.abs().max().item()
+    plan_d = op.plan_3x3(N, H, W, forward=False)
+    assert plan_d["kernel"] == "t32", plan_d
+    dx = op.dgrad(gyd, H, W)
+    torch.cuda.synchronize()
+    assert (dx.float().permute(0, 3, 1, 2).cpu() - dx_ref).abs().max().item() <= tg * gs
+    add = rnd(torch.randn(N, Ci, H, W, generator=g))
+    yact = rnd(torch.randn(N, Ci, H, W, generator=g))
+    cprev = rnd(torch.randn(N, Ci, H, W, generator=g))
+    mean = torch.randn(Ci, generator=g) * 0.1
+    invstd = torch.rand(Ci, generator=g) + 0.5
+    scale = torch.rand(Ci, generator=g) + 0.5
+    shift = torch.randn(Ci, generator=g) * 0.3
+    addd, yd, cd = _nhwc(add, dev, dtype), _nhwc(yact, dev, dtype), _nhwc(cprev, dev, dtype)
+    dxa = op.dgrad(gyd, H, W, addend=addd)
+    dxm = op.dgrad(gyd, H, W, mask=yd)
+    torch.cuda.synchronize()
+    assert (dxa.float().permute(0, 3, 1, 2).cpu() - (dx_ref + add)).abs().max().item() <= tg * (dx_ref + add).abs().max().item()
+    ref_m = torch.where(yact > 0, dx_ref, torch.zeros(()))
+    assert (dxm.float().permute(0, 3, 1, 2).cpu() - ref_m).abs().max().item() <= tg * gs
+    st = ops.BnState(Ci, dev, 1, affine=True)
+    st.mean.copy_(mean); st.invstd.copy_(invstd); st.scale.copy_(scale); st.shift.copy_(shift)
+    st.count = float(N * H * W)
+    xh = (cprev - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+
+    def check_sums(sums, gref):
+        s = sums.sum(0).cpu()
+        r0 = gref.double().sum(dim=(0, 2, 3)); r1 = (gref.double() * xh.double()).sum(dim=(0, 2, 3))
+        big = max(r0.abs().max().item(), r1.abs().max().item())
+        eps = (1e-5 if not lo else 2e-3) * big + (1e-6 if not lo else 1e-3) * gref.double().norm().item() / Ci ** 0.5
+        assert (s[0] - r0).abs().max().item() <= eps and (s[1] - r1).abs().max().item() <= eps
+
+    for kw, gref in (
+            (dict(mask=yd), ref_m),
+            (dict(mask=yd, addend=addd), torch.where(yact > 0, dx_ref + add, torch.zeros(()))),
+            (dict(mask_bn=True), torch.where(cprev * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) > 0, dx_ref, torch.zeros(())))):
+        sums = torch.zeros(8, 2, Ci, dtype=torch.float64, device=dev)
+        d = op.dgrad(gyd, H, W, bn_fuse=(cd, st, sums), **kw)
+        torch.cuda.synchronize()
+        assert (d.float().permute(0, 3, 1, 2).cpu() - gref).abs().max().item() <= tg * max(gs, gref.abs().max().item()), kw.keys()
+        check_sums(sums, gref)
+
+    # operand prologue on this configuration (forward; bf16 and fp32)
+    stp = ops.BnState(Ci, dev, 1, affine=True)
+    stp.scale.copy_(scale); stp.shift.copy_(shift)
+    xn = torch.relu(x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    xn = rnd(xn)
+    ref_p = F.conv2d(xn, w, None, padding=1)
+    stats.zero_()
+    yp = op.forward(xd, stats=stats, pro=(stp, True), out_f32=True)
+    torch.cuda.synchronize()
+    assert (yp.permute(0, 3, 1, 2).cpu() - ref_p).abs().max().item() <= tol * ref_p.abs().max().item()
+
+
+def test_fold_survives_the_t32_switch(dev, monkeypatch):
+    """FSNET_AMD_T32=0 with the default BatchNorm fold: launches that carry a prologue or a derived
+    mask still run (they returned FS_EINVAL and the step raised)"""
+    from fsnet_amd.hip import ops
+    from fsnet_amd.hip.conv import ConvOp
+    monkeypatch.setenv("FSNET_AMD_T32", "0")
+    Ci = Co = 64
+    N, H, W = 12, 48, 160
+    g = torch.Generator().manual_seed(5)
+    x = _bf(torch.randn(N, H, W, Ci, generator=g))
+    w = _bf(torch.randn(Co, Ci, 3, 3, generator=g) / 24)
+    scale, shift = torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.3
+    op = ConvOp(Ci, Co, 3, 3, 1, 1, torch.bfloat16, dev)
+    op.pack(w.to(dev).contiguous())
+    st = ops.BnState(Ci, dev, 1, affine=True)
+    st.scale.copy_(scale); st.shift.copy_(shift)
+    stats = torch.zeros(8, 2, Co, dtype=torch.float64, device=dev)
+    y = op.forward(x.to(dev).bfloat16(), stats=stats, pro=(st, True), out_f32=True)
+    torch.cuda.synchronize()
+    ref = F.conv2d(_affine(x, scale, shift, 1).permute(0, 3, 1, 2), w, None, padding=1)
+    assert (y.permute(0, 3, 1, 2).cpu() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 4: the prologue derives its coefficients in the kernel (no fs_bn_finalize launch), and the data gradient
+# applies the second pass of the BatchNorm backward to dY while staging it
+# ---------------------------------------------------------------------------------------------------------------
+FIN_CASES = [
+    # Ci, Co, N, H, W, groups, kernel the launch runs on
+    (64, 64, 12, 48, 160, 1, "t32"),
+    (128, 128, 24, 24, 80, 2, "t32"),
+    (256, 256, 4, 12, 40, 2, "halo"),     # 128 x 16 tiles
+    (64, 128, 2, 16, 32, 1, "halo"),      # 128 x 32 tiles
+    (512, 512, 12, 6, 20, 1, "halo"),     # layer 4 at the benchmark batch
+]
+
+
+def _spread_slots(per_group, gen):
+    """[G][2][C] f64 sums -> [G][8][2][C] with the total spread over the address slots as the epilogues leave it"""
+    G, _, C = per_group.shape
+    w = torch.rand(G, 8, 1, 1, generator=gen, dtype=torch.float64)
+    w = w / w.sum(1, keepdim=True)
+    out = per_group.unsqueeze(1) * w
+    out[:, 0] += per_group - out.sum(1)            # exact total
+    return out
+
+
+def _bn_dict(C, dev, gen):
+    return {"weight": (torch.rand(C, generator=gen) + 0.5).to(dev), "bias": (torch.randn(C, generator=gen) * 0.2).to(dev),
+            "running_mean": (torch.randn(C, generator=gen) * 0.1).to(dev), "running_var": (torch.rand(C, generator=gen) + 0.5).to(dev),
+            "num_batches_tracked": torch.tensor(3, dtype=torch.int64, device=dev)}
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
+@pytest.mark.parametrize("case", FIN_CASES)
+def test_forward_finalises_batchnorm_statistics_in_its_prologue(dev, case, dtype):
+    """ConvOp.forward(pro=(st, relu, sums, bn, count, track)): the launch == fs_bn_finalize + the coefficient-array
+    prologue, including the saved statistics and the running-statistics update its block 0 makes; and against conv2d of the
+    normalised input on the CPU"""
+    from fsnet_amd.hip import ops
+    from fsnet_amd.hip.conv import ConvOp
+    Ci, Co, N, H, W, G, kern = case
+    lo = dtype == torch.bfloat16
+    g = torch.Generator().manual_seed(400 + Ci + N)
+    rnd = _bf if lo else (lambda t: t)
+    x = rnd(torch.randn(N, H, W, Ci, generator=g) * 1.5 + 0.3)
+    w = rnd(torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5)
+    n = N // G
+    per = torch.stack([torch.stack([x[gi * n:(gi + 1) * n].double().sum(dim=(0, 1, 2)),
+                                    (x[gi * n:(gi + 1) * n].double() ** 2).sum(dim=(0, 1, 2))]) for gi in range(G)])
+    stats_in = _spread_slots(per, g).to(dev)
+    count = float(n * H * W)
+    op = ConvOp(Ci, Co, 3, 3, 1, 1, dtype, dev)
+    op.pack(w.to(dev).contiguous())
+    assert op.plan_3x3(N, H, W, forward=True, pro_mode=1)["kernel"] == kern
+    # reference: the finalize kernel
+    gb = torch.Generator().manual_seed(9)
+    bn_ref, bn_new = _bn_dict(Ci, dev, gb), _bn_dict(Ci, dev, torch.Generator().manual_seed(9))
+    st_ref = ops.BnState(Ci, dev, G, affine=True)
+    ops.bn_finalize(stats_in, bn_ref, st_ref, Ci, count, track=True, groups=G)
+    st = ops.BnState(Ci, dev, G, affine=True)
+    xd = x.to(dev).to(dtype)
+    sA = torch.zeros(G, 8, 2, Co, dtype=torch.float64, device=dev)
+    sB = torch.zeros(G, 8, 2, Co, dtype=torch.float64, device=dev)
+    yA = op.forward(xd, stats=sA, stat_groups=G, pro=(st_ref, True), out_f32=True)
+    yB = op.forward(xd, stats=sB, stat_groups=G, pro=(st, True, stats_in, bn_new, count, True), out_f32=True)
+    torch.cuda.synchronize()
+    for a, b in ((st.mean, st_ref.mean), (st.invstd, st_ref.invstd), (st.scale, st_ref.scale), (st.shift, st_ref.shift),
+                 (bn_new["running_mean"], bn_ref["running_mean"]), (bn_new["running_var"], bn_ref["running_var"])):
+        assert torch.equal(a, b)
+    assert int(bn_new["num_batches_tracked"]) == 3 + G and st.count == count
+    assert torch.equal(yA, yB)                                      # same coefficients, same kernel arithmetic
+    assert torch.equal(sA.sum(1), sB.sum(1)) or float((sA.sum(1) - sB.sum(1)).abs().max()) <= 1e-9 * float(sA.sum(1).abs().max())
+    xn = _affine(x, st_ref.scale.cpu(), st_ref.shift.cpu(), G) if lo else torch.cat(
+        [torch.relu(x[gi * n:(gi + 1) * n] * st_ref.scale.cpu()[gi * Ci:(gi + 1) * Ci] + st_ref.shift.cpu()[gi * Ci:(gi + 1) * Ci]) for gi in range(G)])
+    ref = F.conv2d(xn.permute(0, 3, 1, 2), w, None, padding=1)
+    assert (yB.permute(0, 3, 1, 2).cpu() - ref).abs().max().item() <= (2e-3 if lo else 2e-5) * ref.abs().max().item()
+    # against the definition: mean / biased variance of x per group
+    mean_ref = (per[:, 0] / count).float().flatten()
+    var_ref = (per[:, 1] / count - (per[:, 0] / count) ** 2).clamp_min(0)
+    assert torch.allclose(st.mean.cpu(), mean_ref, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(st.invstd.cpu(), (1.0 / torch.sqrt(var_ref + 1e-5)).float().flatten(), rtol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
+@pytest.mark.parametrize("case", FIN_CASES)
+def test_data_gradient_applies_batchnorm_backward_in_its_prologue(dev, case, dtype):
+    """ConvOp.dgrad(pro_bwd=...): == fs_bn_bwd_apply followed by the plain data gradient (BatchNorm input gradient written
+    out for the weight gradient, dgamma / dbeta accumulated), with the epilogue options the training step combines it
+    with; and against autograd's batch_norm backward + conv_transpose2d on the CPU"""
+    from fsnet_amd.hip import ops
+    from fsnet_amd.hip.conv import ConvOp
+    Ci, Co, N, H, W, G, kern = case
+    lo = dtype == torch.bfloat16
+    gen = torch.Generator().manual_seed(500 + Ci + N)
+    rnd = _bf if lo else (lambda t: t)
+    w = rnd(torch.randn(Co, Ci, 3, 3, generator=gen) / (9 * Ci) ** 0.5)
+    c = rnd(torch.randn(N, H, W, Co, generator=gen) * 1.3 + 0.2)          # raw output of this convolution
+    keepm = torch.rand(N, H, W, Co, generator=gen) > 0.4
+    gg = rnd(torch.randn(N, H, W, Co, generator=gen)) * keepm             # masked gradient w.r.t. the BatchNorm output
+    gamma = torch.rand(Co, generator=gen) + 0.5
+    n = N // G
+    count = float(n * H * W)
+    mean = torch.cat([c[gi * n:(gi + 1) * n].double().mean(dim=(0, 1, 2)) for gi in range(G)]).float()
+    var = torch.cat([c[gi * n:(gi + 1) * n].double().var(dim=(0, 1, 2), unbiased=False) for gi in range(G)])
+    invstd = (1.0 / torch.sqrt(var + 1e-5)).float()
+    xhat = torch.cat([(c[gi * n:(gi + 1) * n] - mean[gi * Co:(gi + 1) * Co]) * invstd[gi * Co:(gi + 1) * Co] for gi in range(G)])
+    per = torch.stack([torch.stack([gg[gi * n:(gi + 1) * n].double().sum(dim=(0, 1, 2)),
+                                    (gg[gi * n:(gi + 1) * n].double() * xhat[gi * n:(gi + 1) * n].double()).sum(dim=(0, 1, 2))])
+                       for gi in range(G)])
+    sums = _spread_slots(per, gen).to(dev)
+    op = ConvOp(Ci, Co, 3, 3, 1, 1, dtype, dev)
+    op.pack(w.to(dev).contiguous())
+    assert op.can_fold_bn_bwd(N, H, W)
+    assert op.plan_3x3(N, H, W, forward=False, pro_mode=2)["kernel"] == kern
+    st = ops.BnState(Co, dev, G)
+    st.mean.copy_(mean); st.invstd.copy_(invstd); st.count = count
+    gd, cd, gam = gg.to(dev).to(dtype), c.to(dev).to(dtype), gamma.to(dev)
+    # unfused on the device
+    dc_ref = torch.empty_like(cd)
+    dgam_ref, dbet_ref = torch.zeros(Co, device=dev), torch.zeros(Co, device=dev)
+    ops.bn_backward(gd, None, cd, gam, st, dc_ref, dgam_ref, dbet_ref, H, W, sums=sums.view(G * 8, 2, Co).clone(), reduced=True)
+    d_ref = op.dgrad(dc_ref, H, W)
+    # fused
+    dc = torch.empty_like(cd)
+    dgam, dbet = torch.zeros(Co, device=dev), torch.zeros(Co, device=dev)
+    pb = dict(c=cd, st=st, gamma=gam, sums=sums, sums_local=None, dgamma=dgam, dbeta=dbet, dc_out=dc)
+    d = op.dgrad(gd, H, W, pro_bwd=pb)
+    torch.cuda.synchronize()
+    ds_ = dc_ref.float().abs().max().item()
+    # (one affine form against bn_bwd_apply's nested one: equal up to fp32 rounding, i.e. at most one bf16 step apart)
+    assert (dc.float() - dc_ref.float()).abs().max().item() <= (1.6e-2 if lo else 1e-5) * ds_
+    assert (dc.float() - dc_ref.float()).abs().mean().item() <= (2e-4 if lo else 1e-6) * ds_
+    assert (d.float() - d_ref.float()).abs().max().item() <= (1e-2 if lo else 2e-5) * d_ref.float().abs().max().item()
+    assert torch.allclose(dgam, dgam_ref, rtol=1e-5, atol=1e-5 * float(dgam_ref.abs().max()))
+    assert torch.allclose(dbet, dbet_ref, rtol=1e-5, atol=1e-5 * float(dbet_ref.abs().max()))
+    # the definition on the CPU (batch_norm backward's input gradient per group), then the transposed convolution
+    dcs = []
+    for gi in range(G):
+        sl = slice(gi * n, (gi + 1) * n)
+        k = gamma * invstd[gi * Co:(gi + 1) * Co]
+        a = (per[gi, 0] / count).float(); b = (per[gi, 1] / count).float()
+        dcs.append(k * (gg[sl] - a - xhat[sl] * b))
+    dc_cpu = torch.cat(dcs)
+    assert (dc.float().cpu() - dc_cpu).abs().max().item() <= (1.6e-2 if lo else 2e-5) * dc_cpu.abs().max().item()
+    d_cpu = F.conv_transpose2d(rnd(dc_cpu).permute(0, 3, 1, 2), w, None, padding=1).permute(0, 2, 3, 1)
+    assert (d.float().cpu() - d_cpu).abs().max().item() <= (2e-2 if lo else 5e-5) * d_cpu.abs().max().item()
+    # with the epilogue of a folded block's conv2 (derived mask + sums of the previous BatchNorm) and of a conv1 (addend +
+    # mask + sums): the fused launch equals the composition of the separate ones
+    cprev = rnd(torch.randn(N, H, W, Ci, generator=gen)).to(dev).to(dtype)
+    yprev = rnd(torch.randn(N, H, W, Ci, generator=gen)).to(dev).to(dtype)
+    addend = rnd(torch.randn(N, H, W, Ci, generator=gen)).to(dev).to(dtype)
+    stp = ops.BnState(Ci, dev, G, affine=True)
+    stp.mean.copy_(torch.randn(G * Ci, generator=gen) * 0.1); stp.invstd.copy_(torch.rand(G * Ci, generator=gen) + 0.5)
+    stp.scale.copy_(torch.rand(G * Ci, generator=gen) + 0.5); stp.shift.copy_(torch.randn(G * Ci, generator=gen) * 0.3)
+    stp.count = count
+    for kw in (dict(mask_bn=True), dict(mask=yprev, addend=addend)):
+        s_ref = torch.zeros(G, 8, 2, Ci, dtype=torch.float64, device=dev)
+        s_new = torch.zeros(G, 8, 2, Ci, dtype=torch.float64, device=dev)
+        r = op.dgrad(dc, H, W, bn_fuse=(cprev, stp, s_ref), **kw)           # from the written-out gradient
+        dc2 = torch.empty_like(cd)
+        pb2 = dict(pb, dc_out=dc2, dgamma=None, dbeta=None)
+        f = op.dgrad(gd, H, W, bn_fuse=(cprev, stp, s_new), pro_bwd=pb2, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(dc2, dc)
+        assert torch.equal(f, r), kw.keys()
+        assert float((s_new.sum(1) - s_ref.sum(1)).abs().max()) <= 1e-9 * float(s_ref.sum(1).abs().max()) + 1e-12
+    # weight gradient from the written-out tensor == from the separate pass's
+    if lo:
+        xin = rnd(torch.randn(N, H, W, Ci, generator=gen)).to(dev).to(dtype)
+        dw_a, dw_b = torch.zeros(Co, Ci, 3, 3, device=dev), torch.zeros(Co, Ci, 3, 3, device=dev)
+        op.wgrad(dc, xin, dw_a); op.wgrad(dc_ref, xin, dw_b)
+        torch.cuda.synchronize()
+        assert (dw_a - dw_b).abs().max().item() <= 2e-2 * dw_b.abs().max().item()

@@ -156,6 +156,11 @@ def test_bf16_training_step_close_to_fp32_oracle(dev):
         rel = (outs[("disp", s)].detach().cpu() - ref).abs() / ref.abs()
         print("bf16 disparity scale %d: mean rel %.4f max rel %.4f" % (s, float(rel.mean()), float(rel.max())))
         assert float(rel.mean()) < 4e-2 and float(rel.max()) < 0.3, (s, float(rel.mean()), float(rel.max()))
+    _bf16_step_against_oracle(dev, sd0, data, H, W)
+
+
+def _bf16_step_against_oracle(dev, sd0, data, H, W):
+    """one bf16 depth+pose step against the fp32 oracle on the same batch, inside the stated mixed-precision band"""
     m2 = build_model(True, H, W, dev, torch.bfloat16, sd0)
     out = m2(to_dev(data, dev), dict(is_training=True))
     out["loss"].backward()
@@ -176,6 +181,31 @@ def test_bf16_training_step_close_to_fp32_oracle(dev):
         assert cos > 0.85, (k, cos)
         assert 0.9 < float(g.norm() / ref.norm()) < 1.2, k
     print("bf16 conv gradients: min cosine %.4f, norm ratio %.3f .. %.3f" % (mincos, min(ratios), max(ratios)))
+    # BatchNorm affine gradients: dgamma / dbeta of the folded BatchNorms come out of a data-gradient launch's block 0
+    for k, p in m2.named_parameters():
+        ref = raw[k]
+        if ref.dim() != 1 or "bn" not in k or float(ref.norm()) < 1e-3 * gmax:
+            continue
+        g = p.grad.cpu()
+        cos = float((g * ref).sum() / (g.norm() * ref.norm()))
+        assert cos > 0.85 and 0.8 < float(g.norm() / ref.norm()) < 1.25, (k, cos, float(g.norm() / ref.norm()))
+
+
+@gpu
+def test_bf16_folded_step_on_the_32x32_tile_kernel_close_to_fp32_oracle(dev):
+    """the BatchNorm-fold launches of the 32x32-tile kernel (prologue modes 1 and 2, derived mask) inside a training step,
+    against the oracle: at 96x320 the stacked pose pass of a 16-sample batch (32 images at 24x80) is the smallest launch
+    that kernel takes by its own choice — the benchmark's layer-1 path at a size the CPU oracle finishes in seconds
+    (reference: vision_base/networks/models/backbone/resnet.py:33-50)"""
+    from fsnet_amd.hip.conv import ConvOp
+    B, H, W = 16, 96, 320
+    probe = ConvOp(64, 64, 3, 3, 1, 1, torch.bfloat16, dev)
+    for fwd, mode in ((True, 1), (False, 2)):
+        assert probe.plan_3x3(2 * B, H // 4, W // 4, forward=fwd, pro_mode=mode)["kernel"] == "t32"
+    assert probe.plan_3x3(B, H // 4, W // 4, forward=True, pro_mode=1)["kernel"] == "halo"      # the depth encoder's: 16x16-tile kernel
+    sd0 = O.init_state(seed=4, with_pose=True)
+    data = O.synthetic_batch(B, H, W, seed=8)
+    _bf16_step_against_oracle(dev, sd0, data, H, W)
 
 
 @gpu
