@@ -240,6 +240,7 @@ def main():
                        "dp_collectives": (None if RT.dp is None else ("rccl-direct" + ("+hipgraph" if RT.dp.capturable else "")
                                                                         if RT.dp.direct else "torch.distributed")),
                        "dp_world": (None if RT.dp is None else RT.dp.world),
+                       "dp_capture_selftest": (None if RT.dp is None or RT.dp._direct is None else RT.dp._direct.capture_test),
                        "syncbn_exchanges_per_step": (None if RT.dp is None else RT.dp.n_small),
                        "gradient_buckets_per_step": (None if RT.dp is None else RT.dp.n_bucket)},
             "roofline": roofline, "kernels": extra,

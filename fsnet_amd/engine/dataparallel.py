@@ -43,6 +43,7 @@ class DataParallelContext:
         self._sum.reduceOp = dist.ReduceOp.SUM
         from .rccl_direct import DirectComm
         self._direct = DirectComm.create(group)
+        self._agreement = None
         self._comm_stream = None
         self._graph_owners = []    # weak references to hooks whose captured step contains this communicator's nodes
         self.capturable = False
@@ -72,9 +73,16 @@ class DataParallelContext:
         if not self._synced:
             with torch.no_grad():
                 arena = meta_arch._arena
-                dist.broadcast(arena.data, src=0, group=self.group)
-                for b in meta_arch.buffers():
-                    dist.broadcast(b, src=0, group=self.group)
+                if self._direct is not None:
+                    # (on the direct communicator: the engine creates no torch.distributed NCCL work object, ever)
+                    self._direct.broadcast(arena.data, 0)
+                    for b in meta_arch.buffers():
+                        if b.is_cuda:
+                            self._direct.broadcast(b if b.is_contiguous() else b.contiguous(), 0)
+                else:
+                    dist.broadcast(arena.data, src=0, group=self.group)
+                    for b in meta_arch.buffers():
+                        dist.broadcast(b, src=0, group=self.group)
             from .runtime import RT
             RT.bump_weights()        # packed MFMA operands follow the broadcast weights
             torch.cuda.synchronize() if torch.cuda.is_available() else None
@@ -154,16 +162,27 @@ class DataParallelContext:
         self._done[id(module)] = [(sl[0], sl[1])]
 
     def all_agree(self, ok):
-        """True on every rank iff `ok` on every rank (MIN all-reduce on the process group; never inside a capture).
-        Used after a rank-local decision that changes WHICH collectives a rank will issue — a rank that fell back to
-        eager launches while the others replay a captured step would hang them."""
-        dev = self._direct.device if self._direct is not None else torch.device("cpu")
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-        if dev.type == "cuda":
-            from .rccl_direct import quiesce_watchdog
-            quiesce_watchdog(dev)        # the process group's watchdog has reaped this collective before the next capture
-        return bool(int(flag.item()))
+        """True on every rank iff `ok` on every rank.  Used after a rank-local decision that changes WHICH collectives
+        a rank will issue — a rank that fell back to eager launches while the others replay a captured step would hang
+        them.  Through the process group's store (rccl_direct.StoreAgreement): no collective, nothing for the NCCL
+        watchdog to poll, valid for any backend."""
+        if self._agreement is None:
+            from .rccl_direct import StoreAgreement
+            self._agreement = self._direct.agreement if self._direct is not None else StoreAgreement(self.group)
+        return self._agreement.all_agree(ok)
+
+    def reset_direct(self):
+        """after a capture that failed on some rank: the direct communicator may hold half-captured launches of the rank
+        whose capture died — every rank closes it and opens a fresh one (collective; falls back to torch.distributed if
+        that fails) before the eager step reuses it"""
+        if self._direct is None:
+            return
+        self._graph_owners = []
+        self._direct.close()
+        from .rccl_direct import DirectComm
+        self._agreement = None
+        self._direct = DirectComm.create(self.group)
+        self.capturable = False                      # this context steps eagerly from here on
 
     def note_graph_owner(self, owner):
         """`owner.reset_graph()` drops a hipGraph captured with this context's collectives"""
@@ -182,6 +201,7 @@ class DataParallelContext:
         for c in ([self._direct] if self._direct is not None else []):
             c.close()
         self._direct = None
+        self._agreement = None
         if self._comm_stream is not None:
             from .runtime import RT
             RT.release_stream(self._comm_stream.cuda_stream)

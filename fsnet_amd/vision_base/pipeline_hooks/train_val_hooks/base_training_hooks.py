@@ -216,8 +216,13 @@ class BaseTrainingHook(object):
                     # Every rank replays or none does: a rank that fell back to eager launches would issue its
                     # collectives from the host while the others replay theirs from a graph, and a rank whose capture
                     # died would not issue them at all.  (MIN all-reduce over torch.distributed, outside any capture.)
-                    if not RT.dp.all_agree(failure is None) and failure is None:
-                        failure = "the capture failed on another rank"
+                    if not RT.dp.all_agree(failure is None):
+                        if failure is None:
+                            failure = "the capture failed on another rank"
+                        # what this rank (or the failing one) captured must not linger on the communicator the eager
+                        # step is about to use
+                        torch.cuda.synchronize()
+                        RT.dp.reset_direct()
                     if failure is None:
                         output = self._first_replay()
                 if failure is None:

@@ -242,3 +242,25 @@ def _syncbn_train_case(rank, world):
 def test_syncbn_backward_protocol_equals_big_batch_autograd():
     res = _run(_syncbn_train_case)
     assert all(v < 2e-5 for v in res.values()), res
+
+
+def _agreement_case(rank, world):
+    """the ranks' yes/no agreement and the small blob hand-off run through the process group's store: no collective,
+    nothing the NCCL watchdog could poll (rccl_direct.StoreAgreement; used for the captured-step decision, the RCCL unique
+    id and the communicator self-tests)"""
+    from fsnet_amd.engine.dataparallel import DataParallelContext
+    from fsnet_amd.engine.rccl_direct import StoreAgreement
+    ag = StoreAgreement()
+    out = [ag.all_agree(True), ag.all_agree(rank != 1), ag.all_agree(rank != 0), ag.all_agree(True)]
+    blob = ag.share(b"unique-id-from-rank-0" if rank == 0 else b"ignored")
+    dp = DataParallelContext(meta_arch=None)
+    out += [dp.all_agree(True), dp.all_agree(rank == 0), dp.all_agree(True)]
+    return out, blob
+
+
+def test_rank_agreement_through_the_store():
+    res = _run(_agreement_case)
+    for r in (0, 1):
+        out, blob = res[r]
+        assert out == [True, False, False, True, True, False, True]
+        assert blob == b"unique-id-from-rank-0"
