@@ -57,12 +57,20 @@ struct HaloGeom {
 // per CU (132 registers without the bound: measured +6 us on a 22 us launch, more than the BatchNorm pass it replaces saves)
 constexpr int halo_minwaves(int PIX, int CO, int PRO) { return (PRO == 1 && PIX == 128) ? 4 : 1; }
 
-template <typename T, int PIX, int CO, int WP, int PRO>
+// STR = 2 (round 4; forward only): the stride-2 3x3 convolutions at the ResNet stage entries (resnet.py:140-160,
+// conv1 of layer2-4 block 0) on the same machinery instead of the generic implicit GEMM (22-42 us for 3.4 GFLOP).  The halo of
+// a TH x TW output tile is (2TH+1) x (2TW+1) source pixels; it is stored with the columns de-interleaved by parity —
+// slot = row * 2(TW+1) + (x & 1) * (TW+1) + (x >> 1) — so that the 16 pixels of an MFMA tile, which sit 2 source columns
+// apart, read consecutive slots (the conflict-free pattern of the stride-1 case) and a tap is still one immediate offset.
+constexpr int halo_hmax(int PIX, int STR) { return STR == 2 ? (PIX == 128 ? 620 : 340) : (PIX == 256 ? 360 : (PIX == 128 ? 208 : 120)); }
+
+template <typename T, int PIX, int CO, int WP, int PRO, int STR = 1>
 __global__ __launch_bounds__(256, halo_minwaves(PIX, CO, PRO)) void conv3x3_halo_kernel(const FsConvArgs p, const HaloGeom g) {
+  static_assert(STR == 1 || PRO == 0, "the stride-2 variant has no operand prologue");
   constexpr int WC = 4 / WP;
   constexpr int WPIX = PIX / WP, WCO = CO / WC;
   constexpr int TP = WPIX / 16, TC = WCO / 16;
-  constexpr int HMAX = PIX == 256 ? 360 : (PIX == 128 ? 208 : 120);   // halo pixels that fit the LDS budget
+  constexpr int HMAX = halo_hmax(PIX, STR);          // halo slots that fit the LDS budget
   constexpr int LH = (HMAX * 4 + 255) / 256;         // halo 16-byte units per thread
   constexpr int LW = (9 * CO * 4 + 255) / 256;       // weight 16-byte units per thread
   constexpr int OOB = 0x7fffffff;
@@ -82,7 +90,8 @@ __global__ __launch_bounds__(256, halo_minwaves(PIX, CO, PRO)) void conv3x3_halo
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wp = wave % WP, wc = wave / WP;
   const int li = lane & 15, lg = lane >> 4;
-  const int HW = g.TW + 2, HH = g.TH + 2;
+  const int HW = STR * g.TW + 3 - STR, HH = STR * g.TH + 3 - STR;      // source halo, pixels
+  const int HWs = STR == 2 ? 2 * (g.TW + 1) : HW;                      // LDS slots per halo row
   const int nhalo = HH * HW;
   const int ntile = g.TH * g.TW;
 
@@ -107,7 +116,7 @@ __global__ __launch_bounds__(256, halo_minwaves(PIX, CO, PRO)) void conv3x3_halo
   const int co0 = cy * CO;
   const int fwd = p.sgn > 0;
   // halo origin in the source image: forward rows y0 - pad ..; dgrad rows y0 + pad - 2 ..
-  const int oy = y0 + p.hb_add + (fwd ? 0 : -2), ox = x0 + p.hb_add + (fwd ? 0 : -2);
+  const int oy = STR * y0 + p.hb_add + (fwd ? 0 : -2), ox = STR * x0 + p.hb_add + (fwd ? 0 : -2);
 
   const __amdgpu_buffer_rsrc_t rs_src =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, (int)p.src_bytes, 0x00020000);
@@ -207,7 +216,12 @@ __global__ __launch_bounds__(256, halo_minwaves(PIX, CO, PRO)) void conv3x3_halo
         if ((interior >> i) & 1u)
           *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.pro_dst) + (long)hvoff[i] + cc * 64) = u;
       }
-      if (hp < HMAX) lds_h[hp * HS + q] = u;
+      if constexpr (STR == 2) {
+        const int hy = fs_fastdiv(hp, g.mHW), hx = hp - hy * HW;
+        if (hp < nhalo) lds_h[(hy * HWs + (hx & 1) * (g.TW + 1) + (hx >> 1)) * HS + q] = u;
+      } else {
+        if (hp < HMAX) lds_h[hp * HS + q] = u;
+      }
     }
 #pragma unroll
     for (int i = 0; i < LW; ++i) {
@@ -224,7 +238,7 @@ __global__ __launch_bounds__(256, halo_minwaves(PIX, CO, PRO)) void conv3x3_halo
     int pi = wp * WPIX + b * 16 + li;
     if (pi >= ntile) pi = 0;                       // padding lanes read a valid halo row; results are discarded
     int ty = fs_fastdiv(pi, g.mTW), tx = pi - ty * g.TW;
-    hbase[b] = (ty * HW + tx) * HS + lg;
+    hbase[b] = (STR * ty * HWs + tx) * HS + lg;
   }
 
   f32x4 acc[TC][TP];
@@ -232,6 +246,7 @@ __global__ __launch_bounds__(256, halo_minwaves(PIX, CO, PRO)) void conv3x3_halo
   for (int a = 0; a < TC; ++a)
 #pragma unroll
     for (int b = 0; b < TP; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int s2_row = HWs * HS, s2_par = (g.TW + 1) * HS;     // stride 2: slot distance of a halo row / of the odd columns
 
   const int nchunk = (p.Cs * (int)sizeof(T) + 63) / 64;
   load_regs(0);
@@ -245,7 +260,8 @@ __global__ __launch_bounds__(256, halo_minwaves(PIX, CO, PRO)) void conv3x3_halo
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int r = tap / 3, s = tap - r * 3;
-      const int hoff = (fwd ? (r * HW + s) : ((2 - r) * HW + (2 - s))) * HS;
+      const int hoff = STR == 2 ? r * s2_row + (s & 1) * s2_par + (s >> 1) * HS
+                                : (fwd ? (r * HW + s) : ((2 - r) * HW + (2 - s))) * HS;
       uint4 fa[TC], fb[TP];
 #pragma unroll
       for (int a = 0; a < TC; ++a) {
@@ -273,6 +289,9 @@ __global__ __launch_bounds__(256, halo_minwaves(PIX, CO, PRO)) void conv3x3_halo
   }
 
   // ---- epilogue ----
+  // (the data-gradient options do not exist in the stride-2 forward variant: their arguments are then never loaded)
+  const bool has_add = STR == 1 && p.addend != nullptr, has_mask = STR == 1 && p.mask != nullptr;
+  const bool has_bnb = STR == 1 && p.bnb_x != nullptr, has_mbn = has_bnb && p.bnb_scale != nullptr;
   float s1[TC][4], s2[TC][4];
 #pragma unroll
   for (int a = 0; a < TC; ++a)
@@ -298,10 +317,10 @@ __global__ __launch_bounds__(256, halo_minwaves(PIX, CO, PRO)) void conv3x3_halo
     if (co >= p.Co) continue;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), mu = bv, is = bv, msc = bv, msh = bv;
     if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + co);
-    if (p.bnb_x) {
+    if (has_bnb) {
       mu = *reinterpret_cast<const float4*>(p.bnb_mean + sgoff + co);
       is = *reinterpret_cast<const float4*>(p.bnb_invstd + sgoff + co);
-      if (p.bnb_scale) {
+      if (has_mbn) {
         msc = *reinterpret_cast<const float4*>(p.bnb_scale + sgoff + co);
         msh = *reinterpret_cast<const float4*>(p.bnb_shift + sgoff + co);
       }
@@ -310,7 +329,7 @@ __global__ __launch_bounds__(256, halo_minwaves(PIX, CO, PRO)) void conv3x3_halo
     for (int b = 0; b < TP; ++b) {
       if (doff[b] < 0) continue;
       float v[4] = {acc[a][b][0] + bv.x, acc[a][b][1] + bv.y, acc[a][b][2] + bv.z, acc[a][b][3] + bv.w};
-      if (p.addend) {
+      if (has_add) {
         float av[4];
         load4<T>(reinterpret_cast<const T*>(p.addend) + aoff[b] + co, av);
         v[0] += av[0]; v[1] += av[1]; v[2] += av[2]; v[3] += av[3];
@@ -319,16 +338,16 @@ __global__ __launch_bounds__(256, halo_minwaves(PIX, CO, PRO)) void conv3x3_halo
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
       }
-      if (p.mask) {
+      if (has_mask) {
         float mv[4];
         load4<T>(reinterpret_cast<const T*>(p.mask) + moff[b] + co, mv);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = mv[j] > 0.f ? v[j] : 0.f;
       }
-      if (p.bnb_x) {   // BatchNorm-backward sums of the layer this gradient flows into: (sum g, sum g*xhat)
+      if (has_bnb) {   // BatchNorm-backward sums of the layer this gradient flows into: (sum g, sum g*xhat)
         float cv[4];
         load4<T>(reinterpret_cast<const T*>(p.bnb_x) + doff[b] + co, cv);   // same layout as dst
-        if (p.bnb_scale) {
+        if (has_mbn) {
           // ReLU mask of a folded BatchNorm: the sign of the forward prologue's own expression
           v[0] = (cv[0] * msc.x + msh.x) > 0.f ? v[0] : 0.f; v[1] = (cv[1] * msc.y + msh.y) > 0.f ? v[1] : 0.f;
           v[2] = (cv[2] * msc.z + msh.z) > 0.f ? v[2] : 0.f; v[3] = (cv[3] * msc.w + msh.w) > 0.f ? v[3] : 0.f;
@@ -396,9 +415,30 @@ HaloGeom pick_geom(int Hd, int Wd, int PIX, int hmax) {
   return best;
 }
 
-template <typename T, int PIX, int CO, int WP, int PRO>
+// stride 2: TH x TW output pixels whose (2TH+1) x (2TW+2) halo slots fit
+HaloGeom pick_geom_s2(int Hd, int Wd, int PIX, int hmax) {
+  HaloGeom best{0, 0, 0, 0, 0u, 0u, FsDiv{0u, 0u}, FsDiv{0u, 0u}, FsDiv{0u, 0u}, FsDiv{0u, 0u}, 0};
+  double best_cost = 1e30;
+  for (int tw = std::min(4, Wd); tw <= std::min(Wd, 64); ++tw) {
+    int th = std::min(PIX / tw, Hd);
+    while (th >= 1 && (2 * th + 1) * (2 * tw + 2) > hmax) --th;
+    if (th < 1) continue;
+    int tx = (Wd + tw - 1) / tw, ty = (Hd + th - 1) / th;
+    double waste = (double)tx * ty * PIX / ((double)Hd * Wd);
+    double halo = (double)(2 * th + 1) * (2 * tw + 1) / (4.0 * th * tw);
+    double cost = waste * (1.0 + 0.15 * halo);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best.TH = th; best.TW = tw; best.tiles_x = tx; best.tiles_y = ty; }
+  }
+  if (best.TW > 0) {
+    best.mTW = fs_div_magic(best.TW); best.mHW = fs_div_magic(2 * best.TW + 1);
+    best.dTX = fs_make_div(best.tiles_x); best.dTY = fs_make_div(best.tiles_y);
+  }
+  return best;
+}
+
+template <typename T, int PIX, int CO, int WP, int PRO, int STR = 1>
 int launch_halo_pro(const FsConvArgs& a, hipStream_t st) {
-  HaloGeom g = pick_geom(a.Hd, a.Wd, PIX, PIX == 256 ? 360 : (PIX == 128 ? 208 : 120));
+  HaloGeom g = STR == 2 ? pick_geom_s2(a.Hd, a.Wd, PIX, halo_hmax(PIX, 2)) : pick_geom(a.Hd, a.Wd, PIX, halo_hmax(PIX, 1));
   if (g.TH == 0) return FS_EINVAL;
   if (a.stat_group_rows > 0) {
     const long hw = (long)a.Hd * a.Wd;
@@ -416,7 +456,7 @@ int launch_halo_pro(const FsConvArgs& a, hipStream_t st) {
     fs_conv3x3_plan_slot[0] = 0; fs_conv3x3_plan_slot[1] = blocks; fs_conv3x3_plan_slot[2] = PIX; fs_conv3x3_plan_slot[3] = CO;
     return FS_OK;
   }
-  hipLaunchKernelGGL((conv3x3_halo_kernel<T, PIX, CO, WP, PRO>), dim3(blocks), dim3(256), pro_lds_bytes<PRO>(a), st, a, g);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<T, PIX, CO, WP, PRO, STR>), dim3(blocks), dim3(256), pro_lds_bytes<PRO>(a), st, a, g);
   return fs_launch_status();
 }
 
@@ -428,6 +468,21 @@ int launch_halo(const FsConvArgs& a, hipStream_t st) {
     case 2: return launch_halo_pro<T, PIX, CO, WP, 2>(a, st);
     default: return FS_EINVAL;
   }
+}
+
+// stride-2 forward: 128-pixel tiles x 32 output channels (two blocks per CU).  Measured alone against the implicit GEMM
+// and against 16-channel tiles (tools/probes/s2_time.py, us, bf16, B = 12 / 24): 64->128 @48x160 21.8 / 31.4 (igemm 24.6 /
+// 31.4; 16-channel tiles 26.7 / 42.6), 128->256 @24x80 19.4 / 27.0 (22.7 / 30.0; 22.5 / 34.3), 256->512 @12x40 20.6 / 25.9
+// (31.0 / 37.2; 21.2 / 32.0): the halo is four times the output tile, so the second channel tile's re-fetch costs more
+// than the extra blocks buy
+template <typename T>
+int dispatch_s2(const FsConvArgs& a, hipStream_t st) {
+  HaloGeom g = pick_geom_s2(a.Hd, a.Wd, 128, halo_hmax(128, 2));
+  if (g.TH == 0 || a.Co_p % 16 != 0) return FS_EINVAL;
+  const char* fe = getenv("FSNET_AMD_S2_CO");          // development knob: channels per block tile
+  const int co = fe ? atoi(fe) : (a.Co_p % 32 == 0 ? 32 : 16);
+  if (co == 32 && a.Co_p % 32 == 0) return launch_halo_pro<T, 128, 32, 4, 0, 2>(a, st);
+  return launch_halo_pro<T, 128, 16, 4, 0, 2>(a, st);
 }
 
 template <typename T>
@@ -465,8 +520,12 @@ namespace {
 int conv3x3_entry(const FsConvArgs* args, int dtype, hipStream_t st) {
   if (!args || !args->src || !args->wgt || !args->dst) return FS_EINVAL;
   const int es = dtype == FS_DTYPE_BF16 ? 2 : 4;
-  if (args->Cs <= 0 || (args->Cs * es) % 32 != 0 || ((args->Cs * es) % 64 != 0 && args->Cs * es != 32) ||
-      args->dshift != 0 || args->hb_mul != 1)
+  if (args->Cs <= 0 || (args->Cs * es) % 32 != 0 || ((args->Cs * es) % 64 != 0 && args->Cs * es != 32) || args->dshift != 0)
+    return FS_EINVAL;
+  // stride 2: forward launches with pad 1 and whole 64-byte channel chunks, no prologue / no derived mask
+  const bool s2 = args->hb_mul == 2;
+  if (args->hb_mul != 1 && !(s2 && args->sgn > 0 && args->hb_add == -1 && (args->Cs * es) % 64 == 0 && args->pro_mode == 0 &&
+                             !args->bnb_x && args->Hd == (args->Hs - 1) / 2 + 1 && args->Wd == (args->Ws - 1) / 2 + 1))
     return FS_EINVAL;
   if (args->Co % 4 != 0 || args->Co_p % 16 != 0 || args->N <= 0) return FS_EINVAL;
   if (args->src_bytes <= 0 || args->src_bytes > 0x7fffffffLL || args->wgt_bytes <= 0 ||
@@ -478,6 +537,11 @@ int conv3x3_entry(const FsConvArgs* args, int dtype, hipStream_t st) {
   if (args->bnb_x && (!args->stats || !args->bnb_mean || !args->bnb_invstd)) return FS_EINVAL;
   // 32x32-tile kernel for the launches it wants (whole 64-byte channel chunks, >= 32 output channels, enough 256-pixel
   // tiles); the 16x16-tile kernel below takes everything else, with the same prologues and epilogues
+  if (s2) {
+    if (dtype == FS_DTYPE_BF16) return dispatch_s2<bf16>(*args, st);
+    if (dtype == FS_DTYPE_F32) return dispatch_s2<float>(*args, st);
+    return FS_EINVAL;
+  }
   const char* te = getenv("FSNET_AMD_T32");
   const bool use_t32 = !(te && te[0] == '0');
   if (use_t32) {

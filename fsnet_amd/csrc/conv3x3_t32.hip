@@ -455,7 +455,7 @@ int t32_dispatch(const FsConvArgs& a, hipStream_t st) {
 // internal entry: FS_EINVAL = "not mine" (fs_conv3x3_halo then runs the 16x16-tile kernel)
 int fs_conv3x3_t32(const FsConvArgs& a, int dtype, hipStream_t st) {
   const int es = dtype == FS_DTYPE_BF16 ? 2 : 4;
-  if ((a.Cs * es) % 64 != 0 || a.Co_p % 32 != 0 || a.Co % 8 != 0) return FS_EINVAL;
+  if ((a.Cs * es) % 64 != 0 || a.Co_p % 32 != 0 || a.Co % 8 != 0 || a.hb_mul != 1) return FS_EINVAL;
   if (a.src_bytes >= 0x7ffff000LL) return FS_EINVAL;
   if (a.bnb_scale && (!a.bnb_x || !a.bnb_shift || a.mask)) return FS_EINVAL;
   if (a.bnb_x && !a.stats) return FS_EINVAL;

@@ -97,6 +97,7 @@ BN_MOMENTUM = 0.1
 USE_1X1 = os.environ.get("FSNET_AMD_CONV1X1", "1") != "0"
 USE_HALO = os.environ.get("FSNET_AMD_HALO", "1") != "0"   # 3x3/s1 LDS-halo kernel (conv3x3_halo.hip)
 USE_STEM_LDS = os.environ.get("FSNET_AMD_STEM_LDS", "1") != "0"   # 7x7/s2 stem kernel (conv_stem.hip)
+USE_HALO_S2 = os.environ.get("FSNET_AMD_HALO_S2", "1") != "0"     # 3x3/s2 forward on the LDS-halo kernel (else implicit GEMM)
 _WGRAD_WS = {}
 
 
@@ -153,6 +154,9 @@ class ConvOp:
         self.stem_lds = (R == 7 and S == 7 and stride == 2 and pad == 3 and dtype == torch.bfloat16 and self.Ci_p == 8
                          and Co == 64 and USE_STEM_LDS)
         self.halo_f = halo_ok and chunks_ok(self.Ci_p) and self.Co_p % 16 == 0
+        # stride-2 3x3 forward (ResNet stage entries) on the LDS-halo kernel too: whole 64-byte channel chunks, pad 1
+        self.halo_f_s2 = (R == 3 and S == 3 and stride == 2 and pad == 1 and (self.Ci_p * eb) % 64 == 0
+                          and self.Co_p % 16 == 0 and USE_HALO_S2)
         self.halo_d = halo_ok and need_dgrad and chunks_ok(self.Co_p) and roundup(self.Ci_p, 16) % 16 == 0
         # wgrad columns (r, s, ci): same grouping as the forward K walk without chunk padding
         self.ncolgroups = R * S * self.Ci_p // eg
@@ -203,7 +207,7 @@ class ConvOp:
         if out is None:
             out = torch.empty(N, Ho, Wo, self.Co_p, dtype=torch.float32 if out_f32 else self.dtype,
                               device=x.device)
-        halo = self.halo_f and USE_HALO
+        halo = (self.halo_f or self.halo_f_s2) and USE_HALO
         stem = (self.stem_lds and bias is None and addend is None and not relu and not out_f32
                 and out.shape[3] == 64 and out.dtype == self.dtype)
         group_rows, grp_imgs = 0, 0
@@ -277,19 +281,20 @@ class ConvOp:
     def plan_3x3(self, N, H, W, forward=True, pro_mode=0, Co_out=None):
         """the launch fs_conv3x3_halo makes for a forward (x [N,H,W,Ci_p]) or data-gradient (dy [N,H,W,Co_p]) call of this
         3x3 / stride-1 layer on dense tensors: {"kernel": "t32" | "halo", "blocks", "pix", "co"} — nothing is launched"""
-        assert self.R == 3 and self.S == 3 and self.stride == 1
+        assert self.R == 3 and self.S == 3 and (self.stride == 1 or forward)
         eb = 2 if self.dtype == torch.bfloat16 else 4
         a = FsConvArgs()
         a.src, a.wgt, a.dst = 16, 16, 16             # only tested against NULL
         Cs, rows = (self.Ci_p, self.Co_p) if forward else (self.Co_p, self.rows_d)
+        Ho, Wo = self.out_hw(H, W) if forward else (H, W)
         a.sN, a.sH, a.sW = H * W * Cs, W * Cs, Cs
-        a.dN, a.dH, a.dW = H * W * rows, W * rows, rows
+        a.dN, a.dH, a.dW = Ho * Wo * rows, Wo * rows, rows
         a.src_bytes = N * H * W * Cs * eb
         a.wgt_bytes = (self.w_f if forward else self.w_d).numel() * eb
-        a.Hs, a.Ws, a.Hd, a.Wd, a.M = H, W, H, W, N * H * W
+        a.Hs, a.Ws, a.Hd, a.Wd, a.M = H, W, Ho, Wo, N * Ho * Wo
         a.Co = Co_out if Co_out is not None else (self.Co_p if forward else self.Ci_p)
         a.Co_p, a.nchunks, a.kg = rows, (self.nch_f if forward else self.nch_d), (self.kg_f if forward else self.kg_d)
-        a.hb_mul, a.hb_add, a.sgn = 1, (-self.pad if forward else self.pad), (1 if forward else -1)
+        a.hb_mul, a.hb_add, a.sgn = (self.stride if forward else 1), (-self.pad if forward else self.pad), (1 if forward else -1)
         a.N, a.Cs = N, Cs
         if pro_mode:
             a.pro_mode, a.pro_a, a.pro_b, a.pro_c, a.pro_m, a.pro_src2 = pro_mode, 16, 16, 16, 16, 16

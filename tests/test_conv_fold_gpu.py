@@ -469,3 +469,43 @@ def test_data_gradient_applies_batchnorm_backward_in_its_prologue(dev, case, dty
         op.wgrad(dc, xin, dw_a); op.wgrad(dc_ref, xin, dw_b)
         torch.cuda.synchronize()
         assert (dw_a - dw_b).abs().max().item() <= 2e-2 * dw_b.abs().max().item()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(64, 128, 12, 48, 160, 1), (128, 256, 24, 24, 80, 2), (256, 512, 12, 12, 40, 1),
+                                  (64, 128, 3, 17, 31, 1), (64, 64, 2, 9, 9, 1)])
+def test_stride2_forward_on_the_halo_kernel(dev, case, dtype):
+    """3x3 / stride-2 / pad-1 forward (ResNet stage entries, vision_base/networks/models/backbone/resnet.py:140-160) on the
+    LDS-halo kernel's stride-2 variant: output and per-group BatchNorm statistics against conv2d on the CPU — full benchmark
+    shapes, odd sizes (ragged tiles, a last row / column whose window hangs over the border), statistics groups"""
+    from fsnet_amd.hip.conv import ConvOp
+    Ci, Co, N, H, W, G = case
+    lo = dtype == torch.bfloat16
+    g = torch.Generator().manual_seed(600 + Ci + H)
+    rnd = _bf if lo else (lambda t: t)
+    x = rnd(torch.randn(N, Ci, H, W, generator=g))
+    w = rnd(torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5)
+    ref = F.conv2d(x, w, None, stride=2, padding=1)
+    op = ConvOp(Ci, Co, 3, 3, 2, 1, dtype, dev)
+    assert op.halo_f_s2 and op.plan_3x3(N, H, W, forward=True)["kernel"] == "halo"
+    op.pack(w.to(dev).contiguous())
+    xd = _nhwc(x, dev, dtype)
+    stats = torch.zeros(G, 8, 2, Co, dtype=torch.float64, device=dev)
+    y = op.forward(xd, stats=stats, stat_groups=G, out_f32=True)
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == (N, ref.shape[2], ref.shape[3], Co)
+    assert (y.permute(0, 3, 1, 2).cpu() - ref).abs().max().item() <= (2e-3 if lo else 2e-5) * ref.abs().max().item()
+    n = N // G
+    for gi in range(G):
+        r = ref[gi * n:(gi + 1) * n].double()
+        s = stats[gi].sum(0).cpu()
+        assert torch.allclose(s[0], r.sum(dim=(0, 2, 3)), rtol=1e-3, atol=1e-3 * (r ** 2).sum(dim=(0, 2, 3)).max().sqrt().item())
+        assert torch.allclose(s[1], (r ** 2).sum(dim=(0, 2, 3)), rtol=2e-3)
+    # the implicit GEMM on the same operands agrees
+    import fsnet_amd.hip.conv as CV
+    op2 = ConvOp(Ci, Co, 3, 3, 2, 1, dtype, dev)
+    op2.halo_f_s2 = False
+    op2.pack(w.to(dev).contiguous())
+    y2 = op2.forward(xd, out_f32=True)
+    torch.cuda.synchronize()
+    assert (y2 - y).abs().max().item() <= (1e-3 if lo else 2e-5) * ref.abs().max().item()
