@@ -414,6 +414,9 @@ int t32_pick_cfg(const FsConvArgs& a) {
   // few times over; everything else is faster on the 16x16-tile kernel (same prologues and epilogues there)
   const bool big = t32_waste(a, 256) <= 1.15 * t32_waste(a, 128);
   if (big && t32_blocks(a, 256, 32) >= 512) return 3;
+  // (development knob: 128 x 32 tiles for launches with at least this many of them, instead of the 16x16-tile kernel)
+  static const int mid = getenv("FSNET_AMD_T32_MID") ? atoi(getenv("FSNET_AMD_T32_MID")) : 0;
+  if (mid > 0 && t32_blocks(a, 128, 32) >= mid) return 2;
   return -1;
 }
 
