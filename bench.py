@@ -199,6 +199,11 @@ def main():
         extra["conv_wgrad"] = {"achieved_tflops": round(tf(wg), 2), "launches_per_step": wg[0] // nprof,
                                "avg_launch_us": round(wg[2] / wg[0] * 1e6, 2)}
         allc = [ch, cg, wg]
+        if "conv3x3_s2" in agg:     # 3x3 / stride-2 forward of the ResNet stage entries (LDS-halo kernel, stride-2 variant)
+            c2 = agg["conv3x3_s2"]
+            extra["conv3x3_s2"] = {"achieved_tflops": round(tf(c2), 2), "launches_per_step": c2[0] // nprof,
+                                   "avg_launch_us": round(c2[2] / c2[0] * 1e6, 2)}
+            allc.append(c2)
         if "conv1x1" in agg:        # 1x1 forward / stride-1 data gradient on the row-streaming GEMM (ResNet-50 configs)
             c1 = agg["conv1x1"]
             extra["conv1x1"] = {"achieved_tflops": round(tf(c1), 2), "launches_per_step": c1[0] // nprof,

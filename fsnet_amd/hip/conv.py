@@ -274,6 +274,8 @@ class ConvOp:
         """launch-profile kind of a 3x3 / stride-1 launch: which of the two kernels fs_conv3x3_halo runs it on"""
         if not LaunchProfile.active:
             return "conv3x3_halo"
+        if a.hb_mul == 2:
+            return "conv3x3_s2"          # stage-entry stride-2 forward: not part of the stride-1 family's roofline figure
         plan = (C.c_int32 * 4)()
         check(lib.fs_conv3x3_halo_plan(C.byref(a), self.code, plan), "conv3x3_plan")
         return "conv3x3_t32" if plan[0] == 1 else "conv3x3_halo"
