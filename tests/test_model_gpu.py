@@ -262,6 +262,49 @@ def test_resnet50_wpose_gradients_match_oracle(dev):
 
 
 @gpu
+def test_resnet50_bf16_gradients_against_fp32_oracle(dev):
+    """the Bottleneck encoder in the benchmarked dtype, per parameter, against the fp32 oracle
+    (reference: vision_base/networks/models/backbone/resnet.py:52-89).  What can be asserted at random initialisation:
+    the loss, every convolution gradient's NORM (0.85 .. 1.02 measured) and the direction of the decoder's un-rectified
+    tail (cosine >= 0.96 measured).  The encoder's gradient DIRECTIONS cannot: this 53-convolution network is chaotic at
+    initialisation — the fp32 gradient itself turns by cosine 0.925 (encoder mean) when every weight moves by 2e-4
+    relative, where ResNet-18 gives 0.995 (tools/probes/bf16_noise_avg.py) — and a bf16 activation is a 4e-3 relative
+    perturbation: encoder cosines of 0.2 .. 0.45 follow on every kernel path alike (implicit GEMM only, no fold, no fused
+    sums: tools/probes/bf16_cos.py), and half of the error averages out over weight-perturbed copies."""
+    from fsnet_amd.configs import meta_arch_cfg
+    from fsnet_amd.engine.runtime import RT
+    from fsnet_amd.vision_base.utils.builder import build
+    RT.set_compute_dtype(torch.bfloat16)
+    RT.tie_noise = False
+    B, H, W = 2, 64, 128
+    sd0 = O.init_state(seed=11, depth=50, with_pose=False)
+    m = build(**meta_arch_cfg(H, W, with_pose=False, depth=50))
+    m.load_state_dict({k: v.clone() for k, v in sd0.items()}, strict=True)
+    m = m.to(dev).train()
+    data = O.synthetic_batch(B, H, W, seed=13)
+    out = m(to_dev(data, dev), dict(is_training=True))
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    tr = O.OracleTrainer(sd0, depth=50, with_pose=False, clip=None)
+    total, ld, _, raw, _ = tr.step(data)
+    RT.set_compute_dtype(torch.float32)
+    assert abs(float(out["loss"].detach()) - float(total)) < 5e-3 * abs(float(total))
+    gmax = max(float(r.norm()) for r in raw.values())
+    ratios, tail = [], []
+    for k, p in m.named_parameters():
+        ref = raw[k]
+        if float(ref.norm()) < 1e-3 * gmax or ref.dim() != 4:
+            continue
+        g = p.grad.cpu()
+        ratios.append(float(g.norm() / ref.norm()))
+        if k.startswith("head.depth_decoder.decoder.") and int(k.split(".")[3]) >= 5:
+            tail.append(float((g * ref).sum() / (g.norm() * ref.norm())))
+    print("R50 bf16: gradient norm ratio %.3f .. %.3f, decoder tail cosine >= %.3f" % (min(ratios), max(ratios), min(tail)))
+    assert 0.75 < min(ratios) and max(ratios) < 1.25, (min(ratios), max(ratios))
+    assert len(tail) >= 8 and min(tail) > 0.92, tail
+
+
+@gpu
 def test_deepcopied_model_repacks_its_own_weights(dev):
     """a copy.deepcopy made after the first forward must keep its MFMA operands in step with ITS weights"""
     import copy
