@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 : > gpurun_out/ab.txt
 for rep in 1 2; do
 for cfg in "$@"; do
-  ms=$(env $cfg timeout 600 python bench.py --steps 100 --warmup 15 --no-cpu-baseline --no-kernel-profile 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.readline())['ms_per_step'])")
+  ms=$(env $cfg timeout 600 python bench.py --steps ${AB_STEPS:-100} --warmup 15 --no-cpu-baseline --no-kernel-profile $BENCH_ARGS 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.readline())['ms_per_step'])")
   echo "$cfg  ->  $ms ms" | tee -a gpurun_out/ab.txt
 done
 done
