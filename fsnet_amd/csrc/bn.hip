@@ -8,6 +8,7 @@
 #include "common.h"
 #include "fsnet_hip_internal.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -106,6 +107,23 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const FsBnApplyArgs p) {
   const double* stats_z = p.stats ? p.stats + z * gstat : nullptr;
   const double* stats2_z = p.stats2 ? p.stats2 + z * gstat : nullptr;
   const bool first = blockIdx.x == 0;
+  // the thread's first vector is requested BEFORE the coefficient preamble (a dependent chain of L2 loads and f64
+  // arithmetic that every block repeats): on the small encoder layers the preamble was half of the kernel's time and the
+  // operand loads only started behind it
+  const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ res = reinterpret_cast<const T*>(p.res);
+  constexpr int V = VecN<T>::N;
+  const int CG = C / V, cg_sh = pow2_shift(CG);
+  const long total = (long)Mg * CG;
+  const long i0 = (long)blockIdx.x * 256 + threadIdx.x;
+  float pv[V], pr[V];
+  if (i0 < total) {
+    int cg; long m;
+    split_vec(i0, CG, cg_sh, cg, m);
+    m += (long)z * Mg;
+    loadv<T>(x + m * C + cg * V, pv);
+    if (res) loadv<T>(res + m * C + cg * V, pr);
+  }
   for (int c = threadIdx.x; c < C; c += 256) {
     float mean, invstd, varb, sc, sh;
     bn_channel_coeffs(stats_z, p.running_mean, p.running_var, C, c, p.count, p.eps, p.gamma[c], p.beta[c], mean, invstd, varb, sc, sh);
@@ -146,25 +164,30 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const FsBnApplyArgs p) {
   }
   __syncthreads();
 
-  const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
-  const T* __restrict__ res = reinterpret_cast<const T*>(p.res);
   T* __restrict__ y = reinterpret_cast<T*>(p.y);
-  constexpr int V = VecN<T>::N;
-  const int CG = C / V, cg_sh = pow2_shift(CG);
-  const long total = (long)Mg * CG;
   const bool dense_y = !p.pad_out && p.yW == C && p.yH == (long)p.W * C && p.yN == (long)p.H * p.W * C;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = i0; i < total; i += stride) {
     int cg; long m;
     split_vec(i, CG, cg_sh, cg, m);
     m += (long)z * Mg;
     int c = cg * V;
-    float v[V];
-    loadv<T>(x + m * C + c, v);
+    float v[V], r[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { v[j] = pv[j]; r[j] = pr[j]; }
+    // the next vector of this thread is in flight while this one is normalised and stored (a block lives for several
+    // vectors: the grid is held to ~4 blocks per CU so that the coefficient preamble is paid that many times, not per 256
+    // vectors)
+    if (i + stride < total) {
+      int cg2; long m2;
+      split_vec(i + stride, CG, cg_sh, cg2, m2);
+      m2 += (long)z * Mg;
+      loadv<T>(x + m2 * C + cg2 * V, pv);
+      if (res) loadv<T>(res + m2 * C + cg2 * V, pr);
+    }
 #pragma unroll
     for (int j = 0; j < V; ++j) v[j] = v[j] * s_scale[c + j] + s_shift[c + j];
     if (res) {
-      float r[V];
-      loadv<T>(res + m * C + c, r);
       if (has2) {
 #pragma unroll
         for (int j = 0; j < V; ++j) r[j] = r[j] * s_scale2[c + j] + s_shift2[c + j];
@@ -319,6 +342,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const FsBnBwdArgs p) 
   const int Mg = p.M / G;
   const double* sums = p.sums + (long)z * FS_STAT_SLOTS * 2 * C;
   const double* sums_local = p.sums_local ? p.sums_local + (long)z * FS_STAT_SLOTS * 2 * C : nullptr;
+  // first vector requested before the coefficient preamble (see bn_apply_kernel)
+  const T* __restrict__ dout = reinterpret_cast<const T*>(p.dout);
+  const T* __restrict__ yv = reinterpret_cast<const T*>(p.y);
+  const T* __restrict__ xv = reinterpret_cast<const T*>(p.x);
+  constexpr int V = VecN<T>::N;
+  const int CG = C / V, cg_sh = pow2_shift(CG);
+  const long total = (long)Mg * CG;
+  const long i0 = (long)blockIdx.x * 256 + threadIdx.x;
+  float pg[V], px[V];
+  if (i0 < total) {
+    int cg; long m;
+    split_vec(i0, CG, cg_sh, cg, m);
+    m += (long)z * Mg;
+    masked_grad<T>(p, dout, yv, m, cg * V, pg);
+    loadv<T>(xv + m * C + cg * V, px);
+  }
   for (int c = threadIdx.x; c < C; c += 256) {
     double sg = 0.0, sgx = 0.0, lg = 0.0, lgx = 0.0;
 #pragma unroll
@@ -343,22 +382,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const FsBnBwdArgs p) 
     }
   }
   __syncthreads();
-  const T* __restrict__ dout = reinterpret_cast<const T*>(p.dout);
-  const T* __restrict__ yv = reinterpret_cast<const T*>(p.y);
-  const T* __restrict__ xv = reinterpret_cast<const T*>(p.x);
   T* __restrict__ dx = reinterpret_cast<T*>(p.dx);
   T* __restrict__ gout = reinterpret_cast<T*>(p.g_out);
-  constexpr int V = VecN<T>::N;
-  const int CG = C / V, cg_sh = pow2_shift(CG);
-  const long total = (long)Mg * CG;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = i0; i < total; i += stride) {
     int cg; long m;
     split_vec(i, CG, cg_sh, cg, m);
     m += (long)z * Mg;
     int c = cg * V;
     float g[V], xr[V], o[V];
-    masked_grad<T>(p, dout, yv, m, c, g);
-    loadv<T>(xv + m * C + c, xr);
+#pragma unroll
+    for (int j = 0; j < V; ++j) { g[j] = pg[j]; xr[j] = px[j]; }
+    if (i + stride < total) {            // next vector in flight (see bn_apply_kernel)
+      int cg2; long m2;
+      split_vec(i + stride, CG, cg_sh, cg2, m2);
+      m2 += (long)z * Mg;
+      masked_grad<T>(p, dout, yv, m2, cg2 * V, pg);
+      loadv<T>(xv + m2 * C + cg2 * V, px);
+    }
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       float xh = (xr[j] - s_mean[c + j]) * s_istd[c + j];
@@ -370,11 +411,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const FsBnBwdArgs p) 
 }
 
 int grid_for(long items) {
-  // one 16-byte vector per thread.  (Measured: 2, 4 or 8 vectors per thread, to amortise the per-block coefficient
-  // prologue, are no faster — 1.83 / 1.82 / 1.92 / 2.24 ms of BatchNorm time per step; these kernels are bound by
-  // launch-level fixed costs on the small layers and by HBM on the large ones.)
   long b = (items + 255) / 256;
-  if (b > 4096) b = 4096;
+  // ~4 blocks per CU, each a grid-stride walk with the next vector in flight: the per-block coefficient preamble (8-64 KB
+  // of f64 sums re-read by EVERY block) is then paid 1 024 times per launch instead of once per 256 vectors — with one
+  // vector per thread it moved more bytes than the tensor on the deep layers.  Measured on the step (cap 4096 / 1536 /
+  // 1024 / 768 / 512): ResNet-18 B=12 5.75 / 5.71 / 5.65 / 5.66 / 5.67 ms, ResNet-50 @320x1024 27.7 / 26.1 / 25.8 / 25.8 /
+  // 25.8 (256: 26.9), fisheye 6.63 / - / 6.53.  FSNET_AMD_BN_GRID overrides (development).
+  static const long cap = getenv("FSNET_AMD_BN_GRID") ? atol(getenv("FSNET_AMD_BN_GRID")) : 1024;
+  if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (int)b;
 }
