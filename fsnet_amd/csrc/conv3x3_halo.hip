@@ -515,6 +515,7 @@ int dispatch(const FsConvArgs& a, hipStream_t st) {
 }  // namespace
 
 int fs_conv3x3_t32(const FsConvArgs& a, int dtype, hipStream_t st);      // conv3x3_t32.hip
+int fs_conv3x3_p1(const FsConvArgs& a, int dtype, hipStream_t st);       // conv3x3_p1.hip
 
 namespace {
 int conv3x3_entry(const FsConvArgs* args, int dtype, hipStream_t st) {
@@ -541,6 +542,12 @@ int conv3x3_entry(const FsConvArgs* args, int dtype, hipStream_t st) {
     if (dtype == FS_DTYPE_BF16) return dispatch_s2<bf16>(*args, st);
     if (dtype == FS_DTYPE_F32) return dispatch_s2<float>(*args, st);
     return FS_EINVAL;
+  }
+  {
+    // one-chunk layers with <= 32 output channels and many pixel tiles (the decoder's 192x640 / 96x320 layers): the
+    // persistent kernel with resident weights
+    const int r = fs_conv3x3_p1(*args, dtype, st);
+    if (r != FS_EINVAL) return r;
   }
   const char* te = getenv("FSNET_AMD_T32");
   const bool use_t32 = !(te && te[0] == '0');

@@ -302,7 +302,7 @@ class ConvOp:
             a.pro_mode, a.pro_a, a.pro_b, a.pro_c, a.pro_m, a.pro_src2 = pro_mode, 16, 16, 16, 16, 16
         plan = (C.c_int32 * 4)()
         check(lib.fs_conv3x3_halo_plan(C.byref(a), self.code, plan), "conv3x3_plan")
-        return {"kernel": "t32" if plan[0] == 1 else "halo", "blocks": int(plan[1]), "pix": int(plan[2]), "co": int(plan[3])}
+        return {"kernel": {0: "halo", 1: "t32", 2: "p1"}[int(plan[0])], "blocks": int(plan[1]), "pix": int(plan[2]), "co": int(plan[3])}
 
     def _try_1x1(self, a, flops, tag):
         """1x1 convolutions (forward, stride-1 data gradient) on the row-streaming GEMM kernel (conv1x1.hip); False =

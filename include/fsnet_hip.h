@@ -158,7 +158,7 @@ int fs_conv1x1(const FsConvArgs* args, int dtype, void* stream);
  */
 int fs_conv3x3_halo(const FsConvArgs* args, int dtype, void* stream);
 /* the launch fs_conv3x3_halo would make for these arguments, nothing launched (pointers are only tested against NULL):
- * plan = {kernel (0: 16x16-MFMA-tile kernel, 1: 32x32-MFMA-tile kernel), blocks, pixels per block tile, output channels per
+ * plan = {kernel (0: 16x16-MFMA-tile kernel, 1: 32x32-MFMA-tile kernel, 2: persistent one-chunk kernel), blocks, pixels per block tile, output channels per
  * block tile}.  bench.py splits the family's time by kernel with it; tests check that a forced configuration is the one that
  * runs. */
 int fs_conv3x3_halo_plan(const FsConvArgs* args, int dtype, int32_t* plan);

@@ -509,3 +509,68 @@ def test_stride2_forward_on_the_halo_kernel(dev, case, dtype):
     y2 = op2.forward(xd, out_f32=True)
     torch.cuda.synchronize()
     assert (y2 - y).abs().max().item() <= (1e-3 if lo else 2e-5) * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(16, 16, 2, 64, 96), (32, 16, 2, 48, 80), (16, 32, 3, 40, 57), (16, 16, 12, 192, 640)])
+def test_persistent_one_chunk_kernel_against_conv2d(dev, monkeypatch, case, dtype):
+    """conv3x3_p1.hip (the depth decoder's 16 / 32-channel layers, depth_encoder.py:45-63: weights resident, a block walks
+    pixel tiles): forward with bias + statistics + fp32 output, bias + ReLU, and the data gradient with addend / ReLU mask /
+    BatchNorm-backward sums, against conv2d and autograd on the CPU — forced on for small launches through FSNET_AMD_P1_MIN,
+    ragged tiles included, and by its own choice at 192x640"""
+    from fsnet_amd.hip import ops
+    from fsnet_amd.hip.conv import ConvOp
+    Ci, Co, N, H, W = case
+    lo = dtype == torch.bfloat16
+    if not lo and Ci > 16:
+        pytest.skip("fp32: one 64-byte chunk is 16 channels")
+    if H < 192:
+        monkeypatch.setenv("FSNET_AMD_P1_MIN", "0")
+    g = torch.Generator().manual_seed(700 + Ci + Co + H)
+    rnd = _bf if lo else (lambda t: t)
+    x = rnd(torch.randn(N, Ci, H, W, generator=g))
+    w = rnd(torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5)
+    b = torch.randn(Co, generator=g)
+    gy = rnd(torch.randn(N, Co, H, W, generator=g))
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, w, b, padding=1)
+    y_ref.backward(gy)
+    op = ConvOp(Ci, Co, 3, 3, 1, 1, dtype, dev)
+    op.pack(w.to(dev).contiguous())
+    assert op.plan_3x3(N, H, W, forward=True)["kernel"] == "p1"
+    # (the data gradient's source is dY: Co channels must fit one 64-byte chunk too, else the other kernels take it)
+    assert op.plan_3x3(N, H, W, forward=False)["kernel"] == ("p1" if op.Co_p * (2 if lo else 4) <= 64 else "halo")
+    xd, gyd = _nhwc(x, dev, dtype), _nhwc(gy, dev, dtype)
+    bias = torch.zeros(op.Co_p, device=dev); bias[:Co] = b.to(dev)
+    stats = torch.zeros(8, 2, op.Co_p, dtype=torch.float64, device=dev)
+    y = op.forward(xd, bias=bias, stats=stats, out_f32=True)
+    yr = op.forward(xd, bias=bias, relu=True)
+    torch.cuda.synchronize()
+    tol = 2e-3 if lo else 2e-5
+    ys = y_ref.detach().abs().max().item()
+    assert (y.permute(0, 3, 1, 2).cpu() - y_ref.detach()).abs().max().item() <= tol * ys
+    assert (yr.float().permute(0, 3, 1, 2).cpu() - y_ref.detach().clamp_min(0)).abs().max().item() <= (6e-3 if lo else 2e-5) * ys
+    s = stats.sum(0).cpu()
+    assert torch.allclose(s[0, :Co], y_ref.detach().double().sum(dim=(0, 2, 3)), rtol=1e-3, atol=1e-3 * ys * (N * H * W) ** 0.5)
+    assert torch.allclose(s[1, :Co], (y_ref.detach().double() ** 2).sum(dim=(0, 2, 3)), rtol=2e-3)
+    # data gradient (dY has Co channels: one chunk; output Ci channels)
+    tg = 1e-2 if lo else 2e-5
+    dx_ref = xr.grad
+    dx = op.dgrad(gyd, H, W)
+    torch.cuda.synchronize()
+    assert (dx.float().permute(0, 3, 1, 2).cpu() - dx_ref).abs().max().item() <= tg * dx_ref.abs().max().item()
+    add, yact, cprev = (rnd(torch.randn(N, Ci, H, W, generator=g)) for _ in range(3))
+    st = ops.BnState(Ci, dev, 1)
+    mean, invstd = torch.randn(Ci, generator=g) * 0.1, torch.rand(Ci, generator=g) + 0.5
+    st.mean.copy_(mean); st.invstd.copy_(invstd); st.count = float(N * H * W)
+    sums = torch.zeros(8, 2, Ci, dtype=torch.float64, device=dev)
+    d = op.dgrad(gyd, H, W, addend=_nhwc(add, dev, dtype), mask=_nhwc(yact, dev, dtype), bn_fuse=(_nhwc(cprev, dev, dtype), st, sums))
+    torch.cuda.synchronize()
+    gref = torch.where(yact > 0, dx_ref + add, torch.zeros(()))
+    assert (d.float().permute(0, 3, 1, 2).cpu() - gref).abs().max().item() <= tg * gref.abs().max().item()
+    xh = (cprev - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+    ss = sums.sum(0).cpu()
+    r0, r1 = gref.double().sum(dim=(0, 2, 3)), (gref.double() * xh.double()).sum(dim=(0, 2, 3))
+    big = max(r0.abs().max().item(), r1.abs().max().item())
+    eps = (2e-3 if lo else 1e-5) * big + (1e-3 if lo else 1e-6) * gref.double().norm().item() / Ci ** 0.5
+    assert (ss[0] - r0).abs().max().item() <= eps and (ss[1] - r1).abs().max().item() <= eps

@@ -12,7 +12,7 @@ import pytest
 
 from fsnet_amd.csrc import build as B
 
-HOT = ["photo_fused.hip", "conv3x3_halo.hip", "conv3x3_t32.hip", "conv_igemm.hip", "conv1x1.hip", "conv_wgrad.hip", "bn.hip"]
+HOT = ["photo_fused.hip", "conv3x3_halo.hip", "conv3x3_t32.hip", "conv3x3_p1.hip", "conv_igemm.hip", "conv1x1.hip", "conv_wgrad.hip", "bn.hip"]
 
 
 @pytest.mark.skipif(shutil.which(B.HIPCC) is None and not os.path.exists(B.HIPCC), reason="hipcc not available")
