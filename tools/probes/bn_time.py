@@ -30,6 +30,8 @@ for N, H, W, C in [(12, 48, 160, 64), (24, 48, 160, 64), (12, 24, 80, 128), (12,
     t_apply = tm(lambda: ops.bn_apply(x, stats, bn, st, y, H, W, N * H * W, relu=True))
     sums = torch.rand(8, 2, C, dtype=torch.float64, device=dev)
     t_bwd = tm(lambda: ops.bn_backward(g, None, x, bn["weight"], st, dx, None, None, H, W, sums=sums, reduced=True))
+    yy = torch.randn(N, H, W, C, device=dev).bfloat16()
+    t_red = tm(lambda: ops.bn_backward(g, yy, x, bn["weight"], st, dx, None, None, H, W, sums=sums, sums_zeroed=True, phase="reduce"))
     t_copy = tm(lambda: y.copy_(x))
-    print("[%2d,%3d,%3d,%3d] %5.1f MB/tensor  bn_apply %5.1f us (%.2f TB/s)  bn_bwd_apply %5.1f us (%.2f TB/s)  copy %5.1f us (%.2f TB/s)" % (
-        N, H, W, C, mb, t_apply, 2 * mb / t_apply, t_bwd, 3 * mb / t_bwd, t_copy, 2 * mb / t_copy))
+    print("[%2d,%3d,%3d,%3d] %5.1f MB/tensor  bn_apply %5.1f us (%.2f TB/s)  bn_bwd_apply %5.1f us (%.2f TB/s)  bn_bwd_reduce %5.1f us (%.2f TB/s)  copy %5.1f us (%.2f TB/s)" % (
+        N, H, W, C, mb, t_apply, 2 * mb / t_apply, t_bwd, 3 * mb / t_bwd, t_red, 3 * mb / t_red, t_copy, 2 * mb / t_copy))
