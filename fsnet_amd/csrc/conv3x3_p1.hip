@@ -317,7 +317,9 @@ int p1_launch(const FsConvArgs& a, hipStream_t st) {
   }
   const long ntiles = (long)a.N * g.tiles_x * g.tiles_y;
   // worth it from two tiles per resident block on (below that the one-tile-per-block kernel has as little to repeat)
-  static const long min_rounds_x10 = getenv("FSNET_AMD_P1_MIN") ? atol(getenv("FSNET_AMD_P1_MIN")) : 20;
+  // (FSNET_AMD_P1_MIN: development / test switch, read per launch so that a test can force small launches onto this kernel)
+  const char* min_env = getenv("FSNET_AMD_P1_MIN");
+  const long min_rounds_x10 = min_env ? atol(min_env) : 20;
   static const int slots = p1_resident(conv3x3_p1_kernel<T, CO, UQ>);
   if (ntiles * 10 < (long)slots * min_rounds_x10 || ntiles > 0x7fffffffL) return FS_EINVAL;
   g.ntiles = (int)ntiles;
