@@ -574,3 +574,49 @@ def test_persistent_one_chunk_kernel_against_conv2d(dev, monkeypatch, case, dtyp
     big = max(r0.abs().max().item(), r1.abs().max().item())
     eps = (2e-3 if lo else 1e-5) * big + (1e-3 if lo else 1e-6) * gref.double().norm().item() / Ci ** 0.5
     assert (ss[0] - r0).abs().max().item() <= eps and (ss[1] - r1).abs().max().item() <= eps
+
+
+def test_persistent_one_chunk_kernel_statistic_groups(dev, monkeypatch):
+    """conv3x3_p1.hip with the batch split into two BatchNorm invocations (stacked calls, resnet.py train-mode BatchNorm per
+    call): forward statistics and the data gradient's BatchNorm-backward sums land in the group of the tile's image"""
+    from fsnet_amd.hip import ops
+    from fsnet_amd.hip.conv import ConvOp
+    monkeypatch.setenv("FSNET_AMD_P1_MIN", "0")
+    dtype, Ci, Co, N, H, W, G = torch.bfloat16, 16, 16, 4, 40, 72, 2
+    g = torch.Generator().manual_seed(911)
+    x, gy = _bf(torch.randn(N, Ci, H, W, generator=g)), _bf(torch.randn(N, Co, H, W, generator=g))
+    w = _bf(torch.randn(Co, Ci, 3, 3, generator=g) / 12.0)
+    op = ConvOp(Ci, Co, 3, 3, 1, 1, dtype, dev)
+    op.pack(w.to(dev).contiguous())
+    assert op.plan_3x3(N, H, W, forward=True)["kernel"] == "p1"
+    xd, gyd = _nhwc(x, dev, dtype), _nhwc(gy, dev, dtype)
+    stats = torch.zeros(G, 8, 2, op.Co_p, dtype=torch.float64, device=dev)
+    y = op.forward(xd, stats=stats, stat_groups=G, out_f32=True)
+    torch.cuda.synchronize()
+    y_ref = F.conv2d(x, w, padding=1)
+    ys = y_ref.abs().max().item()
+    assert (y.permute(0, 3, 1, 2).cpu() - y_ref).abs().max().item() <= 2e-3 * ys
+    s = stats.sum(1).cpu()
+    for k in range(G):
+        part = y_ref[k * (N // G):(k + 1) * (N // G)].double()
+        assert torch.allclose(s[k, 0, :Co], part.sum(dim=(0, 2, 3)), rtol=1e-3, atol=1e-3 * ys * (N * H * W) ** 0.5)
+        assert torch.allclose(s[k, 1, :Co], (part ** 2).sum(dim=(0, 2, 3)), rtol=2e-3)
+    # data gradient with the derived sums of the BatchNorm in front, two groups
+    yact, cprev = (_bf(torch.randn(N, Ci, H, W, generator=g)) for _ in range(2))
+    st = ops.BnState(Ci, dev, G)
+    mean, invstd = torch.randn(G, Ci, generator=g) * 0.1, torch.rand(G, Ci, generator=g) + 0.5
+    st.mean.copy_(mean.reshape(st.mean.shape)); st.invstd.copy_(invstd.reshape(st.invstd.shape)); st.count = float(N // G * H * W)
+    sums = torch.zeros(G * 8, 2, Ci, dtype=torch.float64, device=dev)
+    d = op.dgrad(gyd, H, W, mask=_nhwc(yact, dev, dtype), bn_fuse=(_nhwc(cprev, dev, dtype), st, sums))
+    torch.cuda.synchronize()
+    dx_ref = F.conv_transpose2d(gy, w, padding=1)
+    gref = torch.where(yact > 0, dx_ref, torch.zeros(()))
+    assert (d.float().permute(0, 3, 1, 2).cpu() - gref).abs().max().item() <= 1e-2 * gref.abs().max().item()
+    ss = sums.view(G, 8, 2, Ci).sum(1).cpu()
+    for k in range(G):
+        sl = slice(k * (N // G), (k + 1) * (N // G))
+        xh = (cprev[sl] - mean[k].view(1, -1, 1, 1)) * invstd[k].view(1, -1, 1, 1)
+        r0, r1 = gref[sl].double().sum(dim=(0, 2, 3)), (gref[sl].double() * xh.double()).sum(dim=(0, 2, 3))
+        big = max(r0.abs().max().item(), r1.abs().max().item())
+        eps = 2e-3 * big + 1e-3 * gref[sl].double().norm().item() / Ci ** 0.5
+        assert (ss[k, 0] - r0).abs().max().item() <= eps and (ss[k, 1] - r1).abs().max().item() <= eps
