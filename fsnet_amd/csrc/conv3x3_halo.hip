@@ -534,6 +534,17 @@ int conv3x3_entry(const FsConvArgs* args, int dtype, hipStream_t st) {
     return FS_EINVAL;
   if (!pro_args_ok(*args)) return FS_EINVAL;
   if (args->pro_mode != 0 && (args->Cs * es) % 64 != 0) return FS_EINVAL;   // whole 64-byte chunks with a prologue
+  // every kernel of this family addresses the destination, the addend and the mask with 32-bit element offsets
+  {
+    auto span_ok = [&](const void* ptr, int64_t sn, int64_t sh, int64_t sw) {
+      if (!ptr) return true;
+      if (sn < 0 || sh < 0 || sw < 0) return false;
+      return (int64_t)(args->N - 1) * sn + (int64_t)(args->Hd - 1) * sh + (int64_t)(args->Wd - 1) * sw + args->Co_p < 0x7fffffffLL;
+    };
+    if (!span_ok(args->dst, args->dN, args->dH, args->dW) || !span_ok(args->addend, args->aN, args->aH, args->aW) ||
+        !span_ok(args->mask, args->mN, args->mH, args->mW))
+      return FS_EINVAL;
+  }
   if (args->bnb_scale && (!args->bnb_x || !args->bnb_shift || args->mask)) return FS_EINVAL;
   if (args->bnb_x && (!args->stats || !args->bnb_mean || !args->bnb_invstd)) return FS_EINVAL;
   // 32x32-tile kernel for the launches it wants (whole 64-byte channel chunks, >= 32 output channels, enough 256-pixel

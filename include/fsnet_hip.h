@@ -154,7 +154,8 @@ int fs_conv1x1(const FsConvArgs* args, int dtype, void* stream);
 
 /* 3x3 / stride-1 specialisation (forward: hb_mul=1, hb_add=-pad, sgn=+1; dgrad: hb_add=+pad, sgn=-1) with an
  * LDS-resident input halo tile reused by all nine taps.  Same arguments, packed weights and epilogue as
- * fs_conv_igemm (ktab is not used); requires Cs*sizeof(T) % 64 == 0 and Co_p % 32 == 0.
+ * fs_conv_igemm (ktab is not used); requires Cs*sizeof(T) % 64 == 0 and Co_p % 32 == 0.  The destination, addend and mask
+ * views must each span fewer than 2^31 elements (32-bit element offsets in the kernels): FS_EINVAL otherwise.
  */
 int fs_conv3x3_halo(const FsConvArgs* args, int dtype, void* stream);
 /* the launch fs_conv3x3_halo would make for these arguments, nothing launched (pointers are only tested against NULL):
