@@ -181,12 +181,13 @@ def main():
             return a[1] / a[2] / 1e12
         # (the committed PMC passes were taken on the default workload: no figure for any other)
         default_workload = (args.depth, args.height, args.width, args.batch, args.dtype, fisheye) == (18, 192, 640, 12, "bf16", False)
-        # dominant kernel family by time: 3x3/s1 fwd+dgrad on the two LDS-halo kernels (fs_conv3x3_halo picks per launch;
-        # the profile kind says which one ran: fs_conv3x3_halo_plan)
-        parts = {k: agg[k] for k in ("conv3x3_t32", "conv3x3_halo") if k in agg}
+        # dominant kernel family by time: 3x3/s1 fwd+dgrad on the LDS-halo kernels (fs_conv3x3_halo picks per launch — the
+        # 32x32-tile kernel, the 16x16-tile kernel, the persistent one-chunk kernel of the decoder's 16-channel layers; the
+        # profile kind says which one ran: fs_conv3x3_halo_plan)
+        parts = {k: agg[k] for k in ("conv3x3_t32", "conv3x3_halo", "conv3x3_p1") if k in agg}
         ch = [sum(a[i] for a in parts.values()) for i in range(3)]
         ach = tf(ch)
-        roofline = {"kernel": "conv3x3_t32_kernel + conv3x3_halo_kernel (3x3/s1 fwd+dgrad LDS-halo family, %d launches/step)" % (ch[0] // nprof),
+        roofline = {"kernel": "%s (3x3/s1 fwd+dgrad LDS-halo family, %d launches/step)" % (" + ".join(k + "_kernel" for k in parts), ch[0] // nprof),
                     "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": pmc_traffic("conv3x3_halo") if default_workload else None,
                     "avg_launch_us": round(ch[2] / ch[0] * 1e6, 2),

@@ -271,14 +271,14 @@ class ConvOp:
         return out
 
     def _kind3x3(self, a):
-        """launch-profile kind of a 3x3 / stride-1 launch: which of the two kernels fs_conv3x3_halo runs it on"""
+        """launch-profile kind of a 3x3 / stride-1 launch: which of the three kernels fs_conv3x3_halo runs it on"""
         if not LaunchProfile.active:
             return "conv3x3_halo"
         if a.hb_mul == 2:
             return "conv3x3_s2"          # stage-entry stride-2 forward: not part of the stride-1 family's roofline figure
         plan = (C.c_int32 * 4)()
         check(lib.fs_conv3x3_halo_plan(C.byref(a), self.code, plan), "conv3x3_plan")
-        return "conv3x3_t32" if plan[0] == 1 else "conv3x3_halo"
+        return {1: "conv3x3_t32", 2: "conv3x3_p1"}.get(int(plan[0]), "conv3x3_halo")
 
     def plan_3x3(self, N, H, W, forward=True, pro_mode=0, Co_out=None):
         """the launch fs_conv3x3_halo makes for a forward (x [N,H,W,Ci_p]) or data-gradient (dy [N,H,W,Co_p]) call of this

@@ -6,7 +6,7 @@ import csv
 import json
 import sys
 
-FAMILIES = {"conv3x3_halo": ("conv3x3_halo_kernel", "conv3x3_t32_kernel"), "conv_igemm": "conv_igemm_kernel", "wgrad_halo": "wgrad3x3_halo_kernel",
+FAMILIES = {"conv3x3_halo": ("conv3x3_halo_kernel", "conv3x3_t32_kernel", "conv3x3_p1_kernel"), "conv_igemm": "conv_igemm_kernel", "wgrad_halo": "wgrad3x3_halo_kernel",
             "conv_wgrad": "conv_wgrad_kernel", "photo_loss_fwd": "photo_loss_fwd_kernel", "photo_loss_bwd": "photo_loss_bwd_kernel",
             "photo_warp": "photo_warp_kernel", "photo_fused_fwd": "photo_fused_fwd_kernel", "photo_fused_bwd": "photo_fused_bwd_kernel", "bn_apply": "bn_apply_kernel", "bn_bwd_apply": "bn_bwd_apply_kernel",
             "bn_bwd_reduce": "bn_bwd_reduce_kernel"}
