@@ -90,7 +90,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const FsBnApplyArgs p,
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const FsBnApplyArgs p) {
+__global__ __launch_bounds__(256) void bn_apply_kernel(const FsDual<FsBnApplyArgs, FsNoGeom> d) {
+  // two problems per launch (fsnet_hip_internal.h, FsDual): the statistics groups of both stack along blockIdx.z
+  const int prob = (int)blockIdx.z >= d.nb0 ? 1 : 0;
+  const FsBnApplyArgs& p = d.a[prob];
   // per-channel coefficients in dynamic LDS (4*C floats): a fixed MAXC-sized array would cap the occupancy of
   // these bandwidth-bound kernels at 4-5 blocks per CU
   extern __shared__ float bn_smem[];
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const FsBnApplyArgs p) {
   const bool train = p.stats != nullptr;
   // statistics groups: blockIdx.z owns the rows [z*Mg, (z+1)*Mg) and the z-th statistics / saved-state slice
   const int G = p.groups > 1 ? p.groups : 1;
-  const int z = blockIdx.z;
+  const int z = (int)blockIdx.z - (prob ? d.nb0 : 0);
   const int Mg = p.M / G;
   const long gstat = (long)FS_STAT_SLOTS * 2 * C;
   const double* stats_z = p.stats ? p.stats + z * gstat : nullptr;
@@ -274,7 +277,9 @@ __device__ inline void masked_grad(const FsBnBwdArgs& p, const T* dout, const T*
 // pass 1: per-channel sum(g), sum(g * xhat) with g = dout * (y > 0).  A block covers CGB channel groups
 // (16-byte lanes) x PL pixel lanes; two rows per iteration keep more loads in flight.
 template <typename T, int CGB>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const FsBnBwdArgs p) {
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const FsDual<FsBnBwdArgs, FsNoGeom> d) {
+  const int prob = (int)blockIdx.z >= d.nb0 ? 1 : 0;
+  const FsBnBwdArgs& p = d.a[prob];
   constexpr int V = VecN<T>::N;
   constexpr int PL = 256 / CGB;
   __shared__ float red[2][V][256];
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const FsBnBwdArgs p)
   const T* __restrict__ yv = reinterpret_cast<const T*>(p.y);
   const T* __restrict__ xv = reinterpret_cast<const T*>(p.x);
   const int G = p.groups > 1 ? p.groups : 1;
-  const int z = blockIdx.z;
+  const int z = (int)blockIdx.z - (prob ? d.nb0 : 0);
   const long Mg = p.M / G, m_end = (z + 1) * Mg;
   float mean[V], istd[V], s1[V], s2[V];
 #pragma unroll
@@ -332,13 +337,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const FsBnBwdArgs p)
 
 // pass 2: dx = gamma*invstd * (g - sum_g/count - xhat * sum_gx/count); optional g output; param grads
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const FsBnBwdArgs p) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const FsDual<FsBnBwdArgs, FsNoGeom> d) {
   extern __shared__ float bn_smem[];
+  const int prob = (int)blockIdx.z >= d.nb0 ? 1 : 0;
+  const FsBnBwdArgs& p = d.a[prob];
   const int C = p.C;
   float* s_a = bn_smem; float* s_b = bn_smem + C; float* s_k = bn_smem + 2 * C;
   float* s_mean = bn_smem + 3 * C; float* s_istd = bn_smem + 4 * C;
   const int G = p.groups > 1 ? p.groups : 1;
-  const int z = blockIdx.z;
+  const int z = (int)blockIdx.z - (prob ? d.nb0 : 0);
   const int Mg = p.M / G;
   const double* sums = p.sums + (long)z * FS_STAT_SLOTS * 2 * C;
   const double* sums_local = p.sums_local ? p.sums_local + (long)z * FS_STAT_SLOTS * 2 * C : nullptr;
@@ -436,38 +443,88 @@ extern "C" int fs_bn_finalize(const FsBnApplyArgs* a, float* scale, float* shift
   return fs_launch_status();
 }
 
-extern "C" int fs_bn_apply(const FsBnApplyArgs* a, int dtype, void* stream) {
+namespace {
+int bn_apply_check(const FsBnApplyArgs* a) {
   if (!a || !a->x || !a->y || !a->gamma || !a->beta || !a->save_mean || !a->save_invstd) return FS_EINVAL;
   if (!a->stats && (!a->running_mean || !a->running_var)) return FS_EINVAL;
   if (a->C % 8 != 0 || a->C > MAXC || a->M <= 0) return FS_EINVAL;
   if (a->gamma2 && (!a->res || !a->beta2 || !a->save_mean2 || !a->save_invstd2)) return FS_EINVAL;
   if (a->gamma2 && !a->stats2 && (!a->running_mean2 || !a->running_var2)) return FS_EINVAL;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int G = a->groups > 1 ? a->groups : 1;
   if (a->M % G != 0 || (G > 1 && !a->stats)) return FS_EINVAL;
-  dim3 grid(grid_for((long)(a->M / G) * (a->C / (dtype == FS_DTYPE_BF16 ? 8 : 4))), 1, G);
-  const unsigned lds = (a->gamma2 ? 4u : 2u) * a->C * sizeof(float);
-  if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16>, grid, dim3(256), lds, st, *a);
-  else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), lds, st, *a);
+  return FS_OK;
+}
+int bn_bwd_check(const FsBnBwdArgs* a, bool apply) {
+  if (!a || !a->dout || !a->x || !a->sums || !a->save_mean || !a->save_invstd) return FS_EINVAL;
+  if (apply && (!a->dx || !a->gamma)) return FS_EINVAL;
+  if (a->C % 8 != 0 || a->C > MAXC || a->M <= 0 || (a->relu && !a->y)) return FS_EINVAL;
+  const int G = a->groups > 1 ? a->groups : 1;
+  if (a->M % G != 0) return FS_EINVAL;
+  return FS_OK;
+}
+template <typename A>
+FsDual<A, FsNoGeom> bn_dual(const A* a, const A* b) {
+  FsDual<A, FsNoGeom> d;
+  d.a[0] = *a; d.a[1] = b ? *b : *a;
+  d.g[0].unused = d.g[1].unused = 0;
+  d.nb0 = a->groups > 1 ? a->groups : 1;
+  d.nprob = b ? 2 : 1;
+  return d;
+}
+}  // namespace
+
+// b != NULL: a second BatchNorm of the same width in the same launch (its statistics groups follow a's along blockIdx.z)
+extern "C" int fs_bn_apply2(const FsBnApplyArgs* a, const FsBnApplyArgs* b, int dtype, void* stream) {
+  int r = bn_apply_check(a);
+  if (r != FS_OK) return r;
+  if (b) {
+    r = bn_apply_check(b);
+    if (r != FS_OK) return r;
+    if (b->C != a->C) {
+      r = fs_bn_apply2(a, nullptr, dtype, stream);
+      return r != FS_OK ? r : fs_bn_apply2(b, nullptr, dtype, stream);
+    }
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int vec = dtype == FS_DTYPE_BF16 ? 8 : 4;
+  const int G = a->groups > 1 ? a->groups : 1, G1 = b ? (b->groups > 1 ? b->groups : 1) : 0;
+  long items = (long)(a->M / G) * (a->C / vec);
+  if (b) items = std::max(items, (long)(b->M / G1) * (b->C / vec));
+  dim3 grid(grid_for(items), 1, G + G1);
+  const unsigned lds = ((a->gamma2 || (b && b->gamma2)) ? 4u : 2u) * a->C * sizeof(float);
+  const FsDual<FsBnApplyArgs, FsNoGeom> d = bn_dual(a, b);
+  if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16>, grid, dim3(256), lds, st, d);
+  else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), lds, st, d);
   else return FS_EINVAL;
   return fs_launch_status();
 }
 
-extern "C" int fs_bn_bwd_reduce(const FsBnBwdArgs* a, int dtype, void* stream) {
-  if (!a || !a->dout || !a->x || !a->sums || !a->save_mean || !a->save_invstd) return FS_EINVAL;
-  if (a->C % 8 != 0 || a->C > MAXC || a->M <= 0 || (a->relu && !a->y)) return FS_EINVAL;
+extern "C" int fs_bn_apply(const FsBnApplyArgs* a, int dtype, void* stream) { return fs_bn_apply2(a, nullptr, dtype, stream); }
+
+extern "C" int fs_bn_bwd_reduce2(const FsBnBwdArgs* a, const FsBnBwdArgs* b, int dtype, void* stream) {
+  int r = bn_bwd_check(a, false);
+  if (r != FS_OK) return r;
+  if (b) {
+    r = bn_bwd_check(b, false);
+    if (r != FS_OK) return r;
+    if (b->C != a->C) {
+      r = fs_bn_bwd_reduce2(a, nullptr, dtype, stream);
+      return r != FS_OK ? r : fs_bn_bwd_reduce2(b, nullptr, dtype, stream);
+    }
+  }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int CG = a->C / (dtype == FS_DTYPE_BF16 ? 8 : 4);
-  const int G = a->groups > 1 ? a->groups : 1;
-  if (a->M % G != 0) return FS_EINVAL;
-  const long Mg = a->M / G;
+  const int G = a->groups > 1 ? a->groups : 1, G1 = b ? (b->groups > 1 ? b->groups : 1) : 0;
+  long Mg = a->M / G;
+  if (b) Mg = std::max<long>(Mg, b->M / G1);
+  const FsDual<FsBnBwdArgs, FsNoGeom> d = bn_dual(a, b);
   // channel groups (16-byte lanes) per block: 32 for wide layers (8 pixel lanes), 8, or — for the 16 / 32-channel
   // decoder layers, whose 2 / 4 lanes would leave three quarters of an 8-lane block idle — 4 and 2
 #define LAUNCH_REDUCE(CGB, ROWS_PER_BLOCK, MAXB)                                                               \
   {                                                                                                             \
-    dim3 grid((unsigned)std::min<long>((Mg + (ROWS_PER_BLOCK) - 1) / (ROWS_PER_BLOCK), MAXB), (CG + CGB - 1) / CGB, G); \
-    if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, CGB>), grid, dim3(256), 0, st, *a);  \
-    else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, CGB>), grid, dim3(256), 0, st, *a); \
+    dim3 grid((unsigned)std::min<long>((Mg + (ROWS_PER_BLOCK) - 1) / (ROWS_PER_BLOCK), MAXB), (CG + CGB - 1) / CGB, G + G1); \
+    if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, CGB>), grid, dim3(256), 0, st, d);  \
+    else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, CGB>), grid, dim3(256), 0, st, d); \
     else return FS_EINVAL;                                                                                      \
   }
   if (CG >= 32) LAUNCH_REDUCE(32, 16, 512)
@@ -478,16 +535,31 @@ extern "C" int fs_bn_bwd_reduce(const FsBnBwdArgs* a, int dtype, void* stream) {
   return fs_launch_status();
 }
 
-extern "C" int fs_bn_bwd_apply(const FsBnBwdArgs* a, int dtype, void* stream) {
-  if (!a || !a->dout || !a->x || !a->sums || !a->dx || !a->gamma || !a->save_mean || !a->save_invstd) return FS_EINVAL;
-  if (a->C % 8 != 0 || a->C > MAXC || a->M <= 0 || (a->relu && !a->y)) return FS_EINVAL;
+extern "C" int fs_bn_bwd_reduce(const FsBnBwdArgs* a, int dtype, void* stream) { return fs_bn_bwd_reduce2(a, nullptr, dtype, stream); }
+
+extern "C" int fs_bn_bwd_apply2(const FsBnBwdArgs* a, const FsBnBwdArgs* b, int dtype, void* stream) {
+  int r = bn_bwd_check(a, true);
+  if (r != FS_OK) return r;
+  if (b) {
+    r = bn_bwd_check(b, true);
+    if (r != FS_OK) return r;
+    if (b->C != a->C) {
+      r = fs_bn_bwd_apply2(a, nullptr, dtype, stream);
+      return r != FS_OK ? r : fs_bn_bwd_apply2(b, nullptr, dtype, stream);
+    }
+  }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int G = a->groups > 1 ? a->groups : 1;
-  if (a->M % G != 0) return FS_EINVAL;
-  dim3 grid(grid_for((long)(a->M / G) * (a->C / (dtype == FS_DTYPE_BF16 ? 8 : 4))), 1, G);
+  const int vec = dtype == FS_DTYPE_BF16 ? 8 : 4;
+  const int G = a->groups > 1 ? a->groups : 1, G1 = b ? (b->groups > 1 ? b->groups : 1) : 0;
+  long items = (long)(a->M / G) * (a->C / vec);
+  if (b) items = std::max(items, (long)(b->M / G1) * (b->C / vec));
+  dim3 grid(grid_for(items), 1, G + G1);
   const unsigned lds = 5u * a->C * sizeof(float);
-  if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, grid, dim3(256), lds, st, *a);
-  else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), lds, st, *a);
+  const FsDual<FsBnBwdArgs, FsNoGeom> d = bn_dual(a, b);
+  if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, grid, dim3(256), lds, st, d);
+  else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), lds, st, d);
   else return FS_EINVAL;
   return fs_launch_status();
 }
+
+extern "C" int fs_bn_bwd_apply(const FsBnBwdArgs* a, int dtype, void* stream) { return fs_bn_bwd_apply2(a, nullptr, dtype, stream); }

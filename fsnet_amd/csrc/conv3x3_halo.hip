@@ -65,7 +65,12 @@ constexpr int halo_minwaves(int PIX, int CO, int PRO) { return (PRO == 1 && PIX 
 constexpr int halo_hmax(int PIX, int STR) { return STR == 2 ? (PIX == 128 ? 620 : 340) : (PIX == 256 ? 360 : (PIX == 128 ? 208 : 120)); }
 
 template <typename T, int PIX, int CO, int WP, int PRO, int STR = 1>
-__global__ __launch_bounds__(256, halo_minwaves(PIX, CO, PRO)) void conv3x3_halo_kernel(const FsConvArgs p, const HaloGeom g) {
+__global__ __launch_bounds__(256, halo_minwaves(PIX, CO, PRO)) void conv3x3_halo_kernel(const FsDual<FsConvArgs, HaloGeom> d) {
+  // two problems per launch (fsnet_hip_internal.h, FsDual): blocks [0, nb0) take the first argument set
+  const int prob = (int)blockIdx.x >= d.nb0 ? 1 : 0;
+  const FsConvArgs& p = d.a[prob];
+  const HaloGeom& g = d.g[prob];
+  const int bid = (int)blockIdx.x - (prob ? d.nb0 : 0);
   static_assert(STR == 1 || PRO == 0, "the stride-2 variant has no operand prologue");
   constexpr int WC = 4 / WP;
   constexpr int WPIX = PIX / WP, WCO = CO / WC;
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(256, halo_minwaves(PIX, CO, PRO)) void conv3x3_halo
   const int npix = p.N * g.tiles_y * g.tiles_x, nco = p.Co_p / CO;
   int px, cy;
   {
-    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int id = bid, xcd = id & 7, slot = id >> 3;
     if (g.pix_major) {
       // activations outweigh the weights (layer 1 / 2, the decoder): the channel tiles of ONE pixel tile run on the
       // same XCD in consecutive slots, so the halo is fetched across the fabric once and re-read from that L2
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(256, halo_minwaves(PIX, CO, PRO)) void conv3x3_halo
     }
   }
   // (last, so that its arguments are not live across the walk: saved statistics / running statistics / dgamma, dbeta)
-  if constexpr (PRO != 0) { if (blockIdx.x == 0) pro_block0<PRO>(p, t, 256); }
+  if constexpr (PRO != 0) { if (bid == 0) pro_block0<PRO>(p, t, 256); }
 }
 
 // pick the pixel tile (TH x TW <= PIX, halo <= hmax) that wastes the fewest lanes, preferring wide tiles
@@ -436,13 +441,14 @@ HaloGeom pick_geom_s2(int Hd, int Wd, int PIX, int hmax) {
   return best;
 }
 
-template <typename T, int PIX, int CO, int WP, int PRO, int STR = 1>
-int launch_halo_pro(const FsConvArgs& a, hipStream_t st) {
-  HaloGeom g = STR == 2 ? pick_geom_s2(a.Hd, a.Wd, PIX, halo_hmax(PIX, 2)) : pick_geom(a.Hd, a.Wd, PIX, halo_hmax(PIX, 1));
-  if (g.TH == 0) return FS_EINVAL;
+// geometry and grid of one problem; blocks = 0: the arguments do not fit this tiling
+template <int PIX, int CO, int STR>
+int halo_problem(const FsConvArgs& a, HaloGeom& g) {
+  g = STR == 2 ? pick_geom_s2(a.Hd, a.Wd, PIX, halo_hmax(PIX, 2)) : pick_geom(a.Hd, a.Wd, PIX, halo_hmax(PIX, 1));
+  if (g.TH == 0) return 0;
   if (a.stat_group_rows > 0) {
     const long hw = (long)a.Hd * a.Wd;
-    if (a.stat_group_rows % hw != 0) return FS_EINVAL;          // statistics groups are whole images
+    if (a.stat_group_rows % hw != 0) return 0;                  // statistics groups are whole images
     g.dIPG = fs_make_div((int)(a.stat_group_rows / hw));
   }
   if (a.pro_group_imgs > 0) g.dPRG = fs_make_div(a.pro_group_imgs);
@@ -452,20 +458,39 @@ int launch_halo_pro(const FsConvArgs& a, hipStream_t st) {
   g.pix_major = (nco > 1 && a.src_bytes > 2 * a.wgt_bytes) ? 1 : 0;
   if (g.pix_major) blocks = 8 * ((npix + 7) / 8) * nco;
   else if (nco % 8 != 0 && 8 % nco == 0) { const int q = 8 / nco; blocks = 8 * ((npix + q - 1) / q); }
+  return blocks;
+}
+
+// b != nullptr: a second problem of the same shape class (conv3x3_pairable) in the same launch
+template <typename T, int PIX, int CO, int WP, int PRO, int STR = 1>
+int launch_halo_pro(const FsConvArgs& a, const FsConvArgs* b, hipStream_t st) {
+  FsDual<FsConvArgs, HaloGeom> d;
+  d.a[0] = a; d.a[1] = b ? *b : a;
+  d.nprob = b ? 2 : 1;
+  int blocks = halo_problem<PIX, CO, STR>(a, d.g[0]);
+  if (blocks == 0) return FS_EINVAL;
+  d.g[1] = d.g[0];
+  d.nb0 = blocks;
+  if (b) {
+    const int b1 = halo_problem<PIX, CO, STR>(*b, d.g[1]);
+    if (b1 == 0) return FS_EINVAL;
+    d.nb0 = fs_xcd_round(blocks);
+    blocks = d.nb0 + b1;
+  }
   if (fs_conv3x3_plan_slot) {
     fs_conv3x3_plan_slot[0] = 0; fs_conv3x3_plan_slot[1] = blocks; fs_conv3x3_plan_slot[2] = PIX; fs_conv3x3_plan_slot[3] = CO;
     return FS_OK;
   }
-  hipLaunchKernelGGL((conv3x3_halo_kernel<T, PIX, CO, WP, PRO, STR>), dim3(blocks), dim3(256), pro_lds_bytes<PRO>(a), st, a, g);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<T, PIX, CO, WP, PRO, STR>), dim3(blocks), dim3(256), pro_lds_bytes<PRO>(a), st, d);
   return fs_launch_status();
 }
 
 template <typename T, int PIX, int CO, int WP>
-int launch_halo(const FsConvArgs& a, hipStream_t st) {
+int launch_halo(const FsConvArgs& a, const FsConvArgs* b, hipStream_t st) {
   switch (a.pro_mode) {
-    case 0: return launch_halo_pro<T, PIX, CO, WP, 0>(a, st);
-    case 1: return launch_halo_pro<T, PIX, CO, WP, 1>(a, st);
-    case 2: return launch_halo_pro<T, PIX, CO, WP, 2>(a, st);
+    case 0: return launch_halo_pro<T, PIX, CO, WP, 0>(a, b, st);
+    case 1: return launch_halo_pro<T, PIX, CO, WP, 1>(a, b, st);
+    case 2: return launch_halo_pro<T, PIX, CO, WP, 2>(a, b, st);
     default: return FS_EINVAL;
   }
 }
@@ -476,21 +501,22 @@ int launch_halo(const FsConvArgs& a, hipStream_t st) {
 // (31.0 / 37.2; 21.2 / 32.0): the halo is four times the output tile, so the second channel tile's re-fetch costs more
 // than the extra blocks buy
 template <typename T>
-int dispatch_s2(const FsConvArgs& a, hipStream_t st) {
+int dispatch_s2(const FsConvArgs& a, const FsConvArgs* b, hipStream_t st) {
   HaloGeom g = pick_geom_s2(a.Hd, a.Wd, 128, halo_hmax(128, 2));
   if (g.TH == 0 || a.Co_p % 16 != 0) return FS_EINVAL;
   const char* fe = getenv("FSNET_AMD_S2_CO");          // development knob: channels per block tile
   const int co = fe ? atoi(fe) : (a.Co_p % 32 == 0 ? 32 : 16);
-  if (co == 32 && a.Co_p % 32 == 0) return launch_halo_pro<T, 128, 32, 4, 0, 2>(a, st);
-  return launch_halo_pro<T, 128, 16, 4, 0, 2>(a, st);
+  if (co == 32 && a.Co_p % 32 == 0) return launch_halo_pro<T, 128, 32, 4, 0, 2>(a, b, st);
+  return launch_halo_pro<T, 128, 16, 4, 0, 2>(a, b, st);
 }
 
 template <typename T>
-int dispatch(const FsConvArgs& a, hipStream_t st) {
+int dispatch(const FsConvArgs& a, const FsConvArgs* b, hipStream_t st) {
   const int cop = a.Co_p;
+  const int nimg = a.N + (b ? b->N : 0);           // the tile choice looks at the whole launch
   auto blocks_for = [&](int PIX, int CO) {
     HaloGeom g = pick_geom(a.Hd, a.Wd, PIX, PIX == 256 ? 360 : (PIX == 128 ? 208 : 120));
-    return g.TH == 0 ? 0L : (long)a.N * g.tiles_x * g.tiles_y * (cop / CO);
+    return g.TH == 0 ? 0L : (long)nimg * g.tiles_x * g.tiles_y * (cop / CO);
   };
   if (cop % 32 == 0) {
     // Occupancy decides here, not operand reuse: these launches are latency-bound (one wave of blocks, each a chain
@@ -499,34 +525,36 @@ int dispatch(const FsConvArgs& a, hipStream_t st) {
     // ResNet stage although each halo is then fetched twice, and the 16-channel tile wins when even that leaves the
     // chip short of blocks (layer 4 at batch 12: 192 -> 384 blocks, 33 -> 25 us).  Measured the other way too:
     // 256-pixel tiles, which halve the weight fill per pixel, are 20-30 % slower.
-    if (blocks_for(128, 32) < 256) return launch_halo<T, 128, 16, 4>(a, st);
+    if (blocks_for(128, 32) < 256) return launch_halo<T, 128, 16, 4>(a, b, st);
     // (measured and removed: fragment reads pipelined one / two taps ahead of the MFMAs — within 5 % either way —,
     // 128x64 tiles with 2x4 / 4x2 MFMA tiles per wave at every prefetch depth: 10-20 % slower at two blocks per CU, also
     // on ResNet-50's 164 k-pixel launches — DESIGN section 7)
-    return launch_halo<T, 128, 32, 4>(a, st);
+    return launch_halo<T, 128, 32, 4>(a, b, st);
   }
   if (cop % 16 == 0) {   // 16-channel decoder layers at 96x320 / 192x640: memory-bound, large pixel tiles
-    if (blocks_for(256, 16) >= 1024) return launch_halo<T, 256, 16, 4>(a, st);
-    return launch_halo<T, 128, 16, 4>(a, st);
+    if (blocks_for(256, 16) >= 1024) return launch_halo<T, 256, 16, 4>(a, b, st);
+    return launch_halo<T, 128, 16, 4>(a, b, st);
   }
   return FS_EINVAL;
 }
 
 }  // namespace
 
-int fs_conv3x3_t32(const FsConvArgs& a, int dtype, hipStream_t st);      // conv3x3_t32.hip
+int fs_conv3x3_t32(const FsConvArgs& a, const FsConvArgs* b, int dtype, hipStream_t st);      // conv3x3_t32.hip
 int fs_conv3x3_p1(const FsConvArgs& a, int dtype, hipStream_t st);       // conv3x3_p1.hip
 
 namespace {
-int conv3x3_entry(const FsConvArgs* args, int dtype, hipStream_t st) {
+int conv3x3_check(const FsConvArgs* args, int dtype) {
   if (!args || !args->src || !args->wgt || !args->dst) return FS_EINVAL;
   const int es = dtype == FS_DTYPE_BF16 ? 2 : 4;
   if (args->Cs <= 0 || (args->Cs * es) % 32 != 0 || ((args->Cs * es) % 64 != 0 && args->Cs * es != 32) || args->dshift != 0)
     return FS_EINVAL;
-  // stride 2: forward launches with pad 1 and whole 64-byte channel chunks, no prologue / no derived mask
+  // stride 2: forward launches with pad 1 and whole 64-byte channel chunks, no prologue / no derived mask, and none of the
+  // data-gradient epilogue options (the stride-2 instantiation compiles them out: ADVICE r04)
   const bool s2 = args->hb_mul == 2;
   if (args->hb_mul != 1 && !(s2 && args->sgn > 0 && args->hb_add == -1 && (args->Cs * es) % 64 == 0 && args->pro_mode == 0 &&
-                             !args->bnb_x && args->Hd == (args->Hs - 1) / 2 + 1 && args->Wd == (args->Ws - 1) / 2 + 1))
+                             !args->bnb_x && !args->addend && !args->mask &&
+                             args->Hd == (args->Hs - 1) / 2 + 1 && args->Wd == (args->Ws - 1) / 2 + 1))
     return FS_EINVAL;
   if (args->Co % 4 != 0 || args->Co_p % 16 != 0 || args->N <= 0) return FS_EINVAL;
   if (args->src_bytes <= 0 || args->src_bytes > 0x7fffffffLL || args->wgt_bytes <= 0 ||
@@ -547,40 +575,82 @@ int conv3x3_entry(const FsConvArgs* args, int dtype, hipStream_t st) {
   }
   if (args->bnb_scale && (!args->bnb_x || !args->bnb_shift || args->mask)) return FS_EINVAL;
   if (args->bnb_x && (!args->stats || !args->bnb_mean || !args->bnb_invstd)) return FS_EINVAL;
+  return FS_OK;
+}
+
+// may the two problems share one launch?  Everything that selects a kernel instantiation or a tile geometry must agree;
+// pointers, strides, batch sizes and statistics groups are per problem
+bool conv3x3_pairable(const FsConvArgs& a, const FsConvArgs& b) {
+  auto nn = [](const void* x, const void* y) { return (x == nullptr) == (y == nullptr); };
+  return a.Hs == b.Hs && a.Ws == b.Ws && a.Hd == b.Hd && a.Wd == b.Wd && a.Cs == b.Cs && a.Co == b.Co && a.Co_p == b.Co_p &&
+         a.nchunks == b.nchunks && a.kg == b.kg && a.hb_mul == b.hb_mul && a.hb_add == b.hb_add && a.sgn == b.sgn &&
+         a.relu == b.relu && a.out_f32 == b.out_f32 && a.pro_mode == b.pro_mode && a.pro_relu == b.pro_relu &&
+         a.wgt_bytes == b.wgt_bytes && nn(a.bias, b.bias) && nn(a.addend, b.addend) && nn(a.mask, b.mask) &&
+         nn(a.stats, b.stats) && nn(a.bnb_x, b.bnb_x) && nn(a.bnb_scale, b.bnb_scale) && nn(a.pro_stats, b.pro_stats) &&
+         nn(a.pro_dst, b.pro_dst);
+}
+
+int conv3x3_entry(const FsConvArgs* args, const FsConvArgs* b, int dtype, hipStream_t st) {
+  int r = conv3x3_check(args, dtype);
+  if (r != FS_OK) return r;
+  if (b) {
+    r = conv3x3_check(b, dtype);
+    if (r != FS_OK) return r;
+    if (!conv3x3_pairable(*args, *b)) {
+      // not one launch's worth of agreement: two launches, same results
+      r = conv3x3_entry(args, nullptr, dtype, st);
+      return r != FS_OK ? r : conv3x3_entry(b, nullptr, dtype, st);
+    }
+  }
   // 32x32-tile kernel for the launches it wants (whole 64-byte channel chunks, >= 32 output channels, enough 256-pixel
   // tiles); the 16x16-tile kernel below takes everything else, with the same prologues and epilogues
-  if (s2) {
-    if (dtype == FS_DTYPE_BF16) return dispatch_s2<bf16>(*args, st);
-    if (dtype == FS_DTYPE_F32) return dispatch_s2<float>(*args, st);
+  if (args->hb_mul == 2) {
+    if (dtype == FS_DTYPE_BF16) return dispatch_s2<bf16>(*args, b, st);
+    if (dtype == FS_DTYPE_F32) return dispatch_s2<float>(*args, b, st);
     return FS_EINVAL;
   }
-  {
+  if (!b) {
     // one-chunk layers with <= 32 output channels and many pixel tiles (the decoder's 192x640 / 96x320 layers): the
     // persistent kernel with resident weights
-    const int r = fs_conv3x3_p1(*args, dtype, st);
+    r = fs_conv3x3_p1(*args, dtype, st);
     if (r != FS_EINVAL) return r;
   }
   const char* te = getenv("FSNET_AMD_T32");
   const bool use_t32 = !(te && te[0] == '0');
   if (use_t32) {
-    const int r = fs_conv3x3_t32(*args, dtype, st);
+    r = fs_conv3x3_t32(*args, b, dtype, st);
     if (r != FS_EINVAL) return r;
   }
-  if (dtype == FS_DTYPE_BF16) return dispatch<bf16>(*args, st);
-  if (dtype == FS_DTYPE_F32) return dispatch<float>(*args, st);
+  if (dtype == FS_DTYPE_BF16) return dispatch<bf16>(*args, b, st);
+  if (dtype == FS_DTYPE_F32) return dispatch<float>(*args, b, st);
   return FS_EINVAL;
 }
 }  // namespace
 
 extern "C" int fs_conv3x3_halo(const FsConvArgs* args, int dtype, void* stream) {
-  return conv3x3_entry(args, dtype, reinterpret_cast<hipStream_t>(stream));
+  return conv3x3_entry(args, nullptr, dtype, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int fs_conv3x3_halo2(const FsConvArgs* a0, const FsConvArgs* a1, int dtype, void* stream) {
+  return conv3x3_entry(a0, a1, dtype, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int fs_conv3x3_halo_plan(const FsConvArgs* args, int dtype, int32_t* plan) {
   if (!plan) return FS_EINVAL;
   plan[0] = -1; plan[1] = plan[2] = plan[3] = 0;
   fs_conv3x3_plan_slot = plan;
-  const int r = conv3x3_entry(args, dtype, nullptr);
+  const int r = conv3x3_entry(args, nullptr, dtype, nullptr);
+  fs_conv3x3_plan_slot = nullptr;
+  return r;
+}
+
+extern "C" int fs_conv3x3_halo2_plan(const FsConvArgs* a0, const FsConvArgs* a1, int dtype, int32_t* plan) {
+  if (!plan || !a0) return FS_EINVAL;
+  plan[0] = -1; plan[1] = plan[2] = plan[3] = 0;
+  if (a1 && !(conv3x3_check(a0, dtype) == FS_OK && conv3x3_check(a1, dtype) == FS_OK && conv3x3_pairable(*a0, *a1)))
+    return FS_EINVAL;                       // (two launches: ask for each plan separately)
+  fs_conv3x3_plan_slot = plan;
+  const int r = conv3x3_entry(a0, a1, dtype, nullptr);
   fs_conv3x3_plan_slot = nullptr;
   return r;
 }

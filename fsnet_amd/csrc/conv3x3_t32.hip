@@ -39,7 +39,12 @@ constexpr int t32_minwaves(int PIX, int CO, int EP, int PRO) {
 }
 
 template <typename T, int PIX, int CO, int EP, int PRO>
-__global__ __launch_bounds__(256, t32_minwaves(PIX, CO, EP, PRO)) void conv3x3_t32_kernel(const FsConvArgs p, const T32Geom g) {
+__global__ __launch_bounds__(256, t32_minwaves(PIX, CO, EP, PRO)) void conv3x3_t32_kernel(const FsDual<FsConvArgs, T32Geom> d) {
+  // two problems per launch (fsnet_hip_internal.h, FsDual): blocks [0, nb0) take the first argument set
+  const int prob = (int)blockIdx.x >= d.nb0 ? 1 : 0;
+  const FsConvArgs& p = d.a[prob];
+  const T32Geom& g = d.g[prob];
+  const int bid = (int)blockIdx.x - (prob ? d.nb0 : 0);
   constexpr int WPIX = PIX / 4;                 // pixels per wave
   constexpr int TP = WPIX / 32, TC = CO / 32;   // 32 x 32 MFMA tiles per wave: pixels x channels
   constexpr int HMAX = t32_hmax(PIX);           // halo pixels per stage
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(256, t32_minwaves(PIX, CO, EP, PRO)) void conv3x3_t
   const int npix = p.N * g.tiles_y * g.tiles_x, nco = p.Co_p / CO;
   int px, cy;
   {
-    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int id = bid, xcd = id & 7, slot = id >> 3;
     if (g.pix_major) { cy = slot % nco; px = (slot / nco) * 8 + xcd; }
     else if (nco % 8 == 0) { const int q = nco >> 3; cy = xcd + 8 * (slot % q); px = slot / q; }
     else if (8 % nco == 0) { const int q = 8 / nco; cy = xcd % nco; px = slot * q + xcd / nco; }
@@ -357,17 +362,18 @@ __global__ __launch_bounds__(256, t32_minwaves(PIX, CO, EP, PRO)) void conv3x3_t
     }
   }
   // (last, so that its arguments are not live across the walk: saved statistics / running statistics / dgamma, dbeta)
-  if constexpr (PRO != 0) { if (blockIdx.x == 0) pro_block0<PRO>(p, t, 256); }
+  if constexpr (PRO != 0) { if (bid == 0) pro_block0<PRO>(p, t, 256); }
 }
 
-template <typename T, int PIX, int CO, int EP, int PRO>
-int t32_launch(const FsConvArgs& a, hipStream_t st) {
-  T32Geom g = t32_pick_geom(a.Hd, a.Wd, PIX, t32_hmax(PIX));
-  if (g.TH == 0) return FS_EINVAL;
+// geometry and grid of one problem; 0 blocks: the arguments do not fit this tiling
+template <int PIX, int CO>
+int t32_problem(const FsConvArgs& a, T32Geom& g) {
+  g = t32_pick_geom(a.Hd, a.Wd, PIX, t32_hmax(PIX));
+  if (g.TH == 0) return 0;
   g.dIPG = FsDiv{0u, 0u}; g.dPRG = FsDiv{0u, 0u};
   if (a.stat_group_rows > 0) {
     const long hw = (long)a.Hd * a.Wd;
-    if (a.stat_group_rows % hw != 0) return FS_EINVAL;
+    if (a.stat_group_rows % hw != 0) return 0;
     g.dIPG = fs_make_div((int)(a.stat_group_rows / hw));
   }
   if (a.pro_group_imgs > 0) g.dPRG = fs_make_div(a.pro_group_imgs);
@@ -376,29 +382,48 @@ int t32_launch(const FsConvArgs& a, hipStream_t st) {
   g.pix_major = (nco > 1 && a.src_bytes > 2 * a.wgt_bytes) ? 1 : 0;
   if (g.pix_major) blocks = 8 * ((npix + 7) / 8) * nco;
   else if (nco % 8 != 0 && 8 % nco == 0) { const int q = 8 / nco; blocks = 8 * ((npix + q - 1) / q); }
+  return blocks;
+}
+
+template <typename T, int PIX, int CO, int EP, int PRO>
+int t32_launch(const FsConvArgs& a, const FsConvArgs* b, hipStream_t st) {
+  FsDual<FsConvArgs, T32Geom> d;
+  d.a[0] = a; d.a[1] = b ? *b : a;
+  d.nprob = b ? 2 : 1;
+  int blocks = t32_problem<PIX, CO>(a, d.g[0]);
+  if (blocks == 0) return FS_EINVAL;
+  d.g[1] = d.g[0];
+  d.nb0 = blocks;
+  if (b) {
+    const int b1 = t32_problem<PIX, CO>(*b, d.g[1]);
+    if (b1 == 0) return FS_EINVAL;
+    d.nb0 = fs_xcd_round(blocks);
+    blocks = d.nb0 + b1;
+  }
   if (fs_conv3x3_plan_slot) {
     fs_conv3x3_plan_slot[0] = 1; fs_conv3x3_plan_slot[1] = blocks; fs_conv3x3_plan_slot[2] = PIX; fs_conv3x3_plan_slot[3] = CO;
     return FS_OK;
   }
-  hipLaunchKernelGGL((conv3x3_t32_kernel<T, PIX, CO, EP, PRO>), dim3(blocks), dim3(256), pro_lds_bytes<PRO>(a), st, a, g);
+  hipLaunchKernelGGL((conv3x3_t32_kernel<T, PIX, CO, EP, PRO>), dim3(blocks), dim3(256), pro_lds_bytes<PRO>(a), st, d);
   return fs_launch_status();
 }
 
 // tile configuration (pixels x channels per block; blocks per CU by LDS): 1 = 128 x 64 (3), 2 = 128 x 32 (4),
 // 3 = 256 x 32 (3)
 template <typename T, int EP, int PRO>
-int t32_dispatch_cfg(const FsConvArgs& a, int cfg, hipStream_t st) {
+int t32_dispatch_cfg(const FsConvArgs& a, const FsConvArgs* b, int cfg, hipStream_t st) {
   switch (cfg) {
-    case 1: return t32_launch<T, 128, 64, EP, PRO>(a, st);
-    case 2: return t32_launch<T, 128, 32, EP, PRO>(a, st);
-    default: return t32_launch<T, 256, 32, EP, PRO>(a, st);
+    case 1: return t32_launch<T, 128, 64, EP, PRO>(a, b, st);
+    case 2: return t32_launch<T, 128, 32, EP, PRO>(a, b, st);
+    default: return t32_launch<T, 256, 32, EP, PRO>(a, b, st);
   }
 }
 
-long t32_blocks(const FsConvArgs& a, int PIX, int CO) {
+// (nimg: images of the whole launch — both problems of a paired one)
+long t32_blocks(const FsConvArgs& a, int nimg, int PIX, int CO) {
   T32Geom g = t32_pick_geom(a.Hd, a.Wd, PIX, t32_hmax(PIX));
   if (g.TH == 0) return 0;
-  return (long)a.N * g.tiles_x * g.tiles_y * (a.Co_p / CO);
+  return (long)nimg * g.tiles_x * g.tiles_y * (a.Co_p / CO);
 }
 double t32_waste(const FsConvArgs& a, int PIX) {
   T32Geom g = t32_pick_geom(a.Hd, a.Wd, PIX, t32_hmax(PIX));
@@ -407,61 +432,61 @@ double t32_waste(const FsConvArgs& a, int PIX) {
 }
 
 // -1: leave the launch to the 16x16-tile kernel
-int t32_pick_cfg(const FsConvArgs& a) {
+int t32_pick_cfg(const FsConvArgs& a, int nimg) {
   const char* fe = getenv("FSNET_AMD_T32_CFG");        // development knob (tools/probes/t32_ab.py)
   if (fe) { const int c = atoi(fe); return (a.Co_p % 64 != 0 && c == 1) ? 2 : c; }
   // 256-pixel tiles where they do not waste lanes and the launch still fills the chip's three block slots per CU a
   // few times over; everything else is faster on the 16x16-tile kernel (same prologues and epilogues there)
   const bool big = t32_waste(a, 256) <= 1.15 * t32_waste(a, 128);
-  if (big && t32_blocks(a, 256, 32) >= 512) return 3;
+  if (big && t32_blocks(a, nimg, 256, 32) >= 512) return 3;
   // (development knob: 128 x 32 tiles for launches with at least this many of them, instead of the 16x16-tile kernel)
   static const int mid = getenv("FSNET_AMD_T32_MID") ? atoi(getenv("FSNET_AMD_T32_MID")) : 0;
-  if (mid > 0 && t32_blocks(a, 128, 32) >= mid) return 2;
+  if (mid > 0 && t32_blocks(a, nimg, 128, 32) >= mid) return 2;
   return -1;
 }
 
 template <typename T, int PRO>
-int t32_dispatch_ep(const FsConvArgs& a, int cfg, hipStream_t st) {
+int t32_dispatch_ep(const FsConvArgs& a, const FsConvArgs* b, int cfg, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     switch (t32_ep_mask(a)) {
       // forward: encoder (statistics), decoder (bias + statistics), pose decoder (bias + ReLU)
-      case EP_STATS: return t32_dispatch_cfg<T, EP_STATS, PRO>(a, cfg, st);
-      case EP_BIAS | EP_STATS: return t32_dispatch_cfg<T, EP_BIAS | EP_STATS, PRO>(a, cfg, st);
-      case EP_BIAS | EP_RELU: return t32_dispatch_cfg<T, EP_BIAS | EP_RELU, PRO>(a, cfg, st);
+      case EP_STATS: return t32_dispatch_cfg<T, EP_STATS, PRO>(a, b, cfg, st);
+      case EP_BIAS | EP_STATS: return t32_dispatch_cfg<T, EP_BIAS | EP_STATS, PRO>(a, b, cfg, st);
+      case EP_BIAS | EP_RELU: return t32_dispatch_cfg<T, EP_BIAS | EP_RELU, PRO>(a, b, cfg, st);
       // data gradients
-      case 0: return t32_dispatch_cfg<T, 0, PRO>(a, cfg, st);
-      case EP_ADDEND: return t32_dispatch_cfg<T, EP_ADDEND, PRO>(a, cfg, st);
-      case EP_MASK: return t32_dispatch_cfg<T, EP_MASK, PRO>(a, cfg, st);
-      case EP_MASK | EP_BNB: return t32_dispatch_cfg<T, EP_MASK | EP_BNB, PRO>(a, cfg, st);
-      case EP_ADDEND | EP_MASK | EP_BNB: return t32_dispatch_cfg<T, EP_ADDEND | EP_MASK | EP_BNB, PRO>(a, cfg, st);
-      case EP_BNB | EP_MASKBN: return t32_dispatch_cfg<T, EP_BNB | EP_MASKBN, PRO>(a, cfg, st);
+      case 0: return t32_dispatch_cfg<T, 0, PRO>(a, b, cfg, st);
+      case EP_ADDEND: return t32_dispatch_cfg<T, EP_ADDEND, PRO>(a, b, cfg, st);
+      case EP_MASK: return t32_dispatch_cfg<T, EP_MASK, PRO>(a, b, cfg, st);
+      case EP_MASK | EP_BNB: return t32_dispatch_cfg<T, EP_MASK | EP_BNB, PRO>(a, b, cfg, st);
+      case EP_ADDEND | EP_MASK | EP_BNB: return t32_dispatch_cfg<T, EP_ADDEND | EP_MASK | EP_BNB, PRO>(a, b, cfg, st);
+      case EP_BNB | EP_MASKBN: return t32_dispatch_cfg<T, EP_BNB | EP_MASKBN, PRO>(a, b, cfg, st);
       default: break;
     }
   }
-  return t32_dispatch_cfg<T, -1, PRO>(a, cfg, st);
+  return t32_dispatch_cfg<T, -1, PRO>(a, b, cfg, st);
 }
 
 template <typename T>
-int t32_dispatch(const FsConvArgs& a, hipStream_t st) {
-  const int cfg = t32_pick_cfg(a);
+int t32_dispatch(const FsConvArgs& a, const FsConvArgs* b, hipStream_t st) {
+  const int cfg = t32_pick_cfg(a, a.N + (b ? b->N : 0));
   if (cfg < 0) return FS_EINVAL;
   switch (a.pro_mode) {
-    case 0: return t32_dispatch_ep<T, 0>(a, cfg, st);
-    case 1: return t32_dispatch_ep<T, 1>(a, cfg, st);
-    case 2: return t32_dispatch_ep<T, 2>(a, cfg, st);
+    case 0: return t32_dispatch_ep<T, 0>(a, b, cfg, st);
+    case 1: return t32_dispatch_ep<T, 1>(a, b, cfg, st);
+    case 2: return t32_dispatch_ep<T, 2>(a, b, cfg, st);
     default: return FS_EINVAL;
   }
 }
 
 }  // namespace
 
-// internal entry: FS_EINVAL = "not mine" (fs_conv3x3_halo then runs the 16x16-tile kernel)
-int fs_conv3x3_t32(const FsConvArgs& a, int dtype, hipStream_t st) {
+namespace {
+bool t32_takes(const FsConvArgs& a, int dtype) {
   const int es = dtype == FS_DTYPE_BF16 ? 2 : 4;
-  if ((a.Cs * es) % 64 != 0 || a.Co_p % 32 != 0 || a.Co % 8 != 0 || a.hb_mul != 1) return FS_EINVAL;
-  if (a.src_bytes >= 0x7ffff000LL) return FS_EINVAL;
-  if (a.bnb_scale && (!a.bnb_x || !a.bnb_shift || a.mask)) return FS_EINVAL;
-  if (a.bnb_x && !a.stats) return FS_EINVAL;
+  if ((a.Cs * es) % 64 != 0 || a.Co_p % 32 != 0 || a.Co % 8 != 0 || a.hb_mul != 1) return false;
+  if (a.src_bytes >= 0x7ffff000LL) return false;
+  if (a.bnb_scale && (!a.bnb_x || !a.bnb_shift || a.mask)) return false;
+  if (a.bnb_x && !a.stats) return false;
   // the epilogue moves 16 bytes per lane with 32-bit element offsets: every tensor it touches must keep pixels on
   // 16-byte boundaries and the destination must span fewer than 2^31 elements (strided views that do not: the 16x16-tile
   // kernel, whose pieces are 8 bytes)
@@ -471,10 +496,18 @@ int fs_conv3x3_t32(const FsConvArgs& a, int dtype, hipStream_t st) {
   const int dsz = a.out_f32 ? 4 : es;
   if (!al16(a.dst, a.dN, a.dH, a.dW, dsz) || !al16(a.addend, a.aN, a.aH, a.aW, es) || !al16(a.mask, a.mN, a.mH, a.mW, es) ||
       !al16(a.bnb_x, a.dN, a.dH, a.dW, es))
-    return FS_EINVAL;
+    return false;
   const int64_t span = (int64_t)(a.N - 1) * a.dN + (int64_t)(a.Hd - 1) * a.dH + (int64_t)(a.Wd - 1) * a.dW + a.Co;
-  if (a.dN < 0 || a.dH < 0 || a.dW < 0 || span >= 0x7fffffffLL) return FS_EINVAL;
-  if (dtype == FS_DTYPE_BF16) return t32_dispatch<bf16>(a, st);
-  if (dtype == FS_DTYPE_F32) return t32_dispatch<float>(a, st);
+  if (a.dN < 0 || a.dH < 0 || a.dW < 0 || span >= 0x7fffffffLL) return false;
+  return true;
+}
+}  // namespace
+
+// internal entry: FS_EINVAL = "not mine" (fs_conv3x3_halo then runs the 16x16-tile kernel).  b: a second problem for the
+// same launch (conv3x3_halo.hip has checked that the two agree on everything that selects an instantiation)
+int fs_conv3x3_t32(const FsConvArgs& a, const FsConvArgs* b, int dtype, hipStream_t st) {
+  if (!t32_takes(a, dtype) || (b && !t32_takes(*b, dtype))) return FS_EINVAL;
+  if (dtype == FS_DTYPE_BF16) return t32_dispatch<bf16>(a, b, st);
+  if (dtype == FS_DTYPE_F32) return t32_dispatch<float>(a, b, st);
   return FS_EINVAL;
 }

@@ -25,6 +25,7 @@
 // sgn = -1, plus a parity test and halved strides for stride 2.
 #include "common.h"
 #include "fsnet_hip_internal.h"
+#include <algorithm>
 
 namespace {
 
@@ -38,8 +39,17 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, int vof
   return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
 }
 
+struct IgGeom { FsDiv dW, dH; };
+
 template <typename T, int PIX, int CO, int WP, int KG>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p, const FsDiv dW, const FsDiv dH) {
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const FsDual<FsConvArgs, IgGeom> d) {
+  // two problems per launch (fsnet_hip_internal.h, FsDual): blocks [0, nb0) of blockIdx.x take the first argument set
+  const int prob = (int)blockIdx.x >= d.nb0 ? 1 : 0;
+  const FsConvArgs& p = d.a[prob];
+  const FsDiv dW = d.g[prob].dW, dH = d.g[prob].dH;
+  const int bid = (int)blockIdx.x - (prob ? d.nb0 : 0);
+  // (blockIdx.z spans the larger group count of the two problems)
+  if ((int)blockIdx.z >= (p.grp_imgs > 0 ? p.N / p.grp_imgs : 1)) return;
   using TR = ElemTraits<T>;
   constexpr int WC = 4 / WP;
   constexpr int WPIX = PIX / WP, WCO = CO / WC;
@@ -73,7 +83,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p, con
   int px, cy;
   {
     const int npix = (p.M + PIX - 1) / PIX, nco = p.Co_p / CO;
-    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int id = bid, xcd = id & 7, slot = id >> 3;
     if (nco % 8 == 0) { const int g = nco >> 3; cy = xcd + 8 * (slot % g); px = slot / g; }
     else if (8 % nco == 0) { const int g = 8 / nco; cy = xcd % nco; px = slot * g + xcd / nco; }
     else { cy = id % nco; px = id / nco; }
@@ -323,40 +333,63 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const FsConvArgs p, con
   }
 }
 
-template <typename T, int PIX, int CO, int WP, int KG>
-int launch_tile(const FsConvArgs& a, hipStream_t st) {
+template <int PIX, int CO>
+int igemm_blocks(const FsConvArgs& a) {
   const int npix = (a.M + PIX - 1) / PIX, nco = a.Co_p / CO;
   int blocks = npix * nco;
   if (nco % 8 != 0 && 8 % nco == 0) { const int g = 8 / nco; blocks = 8 * ((npix + g - 1) / g); }
-  hipLaunchKernelGGL((conv_igemm_kernel<T, PIX, CO, WP, KG>), dim3(blocks, a.ncls > 1 ? a.ncls : 1, a.grp_imgs > 0 ? a.N / a.grp_imgs : 1), dim3(256), 0, st, a,
-                     fs_make_div(a.Wd), fs_make_div(a.Hd));
+  return blocks;
+}
+
+// b != nullptr: a second problem of the same shape class in the same launch
+template <typename T, int PIX, int CO, int WP, int KG>
+int launch_tile(const FsConvArgs& a, const FsConvArgs* b, hipStream_t st) {
+  FsDual<FsConvArgs, IgGeom> d;
+  d.a[0] = a; d.a[1] = b ? *b : a;
+  d.g[0] = IgGeom{fs_make_div(a.Wd), fs_make_div(a.Hd)};
+  d.g[1] = b ? IgGeom{fs_make_div(b->Wd), fs_make_div(b->Hd)} : d.g[0];
+  d.nprob = b ? 2 : 1;
+  int blocks = igemm_blocks<PIX, CO>(a);
+  d.nb0 = blocks;
+  int nz = a.grp_imgs > 0 ? a.N / a.grp_imgs : 1;
+  if (b) {
+    d.nb0 = fs_xcd_round(blocks);
+    blocks = d.nb0 + igemm_blocks<PIX, CO>(*b);
+    nz = std::max(nz, b->grp_imgs > 0 ? b->N / b->grp_imgs : 1);
+  }
+  hipLaunchKernelGGL((conv_igemm_kernel<T, PIX, CO, WP, KG>), dim3(blocks, a.ncls > 1 ? a.ncls : 1, nz), dim3(256), 0, st, d);
   return fs_launch_status();
 }
 
 // tile choice: channel tile = largest of {128,64,32,16} dividing Co_p; shrink the pixel tile when the
 // grid would not fill 256 CUs.  kg (16-byte K groups per stage, 4 or 8) is fixed by the caller's packing.
 template <typename T>
-int launch_conv(const FsConvArgs& a, hipStream_t st) {
+int launch_conv(const FsConvArgs& a, const FsConvArgs* b, hipStream_t st) {
   const int cop = a.Co_p;
   const bool k8 = a.kg == 8;
+  // rows of the whole launch (all statistics groups / parity classes / both problems) decide the pixel tile
+  auto rows = [](const FsConvArgs& q) { return (long)q.M * (q.grp_imgs > 0 ? q.N / q.grp_imgs : 1); };
+  const long mtot = rows(a) + (b ? rows(*b) : 0);
+  const long m128 = b ? (mtot + 127) / 128 : (long)((a.M + 127) / 128);
   if (cop % 128 == 0 && !k8) {
-    long blocks = (long)((a.M + 127) / 128) * (cop / 128);
-    if (blocks >= 512) return launch_tile<T, 128, 128, 2, 4>(a, st);
-    return launch_tile<T, 64, 64, 2, 4>(a, st);
+    long blocks = m128 * (cop / 128);
+    if (blocks >= 512) return launch_tile<T, 128, 128, 2, 4>(a, b, st);
+    return launch_tile<T, 64, 64, 2, 4>(a, b, st);
   }
   if (cop % 64 == 0) {
-    long blocks = (long)((a.M + 127) / 128) * (cop / 64);
-    if (blocks >= 512) return k8 ? launch_tile<T, 128, 64, 2, 8>(a, st) : launch_tile<T, 128, 64, 2, 4>(a, st);
-    return k8 ? launch_tile<T, 64, 64, 2, 8>(a, st) : launch_tile<T, 64, 64, 2, 4>(a, st);
+    long blocks = m128 * (cop / 64);
+    if (blocks >= 512) return k8 ? launch_tile<T, 128, 64, 2, 8>(a, b, st) : launch_tile<T, 128, 64, 2, 4>(a, b, st);
+    return k8 ? launch_tile<T, 64, 64, 2, 8>(a, b, st) : launch_tile<T, 64, 64, 2, 4>(a, b, st);
   }
-  if (cop % 32 == 0) return k8 ? launch_tile<T, 128, 32, 4, 8>(a, st) : launch_tile<T, 128, 32, 4, 4>(a, st);
-  if (cop % 16 == 0 && !k8) return launch_tile<T, 256, 16, 4, 4>(a, st);
+  if (cop % 32 == 0) return k8 ? launch_tile<T, 128, 32, 4, 8>(a, b, st) : launch_tile<T, 128, 32, 4, 4>(a, b, st);
+  if (cop % 16 == 0 && !k8) return launch_tile<T, 256, 16, 4, 4>(a, b, st);
   return FS_EINVAL;
 }
 
 }  // namespace
 
-extern "C" int fs_conv_igemm(const FsConvArgs* args, int dtype, void* stream) {
+namespace {
+int igemm_check(const FsConvArgs* args) {
   if (!args || !args->src || !args->wgt || !args->dst || !args->ktab) return FS_EINVAL;
   if (args->kg != 4 && args->kg != 8) return FS_EINVAL;
   const int units = args->nchunks * (args->kg == 8 ? 2 : 4);
@@ -367,8 +400,34 @@ extern "C" int fs_conv_igemm(const FsConvArgs* args, int dtype, void* stream) {
     return FS_EINVAL;
   if (args->dshift && ((args->sH | args->sW) & 1)) return FS_EINVAL;
   if (args->stats && args->stat_group_rows > 0 && args->stat_group_rows % 256 != 0) return FS_EINVAL;
+  if (args->grp_imgs > 0 && (args->N <= 0 || args->N % args->grp_imgs != 0)) return FS_EINVAL;
+  return FS_OK;
+}
+// everything that selects an instantiation or the grid's y extent must agree
+bool igemm_pairable(const FsConvArgs& a, const FsConvArgs& b) {
+  return a.Co_p == b.Co_p && a.kg == b.kg && (a.ncls > 1 ? a.ncls : 1) == (b.ncls > 1 ? b.ncls : 1);
+}
+}  // namespace
+
+// a1 != NULL: a second convolution in the same launch when the two agree on channel tile, K stage depth and parity-class
+// count (otherwise two launches, same results)
+extern "C" int fs_conv_igemm2(const FsConvArgs* args, const FsConvArgs* a1, int dtype, void* stream) {
+  int r = igemm_check(args);
+  if (r != FS_OK) return r;
+  if (a1) {
+    r = igemm_check(a1);
+    if (r != FS_OK) return r;
+    if (!igemm_pairable(*args, *a1)) {
+      r = fs_conv_igemm2(args, nullptr, dtype, stream);
+      return r != FS_OK ? r : fs_conv_igemm2(a1, nullptr, dtype, stream);
+    }
+  }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == FS_DTYPE_BF16) return launch_conv<bf16>(*args, st);
-  if (dtype == FS_DTYPE_F32) return launch_conv<float>(*args, st);
+  if (dtype == FS_DTYPE_BF16) return launch_conv<bf16>(*args, a1, st);
+  if (dtype == FS_DTYPE_F32) return launch_conv<float>(*args, a1, st);
   return FS_EINVAL;
+}
+
+extern "C" int fs_conv_igemm(const FsConvArgs* args, int dtype, void* stream) {
+  return fs_conv_igemm2(args, nullptr, dtype, stream);
 }

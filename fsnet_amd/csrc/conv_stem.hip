@@ -26,9 +26,17 @@ __device__ __forceinline__ uint4 stem_load16(__amdgpu_buffer_rsrc_t rsrc, int vo
   return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
 }
 
-__global__ __launch_bounds__(256) void conv_stem_kernel(const FsConvArgs p, int tiles_x, int tiles_y, int ntiles,
-                                                        int tiles_per_block, const FsDiv dTX, const FsDiv dTY,
-                                                        const FsDiv dIPG) {
+struct StemFwdGeom { int tiles_x, tiles_y, ntiles, tiles_per_block; FsDiv dTX, dTY, dIPG; };
+
+__global__ __launch_bounds__(256) void conv_stem_kernel(const FsDual<FsConvArgs, StemFwdGeom> d) {
+  // two problems per launch (fsnet_hip_internal.h, FsDual): the depth encoder's stem (3 real input channels) and the
+  // stacked pose encoder's (6) are the same kernel on the same 8-channel pixels with different weights
+  const int prob = (int)blockIdx.x >= d.nb0 ? 1 : 0;
+  const FsConvArgs& p = d.a[prob];
+  const int bid = (int)blockIdx.x - (prob ? d.nb0 : 0);
+  const int tiles_x = d.g[prob].tiles_x, tiles_y = d.g[prob].tiles_y, ntiles = d.g[prob].ntiles;
+  const int tiles_per_block = d.g[prob].tiles_per_block;
+  const FsDiv dTX = d.g[prob].dTX, dTY = d.g[prob].dTY, dIPG = d.g[prob].dIPG;
   typedef bf16 T;
   __shared__ uint4 lds_w[CO * TAPS];
   __shared__ uint4 lds_x[PH * PW];
@@ -52,7 +60,7 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const FsConvArgs p, int 
 #pragma unroll
     for (int j = 0; j < 4; ++j) { s1[c][j] = 0.f; s2[c][j] = 0.f; }
   int cur_group = -1;
-  const int tile0 = blockIdx.x * tiles_per_block;
+  const int tile0 = bid * tiles_per_block;
   const int tile1 = min(tile0 + tiles_per_block, ntiles);
 
   auto flush_stats = [&](int group) {
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const FsConvArgs p, int 
       float u = 0.f, w = 0.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) { u += red[(k * CO + t) * 2]; w += red[(k * CO + t) * 2 + 1]; }
-      double* sl = p.stats + ((long)group * FS_STAT_SLOTS + blockIdx.x % FS_STAT_SLOTS) * 2 * p.Co;
+      double* sl = p.stats + ((long)group * FS_STAT_SLOTS + bid % FS_STAT_SLOTS) * 2 * p.Co;
       atomicAdd(sl + t, (double)u);
       atomicAdd(sl + p.Co + t, (double)w);
     }
@@ -152,7 +160,8 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const FsConvArgs p, int 
 
 }  // namespace
 
-extern "C" int fs_conv_stem(const FsConvArgs* a, int dtype, void* stream) {
+namespace {
+int stem_check(const FsConvArgs* a, int dtype) {
   if (!a || !a->src || !a->wgt || !a->dst) return FS_EINVAL;
   if (dtype != FS_DTYPE_BF16 || a->Cs != 8 || a->Co != 64 || a->Co_p != 64) return FS_EINVAL;
   if (a->bias || a->addend || a->mask || a->bnb_x || a->relu || a->out_f32 || a->grp_imgs || a->ncls > 1) return FS_EINVAL;
@@ -160,19 +169,38 @@ extern "C" int fs_conv_stem(const FsConvArgs* a, int dtype, void* stream) {
   if (a->nchunks * a->kg * 8 < TAPS * 8) return FS_EINVAL;
   if (a->src_bytes <= 0 || a->src_bytes > 0x7fffffffLL || a->wgt_bytes <= 0 || a->wgt_bytes > 0x7fffffffLL)
     return FS_EINVAL;
-  const int tiles_x = (a->Wd + TX - 1) / TX, tiles_y = (a->Hd + TY - 1) / TY;
-  const long ntiles = (long)a->N * tiles_x * tiles_y;
-  if (ntiles > 0x7fffffffL) return FS_EINVAL;
-  // persistent blocks: two per CU (62 KB of LDS each), each walking a contiguous run of tiles with the weights resident
-  const int per = (int)std::max<long>(1, (ntiles + 511) / 512);
-  const int blocks = (int)((ntiles + per - 1) / per);
-  FsDiv ipg = fs_make_div(1);
-  if (a->stat_group_rows > 0) {
-    const long hw = (long)a->Hd * a->Wd;
-    if (a->stat_group_rows % hw != 0) return FS_EINVAL;        // statistics groups are whole images
-    ipg = fs_make_div((int)(a->stat_group_rows / hw));
-  }
-  hipLaunchKernelGGL(conv_stem_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a, tiles_x,
-                     tiles_y, (int)ntiles, per, fs_make_div(tiles_x), fs_make_div(tiles_y), ipg);
+  if ((long)a->N * ((a->Wd + TX - 1) / TX) * ((a->Hd + TY - 1) / TY) > 0x7fffffffL) return FS_EINVAL;
+  if (a->stat_group_rows > 0 && a->stat_group_rows % ((long)a->Hd * a->Wd) != 0) return FS_EINVAL;   // whole images
+  return FS_OK;
+}
+// tiles per persistent block when the launch holds `total` tiles: two blocks per CU (62 KB of LDS each), each walking a
+// contiguous run of tiles with the weights resident
+int stem_geom(const FsConvArgs& a, long total, StemFwdGeom& g) {
+  g.tiles_x = (a.Wd + TX - 1) / TX; g.tiles_y = (a.Hd + TY - 1) / TY;
+  g.ntiles = (int)((long)a.N * g.tiles_x * g.tiles_y);
+  g.tiles_per_block = (int)std::max<long>(1, (total + 511) / 512);
+  g.dTX = fs_make_div(g.tiles_x); g.dTY = fs_make_div(g.tiles_y);
+  g.dIPG = a.stat_group_rows > 0 ? fs_make_div((int)(a.stat_group_rows / ((long)a.Hd * a.Wd))) : fs_make_div(1);
+  return (g.ntiles + g.tiles_per_block - 1) / g.tiles_per_block;
+}
+}  // namespace
+
+// a1 != NULL: a second stem (its own weights, images and statistics) in the same launch
+extern "C" int fs_conv_stem2(const FsConvArgs* a, const FsConvArgs* a1, int dtype, void* stream) {
+  int r = stem_check(a, dtype);
+  if (r != FS_OK) return r;
+  if (a1 && (r = stem_check(a1, dtype)) != FS_OK) return r;
+  FsDual<FsConvArgs, StemFwdGeom> d;
+  d.a[0] = *a; d.a[1] = a1 ? *a1 : *a;
+  d.nprob = a1 ? 2 : 1;
+  auto tiles = [](const FsConvArgs& q) { return (long)q.N * ((q.Wd + TX - 1) / TX) * ((q.Hd + TY - 1) / TY); };
+  const long total = tiles(*a) + (a1 ? tiles(*a1) : 0);
+  int blocks = stem_geom(*a, total, d.g[0]);
+  d.g[1] = d.g[0];
+  d.nb0 = blocks;
+  if (a1) blocks += stem_geom(*a1, total, d.g[1]);
+  hipLaunchKernelGGL(conv_stem_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d);
   return fs_launch_status();
 }
+
+extern "C" int fs_conv_stem(const FsConvArgs* a, int dtype, void* stream) { return fs_conv_stem2(a, nullptr, dtype, stream); }

@@ -27,8 +27,17 @@ inline bool wg_plan(int kind, long blocks, int threads, int resident) {
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
+struct WgDiv { FsDiv dW, dH; };
+
+// Two problems per launch (fsnet_hip_internal.h, FsDual) in every kernel of this file: the pixel splits of both stack
+// along blockIdx.z (the persistent stem kernel: along blockIdx.x), [0, nb0) belong to the first argument set; each
+// problem has its own slab region of the workspace and its own dW.
 template <typename T, int COT, int CLT, int WR, int CH>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const FsWgradArgs p, const FsDiv dW, const FsDiv dH) {
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const FsDual<FsWgradArgs, WgDiv> d) {
+  const int prob = (int)blockIdx.z >= d.nb0 ? 1 : 0;
+  const FsWgradArgs& p = d.a[prob];
+  const FsDiv dW = d.g[prob].dW, dH = d.g[prob].dH;
+  const int zb = (int)blockIdx.z - (prob ? d.nb0 : 0);
   using TR = ElemTraits<T>;
   constexpr int EG = TR::EG;
   constexpr int WCn = 4 / WR;                 // waves along columns
@@ -50,7 +59,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const FsWgradArgs p, co
 
   const int col0 = blockIdx.x * CLT;   // first gemm column (r,s,ci) of the tile
   const int co0 = blockIdx.y * COT;
-  const long m_begin = (long)blockIdx.z * p.pix_per_split;
+  const long m_begin = (long)zb * p.pix_per_split;
   long m_end = m_begin + p.pix_per_split; if (m_end > p.M) m_end = p.M;
   const int nch = (int)((m_end - m_begin + CH - 1) / CH);
 
@@ -180,7 +189,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const FsWgradArgs p, co
   // ---- epilogue: D rows = co (lg*4+j), cols = gemm column (li) ----
   if (p.nsplit > 1) {
     // split-K partial: dense slab [split][Cd_t][ncols_t] in the workspace (reduced by wgrad_reduce_kernel)
-    float* ws = p.workspace + (long)blockIdx.z * p.ws_rows * p.ws_cols;
+    float* ws = p.workspace + (long)zb * p.ws_rows * p.ws_cols;
 #pragma unroll
     for (int b = 0; b < TB; ++b) {
       int col = col0 + wcn * WCOL + b * 16 + li;
@@ -218,7 +227,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const FsWgradArgs p, co
 // 16 split lanes, every lane's 16-byte loads (slabs z, z + 16, ...) issued eight at a time — a 128-slab reduction is
 // ONE round of loads per thread (the 4-byte / four-in-flight version spent eight round trips: 10.9 us for 18.9 MB) —
 // then the 16 lanes combine through LDS.  (ncols and ws_cols are multiples of 4 by construction.)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const FsWgradArgs p, int eg) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const FsDual<FsWgradArgs, FsNoGeom> d, int eg) {
+  const FsWgradArgs& p = d.a[blockIdx.z];
   __shared__ float4 red[16][16];
   const int ncols = p.ncolgroups * eg;
   const int cblocks = (ncols + 63) / 64;
@@ -270,7 +280,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const FsWgradArgs p, 
 // the same reduction for fewer than 32 slabs (the 16 split lanes of the kernel above would mostly idle: ResNet-50's 1x1
 // layers, 9-31 slabs, measured 13.1 us on this kernel against 15.2 on that one in the step): 64 consecutive columns x 4
 // split lanes per block, each lane strides the splits by 4 with independent (unrolled) loads, the 4 lanes combine through LDS.
-__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const FsWgradArgs p, int eg) {
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const FsDual<FsWgradArgs, FsNoGeom> d, int eg) {
+  const FsWgradArgs& p = d.a[blockIdx.z];
   __shared__ float red[4][64];
   const int ncols = p.ncolgroups * eg;
   const int cblocks = (ncols + 63) / 64;
@@ -304,7 +315,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const FsWgradArgs p,
 
 // few splits (deep stages: wide dW, 2-8 slabs): one thread per column, all slabs summed with independent loads —
 // the 4-lane kernel above would run 4x the blocks with most lanes idle
-__global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const FsWgradArgs p, int eg) {
+__global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const FsDual<FsWgradArgs, FsNoGeom> d, int eg) {
+  const FsWgradArgs& p = d.a[blockIdx.z];
   const int ncols = p.ncolgroups * eg;
   const int cblocks = (ncols + 255) / 256;
   const int co = blockIdx.x / cblocks, col = (blockIdx.x % cblocks) * 256 + threadIdx.x;
@@ -328,7 +340,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const FsWgradArg
 // 3x3 slabs in tap-major column order (col = tap*Cs + ci), few splits: a block owns one co x 32 ci x 9 taps.  It
 // reads nine 128-byte column segments per slab, transposes through LDS and adds into dW[co][ci][3][3] as ONE
 // contiguous 288-float run (the flat kernel's lanes hit dW with a 36-byte stride: 9x the lines per wave).
-__global__ __launch_bounds__(320) void wgrad_reduce3x3_kernel(const FsWgradArgs p, int Cs) {
+__global__ __launch_bounds__(320) void wgrad_reduce3x3_kernel(const FsDual<FsWgradArgs, FsNoGeom> d, int Cs) {
+  const FsWgradArgs& p = d.a[blockIdx.z];
   __shared__ float tmp[288];
   const int co = blockIdx.y, ci0 = blockIdx.x * 32;
   const int e = threadIdx.x;
@@ -358,16 +371,36 @@ __global__ __launch_bounds__(320) void wgrad_reduce3x3_kernel(const FsWgradArgs 
   }
 }
 
-void launch_reduce(const FsWgradArgs& b, int Co, int ncols, int eg, hipStream_t st) {
+// b: the launch's (filled-in) arguments; b2 != nullptr: the second problem's, same dW shape — one reduce launch for both
+// (blockIdx.z = problem).  A problem that was not split (nsplit == 1) accumulated into its dW directly.
+void launch_reduce(const FsWgradArgs& b, const FsWgradArgs* b2, int Co, int ncols, int eg, hipStream_t st) {
+  FsDual<FsWgradArgs, FsNoGeom> d;
+  d.g[0].unused = d.g[1].unused = 0; d.nb0 = 0;
+  int n = 0, ns = 0;
+  if (b.nsplit > 1) { d.a[n++] = b; ns = std::max(ns, b.nsplit); }
+  if (b2 && b2->nsplit > 1) { d.a[n++] = *b2; ns = std::max(ns, b2->nsplit); }
+  if (n == 0) return;
+  if (n == 1) d.a[1] = d.a[0];
+  d.nprob = n;
   const bool tapmajor3x3 = b.R == 3 && b.S == 3 && ncols % 9 == 0 && (ncols / 9) % 32 == 0;
-  if (tapmajor3x3 && b.nsplit <= 16 && ncols >= 9 * 64)
-    hipLaunchKernelGGL(wgrad_reduce3x3_kernel, dim3((unsigned)(ncols / 9 / 32), (unsigned)Co), dim3(320), 0, st, b, ncols / 9);
-  else if (b.nsplit <= 8 && ncols >= 256)
-    hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)(Co * ((ncols + 255) / 256))), dim3(256), 0, st, b, eg);
-  else if (b.nsplit < 32)
-    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)(Co * ((ncols + 63) / 64))), dim3(256), 0, st, b, eg);
+  if (tapmajor3x3 && ns <= 16 && ncols >= 9 * 64)
+    hipLaunchKernelGGL(wgrad_reduce3x3_kernel, dim3((unsigned)(ncols / 9 / 32), (unsigned)Co, n), dim3(320), 0, st, d, ncols / 9);
+  else if (ns <= 8 && ncols >= 256)
+    hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)(Co * ((ncols + 255) / 256)), 1, n), dim3(256), 0, st, d, eg);
+  else if (ns < 32)
+    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)(Co * ((ncols + 63) / 64)), 1, n), dim3(256), 0, st, d, eg);
   else
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(Co * ((ncols + 63) / 64))), dim3(256), 0, st, b, eg);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(Co * ((ncols + 63) / 64)), 1, n), dim3(256), 0, st, d, eg);
+}
+
+// pixel splits of a launch shared by two problems: `total` slots divided in proportion to their work, at least one each
+inline void wg_share(long total, long work0, long work1, long cap0, long cap1, long& s0, long& s1) {
+  if (total < 2) total = 2;
+  s0 = (total * work0 + (work0 + work1) / 2) / (work0 + work1);
+  s0 = std::max<long>(1, std::min(s0, total - 1));
+  s1 = total - s0;
+  s0 = std::max<long>(1, std::min(s0, cap0));
+  s1 = std::max<long>(1, std::min(s1, cap1));
 }
 
 // resident blocks of a kernel on the whole device (occupancy x CUs).  A split-K grid a little larger than this runs
@@ -384,35 +417,57 @@ int wg_resident_blocks(K kernel, int threads) {
 }
 
 template <typename T, int COT, int CLT, int WR>
-int launch_tile(const FsWgradArgs& a, hipStream_t st) {
+int launch_tile(const FsWgradArgs& a, const FsWgradArgs* a2, hipStream_t st) {
   constexpr int EG = ElemTraits<T>::EG;
   // pixels per pipeline stage: every stage waits one global-load latency, so bf16 tiles that fit the LDS budget
   // take 64 pixels (two MFMA K steps) per stage
   constexpr int CH = (sizeof(T) == 2 && (COT + CLT) <= 192) ? 64 : 32;
-  FsWgradArgs b = a;
+  FsDual<FsWgradArgs, WgDiv> d;
+  FsWgradArgs& b = d.a[0];
+  FsWgradArgs& b2 = d.a[1];
+  b = a; b2 = a2 ? *a2 : a;
+  d.g[0] = WgDiv{fs_make_div(a.Wd), fs_make_div(a.Hd)};
+  d.g[1] = WgDiv{fs_make_div(b2.Wd), fs_make_div(b2.Hd)};
+  d.nprob = a2 ? 2 : 1;
   const int ncols = a.ncolgroups * EG;
   const int ct = (ncols + CLT - 1) / CLT, rt = (a.Cd + COT - 1) / COT;
   const long tiles = (long)ct * rt;
-  const long chunks = (a.M + CH - 1) / CH;
+  const long chunks = (a.M + CH - 1) / CH, chunks2 = a2 ? (a2->M + CH - 1) / CH : 0;
   // split the pixel (K) range until ~640 blocks are in flight, keeping >= 256 pixels per block and the partial
   // slabs inside the caller's workspace.  (Measured: fewer, longer blocks lose — every stage of the pixel loop
   // waits one global-load latency, so the kernel wants many short chains; the slab traffic is the smaller cost.)
-  long splits = (640 + tiles - 1) / tiles;
-  splits = std::min<long>(splits, std::max<long>(1, chunks / (256 / CH)));
+  long splits = (640 + tiles - 1) / tiles, splits2 = 0;
   b.ws_rows = rt * COT; b.ws_cols = ct * CLT;
+  b2.ws_rows = b.ws_rows; b2.ws_cols = b.ws_cols;
   const long slab = (long)b.ws_rows * b.ws_cols;
-  if (!a.workspace) splits = 1;
-  else splits = std::min<long>(splits, std::max<long>(1, a.workspace_elems / slab));
+  if (a2) {
+    const long cap = std::max<long>(1, chunks / (256 / CH)), cap2 = std::max<long>(1, chunks2 / (256 / CH));
+    wg_share(splits, chunks, chunks2, cap, cap2, splits, splits2);
+    // (the two problems share the first problem's workspace: both or neither split)
+    const long room = a.workspace ? a.workspace_elems / slab : 0;
+    if (room < 2) { splits = 1; splits2 = 1; }
+    else if (splits + splits2 > room) { splits = std::max<long>(1, room * splits / (splits + splits2)); splits2 = std::max<long>(1, room - splits); }
+  } else {
+    splits = std::min<long>(splits, std::max<long>(1, chunks / (256 / CH)));
+    if (!a.workspace) splits = 1;
+    else splits = std::min<long>(splits, std::max<long>(1, a.workspace_elems / slab));
+  }
   long cps = (chunks + splits - 1) / splits;
   b.pix_per_split = (int)(cps * CH);
   b.nsplit = (int)((chunks + cps - 1) / cps);
-  dim3 grid(ct, rt, b.nsplit);
-  if (g_plan) return wg_plan(0, (long)ct * rt * b.nsplit, 256, wg_resident_blocks(conv_wgrad_kernel<T, COT, CLT, WR, CH>, 256)) ? 0 : FS_EINVAL;
-  hipLaunchKernelGGL((conv_wgrad_kernel<T, COT, CLT, WR, CH>), grid, dim3(256), 0, st, b, fs_make_div(a.Wd),
-                     fs_make_div(a.Hd));
-  if (b.nsplit > 1) {
-    launch_reduce(b, a.Co, ncols, EG, st);
+  d.nb0 = b.nsplit;
+  int nz = b.nsplit;
+  if (a2) {
+    cps = (chunks2 + splits2 - 1) / splits2;
+    b2.pix_per_split = (int)(cps * CH);
+    b2.nsplit = (int)((chunks2 + cps - 1) / cps);
+    b2.workspace = a.workspace ? a.workspace + (long)b.nsplit * slab : nullptr;
+    nz += b2.nsplit;
   }
+  dim3 grid(ct, rt, nz);
+  if (g_plan) return wg_plan(0, (long)ct * rt * nz, 256, wg_resident_blocks(conv_wgrad_kernel<T, COT, CLT, WR, CH>, 256)) ? 0 : FS_EINVAL;
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, COT, CLT, WR, CH>), grid, dim3(256), 0, st, d);
+  launch_reduce(b, a2 ? &b2 : nullptr, a.Co, ncols, EG, st);
   return fs_launch_status();
 }
 
@@ -435,7 +490,11 @@ __device__ __forceinline__ uint4 wg_buf_load16(__amdgpu_buffer_rsrc_t rsrc, int 
 // (With one group a wave's chain per tile — 88 transposing reads, 72 MFMAs, 16 LDS stores, two barriers — ran alone on
 // its SIMD: ds_read_b64_tr_b16 reaches its rate only from several waves per SIMD, MI355X_MICROARCH.md / LDS.)
 template <int COT, int CIT, int NG>
-__global__ __launch_bounds__(256 * NG) void wgrad3x3_halo_kernel(const FsWgradArgs p, const WGeom g) {
+__global__ __launch_bounds__(256 * NG) void wgrad3x3_halo_kernel(const FsDual<FsWgradArgs, WGeom> d) {
+  const int prob = (int)blockIdx.z >= d.nb0 ? 1 : 0;
+  const FsWgradArgs& p = d.a[prob];
+  const WGeom& g = d.g[prob];
+  const int zb = (int)blockIdx.z - (prob ? d.nb0 : 0);
   typedef bf16 T;
   constexpr int NT = 256 * NG;
   constexpr int TPG = (9 + NG - 1) / NG;               // taps per group (the last groups may hold one fewer)
@@ -581,7 +640,7 @@ __global__ __launch_bounds__(256 * NG) void wgrad3x3_halo_kernel(const FsWgradAr
 
   // the block's pixel tiles z, z + nsplit, ...
   const int step = g.nsplit;
-  int pt = blockIdx.z;
+  int pt = zb;
   if (pt < npix) load_regs(pt);
   for (; pt < npix; pt += step) {
     __syncthreads();
@@ -630,7 +689,7 @@ __global__ __launch_bounds__(256 * NG) void wgrad3x3_halo_kernel(const FsWgradAr
         const int co = co0 + wr * (COT / 2) + a * 16 + li;
         const f32x4 v = acc[tp][a][b];
         if (g.nsplit > 1) {
-          *reinterpret_cast<float4*>(&p.workspace[((long)blockIdx.z * p.ws_rows + co) * p.ws_cols + tap * g.Cs + ci]) =
+          *reinterpret_cast<float4*>(&p.workspace[((long)zb * p.ws_rows + co) * p.ws_cols + tap * g.Cs + ci]) =
               make_float4(v[0], v[1], v[2], v[3]);
         } else if (co < p.Co) {
 #pragma unroll
@@ -821,8 +880,15 @@ __global__ __launch_bounds__(256) void wgrad3x3_narrow_kernel(const FsWgradArgs 
 // 7 of the 28 column tiles (7 kernel rows x 4 tap pairs; the 8th tap of a row does not exist and is not written) for
 // all 64 output channels and keeps them in accumulators over the block's tiles; one fp32 slab per block at the end.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wgrad_stem_kernel(const FsWgradArgs p, int tiles_x, int tiles_y, int ntiles,
-                                                         int tiles_per_block, const FsDiv dTX, const FsDiv dTY) {
+struct StemGeom { int tiles_x, tiles_y, ntiles, tiles_per_block; FsDiv dTX, dTY; };
+
+__global__ __launch_bounds__(256) void wgrad_stem_kernel(const FsDual<FsWgradArgs, StemGeom> d) {
+  const int prob = (int)blockIdx.x >= d.nb0 ? 1 : 0;
+  const FsWgradArgs& p = d.a[prob];
+  const int bid = (int)blockIdx.x - (prob ? d.nb0 : 0);
+  const int tiles_x = d.g[prob].tiles_x, tiles_y = d.g[prob].tiles_y, ntiles = d.g[prob].ntiles;
+  const int tiles_per_block = d.g[prob].tiles_per_block;
+  const FsDiv dTX = d.g[prob].dTX, dTY = d.g[prob].dTY;
   typedef bf16 T;
   constexpr int TY = 8, TX = 16, PIXT = TY * TX, PH = 2 * TY + 5, PW = 2 * TX + 6;
   constexpr int SA = 64 + 8, OOB = 0x7fffffff;
@@ -886,7 +952,7 @@ __global__ __launch_bounds__(256) void wgrad_stem_kernel(const FsWgradArgs p, in
 #pragma unroll
     for (int c = 0; c < 7; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int tile0 = blockIdx.x * tiles_per_block, tile1 = min(tile0 + tiles_per_block, ntiles);
+  const int tile0 = bid * tiles_per_block, tile1 = min(tile0 + tiles_per_block, ntiles);
   if (tile0 < tile1) load_regs(tile0);
   for (int tile = tile0; tile < tile1; ++tile) {
     __syncthreads();
@@ -918,7 +984,7 @@ __global__ __launch_bounds__(256) void wgrad_stem_kernel(const FsWgradArgs p, in
   }
 
   // D rows = co (a*16 + lg*4 + j), cols = li: tap 2*pair + (li >> 3), channel li & 7
-  float* ws = p.workspace + (long)blockIdx.x * p.ws_rows * p.ws_cols;
+  float* ws = p.workspace + (long)bid * p.ws_rows * p.ws_cols;
 #pragma unroll
   for (int c = 0; c < 7; ++c) {
     const int ct = wave * 7 + c, r = ct >> 2, s = 2 * (ct & 3) + (li >> 3);
@@ -951,38 +1017,59 @@ WGeom wgrad_pick_geom(int Hd, int Wd) {
 }
 
 template <int COT, int CIT>
-int launch_wgrad_halo_t(const FsWgradArgs& a, hipStream_t st) {
-  FsWgradArgs b = a;
+int launch_wgrad_halo_t(const FsWgradArgs& a, const FsWgradArgs* a2, hipStream_t st) {
+  FsDual<FsWgradArgs, WGeom> d;
+  FsWgradArgs& b = d.a[0];
+  FsWgradArgs& b2 = d.a[1];
+  b = a; b2 = a2 ? *a2 : a;
+  d.nprob = a2 ? 2 : 1;
   const int Cs = a.ncolgroups * 8 / 9;
-  WGeom g = wgrad_pick_geom(a.Hd, a.Wd);
+  WGeom& g = d.g[0];
+  g = wgrad_pick_geom(a.Hd, a.Wd);
   if (g.TH == 0) return FS_EINVAL;
   g.N = a.M / (a.Hd * a.Wd); g.Cs = Cs;
+  d.g[1] = g;
+  d.g[1].N = b2.M / (b2.Hd * b2.Wd);
   const int out_tiles = (a.Cd / COT) * (Cs / CIT);
-  const int npix = g.N * g.tiles_x * g.tiles_y;
+  const int npix = g.N * g.tiles_x * g.tiles_y, npix2 = a2 ? d.g[1].N * g.tiles_x * g.tiles_y : 0;
   b.ws_rows = a.Cd; b.ws_cols = 9 * Cs;
+  b2.ws_rows = b.ws_rows; b2.ws_cols = b.ws_cols;
   const long slab = (long)b.ws_rows * b.ws_cols;
   // one round of resident blocks: every split adds a Cd x 9Cs fp32 slab to write and re-read, every block beyond the
   // resident ones waits for a whole block to finish
   static const int slots = wg_resident_blocks(wgrad3x3_halo_kernel<COT, CIT, 2>, 512);
-  long splits = std::max<long>(1, std::min<long>(npix / 2 > 0 ? npix / 2 : 1, std::max(1, slots / out_tiles)));
-  if (!a.workspace) splits = 1;
-  else splits = std::min<long>(splits, std::max<long>(1, a.workspace_elems / slab));
+  long splits, splits2 = 0;
+  if (a2) {
+    // both problems in the one round: the device's slots divided by their pixel tiles; one shared slab arena (a's)
+    wg_share(std::max(2, slots / out_tiles), npix, npix2, std::max(1, npix / 2), std::max(1, npix2 / 2), splits, splits2);
+    const long room = a.workspace ? a.workspace_elems / slab : 0;
+    if (room < 2) { splits = 1; splits2 = 1; }
+    else if (splits + splits2 > room) { splits = std::max<long>(1, room * splits / (splits + splits2)); splits2 = std::max<long>(1, room - splits); }
+  } else {
+    splits = std::max<long>(1, std::min<long>(npix / 2 > 0 ? npix / 2 : 1, std::max(1, slots / out_tiles)));
+    if (!a.workspace) splits = 1;
+    else splits = std::min<long>(splits, std::max<long>(1, a.workspace_elems / slab));
+  }
   g.nsplit = (int)splits; b.nsplit = g.nsplit;
-  dim3 grid(Cs / CIT, a.Cd / COT, g.nsplit);
+  d.nb0 = g.nsplit;
+  int nz = g.nsplit;
+  if (a2) {
+    d.g[1].nsplit = (int)splits2; b2.nsplit = (int)splits2;
+    b2.workspace = a.workspace ? a.workspace + (long)b.nsplit * slab : nullptr;
+    nz += (int)splits2;
+  }
+  dim3 grid(Cs / CIT, a.Cd / COT, nz);
   // two tap groups: one, three and four measured — 35.0 / 30.3 / 30.3 / 30.1 us at 288 blocks, 25.0 / 22.9 / - / 22.5 us
   // at 256 (64 -> 64 @48x160 B=12, with the reduce); in the step four groups (1024-thread blocks) lose to two
   if (wg_plan(1, (long)grid.x * grid.y * grid.z, 512, slots)) return 0;
-  hipLaunchKernelGGL((wgrad3x3_halo_kernel<COT, CIT, 2>), grid, dim3(512), 0, st, b, g);
-  if (b.nsplit > 1) {
-    const int ncols = 9 * Cs;
-    launch_reduce(b, a.Co, ncols, 8, st);
-  }
+  hipLaunchKernelGGL((wgrad3x3_halo_kernel<COT, CIT, 2>), grid, dim3(512), 0, st, d);
+  launch_reduce(b, a2 ? &b2 : nullptr, a.Co, 9 * Cs, 8, st);
   return fs_launch_status();
 }
 
-int launch_wgrad_halo(const FsWgradArgs& a, hipStream_t st) {
+int launch_wgrad_halo(const FsWgradArgs& a, const FsWgradArgs* a2, hipStream_t st) {
   // (32 x 32 tiles — twice the tiles, half the pixel splits and slabs — measured 0.5-1 % slower end to end)
-  return launch_wgrad_halo_t<64, 32>(a, st);
+  return launch_wgrad_halo_t<64, 32>(a, a2, st);
 }
 
 int launch_wgrad_narrow(const FsWgradArgs& a, hipStream_t st) {
@@ -1013,77 +1100,149 @@ int launch_wgrad_narrow(const FsWgradArgs& a, hipStream_t st) {
   else if (COT == 16 && CIT == 32) hipLaunchKernelGGL((wgrad3x3_narrow_kernel<16, 32>), grid, dim3(256), 0, st, b, g);
   else if (COT == 16 && CIT == 16) hipLaunchKernelGGL((wgrad3x3_narrow_kernel<16, 16>), grid, dim3(256), 0, st, b, g);
   else return FS_EINVAL;
-  if (b.nsplit > 1) {
-    const int ncols = 9 * Cs;
-    launch_reduce(b, a.Co, ncols, 8, st);
-  }
+  launch_reduce(b, nullptr, a.Co, 9 * Cs, 8, st);
   return fs_launch_status();
 }
 
-int launch_wgrad_stem(const FsWgradArgs& a, hipStream_t st) {
-  FsWgradArgs b = a;
+int launch_wgrad_stem(const FsWgradArgs& a, const FsWgradArgs* a2, hipStream_t st) {
+  FsDual<FsWgradArgs, StemGeom> d;
+  FsWgradArgs& b = d.a[0];
+  FsWgradArgs& b2 = d.a[1];
+  b = a; b2 = a2 ? *a2 : a;
+  d.nprob = a2 ? 2 : 1;
   const int tiles_x = (a.Wd + 15) / 16, tiles_y = (a.Hd + 7) / 8;
   const long ntiles = (long)(a.M / (a.Hd * a.Wd)) * tiles_x * tiles_y;
+  const long ntiles2 = a2 ? (long)(a2->M / (a2->Hd * a2->Wd)) * tiles_x * tiles_y : 0;
   b.ws_rows = 64; b.ws_cols = 49 * 8;
+  b2.ws_rows = 64; b2.ws_cols = 49 * 8;
   const long slab = (long)b.ws_rows * b.ws_cols;
   // one slab per persistent block (100 KB each, written and re-read), as many blocks as the device holds at once
   static const int slots = wg_resident_blocks(wgrad_stem_kernel, 256);   // (320 blocks of this one-block-per-CU kernel ran as two rounds)
   const long max_blocks = std::min<long>(slots, a.workspace_elems / slab);
-  if (max_blocks < 1 || ntiles < 1) return FS_EINVAL;
-  const int per = (int)((ntiles + max_blocks - 1) / max_blocks);
+  if (max_blocks < (a2 ? 2 : 1) || ntiles < 1 || (a2 && ntiles2 < 1)) return FS_EINVAL;
+  long mb = max_blocks, mb2 = 0;
+  if (a2) wg_share(max_blocks, ntiles, ntiles2, ntiles, ntiles2, mb, mb2);
+  const int per = (int)((ntiles + mb - 1) / mb);
   const int blocks = (int)((ntiles + per - 1) / per);
   b.nsplit = blocks;
-  if (wg_plan(3, blocks, 256, slots)) return 0;
-  hipLaunchKernelGGL(wgrad_stem_kernel, dim3(blocks), dim3(256), 0, st, b, tiles_x, tiles_y, (int)ntiles, per,
-                     fs_make_div(tiles_x), fs_make_div(tiles_y));
-  launch_reduce(b, a.Co, 49 * 8, 8, st);
+  d.g[0] = StemGeom{tiles_x, tiles_y, (int)ntiles, per, fs_make_div(tiles_x), fs_make_div(tiles_y)};
+  d.g[1] = d.g[0];
+  d.nb0 = blocks;
+  int total = blocks;
+  if (a2) {
+    const int per2 = (int)((ntiles2 + mb2 - 1) / mb2);
+    const int blocks2 = (int)((ntiles2 + per2 - 1) / per2);
+    b2.nsplit = blocks2;
+    b2.workspace = a.workspace + (long)blocks * slab;
+    d.g[1].ntiles = (int)ntiles2; d.g[1].tiles_per_block = per2;
+    total += blocks2;
+  }
+  if (wg_plan(3, total, 256, slots)) return 0;
+  hipLaunchKernelGGL(wgrad_stem_kernel, dim3(total), dim3(256), 0, st, d);
+  // (the persistent blocks always leave slabs, also a single one)
+  {
+    FsDual<FsWgradArgs, FsNoGeom> r;
+    r.a[0] = b; r.a[1] = b2; r.g[0].unused = r.g[1].unused = 0; r.nb0 = 0; r.nprob = a2 ? 2 : 1;
+    const int ns = std::max(b.nsplit, a2 ? b2.nsplit : 0);
+    const int ncols = 49 * 8;
+    if (ns <= 8) hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)(a.Co * ((ncols + 255) / 256)), 1, r.nprob), dim3(256), 0, st, r, 8);
+    else if (ns < 32) hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)(a.Co * ((ncols + 63) / 64)), 1, r.nprob), dim3(256), 0, st, r, 8);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(a.Co * ((ncols + 63) / 64)), 1, r.nprob), dim3(256), 0, st, r, 8);
+  }
   return fs_launch_status();
 }
 
+// which kernel a problem runs on: 1 stem, 2 3x3 LDS-halo, 3 narrow 3x3, 4 / 5 / 6 / 7 / 8 generic tiles, -1 none
 template <typename T>
-int launch_wgrad(const FsWgradArgs& a, hipStream_t st) {
+int wgrad_path(const FsWgradArgs& a) {
   constexpr bool kBf16 = sizeof(T) == 2;  // f32 tiles are capped by the 64 KB static LDS limit
   if constexpr (kBf16) {
     const int Cs = a.ncolgroups * 8 / (a.R * a.S);
     if (a.use_halo && a.R == 7 && a.S == 7 && a.stride == 2 && a.pad == 3 && Cs == 8 && a.Cd == 64 && a.Co == 64 &&
         a.workspace && a.x_bytes > 0 && a.x_bytes <= 0x7fffffffLL && (long)a.M * a.Cd * 2 <= 0x7fffffffLL &&
         a.M >= 4096 && a.M % (a.Hd * a.Wd) == 0)
-      return launch_wgrad_stem(a, st);
+      return 1;
     if (a.use_halo && a.R == 3 && a.S == 3 && a.stride == 1 && a.Cd % 64 == 0 && Cs % 32 == 0 && a.x_bytes > 0 &&
         a.x_bytes <= 0x7fffffffLL && (long)a.M * a.Cd * 2 <= 0x7fffffffLL && (a.M >= 1024 || a.pro_a))
-      return launch_wgrad_halo(a, st);   // (tiny pixel counts: too few tiles to split, the generic kernel wins)
-    if (a.pro_a) return FS_EINVAL;       // only the halo kernel stages x through the prologue
+      return 2;                          // (tiny pixel counts: too few tiles to split, the generic kernel wins)
+    if (a.pro_a) return -1;              // only the halo kernel stages x through the prologue
     if (a.use_halo && a.R == 3 && a.S == 3 && a.stride == 1 && ((a.Cd == 16 && Cs % 16 == 0) || (a.Cd == 32 && Cs % 32 == 0)) &&
         a.x_bytes > 0 && a.x_bytes <= 0x7fffffffLL && (long)a.M * a.Cd * 2 <= 0x7fffffffLL && a.M >= 4096)
-      return launch_wgrad_narrow(a, st);
-  }
-  if constexpr (kBf16) {
+      return 3;
     // few pixels, wide dW (deep stages, pose decoder): 128x128 tiles halve the operand re-fetch per MFMA and
     // put 16 MFMAs per wave between barriers (the 64x64 tile: 4)
     const int ncols = a.ncolgroups * 8;
-    if (a.Cd % 128 == 0 && ncols >= 1024 && (long)(a.Cd / 128) * ((ncols + 127) / 128) >= 96)
-      return launch_tile<T, 128, 128, 2>(a, st);
-    if (a.Cd % 64 == 0 && ncols >= 256) return launch_tile<T, 64, 128, 2>(a, st);
+    if (a.Cd % 128 == 0 && ncols >= 1024 && (long)(a.Cd / 128) * ((ncols + 127) / 128) >= 96) return 4;
+    if (a.Cd % 64 == 0 && ncols >= 256) return 5;
   }
-  if (a.Cd % 64 == 0) return launch_tile<T, 64, 64, 2>(a, st);
-  if (a.Cd % 32 == 0) return launch_tile<T, 32, 128, 1>(a, st);
-  if (a.Cd % 16 == 0) {
-    if constexpr (kBf16) return launch_tile<T, 16, 256, 1>(a, st);
-    else return launch_tile<T, 16, 128, 1>(a, st);
+  if (a.Cd % 64 == 0) return 6;
+  if (a.Cd % 32 == 0) return 7;
+  if (a.Cd % 16 == 0) return 8;
+  return -1;
+}
+
+// everything that selects a kernel, its tiles or the shape of dW must agree; pixel counts, pointers and statistics
+// groups of the prologue are per problem
+inline bool wgrad_pairable(const FsWgradArgs& a, const FsWgradArgs& b) {
+  return a.Hs == b.Hs && a.Ws == b.Ws && a.Hd == b.Hd && a.Wd == b.Wd && a.Cd == b.Cd && a.Co == b.Co && a.Ci == b.Ci &&
+         a.R == b.R && a.S == b.S && a.stride == b.stride && a.pad == b.pad && a.ncolgroups == b.ncolgroups &&
+         (a.pro_a == nullptr) == (b.pro_a == nullptr) && a.pro_relu == b.pro_relu && a.sH == b.sH && a.sW == b.sW;
+}
+
+template <typename T>
+int launch_wgrad(const FsWgradArgs& a, const FsWgradArgs* a2, hipStream_t st) {
+  constexpr bool kBf16 = sizeof(T) == 2;
+  const int path = wgrad_path<T>(a);
+  if (a2) {
+    // (the stem pairs although the two encoders' Ci differ — 3 and 6 real channels of the same 8-channel pixels: dW is
+    // written through each problem's own Ci)
+    const bool stem_pair = path == 1 && wgrad_path<T>(*a2) == 1 && a.Hd == a2->Hd && a.Wd == a2->Wd && a.Hs == a2->Hs &&
+                           a.Ws == a2->Ws && a.sH == a2->sH && a.sW == a2->sW;
+    if (!(stem_pair || (path != 3 && path == wgrad_path<T>(*a2) && wgrad_pairable(a, *a2))) || !a.workspace) {
+      const int r = launch_wgrad<T>(a, nullptr, st);
+      return r != FS_OK ? r : launch_wgrad<T>(*a2, nullptr, st);
+    }
+  }
+  if constexpr (kBf16) {
+    if (path == 1) return launch_wgrad_stem(a, a2, st);
+    if (path == 2) return launch_wgrad_halo(a, a2, st);
+    if (path == 3) return launch_wgrad_narrow(a, st);
+    if (path == 4) return launch_tile<T, 128, 128, 2>(a, a2, st);
+    if (path == 5) return launch_tile<T, 64, 128, 2>(a, a2, st);
+  }
+  if (path == 6) return launch_tile<T, 64, 64, 2>(a, a2, st);
+  if (path == 7) return launch_tile<T, 32, 128, 1>(a, a2, st);
+  if (path == 8) {
+    if constexpr (kBf16) return launch_tile<T, 16, 256, 1>(a, a2, st);
+    else return launch_tile<T, 16, 128, 1>(a, a2, st);
   }
   return FS_EINVAL;
 }
 
-}  // namespace
-
-extern "C" int fs_conv_wgrad(const FsWgradArgs* args, int dtype, void* stream) {
+int wgrad_check(const FsWgradArgs* args, int dtype) {
   if (!args || !args->dy || !args->x || !args->dw || !args->ktab) return FS_EINVAL;
   if (args->M <= 0 || args->ncolgroups <= 0) return FS_EINVAL;
   if (args->pro_a && (!args->pro_b || dtype != FS_DTYPE_BF16)) return FS_EINVAL;
+  return FS_OK;
+}
+
+}  // namespace
+
+// a1 != NULL: the weight gradient of a second convolution of the same shape in the same launch: the pixel splits of the
+// two share the device's block slots and the FIRST problem's workspace (slab regions back to back), one reduce launch
+// writes both dW.  Problems that do not agree on the kernel run as two launches.
+extern "C" int fs_conv_wgrad2(const FsWgradArgs* args, const FsWgradArgs* a1, int dtype, void* stream) {
+  int r = wgrad_check(args, dtype);
+  if (r != FS_OK) return r;
+  if (a1 && (r = wgrad_check(a1, dtype)) != FS_OK) return r;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == FS_DTYPE_BF16) return launch_wgrad<bf16>(*args, st);
-  if (dtype == FS_DTYPE_F32) return launch_wgrad<float>(*args, st);
+  if (dtype == FS_DTYPE_BF16) return launch_wgrad<bf16>(*args, a1, st);
+  if (dtype == FS_DTYPE_F32) return launch_wgrad<float>(*args, a1, st);
   return FS_EINVAL;
+}
+
+extern "C" int fs_conv_wgrad(const FsWgradArgs* args, int dtype, void* stream) {
+  return fs_conv_wgrad2(args, nullptr, dtype, stream);
 }
 
 extern "C" int fs_conv_wgrad_plan(const FsWgradArgs* args, int dtype, int32_t* plan) {
@@ -1091,8 +1250,18 @@ extern "C" int fs_conv_wgrad_plan(const FsWgradArgs* args, int dtype, int32_t* p
   if (args->pro_a && (!args->pro_b || dtype != FS_DTYPE_BF16)) return FS_EINVAL;
   g_plan = plan;
   int r = FS_EINVAL;
-  if (dtype == FS_DTYPE_BF16) r = launch_wgrad<bf16>(*args, nullptr);
-  else if (dtype == FS_DTYPE_F32) r = launch_wgrad<float>(*args, nullptr);
+  if (dtype == FS_DTYPE_BF16) r = launch_wgrad<bf16>(*args, nullptr, nullptr);
+  else if (dtype == FS_DTYPE_F32) r = launch_wgrad<float>(*args, nullptr, nullptr);
+  g_plan = nullptr;
+  return r;
+}
+
+extern "C" int fs_conv_wgrad2_plan(const FsWgradArgs* args, const FsWgradArgs* a1, int dtype, int32_t* plan) {
+  if (!plan || wgrad_check(args, dtype) != FS_OK || (a1 && wgrad_check(a1, dtype) != FS_OK)) return FS_EINVAL;
+  g_plan = plan;
+  int r = FS_EINVAL;
+  if (dtype == FS_DTYPE_BF16) r = launch_wgrad<bf16>(*args, a1, nullptr);
+  else if (dtype == FS_DTYPE_F32) r = launch_wgrad<float>(*args, a1, nullptr);
   g_plan = nullptr;
   return r;
 }

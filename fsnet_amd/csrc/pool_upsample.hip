@@ -11,16 +11,24 @@
 
 namespace {
 
+// second tensor set of a two-problem max-pool launch: images n >= n0 of the flat index space belong to it
+struct FsPoolPair { const void* in1; void* out1; uint8_t* idx1; const void* add1; int n0; };
+
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                           uint8_t* __restrict__ idx, int N, int H, int W, int C,
-                                                          int Ho, int Wo) {
+                                                          int Ho, int Wo, FsPoolPair pr) {
   constexpr int VN = VecN<T>::N;           // one 16-byte lane per thread: 8 bf16 / 4 f32 channels
   const int CG = C / VN;
   const long total = (long)N * Ho * Wo * CG;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     int cg = (int)(i % CG); long m = i / CG;
     int wo = (int)(m % Wo); long q = m / Wo; int ho = (int)(q % Ho); long n = q / Ho;
+    const T* xs = x; T* ys = y; uint8_t* is = idx;
+    if (n >= pr.n0) {        // images of the second tensor set (two problems in one launch)
+      n -= pr.n0; m -= (long)pr.n0 * Ho * Wo;
+      xs = reinterpret_cast<const T*>(pr.in1); ys = reinterpret_cast<T*>(pr.out1); is = pr.idx1;
+    }
     float best[VN];
     int bi[VN];
 #pragma unroll
@@ -33,19 +41,19 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
         int w = wo * 2 - 1 + s;
         if ((unsigned)w >= (unsigned)W) continue;
         float v[VN];
-        loadv<T>(x + ((n * H + h) * W + w) * C + cg * VN, v);
+        loadv<T>(xs + ((n * H + h) * W + w) * C + cg * VN, v);
 #pragma unroll
         for (int j = 0; j < VN; ++j)
           if (first || v[j] > best[j]) { best[j] = v[j]; bi[j] = r * 3 + s; }  // first max wins (ATen)
         first = false;
       }
     }
-    storev<T>(y + m * C + cg * VN, best);
+    storev<T>(ys + m * C + cg * VN, best);
 #pragma unroll
     for (int k = 0; k < VN / 4; ++k) {
       uint32_t packed = (uint32_t)bi[4 * k] | ((uint32_t)bi[4 * k + 1] << 8) | ((uint32_t)bi[4 * k + 2] << 16) |
                         ((uint32_t)bi[4 * k + 3] << 24);
-      reinterpret_cast<uint32_t*>(idx + m * C + cg * VN)[k] = packed;
+      reinterpret_cast<uint32_t*>(is + m * C + cg * VN)[k] = packed;
     }
   }
 }
@@ -54,17 +62,23 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx,
                                                           const T* __restrict__ addend, T* __restrict__ dx, int N,
-                                                          int H, int W, int C, int Ho, int Wo) {
+                                                          int H, int W, int C, int Ho, int Wo, FsPoolPair pr) {
   constexpr int VN = VecN<T>::N;           // one 16-byte lane per thread: 8 bf16 / 4 f32 channels
   const int CG = C / VN;
   const long total = (long)N * H * W * CG;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     int cg = (int)(i % CG); long m = i / CG;
     int w = (int)(m % W); long q = m / W; int h = (int)(q % H); long n = q / H;
+    const T* dys = dy; T* dxs = dx; const uint8_t* is = idx; const T* ads = addend;
+    if (n >= pr.n0) {
+      n -= pr.n0; m -= (long)pr.n0 * H * W;
+      dys = reinterpret_cast<const T*>(pr.in1); dxs = reinterpret_cast<T*>(pr.out1); is = pr.idx1;
+      ads = reinterpret_cast<const T*>(pr.add1);
+    }
     float acc[VN];
 #pragma unroll
     for (int j = 0; j < VN; ++j) acc[j] = 0.f;
-    if (addend) loadv<T>(addend + m * C + cg * VN, acc);
+    if (ads) loadv<T>(ads + m * C + cg * VN, acc);
     for (int ho = (h - 1 + 1) / 2; ho <= (h + 1) / 2; ++ho) {   // windows with |h - 2ho| <= 1
       if (ho < 0 || ho >= Ho) continue;
       int r = h - (ho * 2 - 1);
@@ -76,16 +90,16 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
         long mo = (n * Ho + ho) * Wo + wo;
         uint32_t packed[VN / 4];
 #pragma unroll
-        for (int k = 0; k < VN / 4; ++k) packed[k] = reinterpret_cast<const uint32_t*>(idx + mo * C + cg * VN)[k];
+        for (int k = 0; k < VN / 4; ++k) packed[k] = reinterpret_cast<const uint32_t*>(is + mo * C + cg * VN)[k];
         float g[VN];
-        loadv<T>(dy + mo * C + cg * VN, g);
+        loadv<T>(dys + mo * C + cg * VN, g);
         int code = r * 3 + s;
 #pragma unroll
         for (int j = 0; j < VN; ++j)
           if ((int)((packed[j >> 2] >> (8 * (j & 3))) & 0xff) == code) acc[j] += g[j];
       }
     }
-    storev<T>(dx + m * C + cg * VN, acc);
+    storev<T>(dxs + m * C + cg * VN, acc);
   }
 }
 
@@ -226,33 +240,52 @@ int grid_for(long items) {
   else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(KERNEL<float>, GRID, dim3(256), 0, st, __VA_ARGS__); \
   else return FS_EINVAL;
 
-extern "C" int fs_maxpool_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int dtype,
-                              void* stream) {
+// x1 != NULL: a second tensor of N1 images with the same H, W, C in the same launch (the two encoders' stems)
+extern "C" int fs_maxpool_fwd2(const void* x, void* y, uint8_t* idx, int N, const void* x1, void* y1, uint8_t* idx1, int N1,
+                               int H, int W, int C, int dtype, void* stream) {
   const int vn = dtype == FS_DTYPE_BF16 ? 8 : 4;
-  if (!x || !y || !idx || C % vn != 0) return FS_EINVAL;
+  if (!x || !y || !idx || C % vn != 0 || N <= 0) return FS_EINVAL;
+  if (x1 && (!y1 || !idx1 || N1 <= 0)) return FS_EINVAL;
+  if (!x1) N1 = 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  dim3 grid(grid_for((long)N * Ho * Wo * (C / vn)));
+  const FsPoolPair pr{x1, y1, idx1, nullptr, x1 ? N : 0x7fffffff};
+  dim3 grid(grid_for((long)(N + N1) * Ho * Wo * (C / vn)));
   if (dtype == FS_DTYPE_BF16)
-    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, (bf16*)y, idx, N, H, W, C, Ho, Wo);
+    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, (bf16*)y, idx, N + N1, H, W, C, Ho, Wo, pr);
   else if (dtype == FS_DTYPE_F32)
-    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (float*)y, idx, N, H, W, C, Ho, Wo);
+    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (float*)y, idx, N + N1, H, W, C, Ho, Wo, pr);
+  else return FS_EINVAL;
+  return fs_launch_status();
+}
+
+extern "C" int fs_maxpool_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int dtype,
+                              void* stream) {
+  return fs_maxpool_fwd2(x, y, idx, N, nullptr, nullptr, nullptr, 0, H, W, C, dtype, stream);
+}
+
+extern "C" int fs_maxpool_bwd2(const void* dy, const uint8_t* idx, const void* addend, void* dx, int N, const void* dy1,
+                               const uint8_t* idx1, const void* addend1, void* dx1, int N1, int H, int W, int C, int dtype,
+                               void* stream) {
+  const int vn = dtype == FS_DTYPE_BF16 ? 8 : 4;
+  if (!dy || !dx || !idx || C % vn != 0 || N <= 0) return FS_EINVAL;
+  if (dy1 && (!dx1 || !idx1 || N1 <= 0)) return FS_EINVAL;
+  if (!dy1) N1 = 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const FsPoolPair pr{dy1, dx1, const_cast<uint8_t*>(idx1), addend1, dy1 ? N : 0x7fffffff};
+  dim3 grid(grid_for((long)(N + N1) * H * W * (C / vn)));
+  if (dtype == FS_DTYPE_BF16)
+    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)dy, idx, (const bf16*)addend, (bf16*)dx, N + N1, H, W, C, Ho, Wo, pr);
+  else if (dtype == FS_DTYPE_F32)
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)dy, idx, (const float*)addend, (float*)dx, N + N1, H, W, C, Ho, Wo, pr);
   else return FS_EINVAL;
   return fs_launch_status();
 }
 
 extern "C" int fs_maxpool_bwd(const void* dy, const uint8_t* idx, const void* addend, void* dx, int N, int H, int W,
                               int C, int dtype, void* stream) {
-  if (!dy || !dx || !idx || C % (dtype == FS_DTYPE_BF16 ? 8 : 4) != 0) return FS_EINVAL;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  dim3 grid(grid_for((long)N * H * W * (C / (dtype == FS_DTYPE_BF16 ? 8 : 4))));
-  if (dtype == FS_DTYPE_BF16)
-    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)dy, idx, (const bf16*)addend, (bf16*)dx, N, H, W, C, Ho, Wo);
-  else if (dtype == FS_DTYPE_F32)
-    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)dy, idx, (const float*)addend, (float*)dx, N, H, W, C, Ho, Wo);
-  else return FS_EINVAL;
-  return fs_launch_status();
+  return fs_maxpool_bwd2(dy, idx, addend, dx, N, nullptr, nullptr, nullptr, nullptr, 0, H, W, C, dtype, stream);
 }
 
 extern "C" int fs_upcat_pad_fwd(const void* a, const void* b, void* out, int N, int h, int w, int Ca, int Cb,

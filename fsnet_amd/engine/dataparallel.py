@@ -77,8 +77,15 @@ class DataParallelContext:
                     # (on the direct communicator: the engine creates no torch.distributed NCCL work object, ever)
                     self._direct.broadcast(arena.data, 0)
                     for b in meta_arch.buffers():
-                        if b.is_cuda:
-                            self._direct.broadcast(b if b.is_contiguous() else b.contiguous(), 0)
+                        if not b.is_cuda:
+                            raise RuntimeError("data parallel: buffer on %s — the direct communicator broadcasts device "
+                                               "memory only (move the module to the GPU first)" % b.device)
+                        if b.is_contiguous():
+                            self._direct.broadcast(b, 0)
+                        else:
+                            tmp = b.contiguous()
+                            self._direct.broadcast(tmp, 0)
+                            b.copy_(tmp)
                 else:
                     dist.broadcast(arena.data, src=0, group=self.group)
                     for b in meta_arch.buffers():
@@ -177,6 +184,12 @@ class DataParallelContext:
         that fails) before the eager step reuses it"""
         if self._direct is None:
             return
+        # a rank whose own capture succeeded still holds a hipGraph with this communicator's RCCL nodes: it goes first (a
+        # graph that outlives its communicator aborts the process when it is finally freed — see close())
+        for ref in self._graph_owners:
+            owner = ref()
+            if owner is not None:
+                owner.reset_graph()
         self._graph_owners = []
         self._direct.close()
         from .rccl_direct import DirectComm

@@ -15,7 +15,7 @@ import torch
 
 from ..hip import ops
 from ..hip.binding import raw_stream
-from ..hip.conv import ConvOp
+from ..hip.conv import ConvOp, run_specs
 from .runtime import RT, grad_of
 
 STAT_SLOTS = ops.STAT_SLOTS
@@ -87,10 +87,37 @@ def _current_stream(device=None):
     return s
 
 
-def _run_param_grads(op, dc, x, gw, gb, nb, pro=None):
-    op.wgrad(dc, x, gw, pro=pro)
-    if gb is not None:
-        ops.channel_sum(dc, gb, nb)
+def _run_param_grads(*item):
+    """one layer's weight (+ bias) gradient — item = (op, dc, x, gw, gb, nb, pro) — or the same layer of two networks in
+    one launch — item = ("lanes", [those tuples]) (fs_conv_wgrad2: one round of blocks, one slab arena, two dW)"""
+    lanes = item[1] if item[0] == "lanes" else [item]
+    run_specs([op.wgrad_spec(dc, x, gw, pro=pro) for (op, dc, x, gw, gb, nb, pro) in lanes])
+    for (op, dc, x, gw, gb, nb, pro) in lanes:
+        if gb is not None:
+            ops.channel_sum(dc, gb, nb)
+
+
+def accumulate_param_grads_multi(cls, ops_, dcs, xs, pros):
+    """ConvLayer.accumulate_param_grads for the same layer of the lanes of an EncoderPass: the lanes whose weights are
+    trained share one weight-gradient launch (deferred to the companion stream like a single layer's)"""
+    lanes = []
+    for cl, op, dc, x, pro in zip(cls, ops_, dcs, xs, pros):
+        gw = grad_of(cl.m.weight)
+        gb = grad_of(cl.m.bias) if cl.m.bias is not None else None
+        if gw is None:                       # frozen layer: nothing to accumulate (a lone trainable bias: its sum)
+            if gb is not None:
+                ops.channel_sum(dc, gb, cl.m.bias.numel())
+            continue
+        lanes.append((op, dc, x, gw, gb, cl.m.bias.numel() if gb is not None else 0, pro))
+    if not lanes:
+        return
+    item = lanes[0] if len(lanes) == 1 else ("lanes", lanes)
+    dc0 = lanes[0][1]
+    mode = RT.wgrad_streams if (dc0.is_cuda and RT.overlap and RT.dp is None) else 0
+    if mode:
+        _defer_param_grads(_current_stream(dc0.device), item)
+        return
+    _run_param_grads(*item)
 
 
 def _defer_param_grads(cur, item):
@@ -371,7 +398,54 @@ def _check_train_bn(bn, what):
 # ==============================================================================================
 # ResNet encoder
 # ==============================================================================================
+def _exchange(pool, tensors, out_of_place=False):
+    """Data-parallel exchange (SUM over the ranks) of f64 statistics slices taken from `pool`: slices that lie back to
+    back in the pool's buffer — the downsample branch's and the main branch's, the depth encoder's and the pose encoder's
+    of the same layer — travel in ONE collective.  In place, or (out_of_place) into fresh tensors that are returned in
+    the order of `tensors` while the inputs keep the local sums.  Returns (world size, results)."""
+    if RT.dp is None:
+        return 1, list(tensors)
+    base = pool.buf.untyped_storage().data_ptr() if pool is not None else None
+    idx = [i for i, t in enumerate(tensors) if t is not None]
+    inside = [i for i in idx if base is not None and tensors[i].untyped_storage().data_ptr() == base]
+    res = list(tensors)
+    runs, cur = [], []
+    for i in sorted(inside, key=lambda i: tensors[i].storage_offset()):
+        if cur and tensors[cur[-1]].storage_offset() + tensors[cur[-1]].numel() == tensors[i].storage_offset():
+            cur.append(i)
+        else:
+            if cur:
+                runs.append(cur)
+            cur = [i]
+    if cur:
+        runs.append(cur)
+    for run in runs:
+        lo = tensors[run[0]].storage_offset()
+        hi = tensors[run[-1]].storage_offset() + tensors[run[-1]].numel()
+        view = pool.buf[lo:hi]
+        if out_of_place:
+            out = torch.empty_like(view)
+            RT.dp.allreduce_small(view, out=out)
+            for i in run:
+                o = tensors[i].storage_offset() - lo
+                res[i] = out[o:o + tensors[i].numel()].view(tensors[i].shape)
+        else:
+            RT.dp.allreduce_small(view)
+    for i in idx:
+        if i in inside:
+            continue
+        if out_of_place:
+            res[i] = torch.empty_like(tensors[i])
+            RT.dp.allreduce_small(tensors[i], out=res[i])
+        else:
+            RT.dp.allreduce_small(tensors[i])
+    return RT.dp.world, res
+
+
 class ResNetRunner:
+    """One encoder's layers bound to their device plans.  Execution is EncoderPass's: forward / backward here run a
+    one-lane pass; MonoDepthMeta runs the depth and the pose encoder as the two lanes of one pass."""
+
     def __init__(self, module):
         self.m = module
         self.stem = ConvLayer(module.conv1, need_dgrad=False)
@@ -390,307 +464,459 @@ class ResNetRunner:
                 blocks.append((units, ds))
             self.stages.append(blocks)
         self.pool = None
+        self._solo = None
 
-    # ------------------------------------------------------------------ forward
-    def _unit_fwd_fold(self, cl, bn, x, pro=None):
-        """convolution + the batch statistics of its BatchNorm only (training mode): returns (raw output, BnState, what
-        the consumer needs to finalise it) — the consuming convolution derives scale / shift from the sums in its own
-        prologue, applies scale * c + shift and the ReLU while staging, and its block 0 fills the BnState (mean, invstd,
-        scale, shift: read by the backward) and updates the running statistics: no launch between the two convolutions"""
-        op = cl.ready(x.dtype, x.device)
-        N, H, W, _ = x.shape
-        Ho, Wo = op.out_hw(H, W)
-        G = self.groups
-        stats = self.pool.take(op.Co_p, G)
-        c = op.forward(x, stats=stats, stat_groups=G, pro=pro)
-        world = _dp_stats(stats)
-        st = ops.BnState(op.Co_p, x.device, G, affine=True)
-        st.count = float((N // G) * Ho * Wo * world)
-        return c, st, (stats, bn_tensors(bn), st.count, True)
+    def signature(self, train):
+        """what two encoders must share to run as the lanes of one pass: layer shapes, BatchNorm modes, which parameters
+        are trained (the pass takes every control-flow decision once for both lanes)"""
+        sig = []
 
-    def _can_fold(self, bn, nxt_cl, c_shape, dtype, device, train):
-        """unit -> next unit of a block: may the BatchNorm + ReLU in between be folded into the next convolution?"""
-        if not (FOLD_BN and FUSE_BN_BWD and train and bn.training):
-            return False
-        N, H, W = c_shape
-        nop = nxt_cl.ready(dtype, device)
-        if not (nop.can_fold_input(N, H, W) and nop.can_fuse_bn_bwd(N, H, W, self.groups) and N * H * W >= 1):
-            return False
-        return int(FOLD_BN) != 2 or nop.plan_3x3(N, H, W, forward=True, pro_mode=1)["kernel"] == "t32"
-
-    def _unit_fwd(self, cl, bn, x, train, relu=True, res=None, ds_c=None, ds_stats=None, ds_bn=None, pro=None):
-        op = cl.ready(x.dtype, x.device)
-        N, H, W, _ = x.shape
-        Ho, Wo = op.out_hw(H, W)
-        # a BatchNorm in eval mode inside a training step (norm_eval / frozen stages, resnet.py:169-197): running
-        # statistics, no update of them, one statistics group; its backward is the batch-statistics formula with the
-        # mean terms switched off (count = inf), dgamma / dbeta from the same sums
-        bt = train and bn.training
-        assert ds_bn is None or (train and ds_bn.training) == bt, "main and downsample BatchNorm modes differ"
-        G = self.groups if bt else 1
-        stats = self.pool.take(op.Co_p, G) if bt else None
-        c = op.forward(x, stats=stats, stat_groups=G, pro=pro)
-        if bt and ds_stats is not None and RT.dp is not None:
-            # block end with a downsample branch: its statistics sit right before this conv's in the pool (taken
-            # back to back) and are consumed by the same bn_apply — one exchange for both
-            both = self.pool.span(ds_stats, stats)
-            if both is not None:
-                RT.dp.allreduce_small(both)
-                world = RT.dp.world
-            else:
-                _dp_stats(ds_stats)
-                world = _dp_stats(stats)
-        else:
-            world = _dp_stats(stats) if bt else 1
-        y = torch.empty(N, Ho, Wo, op.Co_p, dtype=x.dtype, device=x.device)
-        st = ops.BnState(op.Co_p, x.device, G)
-        st2 = ops.BnState(op.Co_p, x.device, G) if ds_bn is not None else None
-        count = (N // G) * Ho * Wo * world if (bt or not train) else float("inf")
-        ops.bn_apply(c, stats, bn_tensors(bn), st, y, Ho, Wo, count, relu=relu,
-                     res=(ds_c if ds_bn is not None else res), stats2=(ds_stats if bt else None),
-                     bn2=(bn_tensors(ds_bn) if ds_bn is not None else None), st2=st2, track=bt, groups=G)
-        return c, y, st, st2
+        def unit(cl, bn):
+            w = cl.m.weight
+            sig.append((tuple(w.shape[2:]), w.shape[0], cl.stride, cl.pad, bool(train and bn.training), w.requires_grad,
+                        bn.weight.requires_grad, bn.bias.requires_grad))
+        unit(self.stem, self.m.bn1)
+        sig[0] = sig[0][:1] + ("stem",) + sig[0][2:]
+        for blocks in self.stages:
+            for units, ds in blocks:
+                for cl, bn in units:
+                    unit(cl, bn)
+                    sig[-1] = sig[-1] + (cl.m.weight.shape[1],)
+                sig.append(None if ds is None else "ds")
+                if ds is not None:
+                    unit(*ds)
+        return tuple(sig)
 
     def forward(self, x, train, groups=1):
         """x: NHWC [N,H,W,Ci_p] in the compute dtype.  Returns (features NHWC x5, ctx).
         groups G > 1 (training): x stacks G independent calls of the module along N — BatchNorm statistics,
         running-statistic updates and gradients are those of G separate calls in that order, the launches are
         shared (the pose encoder's two image pairs run as one pass)."""
-        if self.pool is None or self.pool.buf.device != x.device:
-            self.pool = StatsPool(x.device)
+        if self._solo is None:
+            self._solo = EncoderPass([self])
+        feats, ctx = self._solo.forward([x], train, [groups])
+        return feats[0], ctx
+
+    def backward(self, ctx, gfeats):
+        """gfeats: list of 5 NHWC dense gradients (or None).  Accumulates parameter gradients."""
+        self._solo.backward(ctx, [gfeats])
+
+
+class EncoderPass:
+    """Forward / backward of ONE ResNet — or of TWO of the same architecture in lockstep ("lanes"): the depth encoder on
+    the target images and the pose encoder on the stacked image pairs (monodepth2_model.py:24-43) run the same layer
+    shapes after their stems (resnet.py:199-213), so every launch of the pass carries both lanes' problems through the
+    fs_*2 entry points (include/fsnet_hip.h): one launch's fixed cost and, under data parallelism, one SyncBN exchange
+    per layer for both networks.  Everything per lane — tensors, weights, BatchNorm modules, statistics groups — is a
+    list over the lanes; every control-flow decision is taken once (ResNetRunner.signature guarantees they agree).
+    Numerically each lane is exactly its own pass: no arithmetic depends on the pairing."""
+
+    def __init__(self, runners):
+        self.R = list(runners)
+        self.nl = len(self.R)
+        self.pool = None
+
+    # ------------------------------------------------------------------ helpers
+    def _lanes(self, per_runner):
+        """[f(runner) for each lane]"""
+        return [per_runner(r) for r in self.R]
+
+    def _ready(self, cls, xs):
+        return [cl.ready(x.dtype, x.device) for cl, x in zip(cls, xs)]
+
+    # ------------------------------------------------------------------ forward
+    def _unit_fwd_fold(self, cls, bns, xs, pros):
+        """convolution + the batch statistics of its BatchNorm only (training mode): returns (raw outputs, BnStates, what
+        the consumer needs to finalise them) — the consuming convolution derives scale / shift from the sums in its own
+        prologue, applies scale * c + shift and the ReLU while staging, and its block 0 fills the BnState (mean, invstd,
+        scale, shift: read by the backward) and updates the running statistics: no launch between the two convolutions"""
+        ops_ = self._ready(cls, xs)
+        stats = [self.pool.take(op.Co_p, G) for op, G in zip(ops_, self.groups)]
+        specs = [op.forward_spec(x, stats=s, stat_groups=G, pro=p) for op, x, s, G, p in zip(ops_, xs, stats, self.groups, pros)]
+        run_specs(specs)
+        world, _ = _exchange(self.pool, stats)
+        cs, sts, fins = [], [], []
+        for op, x, sp, s, G, bn in zip(ops_, xs, specs, stats, self.groups, bns):
+            N, H, W, _ = x.shape
+            Ho, Wo = op.out_hw(H, W)
+            st = ops.BnState(op.Co_p, x.device, G, affine=True)
+            st.count = float((N // G) * Ho * Wo * world)
+            cs.append(sp.out); sts.append(st); fins.append((s, bn_tensors(bn), st.count, True))
+        return cs, sts, fins
+
+    def _can_fold(self, bns, nxt_cls, c_shapes, xs, train):
+        """unit -> next unit of a block: may the BatchNorm + ReLU in between be folded into the next convolution?"""
+        if not (FOLD_BN and FUSE_BN_BWD and train and bns[0].training):
+            return False
+        for bn, ncl, (N, H, W), x, G in zip(bns, nxt_cls, c_shapes, xs, self.groups):
+            nop = ncl.ready(x.dtype, x.device)
+            if not (nop.can_fold_input(N, H, W) and nop.can_fuse_bn_bwd(N, H, W, G) and N * H * W >= 1):
+                return False
+            if int(FOLD_BN) == 2 and nop.plan_3x3(N, H, W, forward=True, pro_mode=1)["kernel"] != "t32":
+                return False
+        return True
+
+    def _unit_fwd(self, cls, bns, xs, train, relu=True, res=None, ds_c=None, ds_stats=None, ds_bn=None, pros=None):
+        nl = self.nl
+        ops_ = self._ready(cls, xs)
+        # a BatchNorm in eval mode inside a training step (norm_eval / frozen stages, resnet.py:169-197): running
+        # statistics, no update of them, one statistics group; its backward is the batch-statistics formula with the
+        # mean terms switched off (count = inf), dgamma / dbeta from the same sums
+        bt = train and bns[0].training
+        assert all((train and bn.training) == bt for bn in bns), "lanes disagree on a BatchNorm's mode"
+        assert ds_bn is None or all((train and b.training) == bt for b in ds_bn), "main and downsample BatchNorm modes differ"
+        Gs = [G if bt else 1 for G in self.groups]
+        stats = [self.pool.take(op.Co_p, G) if bt else None for op, G in zip(ops_, Gs)]
+        pros = pros if pros is not None else [None] * nl
+        specs = [op.forward_spec(x, stats=s, stat_groups=G, pro=p) for op, x, s, G, p in zip(ops_, xs, stats, Gs, pros)]
+        run_specs(specs)
+        cs = [sp.out for sp in specs]
+        # block end with a downsample branch: its statistics were taken right before this conv's and are consumed by the
+        # same bn_apply — one exchange for both (and for both lanes)
+        world = 1
+        if bt:
+            world, _ = _exchange(self.pool, (list(ds_stats) if ds_stats is not None else []) + stats)
+        ys, sts, st2s, bspecs = [], [], [], []
+        for l in range(nl):
+            op, x, c = ops_[l], xs[l], cs[l]
+            N, H, W, _ = x.shape
+            Ho, Wo = op.out_hw(H, W)
+            y = torch.empty(N, Ho, Wo, op.Co_p, dtype=x.dtype, device=x.device)
+            st = ops.BnState(op.Co_p, x.device, Gs[l])
+            st2 = ops.BnState(op.Co_p, x.device, Gs[l]) if ds_bn is not None else None
+            count = (N // Gs[l]) * Ho * Wo * world if (bt or not train) else float("inf")
+            bspecs.append(ops.bn_apply_spec(
+                c, stats[l], bn_tensors(bns[l]), st, y, Ho, Wo, count, relu=relu,
+                res=(ds_c[l] if ds_bn is not None else (res[l] if res is not None else None)),
+                stats2=(ds_stats[l] if (bt and ds_stats is not None) else None),
+                bn2=(bn_tensors(ds_bn[l]) if ds_bn is not None else None), st2=st2, track=bt, groups=Gs[l]))
+            ys.append(y); sts.append(st); st2s.append(st2)
+        run_specs(bspecs)
+        return cs, ys, sts, st2s
+
+    def forward(self, xs, train, groups):
+        """xs: per lane NHWC [N,H,W,Ci_p] in the compute dtype; groups: per lane statistics groups (see
+        ResNetRunner.forward).  Returns (per lane: 5 features NHWC, ctx)."""
+        nl = self.nl
+        dev = xs[0].device
+        if self.pool is None or self.pool.buf.device != dev:
+            self.pool = StatsPool(dev)
         self.pool.reset()
-        self.groups = groups if train else 1
-        assert x.shape[0] % self.groups == 0
-        ctx = {"x": x, "blocks": []}
-        c0, y0, st0, _ = self._unit_fwd(self.stem, self.m.bn1, x, train)
-        pooled, idx = ops.maxpool_fwd(y0)
-        ctx.update(c0=c0, y0=y0, st0=st0, idx=idx)
-        feats = [y0]
-        cur = pooled
-        for blocks in self.stages:
-            for units, ds in blocks:
+        self.groups = [g if train else 1 for g in groups]
+        assert all(x.shape[0] % g == 0 for x, g in zip(xs, self.groups))
+        ctx = {"x": xs, "blocks": [], "train": train}
+        c0, y0, st0, _ = self._unit_fwd(self._lanes(lambda r: r.stem), self._lanes(lambda r: r.m.bn1), xs, train)
+        pooled = ops.maxpool_fwd_multi(y0)
+        ctx.update(c0=c0, y0=y0, st0=st0, idx=[p[1] for p in pooled])
+        feats = [[y] for y in y0]
+        cur = [p[0] for p in pooled]
+        for si in range(len(self.R[0].stages)):
+            for bi in range(len(self.R[0].stages[si])):
+                units = [r.stages[si][bi][0] for r in self.R]          # per lane: [(ConvLayer, bn)]
+                dss = [r.stages[si][bi][1] for r in self.R]
+                ds = None if dss[0] is None else dss
+                nu = len(units[0])
                 bctx = {"x": cur, "u": []}
                 # pro: inp is a raw conv output, (BnState, relu) still to be applied — what the weight gradient and the
                 # saved context carry; fin: + (sums, BatchNorm tensors, count, track) for the forward launch that
                 # finalises the statistics itself
-                inp, pro, fin = cur, None, None
-                for j, (cl, bn) in enumerate(units):
-                    if j < len(units) - 1:
-                        op = cl.ready(inp.dtype, inp.device)
-                        Ho, Wo = op.out_hw(inp.shape[1], inp.shape[2])
-                        if self._can_fold(bn, units[j + 1][0], (inp.shape[0], Ho, Wo), inp.dtype, inp.device, train):
-                            c, st, fnext = self._unit_fwd_fold(cl, bn, inp, pro=fin)
+                inp, pro, fin = cur, [None] * nl, [None] * nl
+                for j in range(nu):
+                    cls = [u[j][0] for u in units]
+                    bns = [u[j][1] for u in units]
+                    if j < nu - 1:
+                        ops_ = self._ready(cls, inp)
+                        shapes = [(x.shape[0],) + op.out_hw(x.shape[1], x.shape[2]) for op, x in zip(ops_, inp)]
+                        if self._can_fold(bns, [u[j + 1][0] for u in units], shapes, inp, train):
+                            c, st, fnext = self._unit_fwd_fold(cls, bns, inp, fin)
                             bctx["u"].append((inp, c, None, st, pro))
-                            inp, pro, fin = c, (st, True), (st, True) + fnext
+                            inp, pro = c, [(s, True) for s in st]
+                            fin = [(s, True) + f for s, f in zip(st, fnext)]
                         else:
-                            c, y, st, _ = self._unit_fwd(cl, bn, inp, train, pro=fin)
+                            c, y, st, _ = self._unit_fwd(cls, bns, inp, train, pros=fin)
                             bctx["u"].append((inp, c, y, st, pro))
-                            inp, pro, fin = y, None, None
+                            inp, pro, fin = y, [None] * nl, [None] * nl
                     else:
                         if ds is not None:
-                            dop = ds[0].ready(cur.dtype, cur.device)
-                            dbt = train and ds[1].training
-                            dstats = self.pool.take(dop.Co_p, self.groups) if dbt else None
-                            c_ds = dop.forward(cur, stats=dstats, stat_groups=(self.groups if dbt else 1))
+                            dcl = [d[0] for d in ds]
+                            dbn = [d[1] for d in ds]
+                            dops = self._ready(dcl, cur)
+                            dbt = train and dbn[0].training
+                            dG = [G if dbt else 1 for G in self.groups]
+                            dstats = [self.pool.take(dop.Co_p, G) if dbt else None for dop, G in zip(dops, dG)]
+                            dspecs = [dop.forward_spec(x, stats=s, stat_groups=G) for dop, x, s, G in zip(dops, cur, dstats, dG)]
+                            run_specs(dspecs)
+                            c_ds = [sp.out for sp in dspecs]
                             # (data parallel: exchanged together with the main branch's statistics in _unit_fwd)
-                            c, y, st, st2 = self._unit_fwd(cl, bn, inp, train, ds_c=c_ds, ds_stats=dstats, ds_bn=ds[1], pro=fin)
+                            c, y, st, st2 = self._unit_fwd(cls, bns, inp, train, ds_c=c_ds,
+                                                           ds_stats=(dstats if dbt else None), ds_bn=dbn, pros=fin)
                             bctx["ds"] = (c_ds, st2)
                         else:
-                            c, y, st, _ = self._unit_fwd(cl, bn, inp, train, res=cur, pro=fin)
+                            c, y, st, _ = self._unit_fwd(cls, bns, inp, train, res=cur, pros=fin)
                         bctx["u"].append((inp, c, y, st, pro))
-                        inp, pro, fin = y, None, None
+                        inp, pro, fin = y, [None] * nl, [None] * nl
                 ctx["blocks"].append(bctx)
                 cur = inp
-            feats.append(cur)
+            for l in range(nl):
+                feats[l].append(cur[l])
         return feats, ctx
 
     # ------------------------------------------------------------------ backward
-    def _pend(self, g, c, st, bn, sums):
+    def _pool_bwd(self, dev):
+        return _BWD_POOLS[(dev, raw_stream(dev.index))]
+
+    def _sums(self, cs, sts):
+        """zeroed f64 [groups][SLOTS][2][C] per lane from the current stream's backward pool, back to back"""
+        return [_bwd_sums(c, st) for c, st in zip(cs, sts)]
+
+    def _bn_bwd(self, douts, ys, cs, bns, sts, relu=True, g_out=None, sums=None):
+        """sums given: douts are already ReLU-masked and the sums are accumulated (fused into the producing dgrad).
+        Returns the BatchNorm input gradients, per lane."""
+        nl = self.nl
+        reduced = sums is not None
+        if sums is None:
+            sums = self._sums(cs, sts)
+        dcs = [torch.empty_like(c) for c in cs]
+        calls = []
+        for l in range(nl):
+            c, st, bn = cs[l], sts[l], bns[l]
+            calls.append(dict(dout=douts[l], y=(ys[l] if ys is not None else None), x=c, gamma=bn.weight.data, st=st, dx=dcs[l],
+                              dgamma=grad_of(bn.weight), dbeta=grad_of(bn.bias), H=c.shape[1], W=c.shape[2], relu=relu,
+                              g_out=(g_out[l] if g_out is not None else None), sums=sums[l], sums_zeroed=True, reduced=reduced))
+        # (eval-mode BatchNorm: st.count is inf — no batch-statistics terms in dx, hence no exchange of the sums either)
+        sync = RT.dp is not None and sts[0].count != float("inf")
+        pool = self._pool_bwd(cs[0].device)
+        if sync:
+            if not reduced:
+                ops.bn_backward_multi(calls, phase="reduce")
+            _, globs = _exchange(pool, sums, out_of_place=True)
+            for cl, g in zip(calls, globs):
+                cl["glob"] = g
+            ops.bn_backward_multi(calls, phase="apply")
+        else:
+            ops.bn_backward_multi(calls)
+        return dcs
+
+    def _pend(self, gs, cs, sts, bns, sums):
         """a BatchNorm backward whose second pass is left to the data gradient of the convolution in front of it: g = the
         masked gradient w.r.t. the BatchNorm output, sums = (sum g, sum g*xhat) of the local shard.  Data parallel: the
         global sums are exchanged here, dgamma / dbeta come from the local ones."""
-        glob, local = sums, None
-        if RT.dp is not None and st.count != float("inf"):
-            glob = torch.empty_like(sums)
-            RT.dp.allreduce_small(sums, out=glob)
+        glob, local = sums, [None] * self.nl
+        if RT.dp is not None and sts[0].count != float("inf"):
+            _, glob = _exchange(self._pool_bwd(cs[0].device), sums, out_of_place=True)
             local = sums
-        return dict(g=g, c=c, st=st, bn=bn, sums=glob, sums_local=local)
+        return [dict(g=g, c=c, st=st, bn=bn, sums=gl, sums_local=lo)
+                for g, c, st, bn, gl, lo in zip(gs, cs, sts, bns, glob, local)]
 
     @staticmethod
     def _pend_kw(pend):
-        """ConvOp.dgrad arguments of a pending BatchNorm backward: (source gradient, kwargs, the tensor that receives
-        the BatchNorm input gradient)"""
-        dc = torch.empty_like(pend["c"])
-        bn = pend["bn"]
-        return pend["g"], dict(pro_bwd=dict(c=pend["c"], st=pend["st"], gamma=bn.weight.data, sums=pend["sums"],
-                                            sums_local=pend["sums_local"], dgamma=grad_of(bn.weight),
-                                            dbeta=grad_of(bn.bias), dc_out=dc)), dc
+        """ConvOp.dgrad arguments of the pending BatchNorm backwards: (source gradients, kwargs, the tensors that receive
+        the BatchNorm input gradients), per lane"""
+        srcs, kws, dcs = [], [], []
+        for pd in pend:
+            dc = torch.empty_like(pd["c"])
+            bn = pd["bn"]
+            srcs.append(pd["g"])
+            kws.append(dict(pro_bwd=dict(c=pd["c"], st=pd["st"], gamma=bn.weight.data, sums=pd["sums"],
+                                         sums_local=pd["sums_local"], dgamma=grad_of(bn.weight),
+                                         dbeta=grad_of(bn.bias), dc_out=dc)))
+            dcs.append(dc)
+        return srcs, kws, dcs
 
-    def _can_fold_bwd(self, op, bn, st, c):
-        if not (FOLD_BN_BWD and FUSE_BN_BWD and st.count != float("inf")
-                and op.can_fold_bn_bwd(c.shape[0], c.shape[1], c.shape[2])):
+    def _can_fold_bwd(self, ops_, bns, sts, cs):
+        if not (FOLD_BN_BWD and FUSE_BN_BWD and sts[0].count != float("inf")):
             return False
-        return int(FOLD_BN_BWD) != 2 or op.plan_3x3(c.shape[0], c.shape[1], c.shape[2], forward=False, pro_mode=2)["kernel"] == "t32"
+        for op, c in zip(ops_, cs):
+            if not op.can_fold_bn_bwd(c.shape[0], c.shape[1], c.shape[2]):
+                return False
+            if int(FOLD_BN_BWD) == 2 and op.plan_3x3(c.shape[0], c.shape[1], c.shape[2], forward=False, pro_mode=2)["kernel"] != "t32":
+                return False
+        return True
+
+    def _dgrad(self, ops_, srcs, hws, kws):
+        """one data gradient per lane in one launch: kws = per lane keyword dicts of ConvOp.dgrad_spec"""
+        specs = [op.dgrad_spec(src, hw[0], hw[1], **kw) for op, src, hw, kw in zip(ops_, srcs, hws, kws)]
+        run_specs(specs)
+        return [sp.out for sp in specs]
+
+    def _param_grads(self, cls, ops_, dcs, xs, pros=None):
+        accumulate_param_grads_multi(cls, ops_, dcs, xs, pros if pros is not None else [None] * self.nl)
 
     def _block_bwd(self, units, ds, bctx, dout, extra, dout_sums=None, prev=None):
         """dout: gradient w.r.t. the block output.  dout_sums: set when dout came out of a data-gradient epilogue
         that already masked it with this block's output ReLU and accumulated the BatchNorm-backward sums.
         prev = (y, c, BnState) of the block that consumes the returned gradient (fused the same way).
+        units: per lane [(ConvLayer, bn)], ds: per lane (ConvLayer, bn) or None; every tensor argument is a per-lane list.
 
         A BatchNorm whose masked output gradient and backward sums exist (they come out of the epilogue of the data
         gradient behind it) does not get a second pass of its own where the convolution in front of it is a 3x3 /
         stride-1 one: that convolution's data gradient applies dx = gamma*invstd*(g - mean_g - xhat*mean_gx) to dY while it
         stages it (`pend`), writes it out once, and the weight gradient reads that."""
+        nl = self.nl
         x = bctx["x"]
-        N, H, W, _ = x.shape
-        k = len(units)
+        hw_x = [(t.shape[1], t.shape[2]) for t in x]
+        k = len(units[0])
         inp, c, y, st, pro_in = bctx["u"][k - 1]
-        Ho, Wo = y.shape[1], y.shape[2]
-        op_last = units[k - 1][0].ready(x.dtype, x.device)
-        bn_last = units[k - 1][1]
+        cls_last = [u[k - 1][0] for u in units]
+        bn_last = [u[k - 1][1] for u in units]
+        op_last = self._ready(cls_last, x)
         fold_last = dout_sums is not None and self._can_fold_bwd(op_last, bn_last, st, c)
         pend, dc = None, None
-        joint = (ds is not None and RT.dp is not None and st.count != float("inf")
-                 and bctx["ds"][1].count != float("inf"))
+        joint = (ds is not None and RT.dp is not None and st[0].count != float("inf")
+                 and bctx["ds"][1][0].count != float("inf"))
         if joint:
             # data parallel: the block's last BatchNorm and its downsample BatchNorm take the same gradient — both
-            # first passes run before ONE exchange of their (adjacent) sums, then both second passes
+            # first passes run before ONE exchange of their (adjacent) sums — of both lanes —, then both second passes
             c_ds, st2 = bctx["ds"]
-            dop = ds[0].ready(x.dtype, x.device)
-            bn_m, bn_d = bn_last, ds[1]
+            bn_d = [d[1] for d in ds]
             fused_in = dout_sums is not None
-            pool = _BWD_POOLS[(c.device, raw_stream(c.device.index))]
-            s_m = dout_sums if fused_in else _bwd_sums(c, st)
-            s_d = _bwd_sums(c_ds, st2)
-            dc_ds = torch.empty_like(c_ds)
+            pool = self._pool_bwd(c[0].device)
+            s_m = dout_sums if fused_in else self._sums(c, st)
+            s_d = self._sums(c_ds, st2)
+            dc_ds = [torch.empty_like(t) for t in c_ds]
             if not fold_last:
-                dc = torch.empty_like(c)
-            g = dout if fused_in else torch.empty_like(c)
+                dc = [torch.empty_like(t) for t in c]
+            g = dout if fused_in else [torch.empty_like(t) for t in c]
+
+            def call(l, dout_l, y_l, x_l, bn, st_l, dx_l, relu, sums, **kw):
+                return dict(dout=dout_l, y=y_l, x=x_l, gamma=bn.weight.data, st=st_l, dx=dx_l, dgamma=kw.pop("dgamma", None),
+                            dbeta=kw.pop("dbeta", None), H=x_l.shape[1], W=x_l.shape[2], relu=relu, sums=sums,
+                            sums_zeroed=True, **kw)
             if not fused_in:
-                ops.bn_backward(dout, y, c, bn_m.weight.data, st, dc, None, None, Ho, Wo, relu=True, sums=s_m,
-                                sums_zeroed=True, phase="reduce")
+                ops.bn_backward_multi([call(l, dout[l], y[l], c[l], bn_last[l], st[l], dc[l] if dc is not None else None, True, s_m[l])
+                                       for l in range(nl)], phase="reduce")
             # (the downsample branch's sums need the masked gradient: dout with this block's ReLU mask, or the
             # already masked gradient of a fused producer)
-            ops.bn_backward(dout, None if fused_in else y, c_ds, bn_d.weight.data, st2, dc_ds, None, None, Ho, Wo,
-                            relu=not fused_in, sums=s_d, sums_zeroed=True, phase="reduce")
-            both = pool.span(s_m, s_d)
-            if both is not None:
-                glob = torch.empty_like(both)
-                RT.dp.allreduce_small(both, out=glob)
-                g_m, g_d = glob[: s_m.numel()].view(s_m.shape), glob[s_m.numel():].view(s_d.shape)
-            else:
-                g_m, g_d = torch.empty_like(s_m), torch.empty_like(s_d)
-                RT.dp.allreduce_small(s_m, out=g_m)
-                RT.dp.allreduce_small(s_d, out=g_d)
+            ops.bn_backward_multi([call(l, dout[l], None if fused_in else y[l], c_ds[l], bn_d[l], st2[l], dc_ds[l],
+                                        not fused_in, s_d[l]) for l in range(nl)], phase="reduce")
+            _, globs = _exchange(pool, list(s_m) + list(s_d), out_of_place=True)
+            g_m, g_d = globs[:nl], globs[nl:]
             if fold_last:
-                pend = dict(g=g, c=c, st=st, bn=bn_m, sums=g_m, sums_local=s_m)
+                pend = [dict(g=g[l], c=c[l], st=st[l], bn=bn_last[l], sums=g_m[l], sums_local=s_m[l]) for l in range(nl)]
             else:
-                ops.bn_backward(dout, None if fused_in else y, c, bn_m.weight.data, st, dc, grad_of(bn_m.weight),
-                                grad_of(bn_m.bias), Ho, Wo, relu=not fused_in, g_out=(None if fused_in else g), sums=s_m,
-                                sums_zeroed=True, reduced=fused_in, phase="apply", glob=g_m)
-            ops.bn_backward(g, None, c_ds, bn_d.weight.data, st2, dc_ds, grad_of(bn_d.weight), grad_of(bn_d.bias), Ho, Wo,
-                            relu=False, sums=s_d, sums_zeroed=True, phase="apply", glob=g_d)
+                ops.bn_backward_multi([call(l, dout[l], None if fused_in else y[l], c[l], bn_last[l], st[l], dc[l],
+                                            not fused_in, s_m[l], g_out=(None if fused_in else g[l]), reduced=fused_in,
+                                            glob=g_m[l], dgamma=grad_of(bn_last[l].weight), dbeta=grad_of(bn_last[l].bias))
+                                       for l in range(nl)], phase="apply")
+            ops.bn_backward_multi([call(l, g[l], None, c_ds[l], bn_d[l], st2[l], dc_ds[l], False, s_d[l], glob=g_d[l],
+                                        dgamma=grad_of(bn_d[l].weight), dbeta=grad_of(bn_d[l].bias)) for l in range(nl)],
+                                  phase="apply")
         elif dout_sums is not None:
             g = dout
             if fold_last:
                 pend = self._pend(g, c, st, bn_last, dout_sums)
             else:
-                dc = _bn_bwd(dout, None, c, bn_last, st, Ho, Wo, sums=dout_sums)
+                dc = self._bn_bwd(dout, None, c, bn_last, st, sums=dout_sums)
         else:
-            g = torch.empty_like(c)
-            dc = _bn_bwd(dout, y, c, bn_last, st, Ho, Wo, relu=True, g_out=g)
+            g = [torch.empty_like(t) for t in c]
+            dc = self._bn_bwd(dout, y, c, bn_last, st, relu=True, g_out=g)
         if ds is not None:
             c_ds, st2 = bctx["ds"]
-            dop = ds[0].ready(x.dtype, x.device)
+            dcl = [d[0] for d in ds]
+            dop = self._ready(dcl, x)
             if not joint:
-                dc_ds = _bn_bwd(g, None, c_ds, ds[1], st2, Ho, Wo, relu=False)
-            ds[0].accumulate_param_grads(dop, dc_ds, x)
-            dres = dop.dgrad(dc_ds, H, W, addend=extra)
+                dc_ds = self._bn_bwd(g, None, c_ds, [d[1] for d in ds], st2, relu=False)
+            self._param_grads(dcl, dop, dc_ds, x)
+            dres = self._dgrad(dop, dc_ds, hw_x, [dict(addend=(extra[l] if extra is not None else None)) for l in range(nl)])
         else:
             assert extra is None
             dres = g
         for j in range(k - 1, 0, -1):
-            cl = units[j][0]
-            op = cl.ready(x.dtype, x.device)
+            cls = [u[j][0] for u in units]
+            op = self._ready(cls, x)
             xin, pro_x = inp, pro_in                 # the input of convolution j (raw + prologue where the forward folded)
             inp, c, y, st, pro_in = bctx["u"][j - 1]
-            src, kw = dc, {}
+            hw_in = [(t.shape[1], t.shape[2]) for t in xin]
+            src, kw = dc, [dict() for _ in range(nl)]
             if pend is not None:
                 src, kw, dc = self._pend_kw(pend)
             sums = None
             if y is None:
                 # folded BatchNorm: the activation was never stored — the ReLU mask is the sign of scale * c + shift,
                 # evaluated (with the BatchNorm-backward sums) in the data gradient's epilogue from c
-                sums = _bwd_sums(c, st)
-                dy_prev = op.dgrad(src, xin.shape[1], xin.shape[2], bn_fuse=(c, st, sums), mask_bn=True, **kw)
-            elif FUSE_BN_BWD and op.can_fuse_bn_bwd(N, xin.shape[1], xin.shape[2], st.groups):
-                sums = _bwd_sums(c, st)
-                dy_prev = op.dgrad(src, xin.shape[1], xin.shape[2], mask=y, bn_fuse=(c, st, sums), **kw)
+                sums = self._sums(c, st)
+                dy_prev = self._dgrad(op, src, hw_in, [dict(bn_fuse=(c[l], st[l], sums[l]), mask_bn=True, **kw[l]) for l in range(nl)])
+            elif FUSE_BN_BWD and all(o.can_fuse_bn_bwd(t.shape[0], t.shape[1], t.shape[2], s.groups) for o, t, s in zip(op, xin, st)):
+                sums = self._sums(c, st)
+                dy_prev = self._dgrad(op, src, hw_in, [dict(mask=y[l], bn_fuse=(c[l], st[l], sums[l]), **kw[l]) for l in range(nl)])
             else:
-                dy_prev = op.dgrad(src, xin.shape[1], xin.shape[2], **kw)
+                dy_prev = self._dgrad(op, src, hw_in, kw)
             # (after the data gradient: with a pending BatchNorm backward, dc is its side output)
-            cl.accumulate_param_grads(op, dc, xin, pro=pro_x)
-            bn_prev = units[j - 1][1]
+            self._param_grads(cls, op, dc, xin, pro_x)
+            cls_prev = [u[j - 1][0] for u in units]
+            bn_prev = [u[j - 1][1] for u in units]
             pend = None
-            if sums is not None and self._can_fold_bwd(units[j - 1][0].ready(x.dtype, x.device), bn_prev, st, c):
+            if sums is not None and self._can_fold_bwd(self._ready(cls_prev, x), bn_prev, st, c):
                 pend = self._pend(dy_prev, c, st, bn_prev, sums)
             elif sums is not None:
-                dc = _bn_bwd(dy_prev, None, c, bn_prev, st, c.shape[1], c.shape[2], sums=sums)
+                dc = self._bn_bwd(dy_prev, None, c, bn_prev, st, sums=sums)
             else:
-                dc = _bn_bwd(dy_prev, y, c, bn_prev, st, y.shape[1], y.shape[2], relu=True)
-        cl = units[0][0]
-        op = cl.ready(x.dtype, x.device)
-        src, kw = dc, {}
+                dc = self._bn_bwd(dy_prev, y, c, bn_prev, st, relu=True)
+        cls = [u[0][0] for u in units]
+        op = self._ready(cls, x)
+        src, kw = dc, [dict() for _ in range(nl)]
         if pend is not None:
             src, kw, dc = self._pend_kw(pend)
-        if prev is not None and FUSE_BN_BWD and op.can_fuse_bn_bwd(N, H, W, prev[2].groups):
+        if prev is not None and FUSE_BN_BWD and all(o.can_fuse_bn_bwd(t.shape[0], t.shape[1], t.shape[2], p.groups)
+                                                    for o, t, p in zip(op, x, prev[2])):
             py, pc, pst = prev
-            sums = _bwd_sums(pc, pst)
-            out = op.dgrad(src, H, W, addend=dres, mask=py, bn_fuse=(pc, pst, sums), **kw), sums
+            sums = self._sums(pc, pst)
+            out = self._dgrad(op, src, hw_x, [dict(addend=dres[l], mask=py[l], bn_fuse=(pc[l], pst[l], sums[l]), **kw[l])
+                                               for l in range(nl)]), sums
         else:
-            out = op.dgrad(src, H, W, addend=dres, **kw), None
-        cl.accumulate_param_grads(op, dc, x)
+            out = self._dgrad(op, src, hw_x, [dict(addend=dres[l], **kw[l]) for l in range(nl)]), None
+        self._param_grads(cls, op, dc, x)
         return out
 
     def backward(self, ctx, gfeats):
-        """gfeats: list of 5 NHWC dense gradients (or None).  Accumulates parameter gradients."""
-        nst = len(self.stages)
-        bwd_pool_reset(ctx["x"].device)
-        tag = "enc%d" % ctx["x"].shape[0]
+        """gfeats: per lane a list of 5 NHWC dense gradients (or None).  Accumulates parameter gradients."""
+        nl = self.nl
+        R0 = self.R[0]
+        nst = len(R0.stages)
+        xs = ctx["x"]
+        bwd_pool_reset(xs[0].device)
+        tag = "enc%d" % sum(x.shape[0] for x in xs)
         RT.mark(tag + ".bwd.start")
-        dout = gfeats[nst]
         last = ctx["blocks"][-1]["u"][-1][2]
-        if dout is None:
-            dout = torch.zeros_like(last)
+        dout = [gfeats[l][nst] if gfeats[l][nst] is not None else torch.zeros_like(last[l]) for l in range(nl)]
         bi = len(ctx["blocks"])
         dsums = None
         for si in range(nst - 1, -1, -1):
-            blocks = self.stages[si]
-            for b in range(len(blocks) - 1, -1, -1):
+            nblk = len(R0.stages[si])
+            for b in range(nblk - 1, -1, -1):
                 bi -= 1
-                units, ds = blocks[b]
-                extra = gfeats[si] if (b == 0 and si > 0) else None
-                if extra is not None and ds is None:
-                    raise NotImplementedError("feature gradient into a block without downsample")
+                units = [r.stages[si][b][0] for r in self.R]
+                dss = [r.stages[si][b][1] for r in self.R]
+                ds = None if dss[0] is None else dss
+                extra = None
+                if b == 0 and si > 0 and any(gfeats[l][si] is not None for l in range(nl)):
+                    if ds is None:
+                        raise NotImplementedError("feature gradient into a block without downsample")
+                    # (per lane: one lane's decoder reads this feature, the other's does not — the pose decoder only takes
+                    # the last one; the shared launch's epilogue options are per problem)
+                    extra = [gfeats[l][si] for l in range(nl)]
                 prev = None
-                if bi > 0 and not (b == 0 and gfeats[si] is not None and ds is None):
+                if bi > 0 and not (b == 0 and any(gfeats[l][si] is not None for l in range(nl)) and ds is None):
                     pu = ctx["blocks"][bi - 1]["u"][-1]
                     # the consumer of the returned gradient is the previous block's output BatchNorm, unless a
                     # feature gradient still has to be added to it first (stage boundary without downsample)
                     prev = (pu[2], pu[1], pu[3])
                 dout, dsums = self._block_bwd(units, ds, ctx["blocks"][bi], dout, extra, dout_sums=dsums, prev=prev)
-            if RT.dp is not None and si >= 2 and self.m._pending == 1:
-                # (only the module's LAST pending backward of the step: an encoder that ran several training forwards —
-                # the pose encoder with FSNET_AMD_BATCH_POSE=0 — accumulates every call's gradients first; a slice
-                # reduced after the first backward would be reduced again with the second one's local sums on top)
-                # gradient bucket of this stage (reverse parameter order, like DDP): layer4 and layer3 carry 94 % of
-                # the encoder's parameters and finish first
-                RT.dp.partial_ready(self.m, [getattr(self.m, "layer%d" % (si + 1))])
+            if RT.dp is not None and si >= 2:
+                for r in self.R:
+                    if r.m._pending == 1:
+                        # (only the module's LAST pending backward of the step: an encoder that ran several training forwards —
+                        # the pose encoder with FSNET_AMD_BATCH_POSE=0 — accumulates every call's gradients first; a slice
+                        # reduced after the first backward would be reduced again with the second one's local sums on top)
+                        # gradient bucket of this stage (reverse parameter order, like DDP): layer4 and layer3 carry 94 % of
+                        # the encoder's parameters and finish first
+                        RT.dp.partial_ready(r.m, [getattr(r.m, "layer%d" % (si + 1))])
         y0 = ctx["y0"]
-        d0 = ops.maxpool_bwd(dout, ctx["idx"], y0.shape[1], y0.shape[2], addend=gfeats[0])
-        dc0 = _bn_bwd(d0, y0, ctx["c0"], self.m.bn1, ctx["st0"], y0.shape[1], y0.shape[2], relu=True)
-        op = self.stem.ready(y0.dtype, y0.device)
-        self.stem.accumulate_param_grads(op, dc0, ctx["x"])
+        add0 = [gfeats[l][0] for l in range(nl)]
+        d0 = ops.maxpool_bwd_multi(dout, ctx["idx"], y0[0].shape[1], y0[0].shape[2], add0)
+        dc0 = self._bn_bwd(d0, y0, ctx["c0"], [r.m.bn1 for r in self.R], ctx["st0"], relu=True)
+        stems = [r.stem for r in self.R]
+        self._param_grads(stems, self._ready(stems, y0), dc0, xs)
         RT.mark(tag + ".bwd.end")
         flush_deferred(_current_stream(), spread=True)
 

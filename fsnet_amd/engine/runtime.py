@@ -28,6 +28,9 @@ class _Runtime:
         self.wgrad_spread = 1
         # the pose encoder's image pairs as one stacked pass with per-pair BatchNorm statistics
         self.batch_pose_pairs = os.environ.get("FSNET_AMD_BATCH_POSE", "1") != "0"
+        # the depth encoder and the stacked pose encoder as the two lanes of ONE pass: every post-stem launch carries
+        # both networks' problems (EncoderPass in nets.py; fs_*2 entry points).  0: two passes on two streams (round 1-4)
+        self.lanes = os.environ.get("FSNET_AMD_LANES", "1") != "0"
         self._side = {}
         self._held = {}           # raw stream handle -> Stream: every stream the engine created (see new_stream)
         # FSNET_AMD_MARKS=1: device-clock marks along the step (mark() below), read back with marks_report()

@@ -40,6 +40,70 @@ def _timed(kind, flops, fn, tag=None):
     return r
 
 
+class Spec:
+    """Arguments of ONE launch, built but not issued: `chain` names the C entry points to try in order (fs_<name>; a
+    status of FS_EINVAL from all but the last means "not mine"), `a` is the argument struct, `out` what the caller gets
+    back.  run_specs() issues one spec, or two as ONE launch through the fs_<name>2 entry points (include/fsnet_hip.h,
+    "Two problems per launch"): the depth encoder's and the stacked pose encoder's layer of the same shape."""
+    __slots__ = ("chain", "a", "code", "kind", "work", "tag", "out", "what")
+
+    def __init__(self, chain, a, code, kind, work, tag, out, what):
+        self.chain, self.a, self.code, self.kind, self.work, self.tag, self.out, self.what = chain, a, code, kind, work, tag, out, what
+
+
+# entry points that have a two-problem form
+DUAL_ENTRIES = {"conv3x3_halo", "conv_igemm", "conv_stem", "conv_wgrad", "bn_apply", "bn_bwd_reduce", "bn_bwd_apply"}
+
+
+def _run_chain(chain, a0, a1, code, what):
+    """-> name of the entry point that took the launch"""
+    for k, name in enumerate(chain):
+        if a1 is None:
+            status = getattr(lib, "fs_" + name)(C.byref(a0), code, stream_ptr())
+        else:
+            status = getattr(lib, "fs_" + name + "2")(C.byref(a0), C.byref(a1), code, stream_ptr())
+        if status == 1 and k + 1 < len(chain):      # FS_EINVAL = "not mine": the next entry point of the chain
+            continue
+        check(status, what)
+        return name
+    raise AssertionError("empty launch chain")
+
+
+def run_specs(specs):
+    """issue the launches; two specs whose chains agree run as one launch (the library falls back to two when the
+    problems do not agree on a kernel instantiation — results never depend on the pairing)"""
+    specs = [sp for sp in specs if sp is not None]
+    if len(specs) == 2 and specs[0].chain == specs[1].chain and specs[0].code == specs[1].code \
+            and all(n in DUAL_ENTRIES for n in specs[0].chain):
+        s0, s1 = specs
+        if not LaunchProfile.active:
+            _run_chain(s0.chain, s0.a, s1.a, s0.code, s0.what)
+            return
+        taken = [None]
+
+        def go():
+            taken[0] = _run_chain(s0.chain, s0.a, s1.a, s0.code, s0.what)
+        kind = s0.kind(s1) if callable(s0.kind) else s0.kind
+        _timed(kind, s0.work + s1.work, go, tag=lambda: "%s || %s" % (s0.tag() if callable(s0.tag) else s0.tag,
+                                                                      s1.tag() if callable(s1.tag) else s1.tag))
+        return
+    for sp in specs:
+        if not LaunchProfile.active:
+            _run_chain(sp.chain, sp.a, None, sp.code, sp.what)
+            continue
+        n0 = len(LaunchProfile.records)
+        taken = [None]
+
+        def go(sp=sp):
+            taken[0] = _run_chain(sp.chain, sp.a, None, sp.code, sp.what)
+        kind = sp.kind(None) if callable(sp.kind) else sp.kind
+        _timed(kind, sp.work, go, tag=sp.tag)
+        if len(sp.chain) > 1 and taken[0] != sp.chain[0] and LaunchProfile.records[n0:]:
+            # the first entry point declined: the record belongs to the one that ran
+            r = LaunchProfile.records[-1]
+            LaunchProfile.records[-1] = (taken[0],) + tuple(r[1:])
+
+
 def dtype_code(dtype):
     if dtype == torch.bfloat16:
         return FS_DTYPE_BF16
@@ -197,7 +261,13 @@ class ConvOp:
         return Ho, Wo
 
     # ------------------------------------------------------------------
-    def forward(self, x, out=None, bias=None, addend=None, stats=None, relu=False, out_f32=False, stat_groups=1, pro=None):
+    def forward(self, x, **kw):
+        """one convolution forward, issued now (see forward_spec for the arguments)"""
+        sp = self.forward_spec(x, **kw)
+        run_specs([sp])
+        return sp.out
+
+    def forward_spec(self, x, out=None, bias=None, addend=None, stats=None, relu=False, out_f32=False, stat_groups=1, pro=None):
         """stat_groups G > 1: the batch is G stacked BatchNorm invocations; stats is [G][SLOTS][2][Co].
         pro = (BnState with scale / shift, relu): x is the RAW output of the convolution in front of a BatchNorm (+ ReLU)
         that is applied while the operand is staged (fs_conv3x3_halo prologue; can_fold_input())."""
@@ -259,24 +329,25 @@ class ConvOp:
         flops = 2.0 * a.M * self.Co * self.R * self.S * self.Ci
         if grp_imgs:
             a.stat_group_rows, a.grp_imgs, a.M = 0, grp_imgs, grp_imgs * Ho * Wo
-        fn = lib.fs_conv3x3_halo if halo else lib.fs_conv_igemm
-        if self._try_1x1(a, flops, lambda: "fwd  %s x[%d,%d,%d,%d]" % (self.describe(), N, x.shape[1], x.shape[2], x.shape[3])):
-            return out
+        tag = lambda: "fwd  %s x[%d,%d,%d,%d]" % (self.describe(), N, x.shape[1], x.shape[2], x.shape[3])
+        if self._wants_1x1(a):
+            return Spec(["conv1x1", "conv_igemm"], a, self.code, "conv1x1", flops, tag, out, "conv_fwd")
         if stem:
-            _timed("conv_stem", flops, lambda: check(lib.fs_conv_stem(C.byref(a), self.code, stream_ptr()), "conv_stem"),
-                   tag=lambda: "fwd  %s x[%d,%d,%d,%d]" % (self.describe(), N, x.shape[1], x.shape[2], x.shape[3]))
-            return out
-        _timed(self._kind3x3(a) if halo else "conv_igemm", flops, lambda: check(fn(C.byref(a), self.code, stream_ptr()), "conv_fwd"),
-               tag=lambda: "fwd  %s x[%d,%d,%d,%d]" % (self.describe(), N, x.shape[1], x.shape[2], x.shape[3]))
-        return out
+            return Spec(["conv_stem"], a, self.code, "conv_stem", flops, tag, out, "conv_stem")
+        if halo:
+            return Spec(["conv3x3_halo"], a, self.code, lambda other: self._kind3x3(a, other), flops, tag, out, "conv_fwd")
+        return Spec(["conv_igemm"], a, self.code, "conv_igemm", flops, tag, out, "conv_fwd")
 
-    def _kind3x3(self, a):
-        """launch-profile kind of a 3x3 / stride-1 launch: which of the three kernels fs_conv3x3_halo runs it on"""
+    def _kind3x3(self, a, other=None):
+        """launch-profile kind of a 3x3 / stride-1 launch: which of the three kernels fs_conv3x3_halo runs it on
+        (other: the Spec sharing the launch)"""
         if not LaunchProfile.active:
             return "conv3x3_halo"
         if a.hb_mul == 2:
             return "conv3x3_s2"          # stage-entry stride-2 forward: not part of the stride-1 family's roofline figure
         plan = (C.c_int32 * 4)()
+        if other is not None and lib.fs_conv3x3_halo2_plan(C.byref(a), C.byref(other.a), self.code, plan) == 0:
+            return {1: "conv3x3_t32", 2: "conv3x3_p1"}.get(int(plan[0]), "conv3x3_halo")
         check(lib.fs_conv3x3_halo_plan(C.byref(a), self.code, plan), "conv3x3_plan")
         return {1: "conv3x3_t32", 2: "conv3x3_p1"}.get(int(plan[0]), "conv3x3_halo")
 
@@ -304,29 +375,19 @@ class ConvOp:
         check(lib.fs_conv3x3_halo_plan(C.byref(a), self.code, plan), "conv3x3_plan")
         return {"kernel": {0: "halo", 1: "t32", 2: "p1"}[int(plan[0])], "blocks": int(plan[1]), "pix": int(plan[2]), "co": int(plan[3])}
 
-    def _try_1x1(self, a, flops, tag):
-        """1x1 convolutions (forward, stride-1 data gradient) on the row-streaming GEMM kernel (conv1x1.hip); False =
-        not a case for it (the kernel said FS_EINVAL, or FSNET_AMD_CONV1X1=0): the caller goes on to fs_conv_igemm"""
+    def _wants_1x1(self, a):
+        """1x1 convolutions (forward, stride-1 data gradient) on the row-streaming GEMM kernel (conv1x1.hip); the launch
+        chain is then fs_conv1x1 -> fs_conv_igemm (the kernel may still say FS_EINVAL = "not mine")"""
         if not (USE_1X1 and self.R == 1 and self.S == 1 and self.pad == 0 and self.dtype == torch.bfloat16):
             return False
-        status = [0]
-
-        def run():
-            status[0] = lib.fs_conv1x1(C.byref(a), self.code, stream_ptr())
-            if status[0] != 1:            # FS_EINVAL = "not mine"; anything else non-zero is an error
-                check(status[0], "conv1x1")
         if a.stat_group_rows and a.stat_group_rows % 128 != 0:
             return False
         # measured per shape at ResNet-50 / 320x1024 / B=8 (tools/probes/conv1x1_shapes.py): the streaming kernel wins
         # while the K walk is one or two chunks (forward 64->256 49.5 -> 40.8 us, data gradient 256<-64 43.7 -> 33.9),
         # the implicit GEMM with its deeper K pipeline from there on (forward 256->128 44 vs 52 us, K = 1024: 25.5 vs 29.5)
-        if a.Cs > (128 if a.sgn > 0 else 256) or a.hb_mul != 1:
-            return False
-        n0 = len(LaunchProfile.records)
-        _timed("conv1x1", flops, run, tag=tag)
-        if status[0] != 0:
-            del LaunchProfile.records[n0:]      # "not mine": the implicit GEMM runs (and is timed) instead
-        return status[0] == 0
+        if a.Cs > (128 if a.sgn > 0 else 256) or a.hb_mul != 1 or a.dshift != 0:
+            return False              # (a stride-2 data gradient: the kernel would decline it — straight to the implicit GEMM)
+        return True
 
     def can_fold_input(self, N, H, W):
         """whether this convolution can take its input as (raw convolution output, BatchNorm statistics, ReLU) — forward
@@ -389,7 +450,7 @@ class ConvOp:
         return t
 
     def _dgrad_s2_classes(self, dy, H, W, out, addend, mask, bn_fuse):
-        """all four parity classes in ONE launch (blockIdx.y = class)"""
+        """all four parity classes in ONE launch (blockIdx.y = class) -> Spec"""
         N, Ho, Wo, Cd = dy.shape
         eb = dy.element_size()
         tab, offs, nchs = self._class_tables(*_nhwc_strides(dy)[1:])
@@ -427,11 +488,16 @@ class ConvOp:
             a.stats = sums.data_ptr()
             a.stat_group_rows = (N // st.groups) * (H // 2) * (W // 2) if st.groups > 1 else 0
         flops = 2.0 * N * Ho * Wo * self.Co * self.R * self.S * self.Ci
-        _timed("conv_igemm", flops, lambda: check(lib.fs_conv_igemm(C.byref(a), self.code, stream_ptr()), "conv_dgrad_s2"),
-               tag=lambda: "dgrd %s dy[%d,%d,%d,%d]" % (self.describe(), N, Ho, Wo, Cd))
-        return out
+        return Spec(["conv_igemm"], a, self.code, "conv_igemm", flops,
+                    lambda: "dgrd %s dy[%d,%d,%d,%d]" % (self.describe(), N, Ho, Wo, Cd), out, "conv_dgrad_s2")
 
-    def dgrad(self, dy, H, W, out=None, addend=None, mask=None, bn_fuse=None, mask_bn=False, pro_bwd=None):
+    def dgrad(self, dy, H, W, **kw):
+        """one data gradient, issued now (see dgrad_spec)"""
+        sp = self.dgrad_spec(dy, H, W, **kw)
+        run_specs([sp])
+        return sp.out
+
+    def dgrad_spec(self, dy, H, W, out=None, addend=None, mask=None, bn_fuse=None, mask_bn=False, pro_bwd=None):
         """dy: [N,Ho,Wo,Co_p] -> dx [N,H,W,Ci_p] (out may be a strided view; addend is summed in).
         bn_fuse = (c, BnState, sums): dx is the gradient w.r.t. relu(BN(c)) (+ residual): the epilogue also
         accumulates the BatchNorm-backward sums (sum g, sum g*xhat) of that BatchNorm into `sums` (zeroed f64
@@ -500,18 +566,24 @@ class ConvOp:
             a.pro_group_imgs = N // pst.groups if pst.groups > 1 else 0
         flops = 2.0 * N * Ho * Wo * self.Co * self.R * self.S * self.Ci
         halo = self.halo_d and USE_HALO
-        fn = lib.fs_conv3x3_halo if halo else lib.fs_conv_igemm
-        if self._try_1x1(a, flops, lambda: "dgrd %s dy[%d,%d,%d,%d]" % (self.describe(), N, Ho, Wo, Cd)):
-            return out
-        _timed(self._kind3x3(a) if halo else "conv_igemm", flops, lambda: check(fn(C.byref(a), self.code, stream_ptr()), "conv_dgrad"),
-               tag=lambda: "dgrd %s dy[%d,%d,%d,%d]" % (self.describe(), N, Ho, Wo, Cd))
-        return out
+        tag = lambda: "dgrd %s dy[%d,%d,%d,%d]" % (self.describe(), N, Ho, Wo, Cd)
+        if self._wants_1x1(a):
+            return Spec(["conv1x1", "conv_igemm"], a, self.code, "conv1x1", flops, tag, out, "conv_dgrad")
+        if halo:
+            return Spec(["conv3x3_halo"], a, self.code, lambda other: self._kind3x3(a, other), flops, tag, out, "conv_dgrad")
+        return Spec(["conv_igemm"], a, self.code, "conv_igemm", flops, tag, out, "conv_dgrad")
 
     def describe(self):
         return "%dx%d/s%d p%d %d->%d" % (self.R, self.S, self.stride, self.pad, self.Ci, self.Co)
 
     def wgrad(self, dy, x, dw, pro=None):
-        """accumulates into dw (fp32 OIHW [Co,Ci,R,S]); dy must be dense [N,Ho,Wo,Co_p].  pro as in forward()."""
+        """accumulates into dw (fp32 OIHW [Co,Ci,R,S]), issued now (see wgrad_spec)"""
+        run_specs([self.wgrad_spec(dy, x, dw, pro=pro)])
+        return dw
+
+    def wgrad_spec(self, dy, x, dw, pro=None):
+        """accumulates into dw (fp32 OIHW [Co,Ci,R,S]); dy must be dense [N,Ho,Wo,Co_p].  pro as in forward().
+        (Two specs sharing a launch use the FIRST one's workspace for both slab regions.)"""
         N, Ho, Wo, Cd = dy.shape
         assert dy.is_contiguous() and Cd == self.Co_p and x.shape[3] == self.Ci_p
         assert dw.dtype == torch.float32 and dw.is_contiguous()
@@ -530,6 +602,5 @@ class ConvOp:
             a.pro_a, a.pro_b, a.pro_relu = pst.scale.data_ptr(), pst.shift.data_ptr(), int(prelu)
             a.pro_group_imgs = N // pst.groups if pst.groups > 1 else 0
         flops = 2.0 * a.M * self.Co * self.R * self.S * self.Ci
-        _timed("conv_wgrad", flops, lambda: check(lib.fs_conv_wgrad(C.byref(a), self.code, stream_ptr()), "conv_wgrad"),
-               tag=lambda: "wgrd %s dy[%d,%d,%d,%d]" % (self.describe(), N, Ho, Wo, Cd))
-        return dw
+        return Spec(["conv_wgrad"], a, self.code, "conv_wgrad", flops,
+                    lambda: "wgrd %s dy[%d,%d,%d,%d]" % (self.describe(), N, Ho, Wo, Cd), dw, "conv_wgrad")

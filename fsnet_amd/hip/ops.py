@@ -6,7 +6,7 @@ import os
 import torch
 
 from .binding import (lib, check, stream_ptr, FsBnApplyArgs, FsBnBwdArgs, FsPhotoArgs, FsSmoothArgs)
-from .conv import dtype_code, _timed, BN_EPS, BN_MOMENTUM
+from .conv import dtype_code, _timed, BN_EPS, BN_MOMENTUM, Spec, run_specs
 
 STAT_SLOTS = 8   # FS_STAT_SLOTS in include/fsnet_hip.h
 
@@ -64,9 +64,16 @@ def bn_finalize(stats, bn, st, Cc, count, track=True, groups=1):
     return st
 
 
-def bn_apply(x, stats, bn, st, y, H, W, count, relu=True, pad_out=False, res=None, stats2=None, bn2=None, st2=None,
-             track=True, groups=1):
-    """x: dense [N,H,W,C] raw conv output.  bn/bn2: dict(weight,bias,running_mean,running_var,nbt).
+def bn_apply(x, stats, bn, st, y, H, W, count, **kw):
+    """one BatchNorm (+ residual, + ReLU) forward pass, issued now (see bn_apply_spec)"""
+    run_specs([bn_apply_spec(x, stats, bn, st, y, H, W, count, **kw)])
+    return y
+
+
+def bn_apply_spec(x, stats, bn, st, y, H, W, count, relu=True, pad_out=False, res=None, stats2=None, bn2=None, st2=None,
+                  track=True, groups=1):
+    """-> Spec (conv.run_specs issues it, alone or sharing a launch with another network's BatchNorm of the same width).
+    x: dense [N,H,W,C] raw conv output.  bn/bn2: dict(weight,bias,running_mean,running_var,nbt).
     groups G > 1: G stacked invocations of the module (count is per group; stats are [G][SLOTS][2][C])."""
     a = FsBnApplyArgs()
     a.groups = groups
@@ -94,10 +101,9 @@ def bn_apply(x, stats, bn, st, y, H, W, count, relu=True, pad_out=False, res=Non
     a.M, a.C, a.H, a.W = x.shape[0] * H * W, Cc, H, W
     a.relu, a.pad_out = int(relu), int(pad_out)
     nb = x.numel() * x.element_size() * (2 + (res is not None))
-    _timed("bn_apply", nb, lambda: check(lib.fs_bn_apply(C.byref(a), dtype_code(x.dtype), stream_ptr()), "bn_apply"),
-           tag=lambda: "[%d,%d,%d,%d]%s%s" % (x.shape[0], H, W, Cc, " +res" if res is not None else "",
-                                              " pad" if pad_out else ""))
-    return y
+    return Spec(["bn_apply"], a, dtype_code(x.dtype), "bn_apply", nb,
+                lambda: "[%d,%d,%d,%d]%s%s" % (x.shape[0], H, W, Cc, " +res" if res is not None else "",
+                                               " pad" if pad_out else ""), y, "bn_apply")
 
 
 def bn_backward(dout, y, x, gamma, st, dx, dgamma, dbeta, H, W, relu=True, fold=False, g_out=None, sums=None,
@@ -106,6 +112,15 @@ def bn_backward(dout, y, x, gamma, st, dx, dgamma, dbeta, H, W, relu=True, fold=
     when fold=True); y: saved output activation (interior view) for the ReLU mask.
     reduced=True: the first pass already happened in the epilogue of the convolution that produced dout
     (ConvOp.dgrad(bn_fuse=...)): dout is ReLU-masked and `sums` holds (sum g, sum g*xhat)."""
+    bn_backward_multi([dict(dout=dout, y=y, x=x, gamma=gamma, st=st, dx=dx, dgamma=dgamma, dbeta=dbeta, H=H, W=W, relu=relu,
+                            fold=fold, g_out=g_out, sums=sums, sums_zeroed=sums_zeroed, reduced=reduced, glob=glob)],
+                      allreduce=allreduce, phase=phase)
+    return None if phase == "reduce" else dx
+
+
+def _bn_bwd_call(dout, y, x, gamma, st, dx, dgamma, dbeta, H, W, relu=True, fold=False, g_out=None, sums=None,
+                 sums_zeroed=False, reduced=False, glob=None):
+    """argument struct of one BatchNorm backward -> dict(a=, code=, nb=, shp=, sums=, reduced=, glob=, y=, g_out=)"""
     if reduced:
         assert sums is not None and not fold and g_out is None
         relu, y = False, None
@@ -115,7 +130,7 @@ def bn_backward(dout, y, x, gamma, st, dx, dgamma, dbeta, H, W, relu=True, fold=
         sums = torch.zeros(st.groups * STAT_SLOTS, 2, Cc, dtype=torch.float64, device=x.device)
     elif not sums_zeroed and not reduced:
         sums.zero_()
-    a.dout, a.y, a.x, a.dx, a.g_out = dout.data_ptr(), _p(y), x.data_ptr(), dx.data_ptr(), _p(g_out)
+    a.dout, a.y, a.x, a.dx, a.g_out = dout.data_ptr(), _p(y), x.data_ptr(), _p(dx), _p(g_out)
     a.sums = sums.data_ptr()
     a.gamma, a.save_mean, a.save_invstd = gamma.data_ptr(), st.mean.data_ptr(), st.invstd.data_ptr()
     a.dgamma, a.dbeta = _p(dgamma), _p(dbeta)
@@ -126,47 +141,100 @@ def bn_backward(dout, y, x, gamma, st, dx, dgamma, dbeta, H, W, relu=True, fold=
         a.yN, a.yH, a.yW = y.stride(0), y.stride(1), y.stride(2)
     a.M, a.C, a.H, a.W = x.shape[0] * H * W, Cc, H, W
     a.relu, a.fold = int(relu), int(fold)
-    code = dtype_code(x.dtype)
-    nb = x.numel() * x.element_size()
-    shp = lambda: "[%d,%d,%d,%d]%s" % (x.shape[0], H, W, Cc, " fold" if fold else "")
-    # phase "reduce": only the first pass (the caller exchanges the sums of several BatchNorms in one collective and
-    # comes back with phase "apply", glob = the exchanged sums; `sums` then holds the local ones)
-    if not reduced and phase != "apply":
-        _timed("bn_bwd_reduce", nb * (2 + (y is not None)),
-               lambda: check(lib.fs_bn_bwd_reduce(C.byref(a), code, stream_ptr()), "bn_bwd_reduce"), tag=shp)
+    shape = (x.shape[0], H, W, Cc)
+    return dict(a=a, code=dtype_code(x.dtype), nb=x.numel() * x.element_size(), sums=sums, reduced=reduced, glob=glob,
+                has_y=y is not None, has_g=g_out is not None,
+                shp=lambda: "[%d,%d,%d,%d]%s" % (shape + (" fold" if fold else "",)))
+
+
+def bn_backward_multi(calls, allreduce=None, phase="all", span=None):
+    """The BatchNorm backwards of one or two networks' layers of the same width; each pass is ONE launch for all of them
+    (fs_bn_bwd_reduce2 / fs_bn_bwd_apply2).  calls: keyword dicts of bn_backward (above) without allreduce / phase.
+    allreduce(sums, out=): SyncBN exchange of the sums between the passes — dgamma / dbeta come from the local sums, dx
+    from the global ones; span(a, b) -> one contiguous view over two sums buffers taken back to back (or None): the
+    exchange of two lanes is then one collective.
+    phase "reduce": only the first pass (the caller exchanges the sums of several BatchNorms in one collective and comes
+    back with phase "apply", glob = the exchanged sums in each call; `sums` then holds the local ones)."""
+    cs = [_bn_bwd_call(**c) for c in calls]
+    if phase != "apply":
+        run_specs([Spec(["bn_bwd_reduce"], c["a"], c["code"], "bn_bwd_reduce", c["nb"] * (2 + c["has_y"]), c["shp"], None,
+                        "bn_bwd_reduce") for c in cs if not c["reduced"]])
     if phase == "reduce":
-        return None
-    if glob is not None:
-        a.sums_local, a.sums = sums.data_ptr(), glob.data_ptr()
-    elif allreduce is not None:
-        # SyncBN: dgamma / dbeta come from the local sums, dx from the global ones — reduce out of place instead
-        # of cloning the local copy first (one device copy per BatchNorm and step)
-        glob = torch.empty_like(sums)
-        allreduce(sums, out=glob)
-        a.sums_local, a.sums = sums.data_ptr(), glob.data_ptr()
-    _timed("bn_bwd_apply", nb * (3 + (y is not None) + (g_out is not None)),
-           lambda: check(lib.fs_bn_bwd_apply(C.byref(a), code, stream_ptr()), "bn_bwd_apply"), tag=shp)
-    return dx
+        return
+    pending = [c for c in cs if c["glob"] is None] if allreduce is not None else []
+    if len(pending) == 2 and span is not None:
+        both = span(pending[0]["sums"], pending[1]["sums"])
+        if both is not None:
+            out = torch.empty_like(both)
+            allreduce(both, out=out)
+            n0 = pending[0]["sums"].numel()
+            pending[0]["glob"] = out[:n0].view(pending[0]["sums"].shape)
+            pending[1]["glob"] = out[n0:].view(pending[1]["sums"].shape)
+            pending = []
+    for c in pending:
+        # SyncBN: reduce out of place instead of cloning the local copy first (one device copy per BatchNorm and step)
+        c["glob"] = torch.empty_like(c["sums"])
+        allreduce(c["sums"], out=c["glob"])
+    for c in cs:
+        if c["glob"] is not None:
+            c["a"].sums_local, c["a"].sums = c["sums"].data_ptr(), c["glob"].data_ptr()
+    run_specs([Spec(["bn_bwd_apply"], c["a"], c["code"], "bn_bwd_apply", c["nb"] * (3 + c["has_y"] + c["has_g"]), c["shp"],
+                    None, "bn_bwd_apply") for c in cs])
 
 
 def maxpool_fwd(x):
-    N, H, W, Cc = x.shape
-    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    y = torch.empty(N, Ho, Wo, Cc, dtype=x.dtype, device=x.device)
-    idx = torch.empty(N, Ho, Wo, Cc, dtype=torch.uint8, device=x.device)
-    _timed("maxpool_fwd", x.numel() * x.element_size() * 1.25 + idx.numel(),
-           lambda: check(lib.fs_maxpool_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr(), N, H, W, Cc, dtype_code(x.dtype),
-                                            stream_ptr()), "maxpool_fwd"), tag=str(tuple(x.shape)))
-    return y, idx
+    return maxpool_fwd_multi([x])[0]
+
+
+def maxpool_fwd_multi(xs):
+    """[x NHWC] (one tensor, or two with the same H, W, C: ONE launch) -> [(y, idx)]"""
+    outs = []
+    for x in xs:
+        N, H, W, Cc = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        outs.append((torch.empty(N, Ho, Wo, Cc, dtype=x.dtype, device=x.device),
+                     torch.empty(N, Ho, Wo, Cc, dtype=torch.uint8, device=x.device)))
+    if len(xs) == 2 and xs[0].shape[1:] == xs[1].shape[1:] and xs[0].dtype == xs[1].dtype:
+        x, x1 = xs
+        (y, idx), (y1, idx1) = outs
+        N, H, W, Cc = x.shape
+        _timed("maxpool_fwd", sum(t.numel() * t.element_size() * 1.25 + o[1].numel() for t, o in zip(xs, outs)),
+               lambda: check(lib.fs_maxpool_fwd2(x.data_ptr(), y.data_ptr(), idx.data_ptr(), N, x1.data_ptr(), y1.data_ptr(),
+                                                 idx1.data_ptr(), x1.shape[0], H, W, Cc, dtype_code(x.dtype), stream_ptr()),
+                             "maxpool_fwd"), tag=str(tuple(x.shape)) + " || " + str(tuple(x1.shape)))
+        return outs
+    for x, (y, idx) in zip(xs, outs):
+        N, H, W, Cc = x.shape
+        _timed("maxpool_fwd", x.numel() * x.element_size() * 1.25 + idx.numel(),
+               lambda: check(lib.fs_maxpool_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr(), N, H, W, Cc, dtype_code(x.dtype),
+                                                stream_ptr()), "maxpool_fwd"), tag=str(tuple(x.shape)))
+    return outs
 
 
 def maxpool_bwd(dy, idx, H, W, addend=None):
-    N, Ho, Wo, Cc = dy.shape
-    dx = torch.empty(N, H, W, Cc, dtype=dy.dtype, device=dy.device)
-    _timed("maxpool_bwd", dx.numel() * dx.element_size() * (1.25 + (addend is not None)) + idx.numel(),
-           lambda: check(lib.fs_maxpool_bwd(dy.data_ptr(), idx.data_ptr(), _p(addend), dx.data_ptr(), N, H, W, Cc,
-                                            dtype_code(dy.dtype), stream_ptr()), "maxpool_bwd"), tag=str(tuple(dx.shape)))
-    return dx
+    return maxpool_bwd_multi([dy], [idx], H, W, [addend])[0]
+
+
+def maxpool_bwd_multi(dys, idxs, H, W, addends):
+    """gradients of maxpool_fwd_multi's inputs (+ addend): one launch for two tensors of the same H, W, C"""
+    dxs = [torch.empty(dy.shape[0], H, W, dy.shape[3], dtype=dy.dtype, device=dy.device) for dy in dys]
+    work = lambda dx, idx, ad: dx.numel() * dx.element_size() * (1.25 + (ad is not None)) + idx.numel()
+    if len(dys) == 2 and dys[0].shape[1:] == dys[1].shape[1:] and dys[0].dtype == dys[1].dtype:
+        dy, dy1 = dys
+        Cc = dy.shape[3]
+        _timed("maxpool_bwd", sum(work(dx, i, a) for dx, i, a in zip(dxs, idxs, addends)),
+               lambda: check(lib.fs_maxpool_bwd2(dy.data_ptr(), idxs[0].data_ptr(), _p(addends[0]), dxs[0].data_ptr(),
+                                                 dy.shape[0], dy1.data_ptr(), idxs[1].data_ptr(), _p(addends[1]),
+                                                 dxs[1].data_ptr(), dy1.shape[0], H, W, Cc, dtype_code(dy.dtype),
+                                                 stream_ptr()), "maxpool_bwd"),
+               tag=str(tuple(dxs[0].shape)) + " || " + str(tuple(dxs[1].shape)))
+        return dxs
+    for dy, idx, ad, dx in zip(dys, idxs, addends, dxs):
+        _timed("maxpool_bwd", work(dx, idx, ad),
+               lambda: check(lib.fs_maxpool_bwd(dy.data_ptr(), idx.data_ptr(), _p(ad), dx.data_ptr(), dy.shape[0], H, W,
+                                                dy.shape[3], dtype_code(dy.dtype), stream_ptr()), "maxpool_bwd"),
+               tag=str(tuple(dx.shape)))
+    return dxs
 
 
 def upcat_pad_fwd(a, b):

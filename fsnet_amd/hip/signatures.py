@@ -13,6 +13,18 @@ SIGNATURES = {
     "fs_target_arch": (C.c_char_p, []),
     "fs_debug_timestamp": (C.c_int, [P, P]),
     "fs_conv_igemm": (C.c_int, [P, I, P]),
+    # two problems per launch (ABI 7): (args0, args1 | NULL, dtype, stream)
+    "fs_conv_igemm2": (C.c_int, [P, P, I, P]),
+    "fs_conv3x3_halo2": (C.c_int, [P, P, I, P]),
+    "fs_conv3x3_halo2_plan": (C.c_int, [P, P, I, P]),
+    "fs_conv_stem2": (C.c_int, [P, P, I, P]),
+    "fs_conv_wgrad2": (C.c_int, [P, P, I, P]),
+    "fs_conv_wgrad2_plan": (C.c_int, [P, P, I, P]),
+    "fs_bn_apply2": (C.c_int, [P, P, I, P]),
+    "fs_bn_bwd_reduce2": (C.c_int, [P, P, I, P]),
+    "fs_bn_bwd_apply2": (C.c_int, [P, P, I, P]),
+    "fs_maxpool_fwd2": (C.c_int, [P, P, P, I, P, P, P, I, I, I, I, I, P]),
+    "fs_maxpool_bwd2": (C.c_int, [P, P, P, P, I, P, P, P, P, I, I, I, I, I, P]),
     "fs_conv3x3_halo": (C.c_int, [P, I, P]),
     "fs_conv3x3_halo_plan": (C.c_int, [P, I, P]),
     "fs_conv1x1": (C.c_int, [P, I, P]),

@@ -9,7 +9,7 @@ import math
 import torch
 import torch.nn as nn
 
-from fsnet_amd.engine.nets import ResNetRunner
+from fsnet_amd.engine.nets import EncoderPass, ResNetRunner
 from fsnet_amd.engine.runtime import RT, require_gpu
 from fsnet_amd.hip import ops
 
@@ -73,6 +73,64 @@ class _ResNetFn(torch.autograd.Function):
         if mod._pending == 0 and RT.dp is not None:
             RT.dp.grads_ready(mod)
         return (None, None, None) + (None,) * len(mod._plist)
+
+
+class _ResNetLanesFn(torch.autograd.Function):
+    """Two encoders as the lanes of ONE pass (engine/nets.py, EncoderPass): the autograd node of the depth encoder's call
+    and the stacked pose encoder's call of a training step (monodepth2_model.py:24-43) — every launch of the pass serves
+    both networks.  Outputs: the first lane's five features, then the second's."""
+
+    @staticmethod
+    def forward(ctx, mods, xs, groups, *params):
+        ctx.set_materialize_grads(False)
+        ep = EncoderPass([m._runner for m in mods])
+        feats, c = ep.forward(list(xs), train=True, groups=list(groups))
+        ctx.mods, ctx.ep, ctx.c, ctx.dtype = mods, ep, c, xs[0].dtype
+        ctx.nparams = len(params)
+        for m in mods:
+            m._pending += 1
+            if RT.dp is not None:
+                RT.dp.note_forward(m)
+        return tuple(f.permute(0, 3, 1, 2) for lane in feats for f in lane)
+
+    @staticmethod
+    def backward(ctx, *g):
+        mods = ctx.mods
+        nf = len(g) // len(mods)
+        gf = [[None if gi is None else nhwc_dense(gi, ctx.dtype) for gi in g[l * nf:(l + 1) * nf]] for l in range(len(mods))]
+        ctx.ep.backward(ctx.c, gf)
+        ctx.c = None
+        for m in mods:
+            m._pending -= 1
+            if m._pending == 0 and RT.dp is not None:
+                RT.dp.grads_ready(m)
+        return (None, None, None) + (None,) * ctx.nparams
+
+
+def lanes_compatible(a, b):
+    """may two ResNets run as the lanes of one pass (same layers, BatchNorm modes and trained parameters)?"""
+    return (isinstance(a, ResNet) and isinstance(b, ResNet) and a.training and b.training
+            and a._runner.signature(True) == b._runner.signature(True))
+
+
+def forward_lanes(depth_net, image, pose_net, pairs):
+    """depth_net(image) and pose_net.forward_pairs(pairs) of one training step as ONE encoder pass -> (features of the
+    depth encoder, features of the stacked pose pairs), each exactly what the separate call returns."""
+    require_gpu(image, "ResNet.forward_lanes")
+    op_d = depth_net._runner.stem.ready(RT.compute_dtype, image.device)
+    op_p = pose_net._runner.stem.ready(RT.compute_dtype, image.device)
+    xd = ops.nchw_to_nhwc(image.float(), None, op_d.Ci_p, RT.compute_dtype)
+    G, N = len(pairs), image.shape[0]
+    xp = torch.empty(G * N, image.shape[2], image.shape[3], op_p.Ci_p, dtype=RT.compute_dtype, device=image.device)
+    for g, (a, b) in enumerate(pairs):
+        ops.nchw_to_nhwc(a.float(), b.float(), op_p.Ci_p, RT.compute_dtype, out=xp[g * N:(g + 1) * N])
+    mods = (depth_net, pose_net)
+    for m in mods:
+        if m._plist is None:
+            m._plist = list(m.parameters())
+    outs = _ResNetLanesFn.apply(mods, (xd, xp), (1, G), *(depth_net._plist + pose_net._plist))
+    nf = len(outs) // 2
+    return list(outs[:nf]), list(outs[nf:])
 
 
 class ResNet(nn.Module):

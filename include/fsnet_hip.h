@@ -33,7 +33,7 @@ extern "C" {
 
 /* library/ABI version and the ISA the kernels were compiled for ("gfx950").  FS_ABI_VERSION changes whenever an
  * argument struct or a signature below does; a host binding refuses a library that reports another number. */
-#define FS_ABI_VERSION 6
+#define FS_ABI_VERSION 7
 int fs_abi_version(void);
 const char* fs_target_arch(void);
 /* debugging aid: writes the device's constant-rate clock (wall_clock64, 100 MHz) into *slot (u64) on `stream`;
@@ -146,6 +146,17 @@ typedef struct FsConvArgs {
   float pro_eps, pro_momentum;
 } FsConvArgs;
 int fs_conv_igemm(const FsConvArgs* args, int dtype, void* stream);
+
+/* ---- Two problems per launch (ABI 7) ----
+ * The reference runs the depth encoder on image 0 and the pose encoder on each (source, target) pair
+ * (monodepth2_model.py:24-43: self.depth_backbone(...), self.pose_backbone(torch.cat(...))); after their stems the two
+ * ResNets execute the same layer shapes (resnet.py:199-213), and nothing orders them before the loss.  Every fs_*2 entry
+ * point below takes the arguments of TWO independent launches of its one-problem namesake — own tensors, weights,
+ * statistics, batch sizes and statistics groups — and runs them as ONE kernel launch (the blocks of the second problem
+ * follow the first's in the grid), so a pair of layers pays a launch's fixed cost once.  a1 == NULL is the one-problem
+ * call.  When the two problems do not agree on what selects a kernel instantiation (shapes, epilogue options), the entry
+ * point launches them one after the other: results never depend on whether a pair shared a launch. */
+int fs_conv_igemm2(const FsConvArgs* a0, const FsConvArgs* a1, int dtype, void* stream);
 /* 1x1 convolutions (forward; data gradient at stride 1) as a row-streaming GEMM: same FsConvArgs and epilogue semantics
  * as fs_conv_igemm (ktab unused), bf16 only.  Returns FS_EINVAL for anything it does not take (fp32, padding, a
  * stride-2 data gradient, a K extent that is not whole 64-byte steps): the caller then uses fs_conv_igemm.
@@ -163,12 +174,17 @@ int fs_conv3x3_halo(const FsConvArgs* args, int dtype, void* stream);
  * block tile}.  bench.py splits the family's time by kernel with it; tests check that a forced configuration is the one that
  * runs. */
 int fs_conv3x3_halo_plan(const FsConvArgs* args, int dtype, int32_t* plan);
+/* two problems in one launch (see fs_conv_igemm2); the plan of the shared launch (FS_EINVAL if the pair would run as two) */
+int fs_conv3x3_halo2(const FsConvArgs* a0, const FsConvArgs* a1, int dtype, void* stream);
+int fs_conv3x3_halo2_plan(const FsConvArgs* a0, const FsConvArgs* a1, int dtype, int32_t* plan);
 
 /* 7x7 / stride-2 / pad-3 stem (resnet.py:118-121: conv1 of both encoders) over 8-channel bf16 pixels, forward only:
  * weights resident in LDS, im2col from an LDS input patch, persistent blocks.  Same arguments and packed forward
  * operand as fs_conv_igemm (ktab unused); requires Cs == 8, Co == Co_p == 64, bf16 output, no bias / addend / mask /
  * relu; stats and stat_group_rows as in fs_conv_igemm. */
 int fs_conv_stem(const FsConvArgs* args, int dtype, void* stream);
+/* both encoders' stems (3 and 6 real input channels of the same 8-channel pixels) in one launch (see fs_conv_igemm2) */
+int fs_conv_stem2(const FsConvArgs* a0, const FsConvArgs* a1, int dtype, void* stream);
 
 /* Convolution weight gradient.  Replaces convolution_backward(weight) at the same call sites.
  * dy is dense [M][Cd]; x is the forward input (strided NHWC); dw is the fp32 OIHW gradient
@@ -205,6 +221,11 @@ int fs_conv_wgrad(const FsWgradArgs* args, int dtype, void* stream);
  * 2 narrow 16/32-channel, 3 7x7 stem), blocks, threads per block, blocks of that kernel the device holds at once}.
  * A split-K grid a little above the resident count runs as two rounds; tests hold the grids to one. */
 int fs_conv_wgrad_plan(const FsWgradArgs* args, int dtype, int32_t* plan);
+/* the weight gradients of two convolutions of the same shape in one launch (see fs_conv_igemm2): the pixel splits of both
+ * share the device's block slots and a0's workspace (slab regions back to back: a1's workspace is not used), one reduce
+ * launch adds into both dW.  plan: blocks of the shared launch. */
+int fs_conv_wgrad2(const FsWgradArgs* a0, const FsWgradArgs* a1, int dtype, void* stream);
+int fs_conv_wgrad2_plan(const FsWgradArgs* a0, const FsWgradArgs* a1, int dtype, int32_t* plan);
 
 /* Weight packing.  OIHW fp32 master weights (the reference's state_dict layout,
  * e.g. depth_backbone.conv1.weight (64,3,7,7)) -> [rows_p][ktot_p] K-contiguous
@@ -351,6 +372,9 @@ typedef struct FsBnApplyArgs {
                            in group order. */
 } FsBnApplyArgs;
 int fs_bn_apply(const FsBnApplyArgs* args, int dtype, void* stream);
+/* two BatchNorms of the same width in one launch (see fs_conv_igemm2): bn1 of the depth encoder's block and bn1 of the
+ * pose encoder's, each with its own gamma / beta / running statistics and statistics groups */
+int fs_bn_apply2(const FsBnApplyArgs* a0, const FsBnApplyArgs* a1, int dtype, void* stream);
 /* The statistics part of fs_bn_apply alone: save_mean / save_invstd, the affine form scale = gamma*invstd, shift =
  * beta - mean*scale ([groups][C] each) and the running-statistics update (x, res, y and the second BatchNorm's fields
  * are ignored).  The activation is then normalised by whoever reads it: FsConvArgs.pro_mode = 1 in the consuming
@@ -380,6 +404,8 @@ typedef struct FsBnBwdArgs {
 } FsBnBwdArgs;
 int fs_bn_bwd_reduce(const FsBnBwdArgs* args, int dtype, void* stream);
 int fs_bn_bwd_apply(const FsBnBwdArgs* args, int dtype, void* stream);
+int fs_bn_bwd_reduce2(const FsBnBwdArgs* a0, const FsBnBwdArgs* a1, int dtype, void* stream);
+int fs_bn_bwd_apply2(const FsBnBwdArgs* a0, const FsBnBwdArgs* a1, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Pooling / upsampling / concat (NHWC, dense).
@@ -393,6 +419,12 @@ int fs_bn_bwd_apply(const FsBnBwdArgs* args, int dtype, void* stream);
 int fs_maxpool_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int dtype, void* stream);
 int fs_maxpool_bwd(const void* dy, const uint8_t* idx, const void* addend, void* dx, int N, int H, int W, int C,
                    int dtype, void* stream);
+/* a second tensor of N1 images with the same H, W, C in the same launch (x1 / dy1 == NULL: one tensor) */
+int fs_maxpool_fwd2(const void* x, void* y, uint8_t* idx, int N, const void* x1, void* y1, uint8_t* idx1, int N1, int H,
+                    int W, int C, int dtype, void* stream);
+int fs_maxpool_bwd2(const void* dy, const uint8_t* idx, const void* addend, void* dx, int N, const void* dy1,
+                    const uint8_t* idx1, const void* addend1, void* dx1, int N1, int H, int W, int C, int dtype,
+                    void* stream);
 int fs_upcat_pad_fwd(const void* a, const void* b, void* out, int N, int h, int w, int Ca, int Cb, int dtype,
                      void* stream);
 int fs_upcat_pad_bwd(const void* dpad, void* da, void* db, int N, int h, int w, int Ca, int Cb, int dtype,

@@ -34,4 +34,7 @@ def test_no_scratch(name):
     # private segment: hipcc reserves an emergency slot when it spills SGPRs into VGPR lanes — v_writelane, no memory
     # traffic.  Which instantiation gets it changes with unrelated edits; what matters is that nothing is stored there.)
     assert not re.search(r"^\s*(scratch_(load|store)|buffer_(load|store)\S* .*\boffen\b.*s\[0:3\])", txt, re.M), name
-    assert max(scratch) <= 64, "stack objects in %s: %s" % (name, scratch)
+    # (the two-problem kernels address their argument set through a computed kernarg offset: two more live scalars, and
+    # bn_bwd_apply's emergency slot grew from 36 to 68 bytes with 16-18 SGPRs parked in VGPR lanes — still no scratch
+    # instruction, which the search above establishes)
+    assert max(scratch) <= 128, "stack objects in %s: %s" % (name, scratch)
