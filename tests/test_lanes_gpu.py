@@ -76,13 +76,30 @@ def test_two_weight_launch_against_two_conv2d_calls(dev, case, dtype):
     st_solo = [stats_for(p, G) for p, G in zip(P, groups)]
     y_solo = [p["op"].forward(p["x"], stats=s, stat_groups=G) for p, s, G in zip(P, st_solo, groups)]
     torch.cuda.synchronize()
+    import ctypes as C
+    from fsnet_amd.hip.binding import lib
+    same_kernel = True
+    if k == 3 and stride == 1:
+        # the pair's pixel-tile count can move it onto the other 3x3 kernel (32x32 MFMA tiles from 512 tiles of 256
+        # pixels on): then the two results differ by the summation order inside a tile, not bit for bit
+        plan = (C.c_int32 * 4)()
+        kinds = []
+        for sp in specs:
+            assert lib.fs_conv3x3_halo_plan(C.byref(sp.a), sp.code, plan) == 0
+            kinds.append(plan[0])
+        assert lib.fs_conv3x3_halo2_plan(C.byref(specs[0].a), C.byref(specs[1].a), specs[0].code, plan) == 0
+        same_kernel = all(kd == plan[0] for kd in kinds)
     for p, yp, ys, sp_, ss, G in zip(P, y_pair, y_solo, st_pair, st_solo, groups):
-        assert torch.equal(yp, ys)                                   # same tiles, same arithmetic: bit for bit
+        if same_kernel:
+            assert torch.equal(yp, ys)                               # same tiles, same arithmetic: bit for bit
+        else:
+            assert (yp.float() - ys.float()).abs().max().item() <= (1e-5 if dtype == torch.float32 else 8e-3) * ys.float().abs().max().item()
         got = yp[..., :p["Co"]].permute(0, 3, 1, 2).float().cpu()
         assert (got - p["y_ref"]).abs().max().item() <= max(tol, 8e-3 if dtype == torch.bfloat16 else 0) * p["y_ref"].abs().max().item()
         # statistics per group: f64 atomics in a different order
         a, b = sp_.reshape(G, 8, 2, -1).sum(1), ss.reshape(G, 8, 2, -1).sum(1)
-        assert torch.allclose(a, b, rtol=1e-9, atol=1e-9 * float(b.abs().max()))
+        st_tol = 1e-9 if same_kernel else (1e-5 if dtype == torch.float32 else 2e-3)
+        assert torch.allclose(a, b, rtol=st_tol, atol=st_tol * float(b.abs().max()))
         n = p["y_ref"].shape[0] // G
         yq = yp.float() if dtype == torch.float32 else yp.float()
         for gi in range(G):
@@ -95,7 +112,8 @@ def test_two_weight_launch_against_two_conv2d_calls(dev, case, dtype):
         dx_solo = [p["op"].dgrad(p["gy"], H, W) for p in P]
         torch.cuda.synchronize()
         for p, sp, ds in zip(P, dspecs, dx_solo):
-            assert torch.equal(sp.out, ds)
+            if same_kernel:
+                assert torch.equal(sp.out, ds)
             got = sp.out[..., :p["Ci"]].permute(0, 3, 1, 2).float().cpu()
             assert (got - p["dx_ref"]).abs().max().item() <= (2e-5 if dtype == torch.float32 else 1e-2) * p["dx_ref"].abs().max().item()
     # ---- weight gradient: one launch, two dW
@@ -330,8 +348,14 @@ def test_training_step_with_and_without_lanes(dev, dtype, tol):
         RT.set_compute_dtype(torch.bfloat16)
     assert abs(res[True][0] - res[False][0]) <= tol * abs(res[False][0])
     worst = 0.0
+    gmax = max(float(g.norm()) for g in res[False][1].values())
     for n, ga in res[False][1].items():
         gb = res[True][1][n]
+        if float(ga.norm()) < 1e-4 * gmax:
+            # (convolution biases in front of a BatchNorm: the true gradient is zero, what is there is the rounding of
+            # sums taken in another order)
+            assert float(gb.norm()) < 1e-3 * gmax, n
+            continue
         rel = float((ga - gb).norm() / ga.norm().clamp_min(1e-8))
         worst = max(worst, rel)
         assert rel < (2e-3 if dtype == torch.float32 else 0.15), (n, rel)
