@@ -30,6 +30,8 @@ FOLD_BN = int(os.environ.get("FSNET_AMD_BN_FOLD", "1"))
 # Built, tested against the oracle and MEASURED slower (the data gradient stages two tensors, holds
 # half the blocks per CU and takes +19 us where the pass it replaces took 15): off by default, same values as FOLD_BN.
 FOLD_BN_BWD = int(os.environ.get("FSNET_AMD_BN_FOLD_BWD", "0"))
+# the 1x1 / stride-2 downsample projection's data gradient inside the block's 3x3 / stride-2 data gradient launch
+FOLD_DS_DGRAD = os.environ.get("FSNET_AMD_FOLD_DS_DGRAD", "1") != "0"
 
 
 class StatsPool:
@@ -762,6 +764,7 @@ class EncoderPass:
         op_last = self._ready(cls_last, x)
         fold_last = dout_sums is not None and self._can_fold_bwd(op_last, bn_last, st, c)
         pend, dc = None, None
+        ds_fold = None
         joint = (ds is not None and RT.dp is not None and st[0].count != float("inf")
                  and bctx["ds"][1][0].count != float("inf"))
         if joint:
@@ -817,7 +820,14 @@ class EncoderPass:
             if not joint:
                 dc_ds = self._bn_bwd(g, None, c_ds, [d[1] for d in ds], st2, relu=False)
             self._param_grads(dcl, dop, dc_ds, x)
-            dres = self._dgrad(dop, dc_ds, hw_x, [dict(addend=(extra[l] if extra is not None else None)) for l in range(nl)])
+            op_first = self._ready([u[0][0] for u in units], x)
+            if FOLD_DS_DGRAD and k > 1 and all(o.can_fold_ds_dgrad(dp, t, t) for o, dp, t in zip(op_first, dop, dc_ds)):
+                # the projection's data gradient rides in conv1's (fs_conv3x3_s2d, FsConvArgs.ds_src): its result is one
+                # more K segment of the (even, even) class there, never a tensor; the feature gradient stays the addend
+                ds_fold = [(dop[l], dc_ds[l]) for l in range(nl)]
+                dres = extra if extra is not None else [None] * nl
+            else:
+                dres = self._dgrad(dop, dc_ds, hw_x, [dict(addend=(extra[l] if extra is not None else None)) for l in range(nl)])
         else:
             assert extra is None
             dres = g
@@ -857,6 +867,10 @@ class EncoderPass:
         src, kw = dc, [dict() for _ in range(nl)]
         if pend is not None:
             src, kw, dc = self._pend_kw(pend)
+        if ds_fold is not None:
+            assert pend is None
+            for l in range(nl):
+                kw[l]["ds"] = ds_fold[l]
         if prev is not None and FUSE_BN_BWD and all(o.can_fuse_bn_bwd(t.shape[0], t.shape[1], t.shape[2], p.groups)
                                                     for o, t, p in zip(op, x, prev[2])):
             py, pc, pst = prev
@@ -913,6 +927,10 @@ class EncoderPass:
                         RT.dp.partial_ready(r.m, [getattr(r.m, "layer%d" % (si + 1))])
         y0 = ctx["y0"]
         add0 = [gfeats[l][0] for l in range(nl)]
+        if RT.stem_flush:
+            # layer 1's weight gradients go to the companion now: they run beside the stem's memory-bound passes (pooling
+            # backward, both BatchNorm-backward passes: the largest tensors of the network) instead of behind them
+            flush_deferred(_current_stream())
         d0 = ops.maxpool_bwd_multi(dout, ctx["idx"], y0[0].shape[1], y0[0].shape[2], add0)
         dc0 = self._bn_bwd(d0, y0, ctx["c0"], [r.m.bn1 for r in self.R], ctx["st0"], relu=True)
         stems = [r.stem for r in self.R]

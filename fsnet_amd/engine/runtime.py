@@ -24,7 +24,9 @@ class _Runtime:
         # inline 6.13 ms, main chain only 6.1, onto the pose stream's tail 6.15, this placement 5.93; batches of 6 / 16
         # are 3-4 % slower than 8.  wgrad_streams = 0 (inline) is what data parallelism uses and what tests may set.
         self.wgrad_streams = 2
-        self.wgrad_flush = 8
+        self.wgrad_flush = int(os.environ.get("FSNET_AMD_WGRAD_FLUSH", "8"))
+        # hand over what is pending when an encoder's backward reaches its stem (see EncoderPass.backward)
+        self.stem_flush = os.environ.get("FSNET_AMD_STEM_FLUSH", "1") != "0"
         self.wgrad_spread = 1
         # the pose encoder's image pairs as one stacked pass with per-pair BatchNorm statistics
         self.batch_pose_pairs = os.environ.get("FSNET_AMD_BATCH_POSE", "1") != "0"

@@ -43,6 +43,7 @@ class FsConvArgs(C.Structure):
         ("pro_dgamma", C.c_void_p), ("pro_dbeta", C.c_void_p),
         ("pro_dst", C.c_void_p),
         ("pro_count", C.c_double), ("pro_eps", C.c_float), ("pro_momentum", C.c_float),
+        ("ds_src", C.c_void_p), ("ds_wgt", C.c_void_p), ("ds_wgt_row_bytes", C.c_int64),
     ]
 
 
@@ -152,7 +153,7 @@ class FsSmoothArgs(C.Structure):
     ]
 
 
-ABI_VERSION = 7      # FS_ABI_VERSION of include/fsnet_hip.h (tests/test_abi.py holds the two together)
+ABI_VERSION = 8      # FS_ABI_VERSION of include/fsnet_hip.h (tests/test_abi.py holds the two together)
 _lib = None
 
 

@@ -52,7 +52,7 @@ class Spec:
 
 
 # entry points that have a two-problem form
-DUAL_ENTRIES = {"conv3x3_halo", "conv_igemm", "conv_stem", "conv_wgrad", "bn_apply", "bn_bwd_reduce", "bn_bwd_apply"}
+DUAL_ENTRIES = {"conv3x3_halo", "conv3x3_s2d", "conv_igemm", "conv_stem", "conv_wgrad", "bn_apply", "bn_bwd_reduce", "bn_bwd_apply"}
 
 
 def _run_chain(chain, a0, a1, code, what):
@@ -162,6 +162,7 @@ USE_1X1 = os.environ.get("FSNET_AMD_CONV1X1", "1") != "0"
 USE_HALO = os.environ.get("FSNET_AMD_HALO", "1") != "0"   # 3x3/s1 LDS-halo kernel (conv3x3_halo.hip)
 USE_STEM_LDS = os.environ.get("FSNET_AMD_STEM_LDS", "1") != "0"   # 7x7/s2 stem kernel (conv_stem.hip)
 USE_HALO_S2 = os.environ.get("FSNET_AMD_HALO_S2", "1") != "0"     # 3x3/s2 forward on the LDS-halo kernel (else implicit GEMM)
+USE_S2D = os.environ.get("FSNET_AMD_S2D", "1") != "0"   # 3x3/s2 data gradient: four parity classes from one dY halo (conv3x3_s2d.hip)
 _WGRAD_WS = {}
 
 
@@ -211,6 +212,9 @@ class ConvOp:
         # every pixel and masks 3/4 of them.
         self.s2_classes = bool(need_dgrad and stride == 2 and R == 3 and S == 3 and pad == 1
                                and (self.Co_p * eb) % (self.kg_d * 16) == 0)
+        # ... all four classes from one staged dY halo (conv3x3_s2d.hip) when dY has whole 64-byte channel chunks
+        self.s2d = bool(self.s2_classes and USE_S2D and (self.Co_p * eb) % 64 == 0 and self.rows_d % 32 == 0
+                        and self.Ci_p % 8 == 0)
         halo_ok = (R == 3 and S == 3 and stride == 1)
         def chunks_ok(c):      # whole 64-byte chunks, or exactly half of one (16 bf16 channels)
             return (c * eb) % 64 == 0 or c * eb == 32
@@ -415,7 +419,7 @@ class ConvOp:
         rows = (N // groups) * H * W
         if self.s2_classes and H % 2 == 0 and W % 2 == 0:
             rows //= 4                                  # one launch per output-parity class
-        if groups > 1 and not (self.halo_d and USE_HALO) and rows % 256 != 0:
+        if groups > 1 and not (self.halo_d and USE_HALO) and not self.s2d and rows % 256 != 0:
             return False      # an implicit-GEMM tile could straddle two statistics groups
         return True
 
@@ -449,8 +453,17 @@ class ConvOp:
             t = self._tabs[key] = (torch.from_numpy(np.concatenate(tabs, 0)).to(self.device), offs, nchs)
         return t
 
-    def _dgrad_s2_classes(self, dy, H, W, out, addend, mask, bn_fuse):
-        """all four parity classes in ONE launch (blockIdx.y = class) -> Spec"""
+    def can_fold_ds_dgrad(self, ds_op, dy, dc_ds):
+        """whether this 3x3 / stride-2 convolution's data gradient can carry the data gradient of the block's 1x1 /
+        stride-2 downsample projection ds_op (its dY: dc_ds) in the same launch (fs_conv3x3_s2d with FsConvArgs.ds_src)"""
+        return (self.s2d and ds_op.need_dgrad and ds_op.R == 1 and ds_op.S == 1 and ds_op.stride == 2 and ds_op.pad == 0
+                and ds_op.dtype == self.dtype and ds_op.Ci_p == self.Ci_p and ds_op.Co_p == self.Co_p
+                and ds_op.rows_d == self.rows_d and dy.is_contiguous() and dc_ds.is_contiguous()
+                and dc_ds.shape == dy.shape and dc_ds.dtype == dy.dtype)
+
+    def _dgrad_s2_classes(self, dy, H, W, out, addend, mask, bn_fuse, ds=None):
+        """all four parity classes in ONE launch (blockIdx.y = class) -> Spec.  ds = (downsample ConvOp, its dY): see
+        can_fold_ds_dgrad()"""
         N, Ho, Wo, Cd = dy.shape
         eb = dy.element_size()
         tab, offs, nchs = self._class_tables(*_nhwc_strides(dy)[1:])
@@ -488,7 +501,19 @@ class ConvOp:
             a.stats = sums.data_ptr()
             a.stat_group_rows = (N // st.groups) * (H // 2) * (W // 2) if st.groups > 1 else 0
         flops = 2.0 * N * Ho * Wo * self.Co * self.R * self.S * self.Ci
-        return Spec(["conv_igemm"], a, self.code, "conv_igemm", flops,
+        if ds is not None:
+            ds_op, dc_ds = ds
+            assert self.can_fold_ds_dgrad(ds_op, dy, dc_ds) and out.is_contiguous()
+            assert (addend is None or addend.is_contiguous()) and (mask is None or mask.is_contiguous())
+            a.ds_src, a.ds_wgt, a.ds_wgt_row_bytes = dc_ds.data_ptr(), ds_op.w_d.data_ptr(), ds_op.kd_p * eb
+            flops += 2.0 * N * Ho * Wo * self.Co * self.Ci
+            # (only fs_conv3x3_s2d carries the projection: a declined launch fails loudly)
+            return Spec(["conv3x3_s2d"], a, self.code, "conv3x3_s2d", flops,
+                        lambda: "dgrd %s + 1x1/s2 dy[%d,%d,%d,%d]" % (self.describe(), N, Ho, Wo, Cd), out, "conv_dgrad_s2")
+        # fs_conv3x3_s2d: all four classes from one staged dY halo (whole 64-byte chunks of dY); the implicit GEMM's class
+        # launch takes what it declines
+        return Spec(["conv3x3_s2d", "conv_igemm"] if self.s2d else ["conv_igemm"], a, self.code,
+                    "conv3x3_s2d" if self.s2d else "conv_igemm", flops,
                     lambda: "dgrd %s dy[%d,%d,%d,%d]" % (self.describe(), N, Ho, Wo, Cd), out, "conv_dgrad_s2")
 
     def dgrad(self, dy, H, W, **kw):
@@ -497,7 +522,7 @@ class ConvOp:
         run_specs([sp])
         return sp.out
 
-    def dgrad_spec(self, dy, H, W, out=None, addend=None, mask=None, bn_fuse=None, mask_bn=False, pro_bwd=None):
+    def dgrad_spec(self, dy, H, W, out=None, addend=None, mask=None, bn_fuse=None, mask_bn=False, pro_bwd=None, ds=None):
         """dy: [N,Ho,Wo,Co_p] -> dx [N,H,W,Ci_p] (out may be a strided view; addend is summed in).
         bn_fuse = (c, BnState, sums): dx is the gradient w.r.t. relu(BN(c)) (+ residual): the epilogue also
         accumulates the BatchNorm-backward sums (sum g, sum g*xhat) of that BatchNorm into `sums` (zeroed f64
@@ -520,7 +545,8 @@ class ConvOp:
         if self.s2_classes:
             if H % 2 or W % 2 or H != 2 * Ho or W != 2 * Wo:
                 raise NotImplementedError("stride-2 3x3 data gradient expects an even input size (%dx%d)" % (H, W))
-            return self._dgrad_s2_classes(dy, H, W, out, addend, mask, bn_fuse)
+            return self._dgrad_s2_classes(dy, H, W, out, addend, mask, bn_fuse, ds)
+        assert ds is None
         a = FsConvArgs()
         a.src, a.wgt, a.dst = dy.data_ptr(), self.w_d.data_ptr(), out.data_ptr()
         a.bias, a.stats = None, None

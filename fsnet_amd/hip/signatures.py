@@ -17,6 +17,8 @@ SIGNATURES = {
     "fs_conv_igemm2": (C.c_int, [P, P, I, P]),
     "fs_conv3x3_halo2": (C.c_int, [P, P, I, P]),
     "fs_conv3x3_halo2_plan": (C.c_int, [P, P, I, P]),
+    "fs_conv3x3_s2d": (C.c_int, [P, I, P]),
+    "fs_conv3x3_s2d2": (C.c_int, [P, P, I, P]),
     "fs_conv_stem2": (C.c_int, [P, P, I, P]),
     "fs_conv_wgrad2": (C.c_int, [P, P, I, P]),
     "fs_conv_wgrad2_plan": (C.c_int, [P, P, I, P]),

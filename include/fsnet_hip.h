@@ -33,7 +33,7 @@ extern "C" {
 
 /* library/ABI version and the ISA the kernels were compiled for ("gfx950").  FS_ABI_VERSION changes whenever an
  * argument struct or a signature below does; a host binding refuses a library that reports another number. */
-#define FS_ABI_VERSION 7
+#define FS_ABI_VERSION 8
 int fs_abi_version(void);
 const char* fs_target_arch(void);
 /* debugging aid: writes the device's constant-rate clock (wall_clock64, 100 MHz) into *slot (u64) on `stream`;
@@ -144,6 +144,11 @@ typedef struct FsConvArgs {
   void* pro_dst;
   double pro_count;
   float pro_eps, pro_momentum;
+  /* ---- fs_conv3x3_s2d only (ABI 8): the data gradient of the block's 1x1 / stride-2 downsample projection in the same
+   * launch.  ds_src: its dY, same shape, strides and dtype as src; ds_wgt: its packed data-gradient operand
+   * Wt[ci][co] with rows ds_wgt_row_bytes apart.  dst then receives dgrad(conv1) + dgrad(downsample) (+ addend). */
+  const void* ds_src; const void* ds_wgt;
+  int64_t ds_wgt_row_bytes;
 } FsConvArgs;
 int fs_conv_igemm(const FsConvArgs* args, int dtype, void* stream);
 
@@ -177,6 +182,16 @@ int fs_conv3x3_halo_plan(const FsConvArgs* args, int dtype, int32_t* plan);
 /* two problems in one launch (see fs_conv_igemm2); the plan of the shared launch (FS_EINVAL if the pair would run as two) */
 int fs_conv3x3_halo2(const FsConvArgs* a0, const FsConvArgs* a1, int dtype, void* stream);
 int fs_conv3x3_halo2_plan(const FsConvArgs* a0, const FsConvArgs* a1, int dtype, int32_t* plan);
+
+/* ---- Data gradient of a 3x3 / stride-2 / pad-1 convolution, all four output-parity classes from one staged dY halo (ABI 8)
+ * Replaces convolution_backward(input) of the ResNet stage entries (resnet.py:33-50 with stride 2, instantiated at
+ * resnet.py:199-213 as layer2/3/4[0].conv1).  Takes the class launch's arguments of fs_conv_igemm unchanged (ncls = 4:
+ * src = dY [N,Hs,Ws,Cs], wgt = Wt[ci][class-ordered tap][co] with row stride wgt_row_bytes, dst / addend / mask / bnb_x =
+ * the sub-lattice of class (0,0) with the doubled strides; Hd = Hs, Wd = Ws) and produces the same tensor; epilogue
+ * options: addend, mask, bnb_x + stats (BatchNorm-backward sums per statistics group of stat_group_rows rows).
+ * FS_EINVAL: not taken (ragged channel chunks, other epilogues) — the caller's chain continues with fs_conv_igemm. */
+int fs_conv3x3_s2d(const FsConvArgs* args, int dtype, void* stream);
+int fs_conv3x3_s2d2(const FsConvArgs* a0, const FsConvArgs* a1, int dtype, void* stream);
 
 /* 7x7 / stride-2 / pad-3 stem (resnet.py:118-121: conv1 of both encoders) over 8-channel bf16 pixels, forward only:
  * weights resident in LDS, im2col from an LDS input patch, persistent blocks.  Same arguments and packed forward

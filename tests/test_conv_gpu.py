@@ -244,3 +244,121 @@ def test_pack_table_follows_every_operand_buffer(dev):
     assert cl.ready(torch.bfloat16, dev) is op
     torch.cuda.synchronize()
     assert torch.equal(op.w_d, ref_d) and torch.equal(op.w_f, ref_f)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(64, 128, 2, 16, 32, 1), (64, 128, 3, 20, 44, 1), (128, 256, 4, 24, 80, 2),
+                                  (256, 512, 6, 12, 40, 2), (64, 128, 2, 96, 160, 1)])
+def test_stride2_data_gradient_on_the_class_fused_kernel(dev, case, dtype):
+    """fs_conv3x3_s2d (conv3x3_s2d.hip: the four output-parity classes of a 3x3 / stride-2 data gradient from one staged
+    dY halo) takes the ResNet stage entries' launches and equals autograd's convolution_backward(input) of
+    resnet.py:33-50 with stride 2, with every epilogue the encoders use (residual addend, ReLU mask, BatchNorm-backward
+    sums per statistics group) — and the implicit GEMM's class launch it replaces (FSNET_AMD_S2D=0 path)."""
+    import ctypes as C
+    from fsnet_amd.hip import ops
+    from fsnet_amd.hip.binding import lib, stream_ptr
+    from fsnet_amd.hip.conv import ConvOp, LaunchProfile
+    Ci, Co, N, H, W, G = case
+    g = torch.Generator().manual_seed(3 + Ci + H)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5
+    gy = torch.randn(N, Co, H // 2, W // 2, generator=g)
+    if dtype == torch.bfloat16:
+        x, w, gy = x.bfloat16().float(), w.bfloat16().float(), gy.bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    F.conv2d(xr, w, None, stride=2, padding=1).backward(gy)
+    op = ConvOp(Ci, Co, 3, 3, 2, 1, dtype, dev, need_dgrad=True)
+    op.pack(w.to(dev).contiguous())
+    gyd = to_nhwc(gy.to(dev), op.Co_p, dtype)
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    # plain
+    LaunchProfile.begin()
+    dx = op.dgrad(gyd, H, W)
+    kinds = [k for (k, _, _) in LaunchProfile.end()]
+    assert kinds == ["conv3x3_s2d"], kinds                # the new kernel took the launch
+    got = dx[..., :Ci].permute(0, 3, 1, 2).float().cpu()
+    assert (got - xr.grad).abs().max().item() <= tol * xr.grad.abs().max().item()
+    # against the implicit GEMM's class launch, same arguments
+    sp = op.dgrad_spec(gyd, H, W)
+    assert lib.fs_conv_igemm(C.byref(sp.a), sp.code, stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert (sp.out.float() - dx.float()).abs().max().item() <= (2e-5 if dtype == torch.float32 else 8e-3) * dx.float().abs().max().item()
+    # addend + mask + BatchNorm-backward sums, G statistics groups
+    c = torch.randn(N, H, W, Ci, generator=g).to(dev).to(dtype)
+    yact = torch.randn(N, H, W, Ci, generator=g).to(dev).to(dtype)
+    addend = torch.randn(N, H, W, Ci, generator=g).to(dev).to(dtype)
+    st = ops.BnState(Ci, dev, G)
+    st.mean.copy_(torch.randn(G * Ci, generator=g) * 0.1)
+    st.invstd.copy_(torch.rand(G * Ci, generator=g) + 0.5)
+    st.count = float(N // G * H * W)
+    sums = torch.zeros(G * 8, 2, Ci, dtype=torch.float64, device=dev)
+    LaunchProfile.begin()
+    d_fused = op.dgrad(gyd, H, W, addend=addend, mask=yact, bn_fuse=(c, st, sums))
+    kinds = [k for (k, _, _) in LaunchProfile.end()]
+    assert kinds == ["conv3x3_s2d"], kinds
+    ref = (dx.float() + addend.float()) * (yact.float() > 0)
+    assert (d_fused.float() - ref).abs().max().item() <= (1e-5 if dtype == torch.float32 else 1.6e-2) * ref.abs().max().item()
+    n = N // G
+    gq = d_fused.float().double().view(G, n, H, W, Ci)
+    xhat = (c.float().double().view(G, n, H, W, Ci) - st.mean.double().view(G, 1, 1, 1, Ci)) * st.invstd.double().view(G, 1, 1, 1, Ci)
+    a = sums.view(G, 8, 2, Ci).sum(1)
+    s_tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for k, refsum in enumerate((gq.sum((1, 2, 3)), (gq * xhat).sum((1, 2, 3)))):
+        assert float((a[:, k] - refsum).abs().max()) <= s_tol * float(refsum.abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(64, 128, 2, 16, 32, 1), (128, 256, 4, 24, 80, 2), (256, 512, 3, 12, 40, 1)])
+def test_stride2_data_gradient_carries_the_downsample_projection(dev, case, dtype):
+    """fs_conv3x3_s2d with FsConvArgs.ds_src: dgrad(conv1: 3x3/s2) + dgrad(downsample: 1x1/s2) of a stage-entry
+    BasicBlock (resnet.py:33-50, 152-160: both read the block input) in one launch == autograd of the two convolutions,
+    alone and with the block's epilogue (feature-gradient addend, ReLU mask, BatchNorm-backward sums)."""
+    from fsnet_amd.hip import ops
+    from fsnet_amd.hip.conv import ConvOp, LaunchProfile
+    Ci, Co, N, H, W, G = case
+    g = torch.Generator().manual_seed(5 + Ci + H)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w3 = torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5
+    w1 = torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5
+    gy3 = torch.randn(N, Co, H // 2, W // 2, generator=g)
+    gy1 = torch.randn(N, Co, H // 2, W // 2, generator=g)
+    if dtype == torch.bfloat16:
+        x, w3, w1, gy3, gy1 = (t.bfloat16().float() for t in (x, w3, w1, gy3, gy1))
+    xr = x.clone().requires_grad_(True)
+    (F.conv2d(xr, w3, None, stride=2, padding=1) * gy3).sum().backward()
+    (F.conv2d(xr, w1, None, stride=2, padding=0) * gy1).sum().backward()
+    op3 = ConvOp(Ci, Co, 3, 3, 2, 1, dtype, dev, need_dgrad=True)
+    op1 = ConvOp(Ci, Co, 1, 1, 2, 0, dtype, dev, need_dgrad=True)
+    op3.pack(w3.to(dev).contiguous()); op1.pack(w1.to(dev).contiguous())
+    d3, d1 = to_nhwc(gy3.to(dev), op3.Co_p, dtype), to_nhwc(gy1.to(dev), op1.Co_p, dtype)
+    assert op3.can_fold_ds_dgrad(op1, d3, d1)
+    LaunchProfile.begin()
+    dx = op3.dgrad(d3, H, W, ds=(op1, d1))
+    kinds = [k for (k, _, _) in LaunchProfile.end()]
+    assert kinds == ["conv3x3_s2d"], kinds
+    got = dx[..., :Ci].permute(0, 3, 1, 2).float().cpu()
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    assert (got - xr.grad).abs().max().item() <= tol * xr.grad.abs().max().item()
+    # == the two launches it replaces (the projection's result as the addend)
+    two = op3.dgrad(d3, H, W, addend=op1.dgrad(d1, H, W))
+    assert (two.float() - dx.float()).abs().max().item() <= (2e-5 if dtype == torch.float32 else 1.6e-2) * dx.float().abs().max().item()
+    # with the block's epilogue
+    c = torch.randn(N, H, W, Ci, generator=g).to(dev).to(dtype)
+    yact = torch.randn(N, H, W, Ci, generator=g).to(dev).to(dtype)
+    addend = torch.randn(N, H, W, Ci, generator=g).to(dev).to(dtype)
+    st = ops.BnState(Ci, dev, G)
+    st.mean.copy_(torch.randn(G * Ci, generator=g) * 0.1)
+    st.invstd.copy_(torch.rand(G * Ci, generator=g) + 0.5)
+    st.count = float(N // G * H * W)
+    sums = torch.zeros(G * 8, 2, Ci, dtype=torch.float64, device=dev)
+    d_fused = op3.dgrad(d3, H, W, addend=addend, mask=yact, bn_fuse=(c, st, sums), ds=(op1, d1))
+    torch.cuda.synchronize()
+    ref = (dx.float() + addend.float()) * (yact.float() > 0)
+    assert (d_fused.float() - ref).abs().max().item() <= (1e-5 if dtype == torch.float32 else 1.6e-2) * ref.abs().max().item()
+    n = N // G
+    gq = d_fused.float().double().view(G, n, H, W, Ci)
+    xhat = (c.float().double().view(G, n, H, W, Ci) - st.mean.double().view(G, 1, 1, 1, Ci)) * st.invstd.double().view(G, 1, 1, 1, Ci)
+    a = sums.view(G, 8, 2, Ci).sum(1)
+    s_tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for k, refsum in enumerate((gq.sum((1, 2, 3)), (gq * xhat).sum((1, 2, 3)))):
+        assert float((a[:, k] - refsum).abs().max()) <= s_tol * float(refsum.abs().max())

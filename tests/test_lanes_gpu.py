@@ -192,8 +192,9 @@ def test_batchnorm_and_pool_pairs(dev, dtype):
         mods = [copy.deepcopy(b) for b in bns]
         sts = [ops.BnState(Cc, dev, G) for G in groups]
         ys = [torch.empty_like(x) for x in xs]
-        specs = [ops.bn_apply_spec(x, stats_of(x, G), bn_tensors(m), st, y, H, W, (x.shape[0] // G) * H * W, relu=True, groups=G)
-                 for x, G, m, st, y in zip(xs, groups, mods, sts, ys)]
+        stats = [stats_of(x, G) for x, G in zip(xs, groups)]     # (a Spec holds pointers, not tensors: keep them alive)
+        specs = [ops.bn_apply_spec(x, s_, bn_tensors(m), st, y, H, W, (x.shape[0] // G) * H * W, relu=True, groups=G)
+                 for x, s_, G, m, st, y in zip(xs, stats, groups, mods, sts, ys)]
         if mode == "pair":
             run_specs(specs)
         else:
