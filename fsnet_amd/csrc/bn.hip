@@ -221,6 +221,103 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const FsDual<FsBnApplyArg
   }
 }
 
+
+// BatchNorm + ReLU + MaxPool2d(3, 2, 1) of the encoder stem in one pass (resnet.py:201-206: x = relu(bn1(conv1(x))),
+// features[0] = x, x = maxpool(x)): a thread owns one pooled pixel x 16 bytes of channels, normalises the nine window
+// inputs from the raw convolution output, rounds them to the storage type (the value the separate pass would have
+// stored: same maxima, same argmax codes) and — when the activation itself is wanted (FsBnApplyArgs.y: the depth
+// encoder's features[0]; NULL for the pose encoder, whose decoder only reads the last feature) — stores the 2 x 2
+// pixels (2ho + {0,1}, 2wo + {0,1}) that only this window owns.  The activation of 36 images at 96 x 320 x 64 is 141 MB:
+// the separate passes wrote it, read it back for the pooling, and wrote and read it again in the backward.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_pool_kernel(const FsDual<FsBnApplyArgs, FsNoGeom> d) {
+  const int prob = (int)blockIdx.z >= d.nb0 ? 1 : 0;
+  const FsBnApplyArgs& p = d.a[prob];
+  extern __shared__ float bn_smem[];
+  const int C = p.C;
+  float* s_scale = bn_smem; float* s_shift = bn_smem + C;
+  const int G = p.groups > 1 ? p.groups : 1;
+  const int z = (int)blockIdx.z - (prob ? d.nb0 : 0);
+  const long gstat = (long)FS_STAT_SLOTS * 2 * C;
+  const double* stats_z = p.stats + z * gstat;
+  const bool first = blockIdx.x == 0;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float mean, invstd, varb, sc, sh;
+    bn_channel_coeffs(stats_z, p.running_mean, p.running_var, C, c, p.count, p.eps, p.gamma[c], p.beta[c], mean, invstd, varb, sc, sh);
+    s_scale[c] = sc; s_shift[c] = sh;
+    if (first) { p.save_mean[z * C + c] = mean; p.save_invstd[z * C + c] = invstd; }
+    if (first && z == 0 && p.running_mean) {
+      float rm = p.running_mean[c], rv = p.running_var[c];
+      for (int g = 0; g < G; ++g) {
+        float mg = mean, vg = varb, t0, t1, t2;
+        if (g > 0) bn_channel_coeffs(p.stats + g * gstat, nullptr, nullptr, C, c, p.count, p.eps, 1.f, 0.f, mg, t0, vg, t1, t2);
+        double unb = p.count > 1.0 ? (double)vg * p.count / (p.count - 1.0) : (double)vg;
+        rm = (1.f - p.momentum) * rm + p.momentum * mg;
+        rv = (1.f - p.momentum) * rv + p.momentum * (float)unb;
+      }
+      p.running_mean[c] = rm; p.running_var[c] = rv;
+    }
+  }
+  if (first && z == 0 && threadIdx.x == 0 && p.num_batches_tracked) *p.num_batches_tracked += G;
+  __syncthreads();
+
+  constexpr int V = VecN<T>::N;
+  const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+  T* __restrict__ y = reinterpret_cast<T*>(p.y);
+  T* __restrict__ py = reinterpret_cast<T*>(p.pool_y);
+  const int H = p.H, W = p.W, Ho = H >> 1, Wo = W >> 1;
+  const int CG = C / V, cg_sh = pow2_shift(CG);
+  const int Ng = (p.M / (H * W)) / G;                    // images per statistics group
+  const unsigned total = (unsigned)Ng * Ho * Wo * CG;    // (< 2^31: checked by the host)
+  const unsigned stride = gridDim.x * 256u;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += stride) {
+    unsigned cg, mo;
+    if (cg_sh >= 0) { cg = i & (CG - 1); mo = i >> cg_sh; } else { mo = i / CG; cg = i - mo * CG; }
+    const unsigned q = mo / Wo, wo = mo - q * Wo;
+    const unsigned nn = q / Ho, ho = q - nn * Ho;
+    const long n = (long)z * Ng + nn;
+    const int c = cg * V;
+    float sc[V], sh[V], best[V];
+    int bi[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { sc[j] = s_scale[c + j]; sh[j] = s_shift[c + j]; best[j] = -INFINITY; bi[j] = 0; }
+    bool fst = true;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int h = (int)ho * 2 - 1 + r;
+      if (h < 0) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int w = (int)wo * 2 - 1 + s;
+        if (w < 0) continue;
+        const long off = ((n * H + h) * W + w) * C + c;
+        float v[V];
+        loadv<T>(x + off, v);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          v[j] = v[j] * sc[j] + sh[j];
+          if (p.relu) v[j] = fmaxf(v[j], 0.f);
+        }
+        const uint4 u = Unit<T>::pack(v);         // rounded to the storage type: what the separate pass stores
+        Unit<T>::unpack(u, v);
+        if (y && r >= 1 && s >= 1) *reinterpret_cast<uint4*>(y + off) = u;
+#pragma unroll
+        for (int j = 0; j < V; ++j)
+          if (fst || v[j] > best[j]) { best[j] = v[j]; bi[j] = r * 3 + s; }      // first max wins (ATen)
+        fst = false;
+      }
+    }
+    const long mg = ((n * Ho + ho) * Wo + wo) * C + c;
+    storev<T>(py + mg, best);
+#pragma unroll
+    for (int k = 0; k < V / 4; ++k) {
+      const uint32_t packed = (uint32_t)bi[4 * k] | ((uint32_t)bi[4 * k + 1] << 8) | ((uint32_t)bi[4 * k + 2] << 16) |
+                              ((uint32_t)bi[4 * k + 3] << 24);
+      reinterpret_cast<uint32_t*>(p.pool_idx + mg)[k] = packed;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
@@ -274,9 +371,69 @@ __device__ inline void masked_grad(const FsBnBwdArgs& p, const T* dout, const T*
   }
 }
 
+
+// POOL mode (FsBnBwdArgs.pool_dy): the gradient w.r.t. relu(bn(x)) at pixel m = (n, h, w) is not a tensor — it is the
+// max-pool backward of the pooled gradient (the <= 4 windows that contain the pixel and whose argmax code names it;
+// resnet.py:206, MaxPool2d(3, 2, 1) on an even H x W) plus the dense gradient `dout` of the un-pooled feature (NULL:
+// none), gathered here instead of being written out by fs_maxpool_bwd and read back twice.
+template <typename T>
+__device__ inline void pool_grad(const FsBnBwdArgs& p, long m, int c, float* g) {
+  constexpr int V = VecN<T>::N;
+  const int C = p.C, H = p.H, W = p.W, Ho = H >> 1, Wo = W >> 1;
+  const unsigned u = (unsigned)m, q = u / (unsigned)W, nn = q / (unsigned)H;
+  const int w = (int)(u - q * W), h = (int)(q - nn * H);
+  // h = 2 ho - 1 + r: the window row ho = h >> 1 always holds the pixel (r = 1 for even h, 2 for odd h); for odd h the
+  // row below does too (ho + 1, r = 0) unless it is past the last one.  Columns alike.  All eight loads are issued
+  // unconditionally (an absent window re-reads the first one and is not counted): no branch sits between them.
+  const int h2 = h >> 1, w2 = w >> 1;
+  const int r0 = (h & 1) ? 2 : 1, s0 = (w & 1) ? 2 : 1;
+  const bool vh = (h & 1) && h2 + 1 < Ho, vw = (w & 1) && w2 + 1 < Wo;
+  const long base = (((long)nn * Ho + h2) * Wo + w2) * C + c;
+  const long dh = vh ? (long)Wo * C : 0, dw = vw ? C : 0;
+  const long off[4] = {base, base + dw, base + dh, base + dh + dw};
+  const int code[4] = {r0 * 3 + s0, r0 * 3, s0, 0};
+  const bool ok[4] = {true, vw, vh, vh && vw};
+  const T* __restrict__ dy = reinterpret_cast<const T*>(p.pool_dy);
+  uint32_t packed[4][V / 4];
+  float t[4][V];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int e = 0; e < V / 4; ++e) packed[k][e] = reinterpret_cast<const uint32_t*>(p.pool_idx + off[k])[e];
+    loadv<T>(dy + off[k], t[k]);
+  }
+  if (p.dout) loadv<T>(reinterpret_cast<const T*>(p.dout) + m * C + c, g);
+  else {
+#pragma unroll
+    for (int j = 0; j < V; ++j) g[j] = 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int j = 0; j < V; ++j)
+      if (ok[k] && (int)((packed[k][j >> 2] >> (8 * (j & 3))) & 0xff) == code[k]) g[j] += t[k][j];
+}
+// ... and its ReLU mask: from the stored activation when there is one, else the sign of the forward's own expression
+// scale * x + shift on the raw convolution output x (sc = gamma * invstd, sh = beta - mean * sc: bn_channel_coeffs)
+template <typename T>
+__device__ inline void pool_mask(const FsBnBwdArgs& p, const T* yv, long m, int c, const float* xr, const float* sc,
+                                 const float* sh, float* g) {
+  constexpr int V = VecN<T>::N;
+  if (!p.relu) return;
+  if (yv) {
+    float yy[V];
+    loadv<T>(yv + m * p.C + c, yy);
+#pragma unroll
+    for (int j = 0; j < V; ++j) g[j] = yy[j] > 0.f ? g[j] : 0.f;
+  } else {
+#pragma unroll
+    for (int j = 0; j < V; ++j) g[j] = (xr[j] * sc[j] + sh[j]) > 0.f ? g[j] : 0.f;
+  }
+}
+
 // pass 1: per-channel sum(g), sum(g * xhat) with g = dout * (y > 0).  A block covers CGB channel groups
 // (16-byte lanes) x PL pixel lanes; two rows per iteration keep more loads in flight.
-template <typename T, int CGB>
+template <typename T, int CGB, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const FsDual<FsBnBwdArgs, FsNoGeom> d) {
   const int prob = (int)blockIdx.z >= d.nb0 ? 1 : 0;
   const FsBnBwdArgs& p = d.a[prob];
@@ -297,6 +454,40 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const FsDual<FsBnBwd
   float mean[V], istd[V], s1[V], s2[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) { mean[j] = act ? p.save_mean[z * C + c + j] : 0.f; istd[j] = act ? p.save_invstd[z * C + c + j] : 0.f; s1[j] = 0.f; s2[j] = 0.f; }
+  if constexpr (POOL) {
+    if (act) {
+      float sc[V], sh[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        sc[j] = p.gamma[c + j] * istd[j];
+        sh[j] = (p.beta ? p.beta[c + j] : 0.f) - mean[j] * sc[j];
+      }
+      const long stride = (long)gridDim.x * PL;
+      long m = z * Mg + (long)blockIdx.x * PL + pl;
+      for (; m + stride < m_end; m += 2 * stride) {          // two pixels' loads in flight
+        float g0[V], x0[V], g1[V], x1[V];
+        loadv<T>(xv + m * C + c, x0);
+        loadv<T>(xv + (m + stride) * C + c, x1);
+        pool_grad<T>(p, m, c, g0);
+        pool_grad<T>(p, m + stride, c, g1);
+        pool_mask<T>(p, yv, m, c, x0, sc, sh, g0);
+        pool_mask<T>(p, yv, m + stride, c, x1, sc, sh, g1);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          s1[j] += g0[j] + g1[j];
+          s2[j] += g0[j] * (x0[j] - mean[j]) * istd[j] + g1[j] * (x1[j] - mean[j]) * istd[j];
+        }
+      }
+      for (; m < m_end; m += stride) {
+        float g0[V], x0[V];
+        loadv<T>(xv + m * C + c, x0);
+        pool_grad<T>(p, m, c, g0);
+        pool_mask<T>(p, yv, m, c, x0, sc, sh, g0);
+#pragma unroll
+        for (int j = 0; j < V; ++j) { s1[j] += g0[j]; s2[j] += g0[j] * (x0[j] - mean[j]) * istd[j]; }
+      }
+    }
+  } else
   if (act) {
     const long stride = (long)gridDim.x * PL;
     long m = z * Mg + (long)blockIdx.x * PL + pl;
@@ -336,7 +527,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const FsDual<FsBnBwd
 }
 
 // pass 2: dx = gamma*invstd * (g - sum_g/count - xhat * sum_gx/count); optional g output; param grads
-template <typename T>
+template <typename T, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const FsDual<FsBnBwdArgs, FsNoGeom> d) {
   extern __shared__ float bn_smem[];
   const int prob = (int)blockIdx.z >= d.nb0 ? 1 : 0;
@@ -362,7 +553,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const FsDual<FsBnBwdA
     int cg; long m;
     split_vec(i0, CG, cg_sh, cg, m);
     m += (long)z * Mg;
-    masked_grad<T>(p, dout, yv, m, cg * V, pg);
+    if constexpr (POOL) pool_grad<T>(p, m, cg * V, pg);        // (masked below, once the coefficients are there)
+    else masked_grad<T>(p, dout, yv, m, cg * V, pg);
     loadv<T>(xv + m * C + cg * V, px);
   }
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -375,6 +567,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const FsDual<FsBnBwdA
     float istd = p.save_invstd[z * C + c];
     s_mean[c] = p.save_mean[z * C + c]; s_istd[c] = istd;
     s_k[c] = p.gamma[c] * istd;
+    if constexpr (POOL) bn_smem[5 * C + c] = (p.beta ? p.beta[c] : 0.f) - s_mean[c] * s_k[c];     // the forward's shift
     s_a[c] = (float)(sg / p.count);
     s_b[c] = (float)(sgx / p.count);
     if (blockIdx.x == 0) {
@@ -404,9 +597,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const FsDual<FsBnBwdA
       int cg2; long m2;
       split_vec(i + stride, CG, cg_sh, cg2, m2);
       m2 += (long)z * Mg;
-      masked_grad<T>(p, dout, yv, m2, cg2 * V, pg);
+      if constexpr (POOL) pool_grad<T>(p, m2, cg2 * V, pg);
+      else masked_grad<T>(p, dout, yv, m2, cg2 * V, pg);
       loadv<T>(xv + m2 * C + cg2 * V, px);
     }
+    if constexpr (POOL) pool_mask<T>(p, yv, m, c, xr, s_k + c, bn_smem + 5 * C + c, g);
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       float xh = (xr[j] - s_mean[c + j]) * s_istd[c + j];
@@ -445,7 +640,14 @@ extern "C" int fs_bn_finalize(const FsBnApplyArgs* a, float* scale, float* shift
 
 namespace {
 int bn_apply_check(const FsBnApplyArgs* a) {
-  if (!a || !a->x || !a->y || !a->gamma || !a->beta || !a->save_mean || !a->save_invstd) return FS_EINVAL;
+  if (!a || !a->x || (!a->y && !a->pool_y) || !a->gamma || !a->beta || !a->save_mean || !a->save_invstd) return FS_EINVAL;
+  if (a->pool_y) {
+    // fused max-pool: train mode, dense output, even H x W, no residual; the element index is 32-bit
+    if (!a->pool_idx || !a->stats || a->res || a->gamma2 || a->pad_out || a->H <= 0 || a->W <= 0 || (a->H & 1) || (a->W & 1))
+      return FS_EINVAL;
+    if (a->M % (a->H * a->W) != 0 || (long)a->M * (a->C / 4) >= 0x7fffffffL) return FS_EINVAL;
+    if (a->y && !(a->yW == a->C && a->yH == (long)a->W * a->C && a->yN == (long)a->H * a->W * a->C)) return FS_EINVAL;
+  }
   if (!a->stats && (!a->running_mean || !a->running_var)) return FS_EINVAL;
   if (a->C % 8 != 0 || a->C > MAXC || a->M <= 0) return FS_EINVAL;
   if (a->gamma2 && (!a->res || !a->beta2 || !a->save_mean2 || !a->save_invstd2)) return FS_EINVAL;
@@ -455,7 +657,16 @@ int bn_apply_check(const FsBnApplyArgs* a) {
   return FS_OK;
 }
 int bn_bwd_check(const FsBnBwdArgs* a, bool apply) {
-  if (!a || !a->dout || !a->x || !a->sums || !a->save_mean || !a->save_invstd) return FS_EINVAL;
+  if (!a || (!a->dout && !a->pool_dy) || !a->x || !a->sums || !a->save_mean || !a->save_invstd) return FS_EINVAL;
+  if (a->pool_dy) {
+    if (!a->pool_idx || !a->gamma || a->fold || a->g_out || a->H <= 0 || a->W <= 0 || (a->H & 1) || (a->W & 1)) return FS_EINVAL;
+    if (a->relu && !a->y && !a->beta) return FS_EINVAL;
+    if (a->M % (a->H * a->W) != 0 || (long)a->M >= 0x7fffffffL) return FS_EINVAL;
+    const long hw = (long)a->H * a->W;
+    if (a->dout && !(a->gW == a->C && a->gH == (long)a->W * a->C && a->gN == hw * a->C)) return FS_EINVAL;
+    if (a->y && !(a->yW == a->C && a->yH == (long)a->W * a->C && a->yN == hw * a->C)) return FS_EINVAL;
+    return FS_OK;
+  }
   if (apply && (!a->dx || !a->gamma)) return FS_EINVAL;
   if (a->C % 8 != 0 || a->C > MAXC || a->M <= 0 || (a->relu && !a->y)) return FS_EINVAL;
   const int G = a->groups > 1 ? a->groups : 1;
@@ -480,7 +691,7 @@ extern "C" int fs_bn_apply2(const FsBnApplyArgs* a, const FsBnApplyArgs* b, int 
   if (b) {
     r = bn_apply_check(b);
     if (r != FS_OK) return r;
-    if (b->C != a->C) {
+    if (b->C != a->C || (a->pool_y != nullptr) != (b->pool_y != nullptr) || (a->pool_y && (a->H != b->H || a->W != b->W))) {
       r = fs_bn_apply2(a, nullptr, dtype, stream);
       return r != FS_OK ? r : fs_bn_apply2(b, nullptr, dtype, stream);
     }
@@ -490,9 +701,19 @@ extern "C" int fs_bn_apply2(const FsBnApplyArgs* a, const FsBnApplyArgs* b, int 
   const int G = a->groups > 1 ? a->groups : 1, G1 = b ? (b->groups > 1 ? b->groups : 1) : 0;
   long items = (long)(a->M / G) * (a->C / vec);
   if (b) items = std::max(items, (long)(b->M / G1) * (b->C / vec));
+  const FsDual<FsBnApplyArgs, FsNoGeom> d = bn_dual(a, b);
+  if (a->pool_y) {
+    // one thread per pooled pixel and 16-byte channel lane (nine window loads each): twice the element-wise passes' cap
+    dim3 pgrid(std::min(2 * grid_for(items / 4), (int)((items / 4 + 255) / 256)), 1, G + G1);
+    if (pgrid.x < 1) pgrid.x = 1;
+    const unsigned plds = 2u * a->C * sizeof(float);
+    if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(bn_apply_pool_kernel<bf16>, pgrid, dim3(256), plds, st, d);
+    else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(bn_apply_pool_kernel<float>, pgrid, dim3(256), plds, st, d);
+    else return FS_EINVAL;
+    return fs_launch_status();
+  }
   dim3 grid(grid_for(items), 1, G + G1);
   const unsigned lds = ((a->gamma2 || (b && b->gamma2)) ? 4u : 2u) * a->C * sizeof(float);
-  const FsDual<FsBnApplyArgs, FsNoGeom> d = bn_dual(a, b);
   if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16>, grid, dim3(256), lds, st, d);
   else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), lds, st, d);
   else return FS_EINVAL;
@@ -507,7 +728,7 @@ extern "C" int fs_bn_bwd_reduce2(const FsBnBwdArgs* a, const FsBnBwdArgs* b, int
   if (b) {
     r = bn_bwd_check(b, false);
     if (r != FS_OK) return r;
-    if (b->C != a->C) {
+    if (b->C != a->C || (a->pool_dy != nullptr) != (b->pool_dy != nullptr) || (a->pool_dy && (a->H != b->H || a->W != b->W))) {
       r = fs_bn_bwd_reduce2(a, nullptr, dtype, stream);
       return r != FS_OK ? r : fs_bn_bwd_reduce2(b, nullptr, dtype, stream);
     }
@@ -523,6 +744,11 @@ extern "C" int fs_bn_bwd_reduce2(const FsBnBwdArgs* a, const FsBnBwdArgs* b, int
 #define LAUNCH_REDUCE(CGB, ROWS_PER_BLOCK, MAXB)                                                               \
   {                                                                                                             \
     dim3 grid((unsigned)std::min<long>((Mg + (ROWS_PER_BLOCK) - 1) / (ROWS_PER_BLOCK), MAXB), (CG + CGB - 1) / CGB, G + G1); \
+    if (a->pool_dy) {                                                                                           \
+      if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, CGB, true>), grid, dim3(256), 0, st, d);  \
+      else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, CGB, true>), grid, dim3(256), 0, st, d); \
+      else return FS_EINVAL;                                                                                    \
+    } else                                                                                                      \
     if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, CGB>), grid, dim3(256), 0, st, d);  \
     else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, CGB>), grid, dim3(256), 0, st, d); \
     else return FS_EINVAL;                                                                                      \
@@ -543,7 +769,7 @@ extern "C" int fs_bn_bwd_apply2(const FsBnBwdArgs* a, const FsBnBwdArgs* b, int 
   if (b) {
     r = bn_bwd_check(b, true);
     if (r != FS_OK) return r;
-    if (b->C != a->C) {
+    if (b->C != a->C || (a->pool_dy != nullptr) != (b->pool_dy != nullptr) || (a->pool_dy && (a->H != b->H || a->W != b->W))) {
       r = fs_bn_bwd_apply2(a, nullptr, dtype, stream);
       return r != FS_OK ? r : fs_bn_bwd_apply2(b, nullptr, dtype, stream);
     }
@@ -554,8 +780,14 @@ extern "C" int fs_bn_bwd_apply2(const FsBnBwdArgs* a, const FsBnBwdArgs* b, int 
   long items = (long)(a->M / G) * (a->C / vec);
   if (b) items = std::max(items, (long)(b->M / G1) * (b->C / vec));
   dim3 grid(grid_for(items), 1, G + G1);
-  const unsigned lds = 5u * a->C * sizeof(float);
+  const unsigned lds = (a->pool_dy ? 6u : 5u) * a->C * sizeof(float);
   const FsDual<FsBnBwdArgs, FsNoGeom> d = bn_dual(a, b);
+  if (a->pool_dy) {
+    if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, true>), grid, dim3(256), lds, st, d);
+    else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, true>), grid, dim3(256), lds, st, d);
+    else return FS_EINVAL;
+    return fs_launch_status();
+  }
   if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, grid, dim3(256), lds, st, d);
   else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), lds, st, d);
   else return FS_EINVAL;

@@ -32,6 +32,8 @@ FOLD_BN = int(os.environ.get("FSNET_AMD_BN_FOLD", "1"))
 FOLD_BN_BWD = int(os.environ.get("FSNET_AMD_BN_FOLD_BWD", "0"))
 # the 1x1 / stride-2 downsample projection's data gradient inside the block's 3x3 / stride-2 data gradient launch
 FOLD_DS_DGRAD = os.environ.get("FSNET_AMD_FOLD_DS_DGRAD", "1") != "0"
+# the stem's BatchNorm + ReLU + max-pool as one pass, its backward's pooling gradient gathered inside the BatchNorm passes
+FUSE_STEM_POOL = os.environ.get("FSNET_AMD_FUSE_STEM_POOL", "1") != "0"
 
 
 class StatsPool:
@@ -513,10 +515,13 @@ class EncoderPass:
     list over the lanes; every control-flow decision is taken once (ResNetRunner.signature guarantees they agree).
     Numerically each lane is exactly its own pass: no arithmetic depends on the pairing."""
 
-    def __init__(self, runners):
+    def __init__(self, runners, need_feat0=None):
         self.R = list(runners)
         self.nl = len(self.R)
         self.pool = None
+        # per lane: is features[0] (the stem's activation, resnet.py:201-204) read by anyone?  The pose decoder only takes
+        # the last feature (pose_decoder.py:26-37): the fused stem pass then never stores that lane's 96 x 320 activation
+        self.need_feat0 = list(need_feat0) if need_feat0 is not None else [True] * self.nl
 
     # ------------------------------------------------------------------ helpers
     def _lanes(self, per_runner):
@@ -596,6 +601,40 @@ class EncoderPass:
         run_specs(bspecs)
         return cs, ys, sts, st2s
 
+    def _stem_fusable(self, cls, bns, xs, train):
+        """stem BatchNorm + ReLU + max-pool as one pass (fs_bn_apply with FsBnApplyArgs.pool_y) and, backwards, the pooling
+        gradient gathered inside both BatchNorm-backward passes (FsBnBwdArgs.pool_dy): training-mode BatchNorm and an
+        even convolution output"""
+        if not (FUSE_STEM_POOL and train and all(bn.training for bn in bns)):
+            return False
+        for cl, x in zip(cls, xs):
+            Ho, Wo = cl.ready(x.dtype, x.device).out_hw(x.shape[1], x.shape[2])
+            if Ho % 2 or Wo % 2 or Ho < 2 or Wo < 2:
+                return False
+        return True
+
+    def _stem_fwd_fused(self, cls, bns, xs):
+        """-> (raw stem outputs, activations (None where no one reads features[0]), BnStates, [(pooled, argmax codes)])"""
+        ops_ = self._ready(cls, xs)
+        stats = [self.pool.take(op.Co_p, G) for op, G in zip(ops_, self.groups)]
+        specs = [op.forward_spec(x, stats=s, stat_groups=G) for op, x, s, G in zip(ops_, xs, stats, self.groups)]
+        run_specs(specs)
+        cs = [sp.out for sp in specs]
+        world, _ = _exchange(self.pool, stats)
+        ys, sts, pooled, bspecs = [], [], [], []
+        for l in range(self.nl):
+            c, G = cs[l], self.groups[l]
+            N, H, W, C = c.shape
+            y = torch.empty_like(c) if self.need_feat0[l] else None
+            pl = (torch.empty(N, H // 2, W // 2, C, dtype=c.dtype, device=c.device),
+                  torch.empty(N, H // 2, W // 2, C, dtype=torch.uint8, device=c.device))
+            st = ops.BnState(C, c.device, G)
+            bspecs.append(ops.bn_apply_spec(c, stats[l], bn_tensors(bns[l]), st, y, H, W, (N // G) * H * W * world, relu=True,
+                                            track=True, groups=G, pool=pl))
+            ys.append(y); sts.append(st); pooled.append(pl)
+        run_specs(bspecs)
+        return cs, ys, sts, pooled
+
     def forward(self, xs, train, groups):
         """xs: per lane NHWC [N,H,W,Ci_p] in the compute dtype; groups: per lane statistics groups (see
         ResNetRunner.forward).  Returns (per lane: 5 features NHWC, ctx)."""
@@ -607,8 +646,13 @@ class EncoderPass:
         self.groups = [g if train else 1 for g in groups]
         assert all(x.shape[0] % g == 0 for x, g in zip(xs, self.groups))
         ctx = {"x": xs, "blocks": [], "train": train}
-        c0, y0, st0, _ = self._unit_fwd(self._lanes(lambda r: r.stem), self._lanes(lambda r: r.m.bn1), xs, train)
-        pooled = ops.maxpool_fwd_multi(y0)
+        stem_cls, stem_bns = self._lanes(lambda r: r.stem), self._lanes(lambda r: r.m.bn1)
+        if self._stem_fusable(stem_cls, stem_bns, xs, train):
+            c0, y0, st0, pooled = self._stem_fwd_fused(stem_cls, stem_bns, xs)
+            ctx["stem_fused"] = True
+        else:
+            c0, y0, st0, _ = self._unit_fwd(stem_cls, stem_bns, xs, train)
+            pooled = ops.maxpool_fwd_multi(y0)
         ctx.update(c0=c0, y0=y0, st0=st0, idx=[p[1] for p in pooled])
         feats = [[y] for y in y0]
         cur = [p[0] for p in pooled]
@@ -671,8 +715,10 @@ class EncoderPass:
         """zeroed f64 [groups][SLOTS][2][C] per lane from the current stream's backward pool, back to back"""
         return [_bwd_sums(c, st) for c, st in zip(cs, sts)]
 
-    def _bn_bwd(self, douts, ys, cs, bns, sts, relu=True, g_out=None, sums=None):
+    def _bn_bwd(self, douts, ys, cs, bns, sts, relu=True, g_out=None, sums=None, pools=None):
         """sums given: douts are already ReLU-masked and the sums are accumulated (fused into the producing dgrad).
+        pools = per lane (pooled gradient, argmax codes): the activation gradient is the max-pool backward of the pooled
+        gradient + douts[l] (or nothing), gathered inside both passes; ys[l] may then be None (mask from the raw output).
         Returns the BatchNorm input gradients, per lane."""
         nl = self.nl
         reduced = sums is not None
@@ -684,7 +730,8 @@ class EncoderPass:
             c, st, bn = cs[l], sts[l], bns[l]
             calls.append(dict(dout=douts[l], y=(ys[l] if ys is not None else None), x=c, gamma=bn.weight.data, st=st, dx=dcs[l],
                               dgamma=grad_of(bn.weight), dbeta=grad_of(bn.bias), H=c.shape[1], W=c.shape[2], relu=relu,
-                              g_out=(g_out[l] if g_out is not None else None), sums=sums[l], sums_zeroed=True, reduced=reduced))
+                              g_out=(g_out[l] if g_out is not None else None), sums=sums[l], sums_zeroed=True, reduced=reduced,
+                              pool=((pools[l][0], pools[l][1], bn.bias.data) if pools is not None else None)))
         # (eval-mode BatchNorm: st.count is inf — no batch-statistics terms in dx, hence no exchange of the sums either)
         sync = RT.dp is not None and sts[0].count != float("inf")
         pool = self._pool_bwd(cs[0].device)
@@ -931,10 +978,17 @@ class EncoderPass:
             # layer 1's weight gradients go to the companion now: they run beside the stem's memory-bound passes (pooling
             # backward, both BatchNorm-backward passes: the largest tensors of the network) instead of behind them
             flush_deferred(_current_stream())
-        d0 = ops.maxpool_bwd_multi(dout, ctx["idx"], y0[0].shape[1], y0[0].shape[2], add0)
-        dc0 = self._bn_bwd(d0, y0, ctx["c0"], [r.m.bn1 for r in self.R], ctx["st0"], relu=True)
+        if ctx.get("stem_fused"):
+            # no pooling-backward launch and no gradient tensor at the stem's resolution: both BatchNorm passes gather it
+            # (the ReLU mask from the raw output for every lane: the sign of the forward's own expression — no read of
+            # the activation where one was stored)
+            dc0 = self._bn_bwd(add0, None, ctx["c0"], [r.m.bn1 for r in self.R], ctx["st0"], relu=True,
+                               pools=[(dout[l], ctx["idx"][l]) for l in range(nl)])
+        else:
+            d0 = ops.maxpool_bwd_multi(dout, ctx["idx"], y0[0].shape[1], y0[0].shape[2], add0)
+            dc0 = self._bn_bwd(d0, y0, ctx["c0"], [r.m.bn1 for r in self.R], ctx["st0"], relu=True)
         stems = [r.stem for r in self.R]
-        self._param_grads(stems, self._ready(stems, y0), dc0, xs)
+        self._param_grads(stems, self._ready(stems, xs), dc0, xs)
         RT.mark(tag + ".bwd.end")
         flush_deferred(_current_stream(), spread=True)
 

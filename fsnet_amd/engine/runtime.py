@@ -26,13 +26,16 @@ class _Runtime:
         self.wgrad_streams = 2
         self.wgrad_flush = int(os.environ.get("FSNET_AMD_WGRAD_FLUSH", "8"))
         # hand over what is pending when an encoder's backward reaches its stem (see EncoderPass.backward)
-        self.stem_flush = os.environ.get("FSNET_AMD_STEM_FLUSH", "1") != "0"
+        self.stem_flush = os.environ.get("FSNET_AMD_STEM_FLUSH", "-1")      # -1: with the two-lane pass only (resolved below)
         self.wgrad_spread = 1
         # the pose encoder's image pairs as one stacked pass with per-pair BatchNorm statistics
         self.batch_pose_pairs = os.environ.get("FSNET_AMD_BATCH_POSE", "1") != "0"
         # the depth encoder and the stacked pose encoder as the two lanes of ONE pass: every post-stem launch carries
         # both networks' problems (EncoderPass in nets.py; fs_*2 entry points).  0: two passes on two streams (round 1-4)
         self.lanes = os.environ.get("FSNET_AMD_LANES", "1") != "0"
+        # (measured, same box: two lanes 6.38 -> 6.29 ms with the hand-over; two chains 6.03 -> 6.58 — there the other
+        # chain's launches fill the stem's passes already and the extra cross-stream edge delays the chain)
+        self.stem_flush = self.lanes if self.stem_flush == "-1" else self.stem_flush != "0"
         self._side = {}
         self._held = {}           # raw stream handle -> Stream: every stream the engine created (see new_stream)
         # FSNET_AMD_MARKS=1: device-clock marks along the step (mark() below), read back with marks_report()

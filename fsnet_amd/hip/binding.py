@@ -112,6 +112,7 @@ class FsBnApplyArgs(C.Structure):
         ("yN", C.c_int64), ("yH", C.c_int64), ("yW", C.c_int64),
         ("M", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
         ("relu", C.c_int32), ("pad_out", C.c_int32), ("groups", C.c_int32),
+        ("pool_y", C.c_void_p), ("pool_idx", C.c_void_p),
     ]
 
 
@@ -126,6 +127,7 @@ class FsBnBwdArgs(C.Structure):
         ("yN", C.c_int64), ("yH", C.c_int64), ("yW", C.c_int64),
         ("M", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
         ("relu", C.c_int32), ("fold", C.c_int32), ("groups", C.c_int32),
+        ("pool_dy", C.c_void_p), ("pool_idx", C.c_void_p), ("beta", C.c_void_p),
     ]
 
 

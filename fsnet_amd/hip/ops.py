@@ -71,7 +71,7 @@ def bn_apply(x, stats, bn, st, y, H, W, count, **kw):
 
 
 def bn_apply_spec(x, stats, bn, st, y, H, W, count, relu=True, pad_out=False, res=None, stats2=None, bn2=None, st2=None,
-                  track=True, groups=1):
+                  track=True, groups=1, pool=None):
     """-> Spec (conv.run_specs issues it, alone or sharing a launch with another network's BatchNorm of the same width).
     x: dense [N,H,W,C] raw conv output.  bn/bn2: dict(weight,bias,running_mean,running_var,nbt).
     groups G > 1: G stacked invocations of the module (count is per group; stats are [G][SLOTS][2][C])."""
@@ -79,7 +79,14 @@ def bn_apply_spec(x, stats, bn, st, y, H, W, count, relu=True, pad_out=False, re
     a.groups = groups
     assert st.groups == groups and (st2 is None or st2.groups == groups)
     Cc = x.shape[-1]
-    a.x, a.res, a.y = x.data_ptr(), _p(res), y.data_ptr()
+    a.x, a.res, a.y = x.data_ptr(), _p(res), _p(y)
+    if pool is not None:
+        # pool = (pooled [N,H/2,W/2,C], argmax codes uint8): the stem's MaxPool2d(3, 2, 1) in the same pass; y may be None
+        assert pool[0].is_contiguous() and pool[1].is_contiguous() and pool[0].shape == (x.shape[0], H // 2, W // 2, Cc)
+        assert stats is not None and res is None and bn2 is None and not pad_out and H % 2 == 0 and W % 2 == 0
+        a.pool_y, a.pool_idx = pool[0].data_ptr(), pool[1].data_ptr()
+    else:
+        assert y is not None
     a.stats, a.stats2 = _p(stats), _p(stats2)
     a.gamma, a.beta = bn["weight"].data_ptr(), bn["bias"].data_ptr()
     if track or stats is None:
@@ -97,30 +104,37 @@ def bn_apply_spec(x, stats, bn, st, y, H, W, count, relu=True, pad_out=False, re
     a.count, a.eps, a.momentum = float(count), BN_EPS, BN_MOMENTUM
     if pad_out:
         assert y.shape[1] == H + 2 and y.shape[2] == W + 2
-    a.yN, a.yH, a.yW = y.stride(0), y.stride(1), y.stride(2)
+    if y is not None:
+        a.yN, a.yH, a.yW = y.stride(0), y.stride(1), y.stride(2)
     a.M, a.C, a.H, a.W = x.shape[0] * H * W, Cc, H, W
     a.relu, a.pad_out = int(relu), int(pad_out)
-    nb = x.numel() * x.element_size() * (2 + (res is not None))
-    return Spec(["bn_apply"], a, dtype_code(x.dtype), "bn_apply", nb,
-                lambda: "[%d,%d,%d,%d]%s%s" % (x.shape[0], H, W, Cc, " +res" if res is not None else "",
-                                               " pad" if pad_out else ""), y, "bn_apply")
+    nb = x.numel() * x.element_size() * (1 + (y is not None) + (res is not None))
+    if pool is not None:
+        nb += pool[0].numel() * pool[0].element_size() + pool[1].numel()
+    return Spec(["bn_apply"], a, dtype_code(x.dtype), "bn_apply_pool" if pool is not None else "bn_apply", nb,
+                lambda: "[%d,%d,%d,%d]%s%s%s" % (x.shape[0], H, W, Cc, " +res" if res is not None else "",
+                                                 " pad" if pad_out else "", " +pool" if pool is not None else ""),
+                y, "bn_apply")
 
 
 def bn_backward(dout, y, x, gamma, st, dx, dgamma, dbeta, H, W, relu=True, fold=False, g_out=None, sums=None,
-                allreduce=None, sums_zeroed=False, reduced=False, phase="all", glob=None):
+                allreduce=None, sums_zeroed=False, reduced=False, phase="all", glob=None, pool=None):
     """Two-pass BN backward.  dout: grad w.r.t. the block output (strided view, or the padded buffer
     when fold=True); y: saved output activation (interior view) for the ReLU mask.
     reduced=True: the first pass already happened in the epilogue of the convolution that produced dout
     (ConvOp.dgrad(bn_fuse=...)): dout is ReLU-masked and `sums` holds (sum g, sum g*xhat)."""
     bn_backward_multi([dict(dout=dout, y=y, x=x, gamma=gamma, st=st, dx=dx, dgamma=dgamma, dbeta=dbeta, H=H, W=W, relu=relu,
-                            fold=fold, g_out=g_out, sums=sums, sums_zeroed=sums_zeroed, reduced=reduced, glob=glob)],
+                            fold=fold, g_out=g_out, sums=sums, sums_zeroed=sums_zeroed, reduced=reduced, glob=glob, pool=pool)],
                       allreduce=allreduce, phase=phase)
     return None if phase == "reduce" else dx
 
 
 def _bn_bwd_call(dout, y, x, gamma, st, dx, dgamma, dbeta, H, W, relu=True, fold=False, g_out=None, sums=None,
-                 sums_zeroed=False, reduced=False, glob=None):
-    """argument struct of one BatchNorm backward -> dict(a=, code=, nb=, shp=, sums=, reduced=, glob=, y=, g_out=)"""
+                 sums_zeroed=False, reduced=False, glob=None, pool=None):
+    """argument struct of one BatchNorm backward -> dict(a=, code=, nb=, shp=, sums=, reduced=, glob=, y=, g_out=).
+    pool = (pooled gradient [N,H/2,W/2,C], argmax codes, beta): the gradient w.r.t. the activation is the max-pool backward
+    of the pooled gradient (+ dout, which may be None) gathered inside both passes (FsBnBwdArgs.pool_dy); with y None the
+    ReLU mask is the sign of the forward's own scale * x + shift."""
     if reduced:
         assert sums is not None and not fold and g_out is None
         relu, y = False, None
@@ -130,21 +144,28 @@ def _bn_bwd_call(dout, y, x, gamma, st, dx, dgamma, dbeta, H, W, relu=True, fold
         sums = torch.zeros(st.groups * STAT_SLOTS, 2, Cc, dtype=torch.float64, device=x.device)
     elif not sums_zeroed and not reduced:
         sums.zero_()
-    a.dout, a.y, a.x, a.dx, a.g_out = dout.data_ptr(), _p(y), x.data_ptr(), _p(dx), _p(g_out)
+    a.dout, a.y, a.x, a.dx, a.g_out = _p(dout), _p(y), x.data_ptr(), _p(dx), _p(g_out)
+    if pool is not None:
+        assert not reduced and not fold and g_out is None and pool[0].is_contiguous() and pool[1].is_contiguous()
+        assert (dout is None or dout.is_contiguous()) and (y is None or y.is_contiguous())
+        a.pool_dy, a.pool_idx, a.beta = pool[0].data_ptr(), pool[1].data_ptr(), pool[2].data_ptr()
+    else:
+        assert dout is not None
     a.sums = sums.data_ptr()
     a.gamma, a.save_mean, a.save_invstd = gamma.data_ptr(), st.mean.data_ptr(), st.invstd.data_ptr()
     a.dgamma, a.dbeta = _p(dgamma), _p(dbeta)
     a.count = st.count
     a.groups = st.groups
-    a.gN, a.gH, a.gW = dout.stride(0), dout.stride(1), dout.stride(2)
+    if dout is not None:
+        a.gN, a.gH, a.gW = dout.stride(0), dout.stride(1), dout.stride(2)
     if y is not None:
         a.yN, a.yH, a.yW = y.stride(0), y.stride(1), y.stride(2)
     a.M, a.C, a.H, a.W = x.shape[0] * H * W, Cc, H, W
     a.relu, a.fold = int(relu), int(fold)
     shape = (x.shape[0], H, W, Cc)
     return dict(a=a, code=dtype_code(x.dtype), nb=x.numel() * x.element_size(), sums=sums, reduced=reduced, glob=glob,
-                has_y=y is not None, has_g=g_out is not None,
-                shp=lambda: "[%d,%d,%d,%d]%s" % (shape + (" fold" if fold else "",)))
+                has_y=y is not None, has_g=g_out is not None, has_dout=dout is not None,
+                shp=lambda: "[%d,%d,%d,%d]%s%s" % (shape + (" fold" if fold else "", " pool" if pool is not None else "")))
 
 
 def bn_backward_multi(calls, allreduce=None, phase="all", span=None):
@@ -157,7 +178,7 @@ def bn_backward_multi(calls, allreduce=None, phase="all", span=None):
     back with phase "apply", glob = the exchanged sums in each call; `sums` then holds the local ones)."""
     cs = [_bn_bwd_call(**c) for c in calls]
     if phase != "apply":
-        run_specs([Spec(["bn_bwd_reduce"], c["a"], c["code"], "bn_bwd_reduce", c["nb"] * (2 + c["has_y"]), c["shp"], None,
+        run_specs([Spec(["bn_bwd_reduce"], c["a"], c["code"], "bn_bwd_reduce", c["nb"] * (1 + c["has_dout"] + c["has_y"]), c["shp"], None,
                         "bn_bwd_reduce") for c in cs if not c["reduced"]])
     if phase == "reduce":
         return
@@ -178,7 +199,7 @@ def bn_backward_multi(calls, allreduce=None, phase="all", span=None):
     for c in cs:
         if c["glob"] is not None:
             c["a"].sums_local, c["a"].sums = c["sums"].data_ptr(), c["glob"].data_ptr()
-    run_specs([Spec(["bn_bwd_apply"], c["a"], c["code"], "bn_bwd_apply", c["nb"] * (3 + c["has_y"] + c["has_g"]), c["shp"],
+    run_specs([Spec(["bn_bwd_apply"], c["a"], c["code"], "bn_bwd_apply", c["nb"] * (2 + c["has_dout"] + c["has_y"] + c["has_g"]), c["shp"],
                     None, "bn_bwd_apply") for c in cs])
 
 

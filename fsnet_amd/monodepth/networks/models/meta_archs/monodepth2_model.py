@@ -133,7 +133,7 @@ class MonoDepthMeta(_HipMetaArch):
                     self.head.prefetch_loss_inputs(data)
         RT.mark("depth.fwd.start")
         _, pairs = self._pose_pairs(data, image_0)
-        features, stacked = forward_lanes(self.depth_backbone, image_0, self.pose_backbone, pairs)
+        features, stacked = forward_lanes(self.depth_backbone, image_0, self.pose_backbone, pairs, pose_feat0=False)
         RT.mark("denc.fwd.end")
         if overlap:
             side.wait_stream(main)

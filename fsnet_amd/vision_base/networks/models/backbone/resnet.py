@@ -81,9 +81,9 @@ class _ResNetLanesFn(torch.autograd.Function):
     both networks.  Outputs: the first lane's five features, then the second's."""
 
     @staticmethod
-    def forward(ctx, mods, xs, groups, *params):
+    def forward(ctx, mods, xs, groups, feat0, *params):
         ctx.set_materialize_grads(False)
-        ep = EncoderPass([m._runner for m in mods])
+        ep = EncoderPass([m._runner for m in mods], need_feat0=feat0)
         feats, c = ep.forward(list(xs), train=True, groups=list(groups))
         ctx.mods, ctx.ep, ctx.c, ctx.dtype = mods, ep, c, xs[0].dtype
         ctx.nparams = len(params)
@@ -91,7 +91,8 @@ class _ResNetLanesFn(torch.autograd.Function):
             m._pending += 1
             if RT.dp is not None:
                 RT.dp.note_forward(m)
-        return tuple(f.permute(0, 3, 1, 2) for lane in feats for f in lane)
+        # (a lane's features[0] nobody reads is None: the fused stem pass never stored it)
+        return tuple(None if f is None else f.permute(0, 3, 1, 2) for lane in feats for f in lane)
 
     @staticmethod
     def backward(ctx, *g):
@@ -104,7 +105,7 @@ class _ResNetLanesFn(torch.autograd.Function):
             m._pending -= 1
             if m._pending == 0 and RT.dp is not None:
                 RT.dp.grads_ready(m)
-        return (None, None, None) + (None,) * ctx.nparams
+        return (None, None, None, None) + (None,) * ctx.nparams
 
 
 def lanes_compatible(a, b):
@@ -113,9 +114,11 @@ def lanes_compatible(a, b):
             and a._runner.signature(True) == b._runner.signature(True))
 
 
-def forward_lanes(depth_net, image, pose_net, pairs):
+def forward_lanes(depth_net, image, pose_net, pairs, pose_feat0=True):
     """depth_net(image) and pose_net.forward_pairs(pairs) of one training step as ONE encoder pass -> (features of the
-    depth encoder, features of the stacked pose pairs), each exactly what the separate call returns."""
+    depth encoder, features of the stacked pose pairs), each exactly what the separate call returns.  pose_feat0=False:
+    the caller does not read the pose encoder's features[0] (the pose decoder takes the last feature only,
+    pose_decoder.py:26-37) — that entry comes back None and its 96 x 320 activation is never stored."""
     require_gpu(image, "ResNet.forward_lanes")
     op_d = depth_net._runner.stem.ready(RT.compute_dtype, image.device)
     op_p = pose_net._runner.stem.ready(RT.compute_dtype, image.device)
@@ -128,7 +131,7 @@ def forward_lanes(depth_net, image, pose_net, pairs):
     for m in mods:
         if m._plist is None:
             m._plist = list(m.parameters())
-    outs = _ResNetLanesFn.apply(mods, (xd, xp), (1, G), *(depth_net._plist + pose_net._plist))
+    outs = _ResNetLanesFn.apply(mods, (xd, xp), (1, G), (True, bool(pose_feat0)), *(depth_net._plist + pose_net._plist))
     nf = len(outs) // 2
     return list(outs[:nf]), list(outs[nf:])
 

@@ -385,6 +385,11 @@ typedef struct FsBnApplyArgs {
                            (the pose encoder's two image pairs, monodepth2_model.py:29-35): statistics, save_mean /
                            save_invstd are [G][...], count is per group, running statistics are updated G times
                            in group order. */
+  /* ABI 8: the stem's MaxPool2d(3, 2, 1) in the same pass (resnet.py:201-206: relu(bn1(.)) -> features[0] -> maxpool).
+   * pool_y != NULL: [N,H/2,W/2,C] receives the pooled activation and pool_idx the argmax codes (r*3+s, as fs_maxpool_fwd);
+   * y may then be NULL (the activation itself is not stored: the pose encoder's features[0] has no reader).  Train mode,
+   * even H x W, dense y, no residual. */
+  void* pool_y; uint8_t* pool_idx;
 } FsBnApplyArgs;
 int fs_bn_apply(const FsBnApplyArgs* args, int dtype, void* stream);
 /* two BatchNorms of the same width in one launch (see fs_conv_igemm2): bn1 of the depth encoder's block and bn1 of the
@@ -416,6 +421,11 @@ typedef struct FsBnBwdArgs {
   int32_t M, C, H, W;
   int32_t relu, fold;
   int32_t groups;       /* as FsBnApplyArgs.groups: sums / save_mean / save_invstd are [G][...]; dgamma, dbeta add up */
+  /* ABI 8: the gradient w.r.t. the activation gathered instead of read (the backward of the fused stem pass above):
+   * pool_dy != NULL: g = maxpool backward of pool_dy [N,H/2,W/2,C] through the argmax codes pool_idx (fs_maxpool_bwd's
+   * gather) + dout when dout != NULL (dense [N,H,W,C]: the gradient of the un-pooled features[0]); the ReLU mask
+   * (relu = 1) from y when y != NULL, else the sign of gamma*invstd*x + (beta - mean*gamma*invstd): beta required. */
+  const void* pool_dy; const uint8_t* pool_idx; const float* beta;
 } FsBnBwdArgs;
 int fs_bn_bwd_reduce(const FsBnBwdArgs* args, int dtype, void* stream);
 int fs_bn_bwd_apply(const FsBnBwdArgs* args, int dtype, void* stream);

@@ -448,3 +448,78 @@ def test_overlapped_mask_off_vs_reference_golden(dev):
                 assert (got.cpu() - ref).abs().max() < 1e-2 * ref.abs().max() + 1e-9, key
     finally:
         RT.tie_noise = True
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,H,W,G,keep_y,with_add", [(2, 8, 12, 1, True, True), (4, 12, 20, 2, False, False),
+                                                     (3, 96, 64, 1, True, False), (2, 6, 10, 2, True, True)])
+def test_stem_batchnorm_relu_maxpool_in_one_pass(dev, dtype, N, H, W, G, keep_y, with_add):
+    """fs_bn_apply with FsBnApplyArgs.pool_y (BatchNorm + ReLU + MaxPool2d(3, 2, 1) of the stem, resnet.py:201-206) ==
+    fs_bn_apply followed by fs_maxpool_fwd bit for bit (activation, pooled tensor, argmax codes, saved and running
+    statistics); its backward with the pooling gradient gathered inside both BatchNorm-backward passes
+    (FsBnBwdArgs.pool_dy; the ReLU mask from the stored activation or, where it was never stored, from the raw
+    convolution output) == fs_maxpool_bwd + the two passes on the materialised gradient, and == torch autograd."""
+    import copy
+    import torch.nn.functional as F
+    from fsnet_amd.engine.nets import bn_tensors
+    from fsnet_amd.hip import ops
+    Cc = 64
+    g = torch.Generator().manual_seed(11 + H)
+    x = torch.randn(N, H, W, Cc, generator=g).to(dev).to(dtype)
+    bn0 = torch.nn.BatchNorm2d(Cc).to(dev)
+    bn0.weight.data.copy_(torch.rand(Cc, generator=g) + 0.5); bn0.bias.data.copy_(torch.rand(Cc, generator=g) - 0.5)
+    n = N // G
+    stats = torch.zeros(G, 8, 2, Cc, dtype=torch.float64, device=dev)
+    for gi in range(G):
+        v = x[gi * n:(gi + 1) * n].double()
+        stats[gi, 0, 0] = v.sum((0, 1, 2)); stats[gi, 0, 1] = (v * v).sum((0, 1, 2))
+    stats_arg = stats if G > 1 else stats[0]
+    count = n * H * W
+    # separate passes
+    m_a, st_a = copy.deepcopy(bn0), ops.BnState(Cc, dev, G)
+    y_a = torch.empty_like(x)
+    ops.bn_apply(x, stats_arg, bn_tensors(m_a), st_a, y_a, H, W, count, relu=True, groups=G)
+    p_a, idx_a = ops.maxpool_fwd(y_a)
+    # one pass
+    m_b, st_b = copy.deepcopy(bn0), ops.BnState(Cc, dev, G)
+    y_b = torch.full_like(x, 7.0) if keep_y else None
+    p_b = torch.empty_like(p_a); idx_b = torch.empty_like(idx_a)
+    ops.bn_apply(x, stats_arg, bn_tensors(m_b), st_b, y_b, H, W, count, relu=True, groups=G, pool=(p_b, idx_b))
+    torch.cuda.synchronize()
+    assert torch.equal(p_a, p_b) and torch.equal(idx_a, idx_b)
+    if keep_y:
+        assert torch.equal(y_a, y_b)
+    assert torch.equal(st_a.mean, st_b.mean) and torch.equal(st_a.invstd, st_b.invstd)
+    assert torch.equal(m_a.running_mean, m_b.running_mean) and torch.equal(m_a.running_var, m_b.running_var)
+    assert int(m_a.num_batches_tracked) == int(m_b.num_batches_tracked) == G
+    # backward
+    dpool = torch.randn(p_a.shape, generator=g).to(dev).to(dtype)
+    add = torch.randn(x.shape, generator=g).to(dev).to(dtype) if with_add else None
+    gamma = bn0.weight.data
+    d0 = ops.maxpool_bwd(dpool, idx_a, H, W, addend=add)
+    dx_a = torch.empty_like(x)
+    dg_a, db_a = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev)
+    ops.bn_backward(d0, y_a, x, gamma, st_a, dx_a, dg_a, db_a, H, W, relu=True)
+    dx_b = torch.empty_like(x)
+    dg_b, db_b = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev)
+    ops.bn_backward(add, y_b, x, gamma, st_b, dx_b, dg_b, db_b, H, W, relu=True, pool=(dpool, idx_b, bn0.bias.data))
+    torch.cuda.synchronize()
+    # (the separate path rounds the gathered gradient to the storage type before the BatchNorm passes read it)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    scale = float(dx_a.float().abs().max())
+    assert float((dx_a.float() - dx_b.float()).abs().max()) <= tol * scale
+    assert float((dg_a - dg_b).abs().max()) <= tol * float(dg_a.abs().max()) + 1e-6
+    assert float((db_a - db_b).abs().max()) <= tol * float(db_a.abs().max()) + 1e-6
+    if dtype == torch.float32:
+        # torch autograd of the same chain, group by group (G calls of the module)
+        for gi in range(G):
+            xr = x[gi * n:(gi + 1) * n].permute(0, 3, 1, 2).clone().requires_grad_(True)
+            ref = copy.deepcopy(bn0).train()
+            yy = F.relu(ref(xr))
+            pp = F.max_pool2d(yy, 3, 2, 1)
+            loss = (pp * dpool[gi * n:(gi + 1) * n].permute(0, 3, 1, 2)).sum()
+            if with_add:
+                loss = loss + (yy * add[gi * n:(gi + 1) * n].permute(0, 3, 1, 2)).sum()
+            loss.backward()
+            got = dx_b[gi * n:(gi + 1) * n].permute(0, 3, 1, 2)
+            assert float((got - xr.grad).abs().max()) <= 2e-4 * float(xr.grad.abs().max())
