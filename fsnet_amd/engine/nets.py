@@ -220,6 +220,39 @@ def pack_everything(arena=None):
         pack_all(key, arena)
 
 
+_PACK_PENDING = {}      # device index -> (pack stream, handles of the streams that already wait for it)
+
+
+def pack_everything_async(arena):
+    """pack_everything() on a stream of its own, forked from the current one: the step's first ~0.1 ms — staging the
+    batch, zeroing the gradient arena, converting the images to NHWC, the image-only loss inputs — needs no weights, and
+    the 70 us re-pack of every convolution's MFMA operands after the optimizer step ran in front of all of it.  Every
+    stream that launches a convolution waits for the pack stream once (ConvLayer.ready -> join_pack)."""
+    dev = arena.data.device if arena is not None else None
+    if not (RT.pack_overlap and RT.overlap and RT.dp is None and dev is not None and dev.type == "cuda"):
+        _PACK_PENDING.clear()
+        pack_everything(arena)
+        return
+    cur = _current_stream(dev)
+    ps = RT.pack_stream(dev)
+    ps.wait_stream(cur)
+    with torch.cuda.stream(ps):
+        pack_everything(arena)
+    _PACK_PENDING[dev.index] = (ps, {ps.cuda_stream})
+
+
+def join_pack(device):
+    """the current stream waits (once per step) for the step's weight re-pack"""
+    ent = _PACK_PENDING.get(device.index)
+    if ent is None:
+        return
+    cur = _current_stream(device)
+    if cur.cuda_stream in ent[1]:
+        return
+    cur.wait_stream(ent[0])
+    ent[1].add(cur.cuda_stream)
+
+
 def pack_all(key, arena=None):
     """Re-pack the MFMA weight operands of every registered conv whose master weights changed, in ONE launch
     (fs_pack_weights_multi).  The descriptor table is cached while the pointers stay the same."""
@@ -289,6 +322,8 @@ class ConvLayer:
 
     def ready(self, dtype, device):
         key = (dtype, device)
+        if _PACK_PENDING:
+            join_pack(device)
         if self._key != key or self._owner != id(self):
             # (_owner: a copy.deepcopy of the module copies this object's state but is not in the pack registry —
             # without the check the copy's MFMA operands would never follow its own weights)

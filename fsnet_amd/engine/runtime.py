@@ -32,15 +32,47 @@ class _Runtime:
         self.batch_pose_pairs = os.environ.get("FSNET_AMD_BATCH_POSE", "1") != "0"
         # the depth encoder and the stacked pose encoder as the two lanes of ONE pass: every post-stem launch carries
         # both networks' problems (EncoderPass in nets.py; fs_*2 entry points).  0: two passes on two streams (round 1-4)
-        self.lanes = os.environ.get("FSNET_AMD_LANES", "1") != "0"
+        # Default ("auto"): the two-lane pass under data parallelism (world size > 1: half the SyncBN exchanges, one chain of
+        # collectives instead of two that serialise on the communicator), two chains at world size 1 — measured there on
+        # the same box, 150 replayed steps each (profiles/r05_lanes_ab.txt): two chains 5.59-5.79 ms, two lanes 5.82-6.00 (295
+        # launches instead of 415, but the depth decoder no longer runs beside the pose encoder).
+        self._lanes_env = os.environ.get("FSNET_AMD_LANES", "auto").lower()
+        self._lanes = self._lanes_env not in ("0", "auto")
         # (measured, same box: two lanes 6.38 -> 6.29 ms with the hand-over; two chains 6.03 -> 6.58 — there the other
         # chain's launches fill the stem's passes already and the extra cross-stream edge delays the chain)
-        self.stem_flush = self.lanes if self.stem_flush == "-1" else self.stem_flush != "0"
+        self._stem_flush_env = self.stem_flush
+        self.stem_flush = self._lanes if self.stem_flush == "-1" else self.stem_flush != "0"
+        # the per-step weight re-pack beside the step's weight-free head (nets.pack_everything_async)
+        self.pack_overlap = os.environ.get("FSNET_AMD_PACK_OVERLAP", "1") != "0"
         self._side = {}
         self._held = {}           # raw stream handle -> Stream: every stream the engine created (see new_stream)
         # FSNET_AMD_MARKS=1: device-clock marks along the step (mark() below), read back with marks_report()
         self._marks = {} if os.environ.get("FSNET_AMD_MARKS", "0") != "0" else None
         self._mark_buf = None
+
+    @property
+    def lanes(self):
+        return self._lanes
+
+    @lanes.setter
+    def lanes(self, v):
+        """True / False: explicit; "auto": by world size (resolve_lanes)"""
+        if isinstance(v, str) and v.lower() == "auto":
+            self._lanes_env, self._lanes = "auto", False
+        else:
+            self._lanes_env, self._lanes = ("1" if v else "0"), bool(v)
+        if self._stem_flush_env == "-1":
+            self.stem_flush = self._lanes
+
+    def resolve_lanes(self):
+        """FSNET_AMD_LANES=auto: decided when the first training forward knows the world size"""
+        if self._lanes_env == "auto":
+            import torch.distributed as dist
+            multi = self.dp is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+            self._lanes = bool(multi)
+            if self._stem_flush_env == "-1":
+                self.stem_flush = self._lanes
+        return self._lanes
 
     def mark(self, name):
         """debugging: stamp the device clock on the current stream (a graph node under capture)"""
@@ -79,6 +111,14 @@ class _Runtime:
     def release_stream(self, handle):
         """give a stream from new_stream() back (its owner is gone)"""
         self._held.pop(handle, None)
+
+    def pack_stream(self, device):
+        """stream of the per-step weight re-pack (nets.pack_everything_async)"""
+        key = (device, "pack")
+        s = self._side.get(key)
+        if s is None:
+            s = self._side[key] = self.new_stream(device)
+        return s
 
     def side_stream(self, device):
         s = self._side.get(device)

@@ -40,8 +40,9 @@ class _HipMetaArch(BaseMetaArch):
             RT.dp = DataParallelContext(self)
         if RT.dp is not None:
             RT.dp.begin_step(self)
-        from fsnet_amd.engine.nets import pack_everything
-        pack_everything(self._arena)   # re-pack stale MFMA weight operands once, on the main stream, before any fork
+        # re-pack stale MFMA weight operands once per step, on a stream of its own beside the step's weight-free head
+        from fsnet_amd.engine.nets import pack_everything_async
+        pack_everything_async(self._arena)
 
     def stage_step_inputs(self, data):
         """non-tensor per-step inputs (fisheye calibrations): host-side staging, also ahead of a hipGraph replay"""
@@ -76,7 +77,7 @@ class MonoDepthMeta(_HipMetaArch):
         """the depth encoder and the stacked pose encoder as the two lanes of ONE pass (engine/nets.py, EncoderPass):
         same architecture, BatchNorm modes and trained parameters, gradients wanted, and a pose head that takes the
         stacked feature"""
-        if not (RT.lanes and RT.batch_pose_pairs and image_0.is_cuda and torch.is_grad_enabled()):
+        if not (RT.resolve_lanes() and RT.batch_pose_pairs and image_0.is_cuda and torch.is_grad_enabled()):
             return False
         if len(self.train_cfg.frame_ids) < 3 or not hasattr(self.head, "forward_pose_pairs"):
             return False

@@ -344,7 +344,7 @@ def test_training_step_with_and_without_lanes(dev, dtype, tol):
             res[flag] = (float(out["loss"]), {n: p.grad.detach().float().clone() for n, p in m.named_parameters()},
                          {n: b.detach().clone() for n, b in m.named_buffers()})
     finally:
-        RT.lanes = True
+        RT.lanes = "auto"
         RT.tie_noise = True
         RT.set_compute_dtype(torch.bfloat16)
     assert abs(res[True][0] - res[False][0]) <= tol * abs(res[False][0])
