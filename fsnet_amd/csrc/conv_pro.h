@@ -116,7 +116,9 @@ __device__ inline void pro_block0(const FsConvArgs& p, int t, int nt) {
 inline bool pro_args_ok(const FsConvArgs& a) {
   if (a.pro_mode == 0) return a.pro_dst == nullptr;
   if (a.pro_mode != 1 && a.pro_mode != 2) return false;
-  if (a.Cs % 4 != 0 || a.Cs > 2048) return false;
+  // (the coefficient table is dynamic LDS on top of 38-78 KB of static LDS: 2 or 4 floats per source channel; the widest
+  // 3x3 layer of the networks has 512 — wider layers are declined here, the callers' can_fold_* then never ask)
+  if (a.Cs % 4 != 0 || a.Cs > 512) return false;
   if (a.pro_group_imgs < 0 || (a.pro_group_imgs > 0 && a.N % a.pro_group_imgs != 0)) return false;
   if (a.pro_mode == 2 && !a.pro_src2) return false;
   if (a.pro_mode == 1 && a.pro_dst) return false;

@@ -210,6 +210,39 @@ extern "C" int fs_copy_multi(const void* const* src, void* const* dst, const int
   return fs_launch_status();
 }
 
+namespace {
+// up to FS_COPY_MAX buffers zeroed in ONE launch (the step's scratch: BatchNorm statistics pools, loss accumulators, depth
+// gradient maps, the gradient-norm scalar — each was a fill launch of its own somewhere along the step's chains)
+__global__ __launch_bounds__(256) void zero_multi_kernel(const CopyBatch c) {
+  int k = 0;
+  while (k + 1 < c.n && (long)blockIdx.x >= c.start[k + 1]) ++k;
+  const long nblk = c.start[k + 1] - c.start[k], lb = blockIdx.x - c.start[k];
+  const long n16 = c.bytes[k] >> 4;
+  uint4* d = reinterpret_cast<uint4*>(c.dst[k]);
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (long i = lb * 256 + threadIdx.x; i < n16; i += nblk * 256) d[i] = z;
+  if (lb == 0) {
+    const long tail = c.bytes[k] & 15;
+    if ((long)threadIdx.x < tail) c.dst[k][n16 * 16 + threadIdx.x] = 0;
+  }
+}
+}  // namespace
+
+extern "C" int fs_zero_multi(void* const* dst, const int64_t* bytes, int n, void* stream) {
+  if (!dst || !bytes || n <= 0 || n > FS_COPY_MAX) return FS_EINVAL;
+  CopyBatch c;
+  long blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!dst[i] || bytes[i] <= 0 || (reinterpret_cast<uintptr_t>(dst[i]) & 15)) return FS_EINVAL;
+    c.src[i] = nullptr; c.dst[i] = static_cast<char*>(dst[i]); c.bytes[i] = bytes[i];
+    c.start[i] = blocks;
+    blocks += std::max<long>(1, std::min<long>((bytes[i] / 16 + 1023) / 1024, 512));
+  }
+  c.start[n] = blocks; c.n = n;
+  hipLaunchKernelGGL(zero_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), c);
+  return fs_launch_status();
+}
+
 extern "C" int64_t fs_pack_tile_blocks(int Co, int Ci, int R, int S) {
   if (Co <= 0 || Ci <= 0 || R <= 0 || S <= 0 || R * S > 288) return -1;
   const int IB = pack_ib(R * S, Ci);

@@ -24,12 +24,23 @@ FUSE_BN_BWD = os.environ.get("FSNET_AMD_FUSE_BN_BWD", "1") != "0"
 # BatchNorm + ReLU between two convolutions of a residual block applied by the SECOND convolution while it stages its
 # operand (and by its weight gradient), instead of a pass of its own: the normalised activation never reaches HBM
 # (0: never; 1: wherever the kernels can; 2: only launches the 32x32-tile kernel takes)
-FOLD_BN = int(os.environ.get("FSNET_AMD_BN_FOLD", "1"))
+def _env_level(name, default):
+    """0 / 1 / 2 switches: anything that is not an integer means "on" (as before these were levels)"""
+    v = os.environ.get(name)
+    if v is None:
+        return default
+    try:
+        return int(v)
+    except ValueError:
+        return 0 if v.strip().lower() in ("", "off", "false", "no") else 1
+
+
+FOLD_BN = _env_level("FSNET_AMD_BN_FOLD", 1)
 # the second pass of a BatchNorm's backward applied by the data gradient of the convolution in front of it while it stages
 # dY (coefficients from the sums the previous data gradient's epilogue left; written out once for the weight gradient).
 # Built, tested against the oracle and MEASURED slower (DESIGN section 16: the data gradient stages two tensors, holds
 # half the blocks per CU and takes +19 us where the pass it replaces took 15): off by default, same values as FOLD_BN.
-FOLD_BN_BWD = int(os.environ.get("FSNET_AMD_BN_FOLD_BWD", "0"))
+FOLD_BN_BWD = _env_level("FSNET_AMD_BN_FOLD_BWD", 0)
 # the 1x1 / stride-2 downsample projection's data gradient inside the block's 3x3 / stride-2 data gradient launch
 FOLD_DS_DGRAD = os.environ.get("FSNET_AMD_FOLD_DS_DGRAD", "1") != "0"
 # the stem's BatchNorm + ReLU + max-pool as one pass, its backward's pooling gradient gathered inside the BatchNorm passes
@@ -42,6 +53,16 @@ class StatsPool:
     def __init__(self, device, capacity=1 << 19):
         self.buf = torch.zeros(capacity, dtype=torch.float64, device=device)
         self.off = 0
+        ops.register_prezero(self, StatsPool._prezero)
+
+    def _prezero(self):
+        """(ops.prezero_all, at the step's head) the used prefix is about to be zeroed with the rest of the step's scratch:
+        the reset() at the start of the network's forward / backward then finds nothing to do"""
+        if not self.off:
+            return []
+        t = self.buf[:self.off]
+        self.off = 0
+        return [t]
 
     def reset(self):
         if self.off:
@@ -238,6 +259,7 @@ def pack_everything_async(arena):
     ps.wait_stream(cur)
     with torch.cuda.stream(ps):
         pack_everything(arena)
+        ops.prezero_all(dev)          # ... and the step's scratch, one launch instead of a fill here and there along the chains
     _PACK_PENDING[dev.index] = (ps, {ps.cuda_stream})
 
 
@@ -676,7 +698,11 @@ class EncoderPass:
         nl = self.nl
         dev = xs[0].device
         if self.pool is None or self.pool.buf.device != dev:
-            self.pool = StatsPool(dev)
+            # (a two-lane pass object lives for one step: its pool lives with the first lane's runner)
+            keep = self.R[0].__dict__.get("_pass_pool")
+            if keep is None or keep.buf.device != dev:
+                keep = self.R[0]._pass_pool = StatsPool(dev)
+            self.pool = keep
         self.pool.reset()
         self.groups = [g if train else 1 for g in groups]
         assert all(x.shape[0] % g == 0 for x, g in zip(xs, self.groups))

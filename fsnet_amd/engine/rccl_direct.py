@@ -71,30 +71,44 @@ def quiesce_watchdog(device):
 class StoreAgreement(object):
     """Rank agreement and small blobs through the process group's key-value store (TCPStore / FileStore): no
     collective, no communicator, no watchdog work item.  Every rank must make the same calls in the same order."""
-    _instances = [0]
+    _generations = {}
 
     def __init__(self, group=None):
         self.store = dist.distributed_c10d._get_default_store()
         self.ranks = list(range(dist.get_world_size())) if group is None else dist.get_process_group_ranks(group)
         self.me = dist.get_rank()
-        StoreAgreement._instances[0] += 1
-        # (contexts are created in the same order on every rank: the counter names this one)
-        self.prefix = "fsnet_amd/agree/%d/%s" % (StoreAgreement._instances[0], "-".join(str(r) for r in self.ranks[:4]))
+        # the group is named by ALL its ranks (a digest: groups that share their first ranks do not collide) and by how many
+        # contexts THIS group has had in this process — every member creates a group's contexts in the same order, whatever
+        # other (overlapping) groups it creates in between
+        import hashlib
+        gid = hashlib.sha1(",".join(str(r) for r in self.ranks).encode()).hexdigest()[:16]
+        gen = StoreAgreement._generations[gid] = StoreAgreement._generations.get(gid, 0) + 1
+        self.prefix = "fsnet_amd/agree/%s/%d" % (gid, gen)
         self.seq = 0
+
+    def _prefix(self):
+        return self.prefix
 
     def all_agree(self, ok):
         """True on every rank iff ok on every rank"""
         self.seq += 1
-        self.store.set("%s/%d/%d" % (self.prefix, self.seq, self.me), b"1" if ok else b"0")
+        pre = self._prefix()
+        self.store.set("%s/%d/%d" % (pre, self.seq, self.me), b"1" if ok else b"0")
         good = True
         for r in self.ranks:
-            good = good and bytes(self.store.get("%s/%d/%d" % (self.prefix, self.seq, r))) == b"1"
+            good = good and bytes(self.store.get("%s/%d/%d" % (pre, self.seq, r))) == b"1"
+        if self.seq > 1:
+            # (every rank has read round seq - 1 before it posted round seq: its own old key can go)
+            try:
+                self.store.delete_key("%s/%d/%d" % (pre, self.seq - 1, self.me))
+            except Exception:
+                pass
         return good
 
     def share(self, blob):
         """bytes from the group's first rank to everybody (blob is ignored elsewhere)"""
         self.seq += 1
-        key = "%s/%d/blob" % (self.prefix, self.seq)
+        key = "%s/%d/blob" % (self._prefix(), self.seq)
         if self.me == self.ranks[0]:
             self.store.set(key, bytes(blob))
         return bytes(self.store.get(key))

@@ -438,6 +438,8 @@ class PhotometricLoss:
         self.motion_mask = None      # [B,H,W] fp32 or None: precomputed motion mask (monodepth2_decoder.py:243-246)
         self.lut_table = self.mei = self.warp_mask = None
         self._lut_keep = None
+        self._clean_acc = self._clean_dd = False
+        register_prezero(self, lambda o: o._prezero())
 
     def stage_fisheye(self, tables, mei_rows):
         """tables: B device tensors [4,H,W] (fs_mei_lut); mei_rows: host float32 [B,8] = k1 k2 xi g1 g2 u0 v0 0.
@@ -473,8 +475,17 @@ class PhotometricLoss:
         self._input_only(img0, C.byref(pa), st)
         self._prefetched = (img0.data_ptr(), srcs[0].data_ptr(), srcs[1].data_ptr(), _p(patched_mask))
 
+    def _prezero(self):
+        """(ops.prezero_all) the accumulators and the depth-gradient maps are about to be zeroed at the step's head"""
+        self._clean_acc = self._clean_dd = True
+        return [self.acc, self._dd_flat]
+
     def _input_only(self, img0, pa, st):
-        self.acc.zero_()
+        if getattr(self, "_clean_acc", False):
+            _join_pack(img0.device)         # zeroed at the step's head on the pack stream: this stream waits for it
+        else:
+            self.acc.zero_()
+        self._clean_acc = False
         for i, s in enumerate(self.scales):
             if s != 0:
                 check(lib.fs_color_pyramid(img0.data_ptr(), self.pyr[i].data_ptr(), self.B, self.H, self.W,
@@ -583,7 +594,11 @@ class PhotometricLoss:
         img0, srcs, patched_mask, depths, disps, noise_seed = self._keep
         self._fill(img0, srcs, patched_mask, depths, disps, noise_seed, gout)
         pa, sa = C.byref(self._pa), C.byref(self._sa)
-        self._dd_flat.zero_()
+        if getattr(self, "_clean_dd", False):
+            _join_pack(img0.device)
+        else:
+            self._dd_flat.zero_()
+        self._clean_dd = False
         fork = self._fork(img0.device)
         if fork is not None:                      # smoothness backward beside the photometric backward
             fork[1].wait_stream(fork[0])
@@ -636,6 +651,53 @@ def copy_multi(pairs):
         dsts = (C.c_void_p * n)(*[d.data_ptr() for d, _ in chunk])
         nbytes = (C.c_int64 * n)(*[s.numel() * s.element_size() for _, s in chunk])
         check(lib.fs_copy_multi(srcs, dsts, nbytes, n, stream_ptr()), "copy_multi")
+
+
+def zero_multi(tensors):
+    """contiguous 16-byte aligned device tensors -> zeroed, one launch per 16 (current stream)"""
+    fast = []
+    for t in tensors:
+        if t.numel() == 0:
+            continue
+        if t.is_cuda and t.is_contiguous() and t.data_ptr() % 16 == 0:
+            fast.append(t)
+        else:
+            t.zero_()
+    for i in range(0, len(fast), COPY_MAX):
+        chunk = fast[i:i + COPY_MAX]
+        n = len(chunk)
+        dsts = (C.c_void_p * n)(*[t.data_ptr() for t in chunk])
+        nbytes = (C.c_int64 * n)(*[t.numel() * t.element_size() for t in chunk])
+        check(lib.fs_zero_multi(dsts, nbytes, n, stream_ptr()), "zero_multi")
+
+
+# ---- per-step scratch zeroed together at the step's head (engine/nets.py pack_everything_async -> prezero_all) ----
+_PREZERO = []          # [(weakref to the owner, fn(owner) -> [tensors to zero]; fn marks them clean)]
+
+
+def register_prezero(owner, fn):
+    import weakref
+    _PREZERO.append((weakref.ref(owner), fn))
+
+
+def _join_pack(device):
+    from ..engine.nets import join_pack
+    join_pack(device)
+
+
+def prezero_all(device):
+    """zero every registered scratch buffer that was used since its last zeroing, in one launch on the current stream; the
+    owners' own zero_() calls are then skipped once (their `clean` flags)"""
+    todo, alive = [], []
+    for ref, fn in _PREZERO:
+        o = ref()
+        if o is None:
+            continue
+        alive.append((ref, fn))
+        todo.extend(t for t in fn(o) if t.device == device)
+    _PREZERO[:] = alive
+    if todo:
+        zero_multi(todo)
 
 
 def counter_incr(buf):

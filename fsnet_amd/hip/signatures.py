@@ -41,6 +41,7 @@ SIGNATURES = {
     "fs_resize_linear": (C.c_int, [P, P, I, I, I, I, I, P]),
     "fs_depth_eval": (C.c_int, [P, P, I, I, I, I, I, P, P, P]),
     "fs_copy_multi": (C.c_int, [P, P, P, I, P]),
+    "fs_zero_multi": (C.c_int, [P, P, I, P]),
     "fs_pack_tile_blocks": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "fs_pack_weights_multi": (C.c_int, [P, I, L, I, P]),
     "fs_nchw_to_nhwc": (C.c_int, [P, P, P, I, I, I, I, I, I, I, P]),

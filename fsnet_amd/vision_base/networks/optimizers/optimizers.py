@@ -18,6 +18,7 @@ class FusedAdam(optim.Optimizer):
         self._arena_state = None
         self._readopt = False
         self._sumsq = None
+        self._clean_sq = False
         self._step_count_fused = 0
         self._step_buf = None      # device-resident step count / lr: the step kernel is hipGraph-replayable
         self._lr_buf = None
@@ -60,6 +61,13 @@ class FusedAdam(optim.Optimizer):
         return self._arena_state[1], self._arena_state[2]
 
     @torch.no_grad()
+    def _prezero(self):
+        """(ops.prezero_all) the gradient-norm accumulator is about to be zeroed with the step's scratch"""
+        if self._sumsq is None:
+            return []
+        self._clean_sq = True
+        return [self._sumsq_buf]
+
     def step(self, closure=None, max_norm=None, grad_scale=1.0):
         """max_norm: fused clip_grad_norm_ (joint L2 norm over all parameters) when given."""
         loss = None
@@ -84,8 +92,17 @@ class FusedAdam(optim.Optimizer):
             sq = None
             if max_norm is not None and max_norm > 0:
                 if self._sumsq is None or self._sumsq.device != dev:
-                    self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
-                self._sumsq.zero_()
+                    # (16 bytes: the step's one-launch scratch zeroing takes 16-byte aligned spans)
+                    self._sumsq_buf = torch.zeros(2, dtype=torch.float64, device=dev)
+                    self._sumsq = self._sumsq_buf[:1]
+                    self._clean_sq = False
+                    ops.register_prezero(self, lambda o: o._prezero())
+                if self._clean_sq:
+                    from fsnet_amd.engine.nets import join_pack
+                    join_pack(dev)
+                else:
+                    self._sumsq.zero_()
+                self._clean_sq = False
                 ops.sumsq(arena.grad, self._sumsq, step_counter=self._step_buf)   # also bumps the device step count
                 sq = self._sumsq
             else:

@@ -347,6 +347,10 @@ int fs_depth_eval(const float* pred, const float* gt, int B, int h, int w, int H
  * (base_training_hooks.py:28-31 does one .cuda() per tensor). */
 #define FS_COPY_MAX 16
 int fs_copy_multi(const void* const* src, void* const* dst, const int64_t* bytes, int n, void* stream);
+/* n (<= FS_COPY_MAX) device buffers (16-byte aligned) zeroed in one launch: the per-step scratch (BatchNorm statistics
+ * pools, loss accumulators, depth-gradient maps) that torch.Tensor.zero_() calls cleared one by one along the step
+ * (base_training_hooks.py:34 optimizer.zero_grad() is the reference's only such call: the rest is engine scratch). */
+int fs_zero_multi(void* const* dst, const int64_t* bytes, int n, void* stream);
 
 /* Batch images NCHW fp32 (one tensor, or two concatenated along C as the pose encoder input,
  * monodepth2_model.py:29-35) -> NHWC with Cp >= Ca+Cb zero-padded channels.
