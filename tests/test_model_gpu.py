@@ -432,6 +432,66 @@ def test_bf16_training_run_tracks_fp32_over_50_steps(dev):
 
 
 @gpu
+def test_resnet50_bf16_training_run_tracks_fp32_over_50_steps(dev):
+    """the ResNet-50 throughput lines (BASELINE configs[2], [4]) are bf16, and single-step encoder
+    gradients of that network at random initialisation only reach cosine 0.2-0.45 against fp32 (DESIGN: it turns its own
+    fp32 gradient by 0.925 under a 2e-4 weight perturbation).  What matters is whether bf16 ResNet-50 TRAINS like fp32
+    ResNet-50: 50 optimisation steps (clip 35, Adam 1e-4, hipGraph replay) from the same weights on eight rotating batches
+    — the loss curves stay as close to each other as two fp32 runs of the same thing do (the yardstick: fp32 atomics
+    reorder, and this network amplifies that too); the update DIRECTION does not follow fp32 — printed, see the end."""
+    from fsnet_amd.configs import meta_arch_cfg, training_cfg
+    from fsnet_amd.engine.runtime import RT
+    from fsnet_amd.vision_base.networks.optimizers.optimizers import build_optimizer
+    from fsnet_amd.vision_base.utils.builder import build
+    B, H, W, STEPS = 4, 64, 128, 50      # (at 96x320 this initialisation's loss is the constant identity term: nothing to track)
+    sd0 = O.init_state(seed=33, depth=50, with_pose=True)
+    batches = [to_dev(O.synthetic_batch(B, H, W, seed=900 + i), dev) for i in range(8)]
+    curves = {}
+    for dtype in (torch.float32, torch.bfloat16, "fp32-again"):
+        RT.set_compute_dtype(torch.float32 if dtype == "fp32-again" else dtype)
+        RT.tie_noise = False
+        m = build(**meta_arch_cfg(H, W, with_pose=True, depth=50))
+        m.load_state_dict({k: v.clone() for k, v in sd0.items()}, strict=True)
+        m = m.to(dev).train()
+        tc = training_cfg()
+        opt = build_optimizer(m, **tc.optimizer)
+        hook = build(**tc.training_hook)
+        losses = []
+        for it in range(STEPS):
+            out = hook(dict(batches[it % len(batches)]), m, opt)
+            losses.append(float(out["loss"].detach()))
+        torch.cuda.synchronize()
+        curves[dtype] = np.array(losses)
+        curves[(dtype, "dp")] = torch.cat([(p.detach().cpu() - sd0[k]).flatten() for k, p in m.named_parameters()])
+    RT.set_compute_dtype(torch.bfloat16)
+    RT.tie_noise = True
+    f, b, f2 = curves[torch.float32], curves[torch.bfloat16], curves["fp32-again"]
+    rel = np.abs(b - f) / f
+    rel_ref = np.abs(f2 - f) / f
+    print("ResNet-50 bf16 vs fp32 loss curves: max rel dev %.4f, mean %.4f (two fp32 runs: %.4f / %.4f); fp32 %.5f -> %.5f, "
+          "bf16 %.5f -> %.5f" % (rel.max(), rel.mean(), rel_ref.max(), rel_ref.mean(), f[:8].mean(), f[-8:].mean(),
+                                 b[:8].mean(), b[-8:].mean()))
+    assert np.isfinite(b).all() and np.isfinite(f).all()
+    # (50 steps at lr 1e-4 do not visibly lower this loss for either dtype at 64x128: what is held is that the curves stay
+    # together — the per-batch loss differences of the rotating batches are ten times the band)
+    # measured: bf16 against fp32 max 0.13-0.25 / mean 0.024, two fp32 runs against each other max 0.14 / mean 0.032 — at
+    # this size the network amplifies the reordering of fp32 atomics as much as it amplifies bf16 rounding
+    assert rel.mean() < max(2.5 * rel_ref.mean(), 2e-2) and rel.max() < max(3.0 * rel_ref.max(), 0.15), (
+        rel.max(), rel.mean(), rel_ref.max(), rel_ref.mean())
+    df, db, d2 = curves[(torch.float32, "dp")], curves[(torch.bfloat16, "dp")], curves[("fp32-again", "dp")]
+    cos = float((df * db).sum() / (df.norm() * db.norm()))
+    cos_ref = float((df * d2).sum() / (df.norm() * d2.norm()))
+    print("ResNet-50 50-step parameter updates: cosine bf16/fp32 %.4f (two fp32 runs: %.4f), norm ratio %.4f" % (
+        cos, cos_ref, float(db.norm() / df.norm())))
+    # What does NOT hold, and is therefore not asserted but recorded (DESIGN section 17): the direction of the 50-step update.
+    # Measured cosine bf16/fp32 0.01-0.02 where two fp32 runs reach 0.39-0.45 — Adam moves every weight by ~lr per step, and
+    # with single-step encoder gradient cosines of 0.2-0.45 the bf16 run's walk decorrelates from the fp32 one within tens
+    # of steps at this (random-initialisation, synthetic-batch) operating point.  The loss curves above stay together; the
+    # ResNet-50 configurations are reported with fp32 lines beside the bf16 ones for that reason.
+    assert 0.7 < float(db.norm() / df.norm()) < 1.3
+
+
+@gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
 def test_resnet50_depth_pose_step_matches_oracle(dev, dtype):
     """BASELINE configs[2] wiring (ResNet-50 depth AND pose encoders, learned pose) at 64x128: loss and parameter
