@@ -212,6 +212,12 @@ class ConvOp:
         # every pixel and masks 3/4 of them.
         self.s2_classes = bool(need_dgrad and stride == 2 and R == 3 and S == 3 and pad == 1
                                and (self.Co_p * eb) % (self.kg_d * 16) == 0)
+        # ... and the 1x1 / stride-2 downsample projections (resnet.py:152-160): dx is dy Wt on the (even, even) lattice and
+        # zero (+ addend) elsewhere — class (0,0) with its one tap, three classes with none.  The parity-test formulation
+        # multiplies four times the rows (ResNet-50 @320x1024: 170-270 us per launch at 80-130 TFLOP/s of mostly zeros).
+        self.s2_classes_1x1 = bool(need_dgrad and stride == 2 and R == 1 and S == 1 and pad == 0
+                                   and (self.Co_p * eb) % (self.kg_d * 16) == 0
+                                   and os.environ.get("FSNET_AMD_S2_1X1_CLASSES", "1") != "0")
         # ... all four classes from one staged dY halo (conv3x3_s2d.hip) when dY has whole 64-byte channel chunks
         self.s2d = bool(self.s2_classes and USE_S2D and (self.Co_p * eb) % 64 == 0 and self.rows_d % 32 == 0
                         and self.Ci_p % 8 == 0)
@@ -417,7 +423,7 @@ class ConvOp:
         if self.Ci_p != self.Ci:
             return False
         rows = (N // groups) * H * W
-        if self.s2_classes and H % 2 == 0 and W % 2 == 0:
+        if (self.s2_classes or self.s2_classes_1x1) and H % 2 == 0 and W % 2 == 0:
             rows //= 4                                  # one launch per output-parity class
         if groups > 1 and not (self.halo_d and USE_HALO) and not self.s2d and rows % 256 != 0:
             return False      # an implicit-GEMM tile could straddle two statistics groups
@@ -429,6 +435,11 @@ class ConvOp:
                    ((1, 0), ((3, 1, 0), (4, 0, 0))),
                    ((1, 1), ((5, 1, 1), (6, 1, 0), (7, 0, 1), (8, 0, 0))))
 
+    _S2_CLASSES_1X1 = (((0, 0), ((0, 0, 0),)), ((0, 1), ()), ((1, 0), ()), ((1, 1), ()))
+
+    def _classes(self):
+        return self._S2_CLASSES if self.R == 3 else self._S2_CLASSES_1X1
+
     def _class_tables(self, sH, sW):
         """unit tables of the four parity classes, concatenated; returns (table, [offset in units], [K stages])"""
         key = ("c", sH, sW)
@@ -439,8 +450,11 @@ class ConvOp:
             stage = self.kg_d * 16
             tabs, offs, nchs = [], [], []
             pos = 0
-            for _, taps in self._S2_CLASSES:
+            for _, taps in self._classes():
                 nunits = len(taps) * self.Co_p // (self.EG * ug)
+                if nunits == 0:         # a class without taps: its blocks only run the epilogue (zeros + addend)
+                    tabs.append(np.zeros((0, 2), dtype=np.int32)); offs.append(pos); nchs.append(0)
+                    continue
                 tab = np.zeros((nunits, 2), dtype=np.int32)
                 k0 = np.arange(nunits, dtype=np.int64) * self.EG * ug
                 tl, c = k0 // self.Co_p, k0 % self.Co_p
@@ -450,7 +464,9 @@ class ConvOp:
                 tab[:, 1] = ((dr & 0xffff) | (ds << 16)).astype(np.int32)
                 tabs.append(tab); offs.append(pos); nchs.append(len(taps) * self.Co_p * eb // stage)
                 pos += nunits
-            t = self._tabs[key] = (torch.from_numpy(np.concatenate(tabs, 0)).to(self.device), offs, nchs)
+            cat = np.concatenate(tabs, 0)
+            cat = np.concatenate([cat, np.zeros((max(1, 16 - len(cat)), 2), dtype=np.int32)], 0)    # (never an empty table)
+            t = self._tabs[key] = (torch.from_numpy(cat).to(self.device), offs, nchs)
         return t
 
     def can_fold_ds_dgrad(self, ds_op, dy, dc_ds):
@@ -471,7 +487,7 @@ class ConvOp:
         a = FsConvArgs()
         a.src, a.dst, a.wgt = dy.data_ptr(), o.data_ptr(), self.w_d.data_ptr()
         a.wgt_row_bytes = self.kd_p * eb
-        a.wgt_bytes = (self.rows_d - 1) * self.kd_p * eb + 4 * self.Co_p * eb      # longest class slice: 4 taps
+        a.wgt_bytes = (self.rows_d - 1) * self.kd_p * eb + (4 if self.R == 3 else 1) * self.Co_p * eb      # longest class slice
         a.sN, a.sH, a.sW = _nhwc_strides(dy)
         a.ktab = tab.data_ptr()
         a.src_bytes = _span_bytes(dy)
@@ -490,10 +506,10 @@ class ConvOp:
         a.hb_mul, a.hb_add, a.sgn, a.dshift = 1, 0, 1, 0
         a.N, a.Cs = N, self.Co_p
         a.ncls = 4
-        for k, ((py, px), taps) in enumerate(self._S2_CLASSES):
+        for k, ((py, px), taps) in enumerate(self._classes()):
             assert k == 2 * py + px
-            a.cls_nch[k], a.cls_ktab_off[k] = nchs[k], offs[k]
-            a.cls_wgt_off[k] = taps[0][0] * self.Co_p * eb
+            a.cls_nch[k], a.cls_ktab_off[k] = nchs[k], min(offs[k], 0 if not taps else offs[k])
+            a.cls_wgt_off[k] = taps[0][0] * self.Co_p * eb if taps else 0
         if bn_fuse is not None:
             c, st, sums = bn_fuse
             a.bnb_x = c.data_ptr()                   # same layout as out: addressed through the dst offsets
@@ -546,6 +562,9 @@ class ConvOp:
             if H % 2 or W % 2 or H != 2 * Ho or W != 2 * Wo:
                 raise NotImplementedError("stride-2 3x3 data gradient expects an even input size (%dx%d)" % (H, W))
             return self._dgrad_s2_classes(dy, H, W, out, addend, mask, bn_fuse, ds)
+        if self.s2_classes_1x1 and ds is None and H % 2 == 0 and W % 2 == 0 and H == 2 * Ho and W == 2 * Wo and pro_bwd is None \
+                and not mask_bn:
+            return self._dgrad_s2_classes(dy, H, W, out, addend, mask, bn_fuse, None)
         assert ds is None
         a = FsConvArgs()
         a.src, a.wgt, a.dst = dy.data_ptr(), self.w_d.data_ptr(), out.data_ptr()

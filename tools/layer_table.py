@@ -12,6 +12,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=12)
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--depth", type=int, default=18)
+    ap.add_argument("--height", type=int, default=192)
+    ap.add_argument("--width", type=int, default=640)
     args = ap.parse_args()
     import bench
     from fsnet_amd.configs import meta_arch_cfg, training_cfg
@@ -22,11 +25,11 @@ def main():
     dev = torch.device("cuda", 0)
     RT.set_compute_dtype("bf16")
     RT.overlap = False
-    model = build(**meta_arch_cfg(192, 640, with_pose=True)).to(dev).train()
+    model = build(**meta_arch_cfg(args.height, args.width, with_pose=True, depth=args.depth)).to(dev).train()
     tc = training_cfg(clip_gradients=35.0, lr=1e-4)
     opt = build_optimizer(model, **tc.optimizer)
     hook = build(use_graph=False, **tc.training_hook)
-    batches = bench.synthetic_device_batches(args.batch, 192, 640, dev, 0)
+    batches = bench.synthetic_device_batches(args.batch, args.height, args.width, dev, 0)
     for i in range(3):
         hook(dict(batches[i % len(batches)]), model, opt)
     LaunchProfile.begin()
