@@ -15,9 +15,8 @@
 // dispatch(): occupancy, not reuse, decides the tile on the monodepth shapes.
 // Dgrad = same kernel on dY with Wt[ci][r][s][co] and the taps mirrored (sgn = -1).
 // The epilogue (bias / addend / ReLU / ReLU-mask / fp32 out / fused BN statistics) matches conv_igemm.hip.
-// Round 4: the operand prologues of conv3x3_t32.hip (conv_pro.h: BatchNorm + ReLU in front of the convolution, the
-// second pass of a BatchNorm backward in front of a data gradient, coefficients derived in the kernel) and the derived
-// ReLU mask (bnb_scale) exist here too, so that every BasicBlock of every stage folds, not only the launches large
+// Round 4: the operand prologue of conv3x3_t32.hip (conv_pro.h: BatchNorm + ReLU in front of the convolution, coefficients
+// derived in the kernel) and the derived ReLU mask (bnb_scale) exist here too, so that every BasicBlock of every stage folds, not only the launches large
 // enough for the 32x32-tile kernel.
 #include "common.h"
 #include "fsnet_hip_internal.h"
@@ -127,8 +126,6 @@ __global__ __launch_bounds__(256, halo_minwaves(PIX, CO, PRO)) void conv3x3_halo
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, (int)p.src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wgt =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, (int)p.wgt_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_src2 =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(PRO == 2 ? p.pro_src2 : p.src), 0, (int)p.src_bytes, 0x00020000);
 
   // the prologue's coefficient table first: its f64 sums are the oldest loads in flight when the halo arrives, and
   // none of the walk's scalar state is live yet (the table is complete at the loop's first barrier)
@@ -137,7 +134,6 @@ __global__ __launch_bounds__(256, halo_minwaves(PIX, CO, PRO)) void conv3x3_halo
   // ---- per-thread load units (fixed over the channel walk) ----
   const int row_bytes = p.Cs * (int)sizeof(T);     // real bytes per pixel / per tap
   int hvoff[LH], wvoff[LW];
-  unsigned interior = 0u;        // PRO == 2 with pro_dst: the units this thread writes out (its tile's own pixels)
 #pragma unroll
   for (int i = 0; i < LH; ++i) {
     int idx = t + i * 256;
@@ -147,9 +143,7 @@ __global__ __launch_bounds__(256, halo_minwaves(PIX, CO, PRO)) void conv3x3_halo
     // (a 16-channel bf16 layer fills half a 64-byte chunk: the upper units stay zero, as do their weights)
     bool ok = hp < nhalo && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws && q * 16 < row_bytes;
     hvoff[i] = ok ? (int)(((long)n * p.sN + (long)sy * p.sH + (long)sx * p.sW) * (long)sizeof(T)) + q * 16 : OOB;
-    if (PRO == 2 && ok && hy >= 1 && hy <= g.TH && hx >= 1 && hx <= g.TW) interior |= 1u << i;
   }
-  if (PRO != 2 || p.pro_dst == nullptr || cy != 0) interior = 0u;
 
   const int wrow_bytes = p.nchunks * p.kg * 16;    // packed weight row stride (as packed for conv_igemm)
   const int tap_bytes = p.Cs * (int)sizeof(T);
@@ -162,20 +156,15 @@ __global__ __launch_bounds__(256, halo_minwaves(PIX, CO, PRO)) void conv3x3_halo
   }
 
   uint4 rh[LH], rw[LW];
-  uint4 rh2[PRO == 2 ? LH : 1];
   auto load_regs = [&](int cc) {
     const int coff = cc * 64;
 #pragma unroll
     for (int i = 0; i < LH; ++i) rh[i] = buf_load16(rs_src, hvoff[i] == OOB ? OOB : hvoff[i] + coff);
-    if constexpr (PRO == 2) {
-#pragma unroll
-      for (int i = 0; i < LH; ++i) rh2[i] = buf_load16(rs_src2, hvoff[i] == OOB ? OOB : hvoff[i] + coff);
-    }
 #pragma unroll
     for (int i = 0; i < LW; ++i) rw[i] = buf_load16(rs_wgt, wvoff[i] == OOB ? OOB : wvoff[i] + coff);
   };
   auto store_lds = [&](int cc) {
-    float ka[PRO != 0 ? UN : 1], kb[PRO != 0 ? UN : 1], kc[PRO == 2 ? UN : 1], km[PRO == 2 ? UN : 1];
+    float ka[PRO != 0 ? UN : 1], kb[PRO != 0 ? UN : 1];
     if constexpr (PRO != 0) {
       // this thread's channels of the chunk: 256 % 4 == 0, so slot q = t & 3 of every pixel it stages
       const int c0r = cc * (64 / (int)sizeof(T)) + (t & 3) * UN;
@@ -186,12 +175,6 @@ __global__ __launch_bounds__(256, halo_minwaves(PIX, CO, PRO)) void conv3x3_halo
         const float4 b = *reinterpret_cast<const float4*>(halo_pro_tab + p.Cs + c0 + j);
         ka[j] = a.x; ka[j + 1] = a.y; ka[j + 2] = a.z; ka[j + 3] = a.w;
         kb[j] = b.x; kb[j + 1] = b.y; kb[j + 2] = b.z; kb[j + 3] = b.w;
-        if constexpr (PRO == 2) {
-          const float4 c = *reinterpret_cast<const float4*>(halo_pro_tab + 2 * p.Cs + c0 + j);
-          const float4 m = *reinterpret_cast<const float4*>(halo_pro_tab + 3 * p.Cs + c0 + j);
-          kc[j] = c.x; kc[j + 1] = c.y; kc[j + 2] = c.z; kc[j + 3] = c.w;
-          km[j] = m.x; km[j + 1] = m.y; km[j + 2] = m.z; km[j + 3] = m.w;
-        }
       }
     }
 #pragma unroll
@@ -209,17 +192,6 @@ __global__ __launch_bounds__(256, halo_minwaves(PIX, CO, PRO)) void conv3x3_halo
         }
         u = Unit<T>::pack(v);
         if (hvoff[i] == OOB) u = make_uint4(0u, 0u, 0u, 0u);     // padding applies to the transformed tensor
-      }
-      if constexpr (PRO == 2) {
-        float v[UN], w[UN];
-        Unit<T>::unpack(u, v);
-        Unit<T>::unpack(rh2[i], w);
-#pragma unroll
-        for (int j = 0; j < UN; ++j) v[j] = v[j] * ka[j] + ((w[j] - km[j]) * kb[j] + kc[j]);
-        u = Unit<T>::pack(v);
-        if (hvoff[i] == OOB) u = make_uint4(0u, 0u, 0u, 0u);
-        if ((interior >> i) & 1u)
-          *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.pro_dst) + (long)hvoff[i] + cc * 64) = u;
       }
       if constexpr (STR == 2) {
         const int hy = fs_fastdiv(hp, g.mHW), hx = hp - hy * HW;
@@ -490,7 +462,6 @@ int launch_halo(const FsConvArgs& a, const FsConvArgs* b, hipStream_t st) {
   switch (a.pro_mode) {
     case 0: return launch_halo_pro<T, PIX, CO, WP, 0>(a, b, st);
     case 1: return launch_halo_pro<T, PIX, CO, WP, 1>(a, b, st);
-    case 2: return launch_halo_pro<T, PIX, CO, WP, 2>(a, b, st);
     default: return FS_EINVAL;
   }
 }
@@ -586,8 +557,7 @@ bool conv3x3_pairable(const FsConvArgs& a, const FsConvArgs& b) {
          a.nchunks == b.nchunks && a.kg == b.kg && a.hb_mul == b.hb_mul && a.hb_add == b.hb_add && a.sgn == b.sgn &&
          a.relu == b.relu && a.out_f32 == b.out_f32 && a.pro_mode == b.pro_mode && a.pro_relu == b.pro_relu &&
          a.wgt_bytes == b.wgt_bytes && nn(a.bias, b.bias) && nn(a.addend, b.addend) && nn(a.mask, b.mask) &&
-         nn(a.stats, b.stats) && nn(a.bnb_x, b.bnb_x) && nn(a.bnb_scale, b.bnb_scale) && nn(a.pro_stats, b.pro_stats) &&
-         nn(a.pro_dst, b.pro_dst);
+         nn(a.stats, b.stats) && nn(a.bnb_x, b.bnb_x) && nn(a.bnb_scale, b.bnb_scale) && nn(a.pro_stats, b.pro_stats);
 }
 
 int conv3x3_entry(const FsConvArgs* args, const FsConvArgs* b, int dtype, hipStream_t st) {

@@ -15,11 +15,10 @@
 //   * the per-channel statistics of a wave fold over 16 lanes by a halving exchange (15 DPP adds per 16 values instead
 //     of 80): t32_common.h.
 //   * epilogue options are template flags for the combinations the networks use (EP >= 0), run-time tests otherwise.
-//   * operand prologue (FsConvArgs.pro_mode): the BatchNorm + ReLU in front of the convolution, or the second pass of
-//     its backward in front of a data gradient, is applied while the halo is staged — see fsnet_hip.h.
-//   * round 4: the prologue's coefficients come from an LDS table every block fills itself from the f64 sums of the
-//     producing kernel's epilogue (conv_pro.h: no fs_bn_finalize launch); in a data-gradient launch the transformed
-//     operand — the BatchNorm input gradient — is also written out for the weight gradient (pro_dst).
+//   * operand prologue (FsConvArgs.pro_mode = 1): the BatchNorm + ReLU in front of the convolution is applied while the
+//     halo is staged — see fsnet_hip.h; its coefficients come from an LDS table every block fills itself from the f64
+//     sums of the producing kernel's epilogue (conv_pro.h: no fs_bn_finalize launch).  (Rounds 3-4 also had mode 2, the
+//     second pass of a BatchNorm's backward in the data gradient's staging: measured slower, removed in round 5.)
 // Measured alone (HIP events, bf16, fwd + statistics / dgrad + BatchNorm-backward sums, us): 64->64 @48x160 B=12
 // 14.0 / 16.4 (16x16 kernel 18.8 / 23.9), B=36 33.0 / 39.8 (40.9 / 61.5); 128->128 @24x80 B=36 30.5 / 34.0 (32.3 /
 // 40.6); 256->256 @12x40 B=36 30.3 / 32.9 (33.4 / 36.3); 64->64 @80x256 B=8 20.7 / 25.4 (25.5 / 34.5).  Variants that
@@ -94,8 +93,6 @@ __global__ __launch_bounds__(256, t32_minwaves(PIX, CO, EP, PRO)) void conv3x3_t
 
   const __amdgpu_buffer_rsrc_t rs_src =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, (int)p.src_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_src2 =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(PRO == 2 ? p.pro_src2 : p.src), 0, (int)p.src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wgt =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, (int)p.wgt_bytes, 0x00020000);
 
@@ -104,7 +101,6 @@ __global__ __launch_bounds__(256, t32_minwaves(PIX, CO, EP, PRO)) void conv3x3_t
   const int row_bytes = p.Cs * (int)sizeof(T);
   const int q4 = t & 3;
   int hvoff[LH], wvoff[LW];
-  unsigned interior = 0u;        // PRO == 2 with pro_dst: the units this thread writes out (its tile's own pixels)
 #pragma unroll
   for (int i = 0; i < LH; ++i) {
     const int hp = (t >> 2) + i * 64;
@@ -112,9 +108,7 @@ __global__ __launch_bounds__(256, t32_minwaves(PIX, CO, EP, PRO)) void conv3x3_t
     const int sy = oy + hy, sx = ox + hx;
     const bool ok = hp < nhalo && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws && q4 * 16 < row_bytes;
     hvoff[i] = ok ? (int)(((long)n * p.sN + (long)sy * p.sH + (long)sx * p.sW) * (long)sizeof(T)) + q4 * 16 : OOB;
-    if (PRO == 2 && ok && hy >= 1 && hy <= g.TH && hx >= 1 && hx <= g.TW) interior |= 1u << i;
   }
-  if (PRO != 2 || p.pro_dst == nullptr || cy != 0) interior = 0u;
   const int wrow_bytes = p.nchunks * p.kg * 16;
 #pragma unroll
   for (int i = 0; i < LW; ++i) {
@@ -125,23 +119,17 @@ __global__ __launch_bounds__(256, t32_minwaves(PIX, CO, EP, PRO)) void conv3x3_t
   const int pgrp = (PRO != 0 && p.pro_group_imgs > 0) ? fs_div(n, g.dPRG) : 0;
 
   uint4 rh[LH], rw[LW];
-  uint4 rh2[PRO == 2 ? LH : 1];
   auto load_regs = [&](int cc) {
     const int coff = cc * 64;
 #pragma unroll
     for (int i = 0; i < LH; ++i)
       rh[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, hvoff[i], coff, 0));
-    if constexpr (PRO == 2) {
-#pragma unroll
-      for (int i = 0; i < LH; ++i)
-        rh2[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_src2, hvoff[i], coff, 0));
-    }
 #pragma unroll
     for (int i = 0; i < LW; ++i)
       rw[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_wgt, wvoff[i], coff, 0));
   };
   auto store_lds = [&](int cc) {
-    float ka[PRO != 0 ? UN : 1], kb[PRO != 0 ? UN : 1], kc[PRO == 2 ? UN : 1], km[PRO == 2 ? UN : 1];
+    float ka[PRO != 0 ? UN : 1], kb[PRO != 0 ? UN : 1];
     if constexpr (PRO != 0) {
       // this thread's channels of the chunk (the same 16-byte slot q4 of every pixel it stages), from the block's table
       const int c0r = cc * (64 / (int)sizeof(T)) + q4 * UN;
@@ -152,12 +140,6 @@ __global__ __launch_bounds__(256, t32_minwaves(PIX, CO, EP, PRO)) void conv3x3_t
         const float4 b = *reinterpret_cast<const float4*>(t32_pro_tab + p.Cs + c0 + j);
         ka[j] = a.x; ka[j + 1] = a.y; ka[j + 2] = a.z; ka[j + 3] = a.w;
         kb[j] = b.x; kb[j + 1] = b.y; kb[j + 2] = b.z; kb[j + 3] = b.w;
-        if constexpr (PRO == 2) {
-          const float4 c = *reinterpret_cast<const float4*>(t32_pro_tab + 2 * p.Cs + c0 + j);
-          const float4 m = *reinterpret_cast<const float4*>(t32_pro_tab + 3 * p.Cs + c0 + j);
-          kc[j] = c.x; kc[j + 1] = c.y; kc[j + 2] = c.z; kc[j + 3] = c.w;
-          km[j] = m.x; km[j + 1] = m.y; km[j + 2] = m.z; km[j + 3] = m.w;
-        }
       }
     }
 #pragma unroll
@@ -174,17 +156,6 @@ __global__ __launch_bounds__(256, t32_minwaves(PIX, CO, EP, PRO)) void conv3x3_t
         }
         u = Unit<T>::pack(v);
         if (hvoff[i] == OOB) u = make_uint4(0u, 0u, 0u, 0u);     // padding applies to the transformed tensor
-      }
-      if constexpr (PRO == 2) {
-        float v[UN], w[UN];
-        Unit<T>::unpack(u, v);
-        Unit<T>::unpack(rh2[i], w);
-#pragma unroll
-        for (int j = 0; j < UN; ++j) v[j] = v[j] * ka[j] + ((w[j] - km[j]) * kb[j] + kc[j]);
-        u = Unit<T>::pack(v);
-        if (hvoff[i] == OOB) u = make_uint4(0u, 0u, 0u, 0u);
-        if ((interior >> i) & 1u)
-          *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.pro_dst) + (long)hvoff[i] + cc * 64) = u;
       }
       if (64 * (i + 1) <= HMAX || hp < HMAX) lds[hp * HS + q4] = u;
     }
@@ -473,7 +444,6 @@ int t32_dispatch(const FsConvArgs& a, const FsConvArgs* b, hipStream_t st) {
   switch (a.pro_mode) {
     case 0: return t32_dispatch_ep<T, 0>(a, b, cfg, st);
     case 1: return t32_dispatch_ep<T, 1>(a, b, cfg, st);
-    case 2: return t32_dispatch_ep<T, 2>(a, b, cfg, st);
     default: return FS_EINVAL;
   }
 }

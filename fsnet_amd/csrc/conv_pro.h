@@ -1,8 +1,8 @@
 // Operand prologue of the 3x3 / stride-1 LDS-halo convolution kernels (conv3x3_t32.hip, conv3x3_halo.hip): the
-// BatchNorm in front of a convolution (mode 1) or the second pass of the backward of the BatchNorm behind it (mode 2),
-// applied to 16-byte units while they travel from the load registers to LDS.  FsConvArgs documents the two modes
-// (include/fsnet_hip.h).  The per-channel coefficients live in a small LDS table that every block fills itself — from
-// the f64 sums the producing kernel's epilogue left (bn_apply_kernel's / bn_bwd_apply_kernel's preamble, bn.hip, same
+// BatchNorm (+ ReLU) in front of a convolution (pro_mode 1), applied to 16-byte units while they travel from the load
+// registers to LDS.  FsConvArgs documents it (include/fsnet_hip.h).  (Mode 2 — the second pass of the backward of the
+// BatchNorm behind the convolution, in the data gradient's staging — existed in rounds 3-4, measured slower and is gone.)  The per-channel coefficients live in a small LDS table that every block fills itself — from
+// the f64 sums the producing kernel's epilogue left (bn_apply_kernel's preamble, bn.hip, same
 // arithmetic: no fs_bn_finalize launch and no BatchNorm pass between two convolutions), or from coefficient arrays
 // handed in.  Reference: nn.BatchNorm2d in train mode between conv1 and conv2 of a BasicBlock and its autograd
 // backward, vision_base/networks/models/backbone/resnet.py:33-50.
@@ -12,7 +12,7 @@
 
 namespace {
 
-template <int PRO> constexpr int pro_ncoef() { return PRO == 1 ? 2 : (PRO == 2 ? 4 : 0); }
+template <int PRO> constexpr int pro_ncoef() { return PRO == 1 ? 2 : 0; }
 // dynamic LDS a launch with this prologue needs
 template <int PRO> inline unsigned pro_lds_bytes(const FsConvArgs& a) { return (unsigned)(pro_ncoef<PRO>() * a.Cs * sizeof(float)); }
 
@@ -37,45 +37,24 @@ __device__ inline void pro1_channel(const FsConvArgs& p, int g, int c, float& me
   sh = p.pro_beta[c] - mean * sc;
 }
 
-// mode 2: dx = k*(g - a - xhat*b), k = gamma*invstd, a = sum g / count, b = sum g*xhat / count (bn_bwd_apply_kernel)
-// as g*ka + ((x - m)*kb + kc)
-__device__ inline void pro2_channel(const FsConvArgs& p, int g, int c, float& ka, float& kb, float& kc, float& km) {
-  const int C = p.Cs;
-  double sg, sgx;
-  pro_sum_slots(p.pro_stats + (long)g * FS_STAT_SLOTS * 2 * C, C, c, sg, sgx);
-  const float istd = p.pro_invstd[g * C + c];
-  const float k = p.pro_gamma[c] * istd;
-  const float a = (float)(sg / p.pro_count), b = (float)(sgx / p.pro_count);
-  ka = k; kb = -(k * b) * istd; kc = -(k * a); km = p.pro_mean[g * C + c];
-}
-
 // fills tab[ncoef][Cs] for statistics group grp (all threads of the block; a barrier must follow before it is read)
 template <int PRO>
 __device__ inline void pro_build_table(const FsConvArgs& p, float* tab, int grp, int t, int nt) {
   const int C = p.Cs;
   if (p.pro_stats) {
     for (int c = t; c < C; c += nt) {
-      if constexpr (PRO == 1) {
-        float mean, istd, varb, sc, sh;
-        pro1_channel(p, grp, c, mean, istd, varb, sc, sh);
-        tab[c] = sc; tab[C + c] = sh;
-      } else {
-        float ka, kb, kc, km;
-        pro2_channel(p, grp, c, ka, kb, kc, km);
-        tab[c] = ka; tab[C + c] = kb; tab[2 * C + c] = kc; tab[3 * C + c] = km;
-      }
+      float mean, istd, varb, sc, sh;
+      pro1_channel(p, grp, c, mean, istd, varb, sc, sh);
+      tab[c] = sc; tab[C + c] = sh;
     }
   } else {
-    for (int c = t; c < C; c += nt) {
-      tab[c] = p.pro_a[grp * C + c]; tab[C + c] = p.pro_b[grp * C + c];
-      if constexpr (PRO == 2) { tab[2 * C + c] = p.pro_c[grp * C + c]; tab[3 * C + c] = p.pro_m[grp * C + c]; }
-    }
+    for (int c = t; c < C; c += nt) { tab[c] = p.pro_a[grp * C + c]; tab[C + c] = p.pro_b[grp * C + c]; }
   }
 }
 
 // what ONE block of the launch does besides its tile when the coefficients are derived in the kernel: mode 1 — saved
 // statistics, the affine form for the backward's consumers, running statistics (one momentum update per group, in
-// group order, like bn_finalize_kernel); mode 2 — dgamma / dbeta of the local shard
+// group order, like bn_finalize_kernel)
 template <int PRO>
 __device__ inline void pro_block0(const FsConvArgs& p, int t, int nt) {
   if (!p.pro_stats) return;
@@ -97,46 +76,23 @@ __device__ inline void pro_block0(const FsConvArgs& p, int t, int nt) {
       if (track) { p.pro_running_mean[c] = rm; p.pro_running_var[c] = rv; }
     }
     if (t == 0 && p.pro_nbt) *p.pro_nbt += G;
-  } else if constexpr (PRO == 2) {
-    const double* src = p.pro_stats_local ? p.pro_stats_local : p.pro_stats;
-    for (int c = t; c < C; c += nt) {
-      double lg = 0.0, lgx = 0.0;
-      for (int g = 0; g < G; ++g) {
-        double a, b;
-        pro_sum_slots(src + (long)g * FS_STAT_SLOTS * 2 * C, C, c, a, b);
-        lg += a; lgx += b;
-      }
-      if (p.pro_dgamma) p.pro_dgamma[c] += (float)lgx;
-      if (p.pro_dbeta) p.pro_dbeta[c] += (float)lg;
-    }
   }
 }
 
 // argument checks shared by the two kernels' entry points
 inline bool pro_args_ok(const FsConvArgs& a) {
-  if (a.pro_mode == 0) return a.pro_dst == nullptr;
-  if (a.pro_mode != 1 && a.pro_mode != 2) return false;
-  // (the coefficient table is dynamic LDS on top of 38-78 KB of static LDS: 2 or 4 floats per source channel; the widest
-  // 3x3 layer of the networks has 512 — wider layers are declined here, the callers' can_fold_* then never ask)
+  if (a.pro_mode == 0) return true;
+  if (a.pro_mode != 1) return false;
+  // (the coefficient table is dynamic LDS on top of 38-78 KB of static LDS: 2 floats per source channel; the widest 3x3
+  // layer of the networks has 512 — wider layers are declined here, the callers' can_fold_* then never ask)
   if (a.Cs % 4 != 0 || a.Cs > 512) return false;
   if (a.pro_group_imgs < 0 || (a.pro_group_imgs > 0 && a.N % a.pro_group_imgs != 0)) return false;
-  if (a.pro_mode == 2 && !a.pro_src2) return false;
-  if (a.pro_mode == 1 && a.pro_dst) return false;
   if (a.pro_stats) {
-    if (!a.pro_gamma || !(a.pro_count > 0.0)) return false;
-    if (a.pro_mode == 1 && !a.pro_beta) return false;
-    if (a.pro_mode == 1 && ((a.pro_mean == nullptr) != (a.pro_invstd == nullptr) || (a.pro_save_a == nullptr) != (a.pro_save_b == nullptr))) return false;
-    if (a.pro_mode == 1 && (a.pro_running_mean == nullptr) != (a.pro_running_var == nullptr)) return false;
-    if (a.pro_mode == 2 && (!a.pro_mean || !a.pro_invstd)) return false;
+    if (!a.pro_gamma || !a.pro_beta || !(a.pro_count > 0.0)) return false;
+    if ((a.pro_mean == nullptr) != (a.pro_invstd == nullptr) || (a.pro_save_a == nullptr) != (a.pro_save_b == nullptr)) return false;
+    if ((a.pro_running_mean == nullptr) != (a.pro_running_var == nullptr)) return false;
   } else {
     if (!a.pro_a || !a.pro_b) return false;
-    if (a.pro_mode == 2 && (!a.pro_c || !a.pro_m)) return false;
-  }
-  if (a.pro_dst) {
-    // the copy is written at src's offsets: src must be a dense [N][Hs][Ws][Cs] tensor and the halo origin the pad-1
-    // data gradient's (tile interiors then partition src)
-    if (a.sW != a.Cs || a.sH != (int64_t)a.Ws * a.Cs || a.sN != (int64_t)a.Hs * a.Ws * a.Cs) return false;
-    if (a.sgn > 0 || a.hb_add != 1 || a.Hs != a.Hd || a.Ws != a.Wd) return false;
   }
   return true;
 }

@@ -36,11 +36,9 @@ def _env_level(name, default):
 
 
 FOLD_BN = _env_level("FSNET_AMD_BN_FOLD", 1)
-# the second pass of a BatchNorm's backward applied by the data gradient of the convolution in front of it while it stages
-# dY (coefficients from the sums the previous data gradient's epilogue left; written out once for the weight gradient).
-# Built, tested against the oracle and MEASURED slower (the data gradient stages two tensors, holds
-# half the blocks per CU and takes +19 us where the pass it replaces took 15): off by default, same values as FOLD_BN.
-FOLD_BN_BWD = _env_level("FSNET_AMD_BN_FOLD_BWD", 0)
+# (The backward counterpart — the second pass of a BatchNorm's backward applied by the data gradient in front of it while it
+# stages dY, FsConvArgs.pro_mode = 2 of rounds 3-4 — was built, pinned to the oracle and measured slower: two staged tensors,
+# 172-198 registers, half the blocks per CU, +19-25 us for a 15 us pass.  Removed in round 5 with its kernel paths.)
 # the 1x1 / stride-2 downsample projection's data gradient inside the block's 3x3 / stride-2 data gradient launch
 FOLD_DS_DGRAD = os.environ.get("FSNET_AMD_FOLD_DS_DGRAD", "1") != "0"
 # the stem's BatchNorm + ReLU + max-pool as one pass, its backward's pooling gradient gathered inside the BatchNorm passes
@@ -807,42 +805,6 @@ class EncoderPass:
             ops.bn_backward_multi(calls)
         return dcs
 
-    def _pend(self, gs, cs, sts, bns, sums):
-        """a BatchNorm backward whose second pass is left to the data gradient of the convolution in front of it: g = the
-        masked gradient w.r.t. the BatchNorm output, sums = (sum g, sum g*xhat) of the local shard.  Data parallel: the
-        global sums are exchanged here, dgamma / dbeta come from the local ones."""
-        glob, local = sums, [None] * self.nl
-        if RT.dp is not None and sts[0].count != float("inf"):
-            _, glob = _exchange(self._pool_bwd(cs[0].device), sums, out_of_place=True)
-            local = sums
-        return [dict(g=g, c=c, st=st, bn=bn, sums=gl, sums_local=lo)
-                for g, c, st, bn, gl, lo in zip(gs, cs, sts, bns, glob, local)]
-
-    @staticmethod
-    def _pend_kw(pend):
-        """ConvOp.dgrad arguments of the pending BatchNorm backwards: (source gradients, kwargs, the tensors that receive
-        the BatchNorm input gradients), per lane"""
-        srcs, kws, dcs = [], [], []
-        for pd in pend:
-            dc = torch.empty_like(pd["c"])
-            bn = pd["bn"]
-            srcs.append(pd["g"])
-            kws.append(dict(pro_bwd=dict(c=pd["c"], st=pd["st"], gamma=bn.weight.data, sums=pd["sums"],
-                                         sums_local=pd["sums_local"], dgamma=grad_of(bn.weight),
-                                         dbeta=grad_of(bn.bias), dc_out=dc)))
-            dcs.append(dc)
-        return srcs, kws, dcs
-
-    def _can_fold_bwd(self, ops_, bns, sts, cs):
-        if not (FOLD_BN_BWD and FUSE_BN_BWD and sts[0].count != float("inf")):
-            return False
-        for op, c in zip(ops_, cs):
-            if not op.can_fold_bn_bwd(c.shape[0], c.shape[1], c.shape[2]):
-                return False
-            if int(FOLD_BN_BWD) == 2 and op.plan_3x3(c.shape[0], c.shape[1], c.shape[2], forward=False, pro_mode=2)["kernel"] != "t32":
-                return False
-        return True
-
     def _dgrad(self, ops_, srcs, hws, kws):
         """one data gradient per lane in one launch: kws = per lane keyword dicts of ConvOp.dgrad_spec"""
         specs = [op.dgrad_spec(src, hw[0], hw[1], **kw) for op, src, hw, kw in zip(ops_, srcs, hws, kws)]
@@ -857,11 +819,7 @@ class EncoderPass:
         that already masked it with this block's output ReLU and accumulated the BatchNorm-backward sums.
         prev = (y, c, BnState) of the block that consumes the returned gradient (fused the same way).
         units: per lane [(ConvLayer, bn)], ds: per lane (ConvLayer, bn) or None; every tensor argument is a per-lane list.
-
-        A BatchNorm whose masked output gradient and backward sums exist (they come out of the epilogue of the data
-        gradient behind it) does not get a second pass of its own where the convolution in front of it is a 3x3 /
-        stride-1 one: that convolution's data gradient applies dx = gamma*invstd*(g - mean_g - xhat*mean_gx) to dY while it
-        stages it (`pend`), writes it out once, and the weight gradient reads that."""
+"""
         nl = self.nl
         x = bctx["x"]
         hw_x = [(t.shape[1], t.shape[2]) for t in x]
@@ -870,8 +828,7 @@ class EncoderPass:
         cls_last = [u[k - 1][0] for u in units]
         bn_last = [u[k - 1][1] for u in units]
         op_last = self._ready(cls_last, x)
-        fold_last = dout_sums is not None and self._can_fold_bwd(op_last, bn_last, st, c)
-        pend, dc = None, None
+        dc = None
         ds_fold = None
         joint = (ds is not None and RT.dp is not None and st[0].count != float("inf")
                  and bctx["ds"][1][0].count != float("inf"))
@@ -885,8 +842,7 @@ class EncoderPass:
             s_m = dout_sums if fused_in else self._sums(c, st)
             s_d = self._sums(c_ds, st2)
             dc_ds = [torch.empty_like(t) for t in c_ds]
-            if not fold_last:
-                dc = [torch.empty_like(t) for t in c]
+            dc = [torch.empty_like(t) for t in c]
             g = dout if fused_in else [torch.empty_like(t) for t in c]
 
             def call(l, dout_l, y_l, x_l, bn, st_l, dx_l, relu, sums, **kw):
@@ -894,7 +850,7 @@ class EncoderPass:
                             dbeta=kw.pop("dbeta", None), H=x_l.shape[1], W=x_l.shape[2], relu=relu, sums=sums,
                             sums_zeroed=True, **kw)
             if not fused_in:
-                ops.bn_backward_multi([call(l, dout[l], y[l], c[l], bn_last[l], st[l], dc[l] if dc is not None else None, True, s_m[l])
+                ops.bn_backward_multi([call(l, dout[l], y[l], c[l], bn_last[l], st[l], dc[l], True, s_m[l])
                                        for l in range(nl)], phase="reduce")
             # (the downsample branch's sums need the masked gradient: dout with this block's ReLU mask, or the
             # already masked gradient of a fused producer)
@@ -902,22 +858,16 @@ class EncoderPass:
                                         not fused_in, s_d[l]) for l in range(nl)], phase="reduce")
             _, globs = _exchange(pool, list(s_m) + list(s_d), out_of_place=True)
             g_m, g_d = globs[:nl], globs[nl:]
-            if fold_last:
-                pend = [dict(g=g[l], c=c[l], st=st[l], bn=bn_last[l], sums=g_m[l], sums_local=s_m[l]) for l in range(nl)]
-            else:
-                ops.bn_backward_multi([call(l, dout[l], None if fused_in else y[l], c[l], bn_last[l], st[l], dc[l],
-                                            not fused_in, s_m[l], g_out=(None if fused_in else g[l]), reduced=fused_in,
-                                            glob=g_m[l], dgamma=grad_of(bn_last[l].weight), dbeta=grad_of(bn_last[l].bias))
-                                       for l in range(nl)], phase="apply")
+            ops.bn_backward_multi([call(l, dout[l], None if fused_in else y[l], c[l], bn_last[l], st[l], dc[l],
+                                        not fused_in, s_m[l], g_out=(None if fused_in else g[l]), reduced=fused_in,
+                                        glob=g_m[l], dgamma=grad_of(bn_last[l].weight), dbeta=grad_of(bn_last[l].bias))
+                                   for l in range(nl)], phase="apply")
             ops.bn_backward_multi([call(l, g[l], None, c_ds[l], bn_d[l], st2[l], dc_ds[l], False, s_d[l], glob=g_d[l],
                                         dgamma=grad_of(bn_d[l].weight), dbeta=grad_of(bn_d[l].bias)) for l in range(nl)],
                                   phase="apply")
         elif dout_sums is not None:
             g = dout
-            if fold_last:
-                pend = self._pend(g, c, st, bn_last, dout_sums)
-            else:
-                dc = self._bn_bwd(dout, None, c, bn_last, st, sums=dout_sums)
+            dc = self._bn_bwd(dout, None, c, bn_last, st, sums=dout_sums)
         else:
             g = [torch.empty_like(t) for t in c]
             dc = self._bn_bwd(dout, y, c, bn_last, st, relu=True, g_out=g)
@@ -946,8 +896,6 @@ class EncoderPass:
             inp, c, y, st, pro_in = bctx["u"][j - 1]
             hw_in = [(t.shape[1], t.shape[2]) for t in xin]
             src, kw = dc, [dict() for _ in range(nl)]
-            if pend is not None:
-                src, kw, dc = self._pend_kw(pend)
             sums = None
             if y is None:
                 # folded BatchNorm: the activation was never stored — the ReLU mask is the sign of scale * c + shift,
@@ -959,24 +907,16 @@ class EncoderPass:
                 dy_prev = self._dgrad(op, src, hw_in, [dict(mask=y[l], bn_fuse=(c[l], st[l], sums[l]), **kw[l]) for l in range(nl)])
             else:
                 dy_prev = self._dgrad(op, src, hw_in, kw)
-            # (after the data gradient: with a pending BatchNorm backward, dc is its side output)
             self._param_grads(cls, op, dc, xin, pro_x)
-            cls_prev = [u[j - 1][0] for u in units]
             bn_prev = [u[j - 1][1] for u in units]
-            pend = None
-            if sums is not None and self._can_fold_bwd(self._ready(cls_prev, x), bn_prev, st, c):
-                pend = self._pend(dy_prev, c, st, bn_prev, sums)
-            elif sums is not None:
+            if sums is not None:
                 dc = self._bn_bwd(dy_prev, None, c, bn_prev, st, sums=sums)
             else:
                 dc = self._bn_bwd(dy_prev, y, c, bn_prev, st, relu=True)
         cls = [u[0][0] for u in units]
         op = self._ready(cls, x)
         src, kw = dc, [dict() for _ in range(nl)]
-        if pend is not None:
-            src, kw, dc = self._pend_kw(pend)
         if ds_fold is not None:
-            assert pend is None
             for l in range(nl):
                 kw[l]["ds"] = ds_fold[l]
         if prev is not None and FUSE_BN_BWD and all(o.can_fuse_bn_bwd(t.shape[0], t.shape[1], t.shape[2], p.groups)

@@ -380,7 +380,7 @@ class ConvOp:
         a.hb_mul, a.hb_add, a.sgn = (self.stride if forward else 1), (-self.pad if forward else self.pad), (1 if forward else -1)
         a.N, a.Cs = N, Cs
         if pro_mode:
-            a.pro_mode, a.pro_a, a.pro_b, a.pro_c, a.pro_m, a.pro_src2 = pro_mode, 16, 16, 16, 16, 16
+            a.pro_mode, a.pro_a, a.pro_b = pro_mode, 16, 16
         plan = (C.c_int32 * 4)()
         check(lib.fs_conv3x3_halo_plan(C.byref(a), self.code, plan), "conv3x3_plan")
         return {"kernel": {0: "halo", 1: "t32", 2: "p1"}[int(plan[0])], "blocks": int(plan[1]), "pix": int(plan[2]), "co": int(plan[3])}
@@ -408,15 +408,6 @@ class ConvOp:
         return (USE_HALO and self.dtype == torch.bfloat16 and self.R == 3 and self.S == 3 and self.stride == 1
                 and self.Ci == self.Ci_p and (self.Ci_p * eb) % 64 == 0 and self.Co_p % 64 == 0 and self.Co % 4 == 0
                 and self.need_dgrad and N * H * W * max(self.Co_p, self.Ci_p) * eb < 0x7fffffff)
-
-    def can_fold_bn_bwd(self, N, Ho, Wo):
-        """whether this convolution's data gradient can take (masked gradient g, raw convolution output c, BatchNorm-backward
-        sums) instead of the BatchNorm input gradient: the second pass of the backward of the BatchNorm BEHIND the
-        convolution is applied while dY is staged (FsConvArgs.pro_mode = 2) and written out once for the weight gradient.
-        Both 3x3 LDS-halo kernels, either dtype, whole 64-byte channel chunks of dY."""
-        eb = 2 if self.dtype == torch.bfloat16 else 4
-        return (USE_HALO and self.halo_d and self.pad == 1 and self.Co == self.Co_p and (self.Co_p * eb) % 64 == 0
-                and N * Ho * Wo * self.Co_p * eb < 0x7fffffff)
 
     def can_fuse_bn_bwd(self, N, H, W, groups):
         """whether dgrad(..., bn_fuse=) may carry the BatchNorm-backward sums of a [N,H,W,Ci_p] gradient"""
@@ -538,7 +529,7 @@ class ConvOp:
         run_specs([sp])
         return sp.out
 
-    def dgrad_spec(self, dy, H, W, out=None, addend=None, mask=None, bn_fuse=None, mask_bn=False, pro_bwd=None, ds=None):
+    def dgrad_spec(self, dy, H, W, out=None, addend=None, mask=None, bn_fuse=None, mask_bn=False, ds=None):
         """dy: [N,Ho,Wo,Co_p] -> dx [N,H,W,Ci_p] (out may be a strided view; addend is summed in).
         bn_fuse = (c, BnState, sums): dx is the gradient w.r.t. relu(BN(c)) (+ residual): the epilogue also
         accumulates the BatchNorm-backward sums (sum g, sum g*xhat) of that BatchNorm into `sums` (zeroed f64
@@ -547,13 +538,6 @@ class ConvOp:
         assert Cd == self.Co_p and dy.dtype == self.dtype and self.need_dgrad
         if out is None:
             out = torch.empty(N, H, W, self.Ci_p, dtype=self.dtype, device=dy.device)
-        if pro_bwd is not None:
-            # dy is the masked gradient g w.r.t. the OUTPUT of the BatchNorm behind this convolution; pro_bwd = dict(c= raw
-            # output of this convolution, st= that BatchNorm's BnState, gamma=, sums= (sum g, sum g*xhat) [global under
-            # data parallelism], sums_local=, dgamma=, dbeta=, dc_out= dense tensor that receives the BatchNorm input
-            # gradient for the weight gradient)
-            assert self.can_fold_bn_bwd(N, Ho, Wo) and dy.is_contiguous() and pro_bwd["c"].is_contiguous()
-            assert pro_bwd["c"].shape == dy.shape and pro_bwd["dc_out"].shape == dy.shape and pro_bwd["dc_out"].is_contiguous()
         if bn_fuse is not None:
             c, st, _ = bn_fuse
             assert c.is_contiguous() and out.is_contiguous() and c.shape == out.shape and c.dtype == self.dtype
@@ -562,8 +546,7 @@ class ConvOp:
             if H % 2 or W % 2 or H != 2 * Ho or W != 2 * Wo:
                 raise NotImplementedError("stride-2 3x3 data gradient expects an even input size (%dx%d)" % (H, W))
             return self._dgrad_s2_classes(dy, H, W, out, addend, mask, bn_fuse, ds)
-        if self.s2_classes_1x1 and ds is None and H % 2 == 0 and W % 2 == 0 and H == 2 * Ho and W == 2 * Wo and pro_bwd is None \
-                and not mask_bn:
+        if self.s2_classes_1x1 and ds is None and H % 2 == 0 and W % 2 == 0 and H == 2 * Ho and W == 2 * Wo and not mask_bn:
             return self._dgrad_s2_classes(dy, H, W, out, addend, mask, bn_fuse, None)
         assert ds is None
         a = FsConvArgs()
@@ -597,18 +580,6 @@ class ConvOp:
                 a.bnb_scale, a.bnb_shift = st.scale.data_ptr(), st.shift.data_ptr()
         else:
             assert not mask_bn
-        if pro_bwd is not None:
-            pst = pro_bwd["st"]
-            a.pro_mode, a.pro_src2 = 2, pro_bwd["c"].data_ptr()
-            a.pro_stats = pro_bwd["sums"].data_ptr()
-            a.pro_stats_local = pro_bwd["sums_local"].data_ptr() if pro_bwd.get("sums_local") is not None else None
-            a.pro_gamma = pro_bwd["gamma"].data_ptr()
-            a.pro_mean, a.pro_invstd = pst.mean.data_ptr(), pst.invstd.data_ptr()
-            a.pro_count = float(pst.count)
-            a.pro_dgamma = pro_bwd["dgamma"].data_ptr() if pro_bwd.get("dgamma") is not None else None
-            a.pro_dbeta = pro_bwd["dbeta"].data_ptr() if pro_bwd.get("dbeta") is not None else None
-            a.pro_dst = pro_bwd["dc_out"].data_ptr()
-            a.pro_group_imgs = N // pst.groups if pst.groups > 1 else 0
         flops = 2.0 * N * Ho * Wo * self.Co * self.R * self.S * self.Ci
         halo = self.halo_d and USE_HALO
         tag = lambda: "dgrd %s dy[%d,%d,%d,%d]" % (self.describe(), N, Ho, Wo, Cd)

@@ -105,28 +105,21 @@ typedef struct FsConvArgs {
                               adds to stats + (m / stat_group_rows) * FS_STAT_SLOTS*2*Co.  Groups are whole
                               images and, for fs_conv_igemm, stat_group_rows % 256 == 0 (no tile straddles). */
   /* ---- fs_conv3x3_halo only ----
-   * Operand prologue: the BatchNorm (+ ReLU) that precedes this convolution in the reference
-   * (resnet.py:33-50 conv1 -> bn1 -> relu -> conv2; blocks.py:41-54) — or, in a data-gradient launch, the second pass
-   * of the backward of the BatchNorm that FOLLOWS the convolution — is applied to the source operand while it is staged
-   * into LDS, so the normalised activation / the BatchNorm input gradient is not produced by a pass of its own.
-   * Coefficients are fp32 [groups][Cs], group = image / pro_group_imgs (0: one group).  Out-of-image taps stay zero (the
-   * padding applies to the transformed tensor).
-   *   pro_mode 1: x' = a[c]*x + b[c], then max(x', 0) if pro_relu          (forward: a = gamma*invstd, b = beta - mean*a)
-   *   pro_mode 2: x' = a[c]*x + (b[c]*(pro_src2 - m[c]) + c[c])            (data gradient: x = masked gradient g,
-   *               pro_src2 = the raw convolution output the BatchNorm normalised (same layout and strides as src),
-   *               a = gamma*invstd, b = -a*invstd*sum(g*xhat)/count, c = -a*sum(g)/count, m = mean:
-   *               dx = gamma*invstd*(g - mean_g - xhat*mean_gx), fs_bn_bwd_apply's expression)
+   * Operand prologue: the BatchNorm (+ ReLU) that precedes this convolution in the reference (resnet.py:33-50 conv1 ->
+   * bn1 -> relu -> conv2; blocks.py:41-54) is applied to the source operand while it is staged into LDS, so the normalised
+   * activation is not produced by a pass of its own.  Coefficients are fp32 [groups][Cs], group = image / pro_group_imgs
+   * (0: one group).  Out-of-image taps stay zero (the padding applies to the transformed tensor).
+   *   pro_mode 1: x' = a[c]*x + b[c], then max(x', 0) if pro_relu          (a = gamma*invstd, b = beta - mean*a)
    * Coefficients come from one of two places:
-   *   pro_stats == NULL: pro_a / pro_b (/ pro_c / pro_m) are read as given (fs_bn_finalize made them).
-   *   pro_stats != NULL (ABI 6): every block derives them itself from the f64 sums [groups][FS_STAT_SLOTS][2][Cs] — mode 1:
-   *     (sum x, sum x^2) of src as the producing convolution's epilogue left them (after the data-parallel exchange),
-   *     with pro_gamma / pro_beta / pro_count / pro_eps: bn_apply's preamble, no fs_bn_finalize launch; block 0 also writes
+   *   pro_stats == NULL: pro_a / pro_b are read as given (fs_bn_finalize made them).
+   *   pro_stats != NULL (ABI 6): every block derives them itself from the f64 sums [groups][FS_STAT_SLOTS][2][Cs] — (sum x,
+   *     sum x^2) of src as the producing convolution's epilogue left them (after the data-parallel exchange), with
+   *     pro_gamma / pro_beta / pro_count / pro_eps: bn_apply's preamble, no fs_bn_finalize launch; block 0 also writes
    *     pro_mean / pro_invstd / pro_save_a / pro_save_b ([groups][Cs]: saved for the backward) and updates
    *     pro_running_mean / pro_running_var / pro_nbt (momentum pro_momentum, once per group in group order).
-   *     Mode 2: (sum g, sum g*xhat) with pro_gamma, pro_mean, pro_invstd (inputs) and pro_count; block 0 adds
-   *     dgamma += sum g*xhat, dbeta += sum g from pro_stats_local (NULL: from pro_stats) into pro_dgamma / pro_dbeta.
-   * pro_dst (mode 2): the transformed operand is also written out, dense, at src's offsets — the BatchNorm input
-   * gradient that the weight gradient of the same convolution reads (src must then be dense, as dY always is). */
+   * (ABI 5-7 also had pro_mode 2 — the second pass of the backward of the BatchNorm that FOLLOWS the convolution applied
+   * in a data-gradient launch's staging; measured slower than the pass it replaced and removed in ABI 8.  Its fields —
+   * pro_c, pro_m, pro_src2, pro_stats_local, pro_dgamma, pro_dbeta, pro_dst — keep their slots and must be NULL.) */
   const float* pro_a; const float* pro_b; const float* pro_c; const float* pro_m;
   const void* pro_src2;
   int32_t pro_mode, pro_relu, pro_group_imgs;

@@ -299,8 +299,8 @@ def test_fold_survives_the_t32_switch(dev, monkeypatch):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# round 4: the prologue derives its coefficients in the kernel (no fs_bn_finalize launch), and the data gradient
-# applies the second pass of the BatchNorm backward to dY while staging it
+# round 4: the prologue derives its coefficients in the kernel (no fs_bn_finalize launch).  (The data gradient's
+# counterpart — the second pass of the BatchNorm backward applied to dY while staging it — was removed in round 5.)
 # ---------------------------------------------------------------------------------------------------------------
 FIN_CASES = [
     # Ci, Co, N, H, W, groups, kernel the launch runs on
@@ -377,98 +377,6 @@ def test_forward_finalises_batchnorm_statistics_in_its_prologue(dev, case, dtype
     var_ref = (per[:, 1] / count - (per[:, 0] / count) ** 2).clamp_min(0)
     assert torch.allclose(st.mean.cpu(), mean_ref, rtol=1e-6, atol=1e-7)
     assert torch.allclose(st.invstd.cpu(), (1.0 / torch.sqrt(var_ref + 1e-5)).float().flatten(), rtol=1e-6)
-
-
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
-@pytest.mark.parametrize("case", FIN_CASES)
-def test_data_gradient_applies_batchnorm_backward_in_its_prologue(dev, case, dtype):
-    """ConvOp.dgrad(pro_bwd=...): == fs_bn_bwd_apply followed by the plain data gradient (BatchNorm input gradient written
-    out for the weight gradient, dgamma / dbeta accumulated), with the epilogue options the training step combines it
-    with; and against autograd's batch_norm backward + conv_transpose2d on the CPU"""
-    from fsnet_amd.hip import ops
-    from fsnet_amd.hip.conv import ConvOp
-    Ci, Co, N, H, W, G, kern = case
-    lo = dtype == torch.bfloat16
-    gen = torch.Generator().manual_seed(500 + Ci + N)
-    rnd = _bf if lo else (lambda t: t)
-    w = rnd(torch.randn(Co, Ci, 3, 3, generator=gen) / (9 * Ci) ** 0.5)
-    c = rnd(torch.randn(N, H, W, Co, generator=gen) * 1.3 + 0.2)          # raw output of this convolution
-    keepm = torch.rand(N, H, W, Co, generator=gen) > 0.4
-    gg = rnd(torch.randn(N, H, W, Co, generator=gen)) * keepm             # masked gradient w.r.t. the BatchNorm output
-    gamma = torch.rand(Co, generator=gen) + 0.5
-    n = N // G
-    count = float(n * H * W)
-    mean = torch.cat([c[gi * n:(gi + 1) * n].double().mean(dim=(0, 1, 2)) for gi in range(G)]).float()
-    var = torch.cat([c[gi * n:(gi + 1) * n].double().var(dim=(0, 1, 2), unbiased=False) for gi in range(G)])
-    invstd = (1.0 / torch.sqrt(var + 1e-5)).float()
-    xhat = torch.cat([(c[gi * n:(gi + 1) * n] - mean[gi * Co:(gi + 1) * Co]) * invstd[gi * Co:(gi + 1) * Co] for gi in range(G)])
-    per = torch.stack([torch.stack([gg[gi * n:(gi + 1) * n].double().sum(dim=(0, 1, 2)),
-                                    (gg[gi * n:(gi + 1) * n].double() * xhat[gi * n:(gi + 1) * n].double()).sum(dim=(0, 1, 2))])
-                       for gi in range(G)])
-    sums = _spread_slots(per, gen).to(dev)
-    op = ConvOp(Ci, Co, 3, 3, 1, 1, dtype, dev)
-    op.pack(w.to(dev).contiguous())
-    assert op.can_fold_bn_bwd(N, H, W)
-    assert op.plan_3x3(N, H, W, forward=False, pro_mode=2)["kernel"] == kern
-    st = ops.BnState(Co, dev, G)
-    st.mean.copy_(mean); st.invstd.copy_(invstd); st.count = count
-    gd, cd, gam = gg.to(dev).to(dtype), c.to(dev).to(dtype), gamma.to(dev)
-    # unfused on the device
-    dc_ref = torch.empty_like(cd)
-    dgam_ref, dbet_ref = torch.zeros(Co, device=dev), torch.zeros(Co, device=dev)
-    ops.bn_backward(gd, None, cd, gam, st, dc_ref, dgam_ref, dbet_ref, H, W, sums=sums.view(G * 8, 2, Co).clone(), reduced=True)
-    d_ref = op.dgrad(dc_ref, H, W)
-    # fused
-    dc = torch.empty_like(cd)
-    dgam, dbet = torch.zeros(Co, device=dev), torch.zeros(Co, device=dev)
-    pb = dict(c=cd, st=st, gamma=gam, sums=sums, sums_local=None, dgamma=dgam, dbeta=dbet, dc_out=dc)
-    d = op.dgrad(gd, H, W, pro_bwd=pb)
-    torch.cuda.synchronize()
-    ds_ = dc_ref.float().abs().max().item()
-    # (one affine form against bn_bwd_apply's nested one: equal up to fp32 rounding, i.e. at most one bf16 step apart)
-    assert (dc.float() - dc_ref.float()).abs().max().item() <= (1.6e-2 if lo else 1e-5) * ds_
-    assert (dc.float() - dc_ref.float()).abs().mean().item() <= (2e-4 if lo else 1e-6) * ds_
-    assert (d.float() - d_ref.float()).abs().max().item() <= (1e-2 if lo else 2e-5) * d_ref.float().abs().max().item()
-    assert torch.allclose(dgam, dgam_ref, rtol=1e-5, atol=1e-5 * float(dgam_ref.abs().max()))
-    assert torch.allclose(dbet, dbet_ref, rtol=1e-5, atol=1e-5 * float(dbet_ref.abs().max()))
-    # the definition on the CPU (batch_norm backward's input gradient per group), then the transposed convolution
-    dcs = []
-    for gi in range(G):
-        sl = slice(gi * n, (gi + 1) * n)
-        k = gamma * invstd[gi * Co:(gi + 1) * Co]
-        a = (per[gi, 0] / count).float(); b = (per[gi, 1] / count).float()
-        dcs.append(k * (gg[sl] - a - xhat[sl] * b))
-    dc_cpu = torch.cat(dcs)
-    assert (dc.float().cpu() - dc_cpu).abs().max().item() <= (1.6e-2 if lo else 2e-5) * dc_cpu.abs().max().item()
-    d_cpu = F.conv_transpose2d(rnd(dc_cpu).permute(0, 3, 1, 2), w, None, padding=1).permute(0, 2, 3, 1)
-    assert (d.float().cpu() - d_cpu).abs().max().item() <= (2e-2 if lo else 5e-5) * d_cpu.abs().max().item()
-    # with the epilogue of a folded block's conv2 (derived mask + sums of the previous BatchNorm) and of a conv1 (addend +
-    # mask + sums): the fused launch equals the composition of the separate ones
-    cprev = rnd(torch.randn(N, H, W, Ci, generator=gen)).to(dev).to(dtype)
-    yprev = rnd(torch.randn(N, H, W, Ci, generator=gen)).to(dev).to(dtype)
-    addend = rnd(torch.randn(N, H, W, Ci, generator=gen)).to(dev).to(dtype)
-    stp = ops.BnState(Ci, dev, G, affine=True)
-    stp.mean.copy_(torch.randn(G * Ci, generator=gen) * 0.1); stp.invstd.copy_(torch.rand(G * Ci, generator=gen) + 0.5)
-    stp.scale.copy_(torch.rand(G * Ci, generator=gen) + 0.5); stp.shift.copy_(torch.randn(G * Ci, generator=gen) * 0.3)
-    stp.count = count
-    for kw in (dict(mask_bn=True), dict(mask=yprev, addend=addend)):
-        s_ref = torch.zeros(G, 8, 2, Ci, dtype=torch.float64, device=dev)
-        s_new = torch.zeros(G, 8, 2, Ci, dtype=torch.float64, device=dev)
-        r = op.dgrad(dc, H, W, bn_fuse=(cprev, stp, s_ref), **kw)           # from the written-out gradient
-        dc2 = torch.empty_like(cd)
-        pb2 = dict(pb, dc_out=dc2, dgamma=None, dbeta=None)
-        f = op.dgrad(gd, H, W, bn_fuse=(cprev, stp, s_new), pro_bwd=pb2, **kw)
-        torch.cuda.synchronize()
-        assert torch.equal(dc2, dc)
-        assert torch.equal(f, r), kw.keys()
-        assert float((s_new.sum(1) - s_ref.sum(1)).abs().max()) <= 1e-9 * float(s_ref.sum(1).abs().max()) + 1e-12
-    # weight gradient from the written-out tensor == from the separate pass's
-    if lo:
-        xin = rnd(torch.randn(N, H, W, Ci, generator=gen)).to(dev).to(dtype)
-        dw_a, dw_b = torch.zeros(Co, Ci, 3, 3, device=dev), torch.zeros(Co, Ci, 3, 3, device=dev)
-        op.wgrad(dc, xin, dw_a); op.wgrad(dc_ref, xin, dw_b)
-        torch.cuda.synchronize()
-        assert (dw_a - dw_b).abs().max().item() <= 2e-2 * dw_b.abs().max().item()
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])

@@ -195,14 +195,14 @@ def _bf16_step_against_oracle(dev, sd0, data, H, W, min_cos=0.85):
 
 @gpu
 def test_bf16_folded_step_on_the_32x32_tile_kernel_close_to_fp32_oracle(dev):
-    """the BatchNorm-fold launches of the 32x32-tile kernel (prologue modes 1 and 2, derived mask) inside a training step,
+    """the BatchNorm-fold launches of the 32x32-tile kernel (operand prologue, derived mask) inside a training step,
     against the oracle: at 96x320 the stacked pose pass of a 16-sample batch (32 images at 24x80) is the smallest launch
     that kernel takes by its own choice — the benchmark's layer-1 path at a size the CPU oracle finishes in seconds
     (reference: vision_base/networks/models/backbone/resnet.py:33-50)"""
     from fsnet_amd.hip.conv import ConvOp
     B, H, W = 16, 96, 320
     probe = ConvOp(64, 64, 3, 3, 1, 1, torch.bfloat16, dev)
-    for fwd, mode in ((True, 1), (False, 2)):
+    for fwd, mode in ((True, 1), (False, 0)):
         assert probe.plan_3x3(2 * B, H // 4, W // 4, forward=fwd, pro_mode=mode)["kernel"] == "t32"
     assert probe.plan_3x3(B, H // 4, W // 4, forward=True, pro_mode=1)["kernel"] == "halo"      # the depth encoder's: 16x16-tile kernel
     sd0 = O.init_state(seed=4, with_pose=True)
