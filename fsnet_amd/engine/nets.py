@@ -41,6 +41,11 @@ FOLD_BN = _env_level("FSNET_AMD_BN_FOLD", 1)
 # 172-198 registers, half the blocks per CU, +19-25 us for a 15 us pass.  Removed in round 5 with its kernel paths.)
 # the 1x1 / stride-2 downsample projection's data gradient inside the block's 3x3 / stride-2 data gradient launch
 FOLD_DS_DGRAD = os.environ.get("FSNET_AMD_FOLD_DS_DGRAD", "1") != "0"
+# The pose decoder's four weight gradients: handed to the companion stream at the end of its backward (1), or left with the
+# pose encoder's first batch (0).  Default: only with the two-lane pass.  With two chains the pose chain is the step's tail
+# (its encoder backward ends 0.5 ms after the depth encoder's) and the companion shares a hardware queue with it: the
+# hand-over put 0.15 ms of weight gradients in front of that chain — 5.59 / 5.62 -> 5.52 ms without it (same box).
+PDEC_FLUSH = int(os.environ.get("FSNET_AMD_PDEC_FLUSH", "-1"))
 # the stem's BatchNorm + ReLU + max-pool as one pass, its backward's pooling gradient gathered inside the BatchNorm passes
 FUSE_STEM_POOL = os.environ.get("FSNET_AMD_FUSE_STEM_POOL", "1") != "0"
 
@@ -160,7 +165,7 @@ def _defer_param_grads(cur, item):
         # exception never ran its callback, and must not keep the next one from queueing its own.)
         torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
         _CALLBACK_QUEUED[0] = task
-    if len(ent[1]) >= RT.wgrad_flush:
+    if len(ent[1]) >= (RT.wgrad_flush_side if RT.is_side(cur) else RT.wgrad_flush):
         flush_deferred(cur)
 
 
@@ -1218,5 +1223,6 @@ class PoseDecoderRunner:
             self.cl[j].accumulate_param_grads(op, d, xin)
             # gradient w.r.t. the input activation, masked by the producing ReLU (none for the encoder feature)
             d = op.dgrad(d, xin.shape[1], xin.shape[2], mask=(xin if j > 0 else None))
-        flush_deferred(_current_stream())
+        if PDEC_FLUSH == 1 or (PDEC_FLUSH < 0 and RT.lanes):
+            flush_deferred(_current_stream())
         return d

@@ -25,6 +25,7 @@ class _Runtime:
         # are 3-4 % slower than 8.  wgrad_streams = 0 (inline) is what data parallelism uses and what tests may set.
         self.wgrad_streams = 2
         self.wgrad_flush = int(os.environ.get("FSNET_AMD_WGRAD_FLUSH", "8"))
+        self.wgrad_flush_side = int(os.environ.get("FSNET_AMD_WGRAD_FLUSH_SIDE", str(self.wgrad_flush)))
         # hand over what is pending when an encoder's backward reaches its stem (see EncoderPass.backward)
         self.stem_flush = os.environ.get("FSNET_AMD_STEM_FLUSH", "-1")      # -1: with the two-lane pass only (resolved below)
         self.wgrad_spread = 1
