@@ -185,13 +185,13 @@ __global__ __launch_bounds__(256) void upcat_pad_bwd_kernel(const T* __restrict_
 // out[c] += sum_m x[m][c]   (x dense [M][C], fp32 accumulate, one atomic per channel per block).
 // 16-byte lanes when C allows (VL = 8 bf16 / 4 f32 channels per lane, else 4), four rows in flight per thread.
 template <typename T, int VL>
-__global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ x, float* __restrict__ out, long M,
-                                                          int C, int Creal, int CGB) {
+__device__ __forceinline__ void channel_sum_body(const T* __restrict__ x, float* __restrict__ out, long M, int C, int Creal,
+                                                 int CGB, int bx, int by, int gx) {
   __shared__ float red[VL][256];
   const int CG = C / VL;
   const int PL = 256 / CGB;
   const int cgl = threadIdx.x % CGB, pl = threadIdx.x / CGB;
-  const int cg = blockIdx.y * CGB + cgl;
+  const int cg = by * CGB + cgl;
   float s[VL];
 #pragma unroll
   for (int j = 0; j < VL; ++j) s[j] = 0.f;
@@ -200,8 +200,8 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ 
     else loadv<T>(x + m * C + cg * VL, v);
   };
   if (cg < CG) {
-    const long stride = (long)gridDim.x * PL;
-    long m = (long)blockIdx.x * PL + pl;
+    const long stride = (long)gx * PL;
+    long m = (long)bx * PL + pl;
     for (; m + 3 * stride < M; m += 4 * stride) {
       float v0[VL], v1[VL], v2[VL], v3[VL];
       ld(m, v0); ld(m + stride, v1); ld(m + 2 * stride, v2); ld(m + 3 * stride, v3);
@@ -226,6 +226,27 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ 
       if (cg * VL + j < Creal) atomicAdd(out + cg * VL + j, a);
     }
   }
+}
+
+template <typename T, int VL>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ x, float* __restrict__ out, long M,
+                                                          int C, int Creal, int CGB) {
+  channel_sum_body<T, VL>(x, out, M, C, Creal, CGB, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+}
+
+// up to FS_CSUM_MAX column sums in ONE launch (the bias gradients of a hand-off batch of weight gradients: each was a
+// launch of its own behind its layer's weight gradient): block b belongs to the descriptor whose [start, start + gx * gy)
+// range holds it
+constexpr int FS_CSUM_MAX = 16;
+struct CsumBatch { const void* x[FS_CSUM_MAX]; float* out[FS_CSUM_MAX]; long M[FS_CSUM_MAX]; int C[FS_CSUM_MAX], Creal[FS_CSUM_MAX],
+                   CGB[FS_CSUM_MAX], gx[FS_CSUM_MAX], start[FS_CSUM_MAX + 1]; int n; };
+template <typename T, int VL>
+__global__ __launch_bounds__(256) void channel_sum_multi_kernel(const CsumBatch c) {
+  int k = 0;
+  while (k + 1 < c.n && (int)blockIdx.x >= c.start[k + 1]) ++k;
+  const int lb = (int)blockIdx.x - c.start[k];
+  const int gx = c.gx[k];
+  channel_sum_body<T, VL>(reinterpret_cast<const T*>(c.x[k]), c.out[k], c.M[k], c.C[k], c.Creal[k], c.CGB[k], lb % gx, lb / gx, gx);
 }
 
 int grid_for(long items) {
@@ -318,6 +339,41 @@ extern "C" int fs_upcat_pad_bwd(const void* dpad, void* da, void* db, int N, int
   else if (dtype == FS_DTYPE_F32)
     hipLaunchKernelGGL((upcat_pad_bwd_kernel<float, 4>), grid, dim3(256), 0, st, (const float*)dpad, (float*)da, (float*)db, N, h, w, Ca, Cb);
   else return FS_EINVAL;
+  return fs_launch_status();
+}
+
+extern "C" int fs_channel_sum_multi(const void* const* x, float* const* out, const int64_t* M, const int32_t* C,
+                                    const int32_t* Creal, int n, int dtype, void* stream) {
+  if (!x || !out || !M || !C || !Creal || n < 1 || n > FS_CSUM_MAX) return FS_EINVAL;
+  const int es = dtype == FS_DTYPE_BF16 ? 2 : 4;
+  const int VW = 16 / es;
+  CsumBatch b;
+  int blocks = 0;
+  bool wide = true;
+  for (int i = 0; i < n; ++i) {
+    if (!x[i] || !out[i] || C[i] % 4 != 0 || M[i] <= 0) return FS_EINVAL;
+    wide = wide && (C[i] % VW == 0 && VW != 4);
+  }
+  const int VL = wide ? VW : 4;
+  for (int i = 0; i < n; ++i) {
+    const int CG = C[i] / VL;
+    int CGB = 1;
+    while (CGB < CG && CGB < 64) CGB <<= 1;
+    const int PL = 256 / CGB;
+    const int gx = (int)std::max<long>(1, std::min<long>((M[i] + 4L * PL - 1) / (4L * PL), 256));
+    const int gy = (CG + CGB - 1) / CGB;
+    b.x[i] = x[i]; b.out[i] = out[i]; b.M[i] = M[i]; b.C[i] = C[i]; b.Creal[i] = Creal[i]; b.CGB[i] = CGB; b.gx[i] = gx;
+    b.start[i] = blocks;
+    blocks += gx * gy;
+  }
+  b.start[n] = blocks; b.n = n;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == FS_DTYPE_BF16) {
+    if (wide) hipLaunchKernelGGL((channel_sum_multi_kernel<bf16, 8>), dim3(blocks), dim3(256), 0, st, b);
+    else hipLaunchKernelGGL((channel_sum_multi_kernel<bf16, 4>), dim3(blocks), dim3(256), 0, st, b);
+  } else if (dtype == FS_DTYPE_F32) {
+    hipLaunchKernelGGL((channel_sum_multi_kernel<float, 4>), dim3(blocks), dim3(256), 0, st, b);
+  } else return FS_EINVAL;
   return fs_launch_status();
 }
 

@@ -46,6 +46,7 @@ FOLD_DS_DGRAD = os.environ.get("FSNET_AMD_FOLD_DS_DGRAD", "1") != "0"
 # (its encoder backward ends 0.5 ms after the depth encoder's) and the companion shares a hardware queue with it: the
 # hand-over put 0.15 ms of weight gradients in front of that chain — 5.59 / 5.62 -> 5.52 ms without it (same box).
 PDEC_FLUSH = int(os.environ.get("FSNET_AMD_PDEC_FLUSH", "-1"))
+CSUM_BATCH = os.environ.get("FSNET_AMD_CSUM_BATCH", "1") != "0"      # a hand-off batch's bias gradients in one launch
 # the stem's BatchNorm + ReLU + max-pool as one pass, its backward's pooling gradient gathered inside the BatchNorm passes
 FUSE_STEM_POOL = os.environ.get("FSNET_AMD_FUSE_STEM_POOL", "1") != "0"
 
@@ -115,14 +116,17 @@ def _current_stream(device=None):
     return s
 
 
-def _run_param_grads(*item):
+def _run_param_grads(*item, bias_later=None):
     """one layer's weight (+ bias) gradient — item = (op, dc, x, gw, gb, nb, pro) — or the same layer of two networks in
     one launch — item = ("lanes", [those tuples]) (fs_conv_wgrad2: one round of blocks, one slab arena, two dW)"""
     lanes = item[1] if item[0] == "lanes" else [item]
     run_specs([op.wgrad_spec(dc, x, gw, pro=pro) for (op, dc, x, gw, gb, nb, pro) in lanes])
     for (op, dc, x, gw, gb, nb, pro) in lanes:
         if gb is not None:
-            ops.channel_sum(dc, gb, nb)
+            if bias_later is not None:
+                bias_later.append((dc, gb, nb))     # (the caller sums the batch's biases in one launch)
+            else:
+                ops.channel_sum(dc, gb, nb)
 
 
 def accumulate_param_grads_multi(cls, ops_, dcs, xs, pros):
@@ -191,8 +195,11 @@ def flush_deferred(cur=None, spread=False):
                 continue
             ws.wait_stream(chain)                   # one cross-stream edge per batch
             with torch.cuda.stream(ws):
+                sums = [] if CSUM_BATCH else None
                 for it in mine:
-                    _run_param_grads(*it)
+                    _run_param_grads(*it, bias_later=sums)
+                if sums:
+                    ops.channel_sum_multi(sums)     # the batch's bias gradients in one launch
             _PENDING_JOIN.add((chain, ws))
         _PENDING_KEEP.extend(items)
         ent[1].clear()

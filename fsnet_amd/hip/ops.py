@@ -288,6 +288,26 @@ def channel_sum(x, out, creal):
                                             stream_ptr()), "channel_sum"), tag=str(tuple(x.shape)))
 
 
+def channel_sum_multi(items):
+    """[(x, out, creal)]: out[c] += column sums of dense x [..., C] — one launch per 16 (same dtype)"""
+    items = list(items)
+    if len(items) == 1:
+        return channel_sum(*items[0])
+    for i in range(0, len(items), 16):
+        chunk = items[i:i + 16]
+        n = len(chunk)
+        code = dtype_code(chunk[0][0].dtype)
+        assert all(dtype_code(x.dtype) == code for x, _, _ in chunk)
+        xs = (C.c_void_p * n)(*[x.data_ptr() for x, _, _ in chunk])
+        outs = (C.c_void_p * n)(*[o.data_ptr() for _, o, _ in chunk])
+        Ms = (C.c_int64 * n)(*[x.numel() // x.shape[-1] for x, _, _ in chunk])
+        Cs = (C.c_int32 * n)(*[x.shape[-1] for x, _, _ in chunk])
+        Cr = (C.c_int32 * n)(*[int(cr) for _, _, cr in chunk])
+        _timed("channel_sum", sum(x.numel() * x.element_size() for x, _, _ in chunk),
+               lambda: check(lib.fs_channel_sum_multi(xs, outs, Ms, Cs, Cr, n, code, stream_ptr()), "channel_sum_multi"),
+               tag="%d tensors" % n)
+
+
 def depth_head_fwd(logits, bins, K, min_depth, max_depth):
     N, H, W, Cl = logits.shape
     depth = torch.empty(N, 1, H, W, dtype=torch.float32, device=logits.device)

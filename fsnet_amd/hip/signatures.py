@@ -54,6 +54,7 @@ SIGNATURES = {
     "fs_upcat_pad_fwd": (C.c_int, [P, P, P, I, I, I, I, I, I, P]),
     "fs_upcat_pad_bwd": (C.c_int, [P, P, P, I, I, I, I, I, I, P]),
     "fs_channel_sum": (C.c_int, [P, P, L, I, I, I, P]),
+    "fs_channel_sum_multi": (C.c_int, [P, P, P, P, P, I, I, P]),
     "fs_depth_head_fwd": (C.c_int, [P, P, P, P, L, I, I, F, F, P]),
     "fs_depth_head_bwd": (C.c_int, [P, P, P, P, P, L, I, I, F, F, I, P]),
     "fs_depth_head_fwd_multi": (C.c_int, [P, P, I, I, F, F, P]),

@@ -452,6 +452,10 @@ int fs_upcat_pad_fwd(const void* a, const void* b, void* out, int N, int h, int 
 int fs_upcat_pad_bwd(const void* dpad, void* da, void* db, int N, int h, int w, int Ca, int Cb, int dtype,
                      void* stream);
 int fs_channel_sum(const void* x, float* out, int64_t M, int C, int Creal, int dtype, void* stream);
+/* n (<= 16) column sums in one launch: the bias gradients of a hand-off batch of weight gradients (each convolution bias
+ * gradient = sum over N,H,W of its dY: autograd of nn.Conv2d(bias=True), blocks.py:41-46, depth_encoder.py:45-63). */
+int fs_channel_sum_multi(const void* const* x, float* const* out, const int64_t* M, const int32_t* C, const int32_t* Creal,
+                         int n, int dtype, void* stream);
 
 /* Depth-bin head: logits fp32 [M][Cl] (first K used) -> depth, disp (fp32 [M]).
  * Replaces MultiChannelDepthDecoder._gather_activation / gather_output (depth_encoder.py:76-88,
