@@ -11,6 +11,7 @@
 // K chunk are in flight while the weights are staged.  MFMA roles as in conv_igemm (A = weights, B = pixels), so the
 // epilogue (bias, addend, ReLU, ReLU-backward mask, BatchNorm statistics / backward sums, fp32 output, statistics
 // groups) is the same code.
+#include <cstdlib>
 #include "common.h"
 #include "fsnet_hip_internal.h"
 
@@ -274,6 +275,11 @@ extern "C" int fs_conv1x1(const FsConvArgs* args, int dtype, void* stream) {
     return FS_EINVAL;
   if (args->stats && args->stat_group_rows > 0 && args->stat_group_rows % 128 != 0) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  static const bool use_gemm = [] { const char* e = getenv("FSNET_AMD_1X1_GEMM"); return !(e && e[0] == '0'); }();
+  if (use_gemm) {
+    const int r = fs_conv1x1_gemm(*args, st);
+    if (r != FS_EINVAL) return r;
+  }
   const int cop = args->Co_p;
   if (cop % 64 == 0) return launch_co<bf16, 64>(*args, st);
   if (cop % 32 == 0) return launch_co<bf16, 32>(*args, st);

@@ -21,3 +21,7 @@ struct FsNoGeom { int unused; };
 // leading-dimension blocks of a problem rounded up to whole XCD rounds: block b of the grid runs on XCD b % 8, and the
 // kernels' tile mappings derive the XCD from the problem-local block index
 inline int fs_xcd_round(long blocks) { return (int)((blocks + 7) / 8 * 8); }
+
+// the LDS-staged GEMM form of fs_conv1x1 (conv1x1_gemm.hip); FS_EINVAL = not a case for it.  FSNET_AMD_1X1_GEMM=0 keeps
+// every 1x1 launch on the row-streaming kernel (A/B runs).
+int fs_conv1x1_gemm(const FsConvArgs& a, hipStream_t st);

@@ -159,6 +159,9 @@ BN_EPS = 1e-5            # nn.BatchNorm2d defaults (resnet.py:17-19, blocks.py:4
 BN_MOMENTUM = 0.1
 
 USE_1X1 = os.environ.get("FSNET_AMD_CONV1X1", "1") != "0"
+# the LDS-staged GEMM form of the 1x1 kernel (conv1x1_gemm.hip; fs_conv1x1 picks it per launch): every 1x1 / pad-0
+# forward and stride-1 data gradient then goes to fs_conv1x1, whatever its K extent or stride
+USE_1X1_GEMM = os.environ.get("FSNET_AMD_1X1_GEMM", "1") != "0"
 USE_HALO = os.environ.get("FSNET_AMD_HALO", "1") != "0"   # 3x3/s1 LDS-halo kernel (conv3x3_halo.hip)
 USE_STEM_LDS = os.environ.get("FSNET_AMD_STEM_LDS", "1") != "0"   # 7x7/s2 stem kernel (conv_stem.hip)
 USE_HALO_S2 = os.environ.get("FSNET_AMD_HALO_S2", "1") != "0"     # 3x3/s2 forward on the LDS-halo kernel (else implicit GEMM)
@@ -395,8 +398,12 @@ class ConvOp:
         # measured per shape at ResNet-50 / 320x1024 / B=8 (tools/probes/conv1x1_shapes.py): the streaming kernel wins
         # while the K walk is one or two chunks (forward 64->256 49.5 -> 40.8 us, data gradient 256<-64 43.7 -> 33.9),
         # the implicit GEMM with its deeper K pipeline from there on (forward 256->128 44 vs 52 us, K = 1024: 25.5 vs 29.5)
-        if a.Cs > (128 if a.sgn > 0 else 256) or a.hb_mul != 1 or a.dshift != 0:
+        if a.dshift != 0 or a.ncls > 1:
             return False              # (a stride-2 data gradient: the kernel would decline it — straight to the implicit GEMM)
+        if USE_1X1_GEMM:
+            return True               # LDS-staged GEMM: any K extent, strided projections too
+        if a.Cs > (128 if a.sgn > 0 else 256) or a.hb_mul != 1:
+            return False
         return True
 
     def can_fold_input(self, N, H, W):

@@ -35,6 +35,12 @@ CASES = [
     (2048, 512, 1, 1, 0, 2, 5, 8),    # eight K chunks
     (256, 512, 1, 2, 0, 2, 20, 24),   # strided projection (downsample)
     (512, 96, 1, 1, 0, 2, 6, 10),     # Co_p = 96: 32-channel tiles
+    # ... and on its LDS-staged GEMM form (conv1x1_gemm.hip) at sizes that reach every tile configuration
+    (256, 1024, 1, 1, 0, 4, 20, 64),  # 128 x 128 tiles, eight K stages
+    (64, 256, 1, 1, 0, 8, 80, 128),   # 256 x 128 tiles
+    (256, 64, 1, 1, 0, 8, 80, 256),   # 256 x 64 tiles
+    (1024, 512, 1, 2, 0, 2, 20, 64),  # strided projection, 32 K stages
+    (128, 72, 1, 1, 0, 3, 17, 23),    # ragged M, Co_p = 80 (a partly filled channel tile)
 ]
 
 
@@ -362,3 +368,43 @@ def test_stride2_data_gradient_carries_the_downsample_projection(dev, case, dtyp
     s_tol = 1e-5 if dtype == torch.float32 else 2e-2
     for k, refsum in enumerate((gq.sum((1, 2, 3)), (gq * xhat).sum((1, 2, 3)))):
         assert float((a[:, k] - refsum).abs().max()) <= s_tol * float(refsum.abs().max())
+
+
+@pytest.mark.parametrize("case", [(64, 256, 4, 40, 64, 2, False), (256, 128, 4, 40, 64, 2, True), (512, 128, 6, 9, 16, 3, False),
+                                  (128, 64, 8, 80, 256, 2, True)])
+def test_conv1x1_gemm_epilogues(dev, case):
+    """fs_conv1x1's LDS-staged GEMM (conv1x1_gemm.hip): addend + ReLU, BatchNorm statistics per statistics group
+    (stacked pose pairs), bf16 and fp32 stores, strided (channel-slice) source and destination views — against conv2d
+    (resnet.py:52-89: conv1x1 -> bn -> relu of the Bottleneck)."""
+    from fsnet_amd.hip.conv import ConvOp
+    Ci, Co, N, H, W, G, f32 = case
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(11 + Ci + Co)
+    x = torch.randn(N, H, W, Ci, generator=g).to(dt)
+    w = (torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5).to(dt).float()
+    add = torch.randn(N, H, W, Co, generator=g).to(dt)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w).permute(0, 2, 3, 1)
+    op = ConvOp(Ci, Co, 1, 1, 1, 0, dt, dev, need_dgrad=True)
+    op.pack(w.to(dev))
+    # source and destination are channel slices of wider buffers (a concatenated skip tensor): pixel rows 2x apart
+    xw = torch.zeros(N, H, W, 2 * Ci, dtype=dt, device=dev)
+    xw[..., Ci:] = x.to(dev)
+    yw = torch.full((N, H, W, 2 * Co), -3.0, dtype=torch.float32 if f32 else dt, device=dev)
+    stats = torch.zeros(G, 8, 2, Co, dtype=torch.float64, device=dev)
+    op.forward(xw[..., Ci:], out=yw[..., :Co], stats=stats, stat_groups=G, out_f32=f32)
+    torch.cuda.synchronize()
+    got = yw[..., :Co].float().cpu()
+    assert (yw[..., Co:] == -3).all()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= (2e-3 if f32 else 1e-2) * scale
+    n = N // G
+    for k in range(G):
+        r = ref[k * n:(k + 1) * n].double()
+        s = stats[k].sum(0).cpu()
+        assert torch.allclose(s[0], r.sum(dim=(0, 1, 2)), rtol=1e-3, atol=1e-3 * float((r ** 2).sum(dim=(0, 1, 2)).max().sqrt()))
+        assert torch.allclose(s[1], (r ** 2).sum(dim=(0, 1, 2)), rtol=2e-3)
+    # addend + ReLU (the Bottleneck's residual exit has no statistics: its BatchNorm sits in front of the add)
+    y2 = op.forward(x.to(dev), addend=add.to(dev), relu=True)
+    torch.cuda.synchronize()
+    ref2 = F.relu(ref + add.float())
+    assert float((y2.float().cpu() - ref2).abs().max()) <= 1e-2 * float(ref2.abs().max())
