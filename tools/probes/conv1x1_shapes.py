@@ -3,19 +3,26 @@ import sys; sys.path.insert(0, '.')
 import torch
 from fsnet_amd.hip.conv import ConvOp, USE_1X1
 dev = torch.device('cuda:0'); dt = torch.bfloat16
-B = 8
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 SHAPES = [("l1 64-64", 64, 64, 1, 80, 256), ("l1 64-256", 64, 256, 1, 80, 256), ("l1 256-64", 256, 64, 1, 80, 256),
           ("l2 256-128", 256, 128, 1, 80, 256), ("l2 128-512", 128, 512, 1, 40, 128), ("l2 512-128", 512, 128, 1, 40, 128),
           ("l3 256-1024", 256, 1024, 1, 20, 64), ("l3 1024-256", 1024, 256, 1, 20, 64), ("l4 512-2048", 512, 2048, 1, 10, 32),
           ("l4 2048-512", 2048, 512, 1, 10, 32), ("ds 256-512 s2", 256, 512, 2, 80, 256), ("ds 1024-2048 s2", 1024, 2048, 2, 20, 64)]
 def timeit(fn, n=20):
+    """n launches replayed as one hipGraph (the launches are shorter than the host's issue time)"""
     for _ in range(3): fn()
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(n): fn()
+    g.replay(); torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(n): fn()
+    for _ in range(5): g.replay()
     e.record(); torch.cuda.synchronize()
-    return s.elapsed_time(e) / n * 1e-3
+    return s.elapsed_time(e) / (5 * n) * 1e-3
 print("conv1x1 kernel:", USE_1X1)
 for name, Ci, Co, st, H, W in SHAPES:
     op = ConvOp(Ci, Co, 1, 1, st, 0, dt, dev)
@@ -28,5 +35,6 @@ for name, Ci, Co, st, H, W in SHAPES:
     fl = 2.0 * B * Ho * Wo * Co * Ci
     mb = (B * Ho * Wo * (Ci + Co) * 2) / 1e6
     tf = timeit(lambda: op.forward(x, out=y, stats=stats))
+    tn = timeit(lambda: op.forward(x, out=y))
     td = timeit(lambda: op.dgrad(gy, H, W)) if st == 1 else float('nan')
-    print("%-16s %6.2f GF %6.1f MB | fwd %6.1f us %6.1f TF %5.2f TB/s | dgrad %6.1f us" % (name, fl / 1e9, mb, tf * 1e6, fl / tf / 1e12, mb / tf / 1e6, td * 1e6))
+    print("%-16s %6.2f GF %6.1f MB | fwd %6.1f us %6.1f TF %5.2f TB/s | no stats %6.1f us | dgrad %6.1f us %6.1f TF" % (name, fl / 1e9, mb, tf * 1e6, fl / tf / 1e12, mb / tf / 1e6, tn * 1e6, td * 1e6, fl / td / 1e12))
