@@ -21,31 +21,11 @@
 #include <cstdlib>
 #include "common.h"
 #include "fsnet_hip_internal.h"
+#include "lds_dma.h"
 
 namespace {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) int i32x4;
-
-// 16 bytes per lane global -> LDS without a register stop: LDS byte lds_addr + 16 * lane receives the 16 bytes at buffer
-// offset voff (zero when out of range).  Inline assembly because hipcc orders every later ds_read behind an LDS-DMA it
-// knows about with `s_waitcnt vmcnt(0)` — which would land the next stage before the current one is multiplied; the
-// kernel counts these loads itself (vmcnt(0) in front of the stage barrier).
-__device__ __forceinline__ void glds16(const i32x4 rsrc, int voff, unsigned lds_addr) {
-  int keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
-}
-__device__ __forceinline__ i32x4 make_rsrc(const void* base, long bytes) {
-  const unsigned long long b = (unsigned long long)base;
-  i32x4 r;
-  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
-  r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((b >> 32) & 0xffffu));
-  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
-  r[3] = 0x00020000;
-  return r;
-}
-
 template <int CO, int PIX, int NST>
 struct GemmCfg {
   static constexpr int WPIX = PIX / 4;                 // pixels of a wave
@@ -57,9 +37,6 @@ struct GemmCfg {
   static constexpr int WORK = NST * STAGE > 4 * OSTG ? NST * STAGE : 4 * OSTG;   // stages, aliased by the staging rows
   static constexpr int LDS = WORK + 4 * CO * 2 * 4;    // + the waves' statistics sums [4][CO][2] fp32
 };
-
-template <int N>
-__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // NST: K stages resident in LDS (NST - 1 in flight while one is multiplied)
 template <int CO, int PIX, int NST>
@@ -168,8 +145,8 @@ __global__ __launch_bounds__(256, NST == 2 && PIX == 128 ? 4 : 2) void conv1x1_g
     if (s < nkt) issue(s, s);
   int cb = 0, ib = NST - 1;
   for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + NST - 2 < nkt) wait_vm<(NST - 2) * LPS>();
-    else wait_vm<0>();
+    if (kt + NST - 2 < nkt) fs_wait_vm<(NST - 2) * LPS>();
+    else fs_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     if (kt + NST - 1 < nkt) issue(kt + NST - 1, ib);
     multiply(lds + cb * STAGE);

@@ -11,6 +11,7 @@
 // atomics serialise at ~12 ns each on MI355X and dominated the first version of this kernel).
 #include "common.h"
 #include "fsnet_hip_internal.h"
+#include "lds_dma.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -1152,7 +1153,233 @@ int launch_wgrad_stem(const FsWgradArgs& a, const FsWgradArgs* a2, hipStream_t s
   return fs_launch_status();
 }
 
-// which kernel a problem runs on: 1 stem, 2 3x3 LDS-halo, 3 narrow 3x3, 4 / 5 / 6 / 7 / 8 generic tiles, -1 none
+// ---------------------------------------------------------------------------------------------
+// 1x1 weight gradient (bf16) with the operands brought in by LDS-DMA.  dW[co][ci] = sum over pixels of dY[m][co] x[m][ci]
+// is a GEMM whose K axis is the pixel axis: at ResNet-50 / 320x1024 the Bottleneck's 1x1 layers (resnet.py:52-89) are 80
+// of these per step with K = 2.5 k .. 328 k pixels, and the generic kernel above — one register-staged stage in flight,
+// every 64-pixel stage waiting out a global-load latency — ran them at 150-250 TFLOP/s however its splits were chosen.
+// Here a ring of NST 32-pixel stages sits in LDS, filled by `buffer_load ... lds` (lds_dma.h) with NST-1 stages in flight
+// across one barrier per stage; the images are the natural [pixel][channel] rows (a 1 KB load instruction = 4 or 8 whole
+// rows), the fragments are read transposed (ds_read_b64_tr_b16) as in the kernels above, and the 16-byte units of a row
+// are XOR-permuted on the source side so that the 32 lanes a transposed read serves together (pixel rows 0-3 and 8-11
+// of a k group pair) fall into 64 distinct banks.  Split-K, slabs and the reduce launch are the generic kernel's.
+// ---------------------------------------------------------------------------------------------
+template <int RB>
+__device__ __forceinline__ int w1_key(int r) {     // XOR key (in 16-byte units) of pixel row r of an image with RB-byte rows
+  if constexpr (RB == 256) return ((r & 3) | ((r >> 1) & 4)) << 1;
+  else return (((r >> 1) & 1) | (((r >> 3) & 1) << 1)) << 1;   // (128-byte rows: odd rows already sit in the other bank half)
+}
+
+template <int COT, int CIT, int NST>
+__global__ __launch_bounds__(256, 2) void wgrad1x1_kernel(const FsDual<FsWgradArgs, WgDiv> d) {
+  constexpr int RBA = COT * 2, RBB = CIT * 2;          // row bytes of the dY / x images
+  constexpr int IMA = 32 * RBA, STAGE = 32 * (RBA + RBB);
+  constexpr int NA = RBA / 32, NB = RBB / 32;           // 1 KB load instructions per stage and image
+  constexpr int LPW = (NA + NB) / 4;                    // ... per wave
+  constexpr int UA = RBA / 16, UB = RBB / 16;           // 16-byte units per row
+  constexpr int WROW = COT / 2, WCOL = CIT / 2, TA = WROW / 16, TB = WCOL / 16;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE];
+
+  const int prob = (int)blockIdx.z >= d.nb0 ? 1 : 0;
+  const FsWgradArgs& p = d.a[prob];
+  const FsDiv dW = d.g[prob].dW, dH = d.g[prob].dH;
+  const int zb = (int)blockIdx.z - (prob ? d.nb0 : 0);
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = wave & 1, wcn = wave >> 1;
+  const int li = lane & 15, lg = lane >> 4;
+  const int ci0 = blockIdx.x * CIT, co0 = blockIdx.y * COT;
+  const int Cs = p.ncolgroups * 8;
+  const long m_begin = (long)zb * p.pix_per_split;
+  long m_end = m_begin + p.pix_per_split; if (m_end > p.M) m_end = p.M;
+  const int nkt = (int)((m_end - m_begin + 31) / 32);
+  const int OOB = 0x7fffffff;
+  // dY is dense [M][Cd]: rows from m_end on are beyond the descriptor's extent (they read as zero)
+  const i32x4 rs_dy = make_rsrc(p.dy, m_end * p.Cd * 2), rs_x = make_rsrc(p.x, p.x_bytes);
+  const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)lds;
+
+  // ---- loader state: instruction q = wave + 4 i of a stage; q < NA fills rows of the dY image, the rest the x image ----
+  int aoff[LPW];            // dY instructions: byte offset of this lane's unit at stage 0 (OOB: channel tail)
+  int brow[LPW], bcol[LPW]; // x instructions: this lane's pixel row of the stage and its channel offset in bytes (-1: tail)
+#pragma unroll
+  for (int i = 0; i < LPW; ++i) {
+    const int q = wave + 4 * i;
+    if (q < NA) {
+      const int r = q * (64 / UA) + lane / UA, u = (lane % UA) ^ w1_key<RBA>(r);
+      aoff[i] = (co0 + u * 8 < p.Cd) ? (int)(((m_begin + r) * p.Cd + co0 + u * 8) * 2) : OOB;
+      brow[i] = 0; bcol[i] = 0;
+    } else {
+      const int r = (q - NA) * (64 / UB) + lane / UB, u = (lane % UB) ^ w1_key<RBB>(r);
+      brow[i] = r; bcol[i] = (ci0 + u * 8 < Cs) ? (ci0 + u * 8) * 2 : -1;
+      aoff[i] = 0;
+    }
+  }
+  auto issue = [&](int kt, int buf) {
+    const unsigned base = lds0 + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+      const int q = wave + 4 * i;
+      if (q < NA) {
+        glds16(rs_dy, aoff[i] == OOB ? OOB : aoff[i] + kt * (32 * p.Cd * 2), base + q * 1024);
+      } else {
+        const long m = m_begin + (long)kt * 32 + brow[i];
+        int voff = OOB;
+        if (m < m_end && bcol[i] >= 0) {
+          const int mi = (int)m;
+          int qd = fs_div(mi, dW); int x = mi - qd * p.Wd; int n = fs_div(qd, dH); int y = qd - n * p.Hd;
+          voff = (int)((n * p.sN + (long)(y * p.stride) * p.sH + (long)(x * p.stride) * p.sW) * 2) + bcol[i];
+        }
+        glds16(rs_x, voff, base + IMA + (q - NA) * 1024);
+      }
+    }
+  };
+
+  // ---- transposed fragment reads (16x16x32): lane (li, lg) addresses the 8-byte piece [pixel lg*8 + (li >> 2) (+4)]
+  // [channel tile*16 + (li & 3)*4 ..] and receives channel tile*16 + li for pixels lg*8 + 0..3 (+4) ----
+  const int r_lo = lg * 8 + (li >> 2);
+  const int sub = ((li & 3) & 1) * 8, uq = (li & 3) >> 1;
+  const int keyA = w1_key<RBA>(r_lo), keyB = w1_key<RBB>(r_lo);      // (rows r and r + 4 share a key)
+  int fa_off[TA], fb_off[TB];
+#pragma unroll
+  for (int a = 0; a < TA; ++a) fa_off[a] = r_lo * RBA + (((wr * (WROW / 8) + a * 2 + uq) ^ keyA) << 4) + sub;
+#pragma unroll
+  for (int b = 0; b < TB; ++b) fb_off[b] = IMA + r_lo * RBB + (((wcn * (WCOL / 8) + b * 2 + uq) ^ keyB) << 4) + sub;
+
+  f32x4 acc[TA][TB];
+#pragma unroll
+  for (int a = 0; a < TA; ++a)
+#pragma unroll
+    for (int b = 0; b < TB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nkt) issue(s, s);
+  int cb = 0, ib = NST - 1;
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + NST - 2 < nkt) fs_wait_vm<(NST - 2) * LPW>();
+    else fs_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + NST - 1 < nkt) issue(kt + NST - 1, ib);
+    const unsigned char* sb = lds + cb * STAGE;
+    bf16x8 fa[TA], fb[TB];
+#pragma unroll
+    for (int a = 0; a < TA; ++a) {
+      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sb + fa_off[a]));
+      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sb + fa_off[a] + 4 * RBA));
+      uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+      fa[a] = __builtin_bit_cast(bf16x8, make_uint4(l2.x, l2.y, h2.x, h2.y));
+    }
+#pragma unroll
+    for (int b = 0; b < TB; ++b) {
+      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sb + fb_off[b]));
+      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sb + fb_off[b] + 4 * RBB));
+      uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+      fb[b] = __builtin_bit_cast(bf16x8, make_uint4(l2.x, l2.y, h2.x, h2.y));
+    }
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+      for (int b = 0; b < TB; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    cb = cb + 1 == NST ? 0 : cb + 1;
+    ib = ib + 1 == NST ? 0 : ib + 1;
+  }
+
+  // ---- epilogue: D rows = co (lg*4 + j), columns = ci (li) ----
+  if (p.nsplit > 1) {
+    float* ws = p.workspace + (long)zb * p.ws_rows * p.ws_cols;
+#pragma unroll
+    for (int b = 0; b < TB; ++b) {
+      const int col = ci0 + wcn * WCOL + b * 16 + li;
+#pragma unroll
+      for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int co = co0 + wr * WROW + a * 16 + lg * 4 + j;
+          ws[(long)co * p.ws_cols + col] = acc[a][b][j];
+        }
+    }
+    return;
+  }
+#pragma unroll
+  for (int b = 0; b < TB; ++b) {
+    const int ci = ci0 + wcn * WCOL + b * 16 + li;
+    if (ci >= p.Ci) continue;
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int co = co0 + wr * WROW + a * 16 + lg * 4 + j;
+        if (co < p.Co) p.dw[(long)co * p.Ci + ci] += acc[a][b][j];      // sole owner: plain RMW
+      }
+  }
+}
+
+template <int COT, int CIT>
+int launch_w1(const FsWgradArgs& a, const FsWgradArgs* a2, hipStream_t st) {
+  constexpr int NST = 4;
+  FsDual<FsWgradArgs, WgDiv> d;
+  FsWgradArgs& b = d.a[0];
+  FsWgradArgs& b2 = d.a[1];
+  b = a; b2 = a2 ? *a2 : a;
+  d.g[0] = WgDiv{fs_make_div(a.Wd), fs_make_div(a.Hd)};
+  d.g[1] = WgDiv{fs_make_div(b2.Wd), fs_make_div(b2.Hd)};
+  d.nprob = a2 ? 2 : 1;
+  const int ncols = a.ncolgroups * 8;
+  const int ct = (ncols + CIT - 1) / CIT, rt = (a.Cd + COT - 1) / COT;
+  const long tiles = (long)ct * rt;
+  const long chunks = (a.M + 31) / 32, chunks2 = a2 ? (a2->M + 31) / 32 : 0;
+  // one round of resident blocks (two per CU), >= 256 pixels per block, the slabs inside the caller's workspace
+  static const int slots = wg_resident_blocks(wgrad1x1_kernel<COT, CIT, NST>, 256);
+  long splits = std::max<long>(1, slots / tiles), splits2 = 0;
+  b.ws_rows = rt * COT; b.ws_cols = ct * CIT;
+  b2.ws_rows = b.ws_rows; b2.ws_cols = b.ws_cols;
+  const long slab = (long)b.ws_rows * b.ws_cols;
+  if (a2) {
+    wg_share(std::max<long>(2, splits), chunks, chunks2, std::max<long>(1, chunks / 8), std::max<long>(1, chunks2 / 8), splits, splits2);
+    const long room = a.workspace ? a.workspace_elems / slab : 0;
+    if (room < 2) { splits = 1; splits2 = 1; }
+    else if (splits + splits2 > room) { splits = std::max<long>(1, room * splits / (splits + splits2)); splits2 = std::max<long>(1, room - splits); }
+  } else {
+    splits = std::min<long>(splits, std::max<long>(1, chunks / 8));
+    if (!a.workspace) splits = 1;
+    else splits = std::min<long>(splits, std::max<long>(1, a.workspace_elems / slab));
+  }
+  long cps = (chunks + splits - 1) / splits;
+  b.pix_per_split = (int)(cps * 32);
+  b.nsplit = (int)((chunks + cps - 1) / cps);
+  d.nb0 = b.nsplit;
+  int nz = b.nsplit;
+  if (a2) {
+    cps = (chunks2 + splits2 - 1) / splits2;
+    b2.pix_per_split = (int)(cps * 32);
+    b2.nsplit = (int)((chunks2 + cps - 1) / cps);
+    b2.workspace = a.workspace ? a.workspace + (long)b.nsplit * slab : nullptr;
+    nz += b2.nsplit;
+  }
+  if (g_plan) return wg_plan(0, tiles * nz, 256, slots) ? 0 : FS_EINVAL;
+  hipLaunchKernelGGL((wgrad1x1_kernel<COT, CIT, NST>), dim3(ct, rt, nz), dim3(256), 0, st, d);
+  launch_reduce(b, a2 ? &b2 : nullptr, a.Co, ncols, 8, st);
+  return fs_launch_status();
+}
+
+// 1x1 / pad 0 layers with whole 64-channel tiles on both sides and enough pixels to pipeline (FSNET_AMD_WGRAD_1X1=0: off)
+inline bool w1_takes(const FsWgradArgs& a) {
+  static const bool on = [] { const char* e = getenv("FSNET_AMD_WGRAD_1X1"); return !(e && e[0] == '0'); }();
+  const int Cs = a.ncolgroups * 8;
+  return on && a.R == 1 && a.S == 1 && a.pad == 0 && !a.pro_a && a.stride >= 1 && a.Cd % 64 == 0 && Cs % 64 == 0 && a.M >= 2048 &&
+         a.x_bytes > 0 && a.x_bytes <= 0x7fffffffLL && (long)a.M * a.Cd * 2 <= 0x7fffffffLL &&
+         a.sN % 8 == 0 && a.sH % 8 == 0 && a.sW % 8 == 0 && ((uintptr_t)a.dy | (uintptr_t)a.x) % 16 == 0;
+}
+inline int launch_wgrad_1x1(const FsWgradArgs& a, const FsWgradArgs* a2, hipStream_t st) {
+  const int Cs = a.ncolgroups * 8;
+  const bool co128 = a.Cd % 128 == 0, ci128 = Cs % 128 == 0;
+  if (co128 && ci128) return launch_w1<128, 128>(a, a2, st);
+  if (co128) return launch_w1<128, 64>(a, a2, st);
+  if (ci128) return launch_w1<64, 128>(a, a2, st);
+  return launch_w1<64, 64>(a, a2, st);
+}
+
+// which kernel a problem runs on: 1 stem, 2 3x3 LDS-halo, 3 narrow 3x3, 4 / 5 / 6 / 7 / 8 generic tiles, 9 1x1 LDS-DMA, -1 none
 template <typename T>
 int wgrad_path(const FsWgradArgs& a) {
   constexpr bool kBf16 = sizeof(T) == 2;  // f32 tiles are capped by the 64 KB static LDS limit
@@ -1166,6 +1393,7 @@ int wgrad_path(const FsWgradArgs& a) {
         a.x_bytes <= 0x7fffffffLL && (long)a.M * a.Cd * 2 <= 0x7fffffffLL && (a.M >= 1024 || a.pro_a))
       return 2;                          // (tiny pixel counts: too few tiles to split, the generic kernel wins)
     if (a.pro_a) return -1;              // only the halo kernel stages x through the prologue
+    if (w1_takes(a)) return 9;
     if (a.use_halo && a.R == 3 && a.S == 3 && a.stride == 1 && ((a.Cd == 16 && Cs % 16 == 0) || (a.Cd == 32 && Cs % 32 == 0)) &&
         a.x_bytes > 0 && a.x_bytes <= 0x7fffffffLL && (long)a.M * a.Cd * 2 <= 0x7fffffffLL && a.M >= 4096)
       return 3;
@@ -1207,6 +1435,7 @@ int launch_wgrad(const FsWgradArgs& a, const FsWgradArgs* a2, hipStream_t st) {
     if (path == 1) return launch_wgrad_stem(a, a2, st);
     if (path == 2) return launch_wgrad_halo(a, a2, st);
     if (path == 3) return launch_wgrad_narrow(a, st);
+    if (path == 9) return launch_wgrad_1x1(a, a2, st);
     if (path == 4) return launch_tile<T, 128, 128, 2>(a, a2, st);
     if (path == 5) return launch_tile<T, 64, 128, 2>(a, a2, st);
   }

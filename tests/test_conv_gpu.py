@@ -41,6 +41,10 @@ CASES = [
     (256, 64, 1, 1, 0, 8, 80, 256),   # 256 x 64 tiles
     (1024, 512, 1, 2, 0, 2, 20, 64),  # strided projection, 32 K stages
     (128, 72, 1, 1, 0, 3, 17, 23),    # ragged M, Co_p = 80 (a partly filled channel tile)
+    # ... whose weight gradients run on the LDS-DMA 1x1 kernel (wgrad1x1_kernel: >= 2048 pixels, 64-channel tiles)
+    (64, 64, 1, 1, 0, 4, 40, 64),     # 64 x 64 tiles
+    (128, 128, 1, 1, 0, 3, 27, 31),   # 2511 pixels: the last stage is ragged (rows past the end read as zero)
+    (256, 512, 1, 2, 0, 4, 40, 64),   # strided projection with 2560 output pixels
 ]
 
 

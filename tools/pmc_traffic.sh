@@ -5,7 +5,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp PYTHONPATH=$R
 export FSNET_AMD_GRAPH=0   # per-dispatch counters: eager launches (the same kernels the graph replays)
-CMD="python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-profile"
+CMD="python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-profile $BENCH_ARGS"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_traffic/fetch -o pmc --output-format csv -- $CMD > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pmc_traffic/write -o pmc --output-format csv -- $CMD > /dev/null 2>&1
 ls $R/gpurun_out/pmc_traffic/*

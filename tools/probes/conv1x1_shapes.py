@@ -37,4 +37,6 @@ for name, Ci, Co, st, H, W in SHAPES:
     tf = timeit(lambda: op.forward(x, out=y, stats=stats))
     tn = timeit(lambda: op.forward(x, out=y))
     td = timeit(lambda: op.dgrad(gy, H, W)) if st == 1 else float('nan')
-    print("%-16s %6.2f GF %6.1f MB | fwd %6.1f us %6.1f TF %5.2f TB/s | no stats %6.1f us | dgrad %6.1f us %6.1f TF" % (name, fl / 1e9, mb, tf * 1e6, fl / tf / 1e12, mb / tf / 1e6, tn * 1e6, td * 1e6, fl / td / 1e12))
+    dw = torch.zeros(Co, Ci, 1, 1, device=dev)
+    tw = timeit(lambda: op.wgrad(gy, x, dw))
+    print("%-16s %6.2f GF %6.1f MB | fwd %6.1f us %6.1f TF %5.2f TB/s | no stats %6.1f us | dgrad %6.1f us %6.1f TF | wgrad %6.1f us %6.1f TF" % (name, fl / 1e9, mb, tf * 1e6, fl / tf / 1e12, mb / tf / 1e6, tn * 1e6, td * 1e6, fl / td / 1e12, tw * 1e6, fl / tw / 1e12))
