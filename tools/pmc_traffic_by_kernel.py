@@ -17,6 +17,8 @@ def load(path, counter):
             continue
         name = re.sub(r"\(anonymous namespace\)::|void ", "", r["Kernel_Name"])
         name = re.sub(r"[<(].*", "", name)
+        name = re.sub(r"_ZN12_GLOBAL__N_1\d+", "", name)            # (mangled template instantiations)
+        name = re.sub(r"_kernelI.*|_kernel$", "_kernel", name)
         acc[name][0] += 1
         acc[name][1] += float(r["Counter_Value"])
     return acc
