@@ -98,8 +98,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const FsDual<FsBnApplyArg
   // these bandwidth-bound kernels at 4-5 blocks per CU
   extern __shared__ float bn_smem[];
   const int C = p.C;
-  float* s_scale = bn_smem; float* s_shift = bn_smem + C;
-  float* s_scale2 = bn_smem + 2 * C; float* s_shift2 = bn_smem + 3 * C;
+  constexpr int V = VecN<T>::N;
+  // channel slabs: with more than 32 16-byte channel groups per row (C > 256 at bf16) blockIdx.y picks a slab of 32 groups
+  // and the block only derives THAT slab's coefficients — the preamble re-reads 128 bytes of f64 sums per channel and
+  // block: at C = 2048 that was 262 KB per block, 134-268 MB per launch for a 21 MB tensor (ResNet-50 layer 4: 1.2 TB/s)
+  const int CG = C / V, cg_sh = pow2_shift(CG);
+  const int SCG = gridDim.y > 1 ? 32 : CG, scg_sh = gridDim.y > 1 ? 5 : cg_sh;
+  const int SC = SCG * V, c0 = (int)blockIdx.y * SC;
+  float* s_scale = bn_smem; float* s_shift = bn_smem + SC;
+  float* s_scale2 = bn_smem + 2 * SC; float* s_shift2 = bn_smem + 3 * SC;
   const bool has2 = p.gamma2 != nullptr;
   const bool train = p.stats != nullptr;
   // statistics groups: blockIdx.z owns the rows [z*Mg, (z+1)*Mg) and the z-th statistics / saved-state slice
@@ -115,22 +122,21 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const FsDual<FsBnApplyArg
   // operand loads only started behind it
   const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
   const T* __restrict__ res = reinterpret_cast<const T*>(p.res);
-  constexpr int V = VecN<T>::N;
-  const int CG = C / V, cg_sh = pow2_shift(CG);
-  const long total = (long)Mg * CG;
+  const long total = (long)Mg * SCG;
   const long i0 = (long)blockIdx.x * 256 + threadIdx.x;
   float pv[V], pr[V];
   if (i0 < total) {
     int cg; long m;
-    split_vec(i0, CG, cg_sh, cg, m);
+    split_vec(i0, SCG, scg_sh, cg, m);
     m += (long)z * Mg;
-    loadv<T>(x + m * C + cg * V, pv);
-    if (res) loadv<T>(res + m * C + cg * V, pr);
+    loadv<T>(x + m * C + c0 + cg * V, pv);
+    if (res) loadv<T>(res + m * C + c0 + cg * V, pr);
   }
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int cl = threadIdx.x; cl < SC; cl += 256) {
+    const int c = c0 + cl;
     float mean, invstd, varb, sc, sh;
     bn_channel_coeffs(stats_z, p.running_mean, p.running_var, C, c, p.count, p.eps, p.gamma[c], p.beta[c], mean, invstd, varb, sc, sh);
-    s_scale[c] = sc; s_shift[c] = sh;
+    s_scale[cl] = sc; s_shift[cl] = sh;
     if (first) { p.save_mean[z * C + c] = mean; p.save_invstd[z * C + c] = invstd; }
     if (first && z == 0 && train && p.running_mean) {
       // one momentum update per group, in group order (= the order the reference calls the module in)
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const FsDual<FsBnApplyArg
     }
     if (has2) {
       bn_channel_coeffs(stats2_z, p.running_mean2, p.running_var2, C, c, p.count, p.eps, p.gamma2[c], p.beta2[c], mean, invstd, varb, sc, sh);
-      s_scale2[c] = sc; s_shift2[c] = sh;
+      s_scale2[cl] = sc; s_shift2[cl] = sh;
       if (first) { p.save_mean2[z * C + c] = mean; p.save_invstd2[z * C + c] = invstd; }
       if (first && z == 0 && train && p.running_mean2) {
         float rm = p.running_mean2[c], rv = p.running_var2[c];
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const FsDual<FsBnApplyArg
       }
     }
   }
-  if (first && z == 0 && threadIdx.x == 0) {
+  if (first && z == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     if (train && p.num_batches_tracked) *p.num_batches_tracked += G;
     if (train && p.num_batches_tracked2) *p.num_batches_tracked2 += G;
   }
@@ -172,9 +178,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const FsDual<FsBnApplyArg
   const long stride = (long)gridDim.x * 256;
   for (long i = i0; i < total; i += stride) {
     int cg; long m;
-    split_vec(i, CG, cg_sh, cg, m);
+    split_vec(i, SCG, scg_sh, cg, m);
     m += (long)z * Mg;
-    int c = cg * V;
+    const int cl = cg * V, c = c0 + cl;
     float v[V], r[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) { v[j] = pv[j]; r[j] = pr[j]; }
@@ -183,17 +189,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const FsDual<FsBnApplyArg
     // vectors)
     if (i + stride < total) {
       int cg2; long m2;
-      split_vec(i + stride, CG, cg_sh, cg2, m2);
+      split_vec(i + stride, SCG, scg_sh, cg2, m2);
       m2 += (long)z * Mg;
-      loadv<T>(x + m2 * C + cg2 * V, pv);
-      if (res) loadv<T>(res + m2 * C + cg2 * V, pr);
+      loadv<T>(x + m2 * C + c0 + cg2 * V, pv);
+      if (res) loadv<T>(res + m2 * C + c0 + cg2 * V, pr);
     }
 #pragma unroll
-    for (int j = 0; j < V; ++j) v[j] = v[j] * s_scale[c + j] + s_shift[c + j];
+    for (int j = 0; j < V; ++j) v[j] = v[j] * s_scale[cl + j] + s_shift[cl + j];
     if (res) {
       if (has2) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) r[j] = r[j] * s_scale2[c + j] + s_shift2[c + j];
+        for (int j = 0; j < V; ++j) r[j] = r[j] * s_scale2[cl + j] + s_shift2[cl + j];
       }
 #pragma unroll
       for (int j = 0; j < V; ++j) v[j] += r[j];
@@ -533,8 +539,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const FsDual<FsBnBwdA
   const int prob = (int)blockIdx.z >= d.nb0 ? 1 : 0;
   const FsBnBwdArgs& p = d.a[prob];
   const int C = p.C;
-  float* s_a = bn_smem; float* s_b = bn_smem + C; float* s_k = bn_smem + 2 * C;
-  float* s_mean = bn_smem + 3 * C; float* s_istd = bn_smem + 4 * C;
+  constexpr int V = VecN<T>::N;
+  // channel slabs as in bn_apply_kernel (blockIdx.y: 32 channel groups of a row wider than that)
+  const int CG = C / V, cg_sh = pow2_shift(CG);
+  const int SCG = gridDim.y > 1 ? 32 : CG, scg_sh = gridDim.y > 1 ? 5 : cg_sh;
+  const int SC = SCG * V, c0 = (int)blockIdx.y * SC;
+  float* s_a = bn_smem; float* s_b = bn_smem + SC; float* s_k = bn_smem + 2 * SC;
+  float* s_mean = bn_smem + 3 * SC; float* s_istd = bn_smem + 4 * SC;
   const int G = p.groups > 1 ? p.groups : 1;
   const int z = (int)blockIdx.z - (prob ? d.nb0 : 0);
   const int Mg = p.M / G;
@@ -544,20 +555,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const FsDual<FsBnBwdA
   const T* __restrict__ dout = reinterpret_cast<const T*>(p.dout);
   const T* __restrict__ yv = reinterpret_cast<const T*>(p.y);
   const T* __restrict__ xv = reinterpret_cast<const T*>(p.x);
-  constexpr int V = VecN<T>::N;
-  const int CG = C / V, cg_sh = pow2_shift(CG);
-  const long total = (long)Mg * CG;
+  const long total = (long)Mg * SCG;
   const long i0 = (long)blockIdx.x * 256 + threadIdx.x;
   float pg[V], px[V];
   if (i0 < total) {
     int cg; long m;
-    split_vec(i0, CG, cg_sh, cg, m);
+    split_vec(i0, SCG, scg_sh, cg, m);
     m += (long)z * Mg;
-    if constexpr (POOL) pool_grad<T>(p, m, cg * V, pg);        // (masked below, once the coefficients are there)
-    else masked_grad<T>(p, dout, yv, m, cg * V, pg);
-    loadv<T>(xv + m * C + cg * V, px);
+    if constexpr (POOL) pool_grad<T>(p, m, c0 + cg * V, pg);   // (masked below, once the coefficients are there)
+    else masked_grad<T>(p, dout, yv, m, c0 + cg * V, pg);
+    loadv<T>(xv + m * C + c0 + cg * V, px);
   }
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int cl = threadIdx.x; cl < SC; cl += 256) {
+    const int c = c0 + cl;
     double sg = 0.0, sgx = 0.0, lg = 0.0, lgx = 0.0;
 #pragma unroll
     for (int k = 0; k < FS_STAT_SLOTS; ++k) {
@@ -565,11 +575,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const FsDual<FsBnBwdA
       if (sums_local) { lg += sums_local[(long)k * 2 * C + c]; lgx += sums_local[(long)k * 2 * C + C + c]; }
     }
     float istd = p.save_invstd[z * C + c];
-    s_mean[c] = p.save_mean[z * C + c]; s_istd[c] = istd;
-    s_k[c] = p.gamma[c] * istd;
-    if constexpr (POOL) bn_smem[5 * C + c] = (p.beta ? p.beta[c] : 0.f) - s_mean[c] * s_k[c];     // the forward's shift
-    s_a[c] = (float)(sg / p.count);
-    s_b[c] = (float)(sgx / p.count);
+    s_mean[cl] = p.save_mean[z * C + c]; s_istd[cl] = istd;
+    s_k[cl] = p.gamma[c] * istd;
+    if constexpr (POOL) bn_smem[5 * SC + cl] = (p.beta ? p.beta[c] : 0.f) - s_mean[cl] * s_k[cl];     // the forward's shift
+    s_a[cl] = (float)(sg / p.count);
+    s_b[cl] = (float)(sgx / p.count);
     if (blockIdx.x == 0) {
       // dgamma / dbeta of the local shard (the data-parallel all-reduce of gradients averages them later)
       if (G > 1) {       // the groups' blocks add concurrently
@@ -587,30 +597,33 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const FsDual<FsBnBwdA
   const long stride = (long)gridDim.x * 256;
   for (long i = i0; i < total; i += stride) {
     int cg; long m;
-    split_vec(i, CG, cg_sh, cg, m);
+    split_vec(i, SCG, scg_sh, cg, m);
     m += (long)z * Mg;
-    int c = cg * V;
+    const int cl = cg * V, c = c0 + cl;
     float g[V], xr[V], o[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) { g[j] = pg[j]; xr[j] = px[j]; }
     if (i + stride < total) {            // next vector in flight (see bn_apply_kernel)
       int cg2; long m2;
-      split_vec(i + stride, CG, cg_sh, cg2, m2);
+      split_vec(i + stride, SCG, scg_sh, cg2, m2);
       m2 += (long)z * Mg;
-      if constexpr (POOL) pool_grad<T>(p, m2, cg2 * V, pg);
-      else masked_grad<T>(p, dout, yv, m2, cg2 * V, pg);
-      loadv<T>(xv + m2 * C + cg2 * V, px);
+      if constexpr (POOL) pool_grad<T>(p, m2, c0 + cg2 * V, pg);
+      else masked_grad<T>(p, dout, yv, m2, c0 + cg2 * V, pg);
+      loadv<T>(xv + m2 * C + c0 + cg2 * V, px);
     }
-    if constexpr (POOL) pool_mask<T>(p, yv, m, c, xr, s_k + c, bn_smem + 5 * C + c, g);
+    if constexpr (POOL) pool_mask<T>(p, yv, m, c, xr, s_k + cl, bn_smem + 5 * SC + cl, g);
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      float xh = (xr[j] - s_mean[c + j]) * s_istd[c + j];
-      o[j] = s_k[c + j] * (g[j] - s_a[c + j] - xh * s_b[c + j]);
+      float xh = (xr[j] - s_mean[cl + j]) * s_istd[cl + j];
+      o[j] = s_k[cl + j] * (g[j] - s_a[cl + j] - xh * s_b[cl + j]);
     }
     storev<T>(dx + m * C + c, o);
     if (gout) storev<T>(gout + m * C + c, g);
   }
 }
+
+// channel slabs of the element-wise passes: 32 16-byte groups each where a row has more (a power of two of them)
+int bn_slabs(int CG) { return (CG > 32 && (CG & (CG - 1)) == 0) ? CG / 32 : 1; }
 
 int grid_for(long items) {
   long b = (items + 255) / 256;
@@ -712,8 +725,9 @@ extern "C" int fs_bn_apply2(const FsBnApplyArgs* a, const FsBnApplyArgs* b, int 
     else return FS_EINVAL;
     return fs_launch_status();
   }
-  dim3 grid(grid_for(items), 1, G + G1);
-  const unsigned lds = ((a->gamma2 || (b && b->gamma2)) ? 4u : 2u) * a->C * sizeof(float);
+  const int nslab = bn_slabs(a->C / vec);
+  dim3 grid(std::min(grid_for(items / nslab), std::max(32, grid_for(1L << 40) / nslab)), nslab, G + G1);   // (the cap holds per launch)
+  const unsigned lds = ((a->gamma2 || (b && b->gamma2)) ? 4u : 2u) * (a->C / nslab) * sizeof(float);
   if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16>, grid, dim3(256), lds, st, d);
   else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), lds, st, d);
   else return FS_EINVAL;
@@ -753,7 +767,9 @@ extern "C" int fs_bn_bwd_reduce2(const FsBnBwdArgs* a, const FsBnBwdArgs* b, int
     else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, CGB>), grid, dim3(256), 0, st, d); \
     else return FS_EINVAL;                                                                                      \
   }
-  if (CG >= 32) LAUNCH_REDUCE(32, 16, 512)
+  // (wide rows: every block ends in 2 x 256 f64 atomics and a block-wide fold — hold the grid near 1024 blocks)
+  const long wide_cap = std::max<long>(32, std::min<long>(512, 1024 / ((long)((CG + 31) / 32) * (G + G1))));
+  if (CG >= 32) LAUNCH_REDUCE(32, 16, wide_cap)
   else if (CG >= 8) LAUNCH_REDUCE(8, 64, 1024)
   else if (CG >= 4) LAUNCH_REDUCE(4, 128, 1024)
   else LAUNCH_REDUCE(2, 256, 1024)
@@ -779,8 +795,9 @@ extern "C" int fs_bn_bwd_apply2(const FsBnBwdArgs* a, const FsBnBwdArgs* b, int 
   const int G = a->groups > 1 ? a->groups : 1, G1 = b ? (b->groups > 1 ? b->groups : 1) : 0;
   long items = (long)(a->M / G) * (a->C / vec);
   if (b) items = std::max(items, (long)(b->M / G1) * (b->C / vec));
-  dim3 grid(grid_for(items), 1, G + G1);
-  const unsigned lds = (a->pool_dy ? 6u : 5u) * a->C * sizeof(float);
+  const int nslab = a->pool_dy ? 1 : bn_slabs(a->C / vec);
+  dim3 grid(std::min(grid_for(items / nslab), std::max(32, grid_for(1L << 40) / nslab)), nslab, G + G1);
+  const unsigned lds = (a->pool_dy ? 6u : 5u) * (a->C / nslab) * sizeof(float);
   const FsDual<FsBnBwdArgs, FsNoGeom> d = bn_dual(a, b);
   if (a->pool_dy) {
     if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, true>), grid, dim3(256), lds, st, d);

@@ -18,7 +18,10 @@ def tm(fn, n=30):
     return ts[len(ts) // 2]
 
 
-for N, H, W, C in [(12, 48, 160, 64), (24, 48, 160, 64), (12, 24, 80, 128), (12, 12, 40, 256), (12, 6, 20, 512), (12, 192, 640, 16)]:
+SHAPES = [(12, 48, 160, 64), (24, 48, 160, 64), (12, 24, 80, 128), (12, 12, 40, 256), (12, 6, 20, 512), (12, 192, 640, 16)]
+if len(sys.argv) > 1 and sys.argv[1] == "r50":       # ResNet-50 at 320x1024: the wide tensors of layers 1-4, pose (16) and depth (8) batch
+    SHAPES = [(16, 80, 256, 256), (8, 80, 256, 256), (16, 40, 128, 512), (16, 20, 64, 1024), (16, 10, 32, 2048), (16, 80, 256, 64)]
+for N, H, W, C in SHAPES + [(12, 48, 160, 64), (24, 48, 160, 64), (12, 24, 80, 128), (12, 12, 40, 256), (12, 6, 20, 512), (12, 192, 640, 16)][:0]:
     x = torch.randn(N, H, W, C, device=dev).bfloat16()
     g = torch.randn(N, H, W, C, device=dev).bfloat16()
     y = torch.empty_like(x); dx = torch.empty_like(x)
