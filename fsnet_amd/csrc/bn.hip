@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const FsBnApplyArgs p,
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const FsDual<FsBnApplyArgs, FsNoGeom> d) {
+__global__ __launch_bounds__(256) void bn_apply_kernel(const FsDual<FsBnApplyArgs, FsNoGeom> d, const int fast) {
   // two problems per launch (fsnet_hip_internal.h, FsDual): the statistics groups of both stack along blockIdx.z
   const int prob = (int)blockIdx.z >= d.nb0 ? 1 : 0;
   const FsBnApplyArgs& p = d.a[prob];
@@ -176,6 +176,53 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const FsDual<FsBnApplyArg
   T* __restrict__ y = reinterpret_cast<T*>(p.y);
   const bool dense_y = !p.pad_out && p.yW == C && p.yH == (long)p.W * C && p.yN == (long)p.H * p.W * C;
   const long stride = (long)gridDim.x * 256;
+  if (fast && dense_y && scg_sh >= 0) {
+    // dense output (every encoder layer): fixed channel group per thread, coefficients in registers, the raw operands of
+    // two later rows in flight (see bn_bwd_apply_kernel)
+    if (i0 >= total) return;
+    const int cl = (int)(i0 & (SCG - 1)) * V;
+    const long step = (stride >> scg_sh) * C;
+    long off = ((long)z * Mg + (i0 >> scg_sh)) * C + c0 + cl;
+    long left = (total - i0 + stride - 1) / stride;
+    float ks[V], kh[V], ks2[V], kh2[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      ks[j] = s_scale[cl + j]; kh[j] = s_shift[cl + j];
+      ks2[j] = has2 ? s_scale2[cl + j] : 1.f; kh2[j] = has2 ? s_shift2[cl + j] : 0.f;
+    }
+    const bool relu = p.relu != 0;
+    uint4 x1, r1, x2, r2;
+    x1 = r1 = x2 = r2 = make_uint4(0, 0, 0, 0);
+    if (left > 1) { x1 = *reinterpret_cast<const uint4*>(x + off + step); if (res) r1 = *reinterpret_cast<const uint4*>(res + off + step); }
+    if (left > 2) { x2 = *reinterpret_cast<const uint4*>(x + off + 2 * step); if (res) r2 = *reinterpret_cast<const uint4*>(res + off + 2 * step); }
+    float v[V], r[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { v[j] = pv[j]; r[j] = pr[j]; }
+    for (;;) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) v[j] = v[j] * ks[j] + kh[j];
+      if (res) {
+        if (has2) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) r[j] = r[j] * ks2[j] + kh2[j];
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j] += r[j];
+      }
+      if (relu) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      storev<T>(y + off, v);
+      if (--left == 0) break;
+      off += step;
+      Unit<T>::unpack(x1, v);
+      if (res) Unit<T>::unpack(r1, r);
+      x1 = x2; r1 = r2;
+      if (left > 2) { x2 = *reinterpret_cast<const uint4*>(x + off + 2 * step); if (res) r2 = *reinterpret_cast<const uint4*>(res + off + 2 * step); }
+    }
+    return;
+  }
   for (long i = i0; i < total; i += stride) {
     int cg; long m;
     split_vec(i, SCG, scg_sh, cg, m);
@@ -785,8 +832,9 @@ extern "C" int fs_bn_apply2(const FsBnApplyArgs* a, const FsBnApplyArgs* b, int 
   const int nslab = bn_slabs(a->C / vec);
   dim3 grid(std::min(grid_for(items / nslab), std::max(32, grid_for(1L << 40) / nslab)), nslab, G + G1);   // (the cap holds per launch)
   const unsigned lds = ((a->gamma2 || (b && b->gamma2)) ? 4u : 2u) * (a->C / nslab) * sizeof(float);
-  if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16>, grid, dim3(256), lds, st, d);
-  else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), lds, st, d);
+  static const int fast = [] { const char* e = getenv("FSNET_AMD_BN_FAST"); return e ? atoi(e) : 1; }();   // (0: A/B runs)
+  if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16>, grid, dim3(256), lds, st, d, fast);
+  else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), lds, st, d, fast);
   else return FS_EINVAL;
   return fs_launch_status();
 }
