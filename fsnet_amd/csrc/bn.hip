@@ -484,6 +484,170 @@ __device__ inline void pool_mask(const FsBnBwdArgs& p, const T* yv, long m, int 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// POOL mode by 2 x 2 pixel quads.  The per-pixel gather above (pool_grad) decodes four windows per pixel — two integer
+// divisions, eight gather loads and 128 compare / select operations per 16-byte vector: the stem's two backward passes ran
+// at 1.3-2.5 TB/s, bound by vector-ALU issue (ResNet-18, 36 images: 245 us of the step).  The quad (2a, 2b) .. (2a+1, 2b+1)
+// is reached by exactly the windows (a, b), (a, b+1), (a+1, b), (a+1, b+1): four window loads serve four pixels (nine
+// window-pixel matches instead of sixteen), the index arithmetic is per quad, and a quad IS a pooled position, so the
+// thread index decodes with the pooled sizes.  Same additions in the same order per pixel as pool_grad.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void pool_quad(const FsBnBwdArgs& p, long nn, int a, int b, int c, float g[4][VecN<T>::N]) {
+  constexpr int V = VecN<T>::N;
+  const int C = p.C, H = p.H, W = p.W, Ho = H >> 1, Wo = W >> 1;
+  const bool v01 = b + 1 < Wo, v10 = a + 1 < Ho;
+  const long base = ((nn * Ho + a) * Wo + b) * C + c;
+  const long o01 = v01 ? C : 0, o10 = v10 ? (long)Wo * C : 0;
+  const long off[4] = {base, base + o01, base + o10, base + o10 + o01};
+  const T* __restrict__ dy = reinterpret_cast<const T*>(p.pool_dy);
+  uint32_t pk[4][V / 4];
+  float t[4][V];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int e = 0; e < V / 4; ++e) pk[k][e] = reinterpret_cast<const uint32_t*>(p.pool_idx + off[k])[e];
+    loadv<T>(dy + off[k], t[k]);
+  }
+  if (p.dout) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      loadv<T>(reinterpret_cast<const T*>(p.dout) + ((nn * H + 2 * a + (k >> 1)) * W + 2 * b + (k & 1)) * C + c, g[k]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < V; ++j) g[k][j] = 0.f;
+  }
+  // pixel (dh, dw) at window (a + i, b + j) sits at row 2 dh' .. : code = r * 3 + s with r = dh + 1 - 2 i, s = dw + 1 - 2 j
+  auto add = [&](int pix, int win, int code, bool ok) {
+#pragma unroll
+    for (int j = 0; j < V; ++j)
+      if (ok && (int)((pk[win][j >> 2] >> (8 * (j & 3))) & 0xff) == code) g[pix][j] += t[win][j];
+  };
+  add(0, 0, 4, true);
+  add(1, 0, 5, true); add(1, 1, 3, v01);
+  add(2, 0, 7, true); add(2, 2, 1, v10);
+  add(3, 0, 8, true); add(3, 1, 6, v01); add(3, 2, 2, v10); add(3, 3, 0, v01 && v10);
+}
+
+// pass 1 of POOL mode: a thread owns one 16-byte channel lane of one quad per iteration
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const FsDual<FsBnBwdArgs, FsNoGeom> d) {
+  const int prob = (int)blockIdx.z >= d.nb0 ? 1 : 0;
+  const FsBnBwdArgs& p = d.a[prob];
+  constexpr int V = VecN<T>::N;
+  __shared__ float red[2][V][256];
+  const int C = p.C, CG = C / V, PL = 256 / CG;          // CG: a power of two <= 32 (host)
+  const int cgl = threadIdx.x % CG, pl = threadIdx.x / CG, c = cgl * V;
+  const T* __restrict__ yv = reinterpret_cast<const T*>(p.y);
+  const T* __restrict__ xv = reinterpret_cast<const T*>(p.x);
+  const int G = p.groups > 1 ? p.groups : 1;
+  const int z = (int)blockIdx.z - (prob ? d.nb0 : 0);
+  const int H = p.H, W = p.W, Ho = H >> 1, Wo = W >> 1;
+  const unsigned Qg = (unsigned)(p.M / G) / 4;           // quads of a statistics group (whole images)
+  float mean[V], istd[V], sc[V], sh[V], s1[V], s2[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    mean[j] = p.save_mean[z * C + c + j]; istd[j] = p.save_invstd[z * C + c + j];
+    sc[j] = p.gamma[c + j] * istd[j];
+    sh[j] = (p.beta ? p.beta[c + j] : 0.f) - mean[j] * sc[j];
+    s1[j] = 0.f; s2[j] = 0.f;
+  }
+  for (unsigned q = blockIdx.x * PL + pl; q < Qg; q += gridDim.x * PL) {
+    const unsigned qq = (unsigned)z * Qg + q, r = qq / (unsigned)Wo, nn = r / (unsigned)Ho;
+    const int b = (int)(qq - r * Wo), a = (int)(r - nn * Ho);
+    float g[4][V], x[4][V];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) loadv<T>(xv + (((long)nn * H + 2 * a + (k >> 1)) * W + 2 * b + (k & 1)) * C + c, x[k]);
+    pool_quad<T>(p, nn, a, b, c, g);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      pool_mask<T>(p, yv, ((long)nn * H + 2 * a + (k >> 1)) * W + 2 * b + (k & 1), c, x[k], sc, sh, g[k]);
+#pragma unroll
+      for (int j = 0; j < V; ++j) { s1[j] += g[k][j]; s2[j] += g[k][j] * (x[k][j] - mean[j]) * istd[j]; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) { red[0][j][threadIdx.x] = s1[j]; red[1][j][threadIdx.x] = s2[j]; }
+  __syncthreads();
+  if (pl < 2 * V && pl < PL) {
+    for (int kj = pl; kj < 2 * V; kj += PL) {
+      const int kind = kj / V, j = kj % V;
+      float acc = 0.f;
+      for (int k = 0; k < PL; ++k) acc += red[kind][j][k * CG + cgl];
+      double* sl = p.sums + ((long)z * FS_STAT_SLOTS + blockIdx.x % FS_STAT_SLOTS) * 2 * C;
+      atomicAdd(sl + kind * C + c + j, (double)acc);
+    }
+  }
+}
+
+// pass 2 of POOL mode
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const FsDual<FsBnBwdArgs, FsNoGeom> d) {
+  extern __shared__ float bn_smem[];
+  const int prob = (int)blockIdx.z >= d.nb0 ? 1 : 0;
+  const FsBnBwdArgs& p = d.a[prob];
+  constexpr int V = VecN<T>::N;
+  const int C = p.C, CG = C / V, PL = 256 / CG;
+  float* s_a = bn_smem; float* s_b = bn_smem + C; float* s_k = bn_smem + 2 * C;
+  float* s_mean = bn_smem + 3 * C; float* s_istd = bn_smem + 4 * C; float* s_sh = bn_smem + 5 * C;
+  const int G = p.groups > 1 ? p.groups : 1;
+  const int z = (int)blockIdx.z - (prob ? d.nb0 : 0);
+  const double* sums = p.sums + (long)z * FS_STAT_SLOTS * 2 * C;
+  const double* sums_local = p.sums_local ? p.sums_local + (long)z * FS_STAT_SLOTS * 2 * C : nullptr;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double sg = 0.0, sgx = 0.0, lg = 0.0, lgx = 0.0;
+#pragma unroll
+    for (int k = 0; k < FS_STAT_SLOTS; ++k) {
+      sg += sums[(long)k * 2 * C + c]; sgx += sums[(long)k * 2 * C + C + c];
+      if (sums_local) { lg += sums_local[(long)k * 2 * C + c]; lgx += sums_local[(long)k * 2 * C + C + c]; }
+    }
+    const float istd = p.save_invstd[z * C + c];
+    s_mean[c] = p.save_mean[z * C + c]; s_istd[c] = istd;
+    s_k[c] = p.gamma[c] * istd;
+    s_sh[c] = (p.beta ? p.beta[c] : 0.f) - s_mean[c] * s_k[c];     // the forward's shift
+    s_a[c] = (float)(sg / p.count);
+    s_b[c] = (float)(sgx / p.count);
+    if (blockIdx.x == 0) {
+      if (G > 1) {
+        if (p.dgamma) atomicAdd(p.dgamma + c, (float)(sums_local ? lgx : sgx));
+        if (p.dbeta) atomicAdd(p.dbeta + c, (float)(sums_local ? lg : sg));
+      } else {
+        if (p.dgamma) p.dgamma[c] += (float)(sums_local ? lgx : sgx);
+        if (p.dbeta) p.dbeta[c] += (float)(sums_local ? lg : sg);
+      }
+    }
+  }
+  __syncthreads();
+  const int cgl = threadIdx.x % CG, pl = threadIdx.x / CG, c = cgl * V;
+  const T* __restrict__ yv = reinterpret_cast<const T*>(p.y);
+  const T* __restrict__ xv = reinterpret_cast<const T*>(p.x);
+  T* __restrict__ dx = reinterpret_cast<T*>(p.dx);
+  const int H = p.H, W = p.W, Ho = H >> 1, Wo = W >> 1;
+  const unsigned Qg = (unsigned)(p.M / G) / 4;
+  for (unsigned q = blockIdx.x * PL + pl; q < Qg; q += gridDim.x * PL) {
+    const unsigned qq = (unsigned)z * Qg + q, r = qq / (unsigned)Wo, nn = r / (unsigned)Ho;
+    const int b = (int)(qq - r * Wo), a = (int)(r - nn * Ho);
+    float g[4][V], x[4][V];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) loadv<T>(xv + (((long)nn * H + 2 * a + (k >> 1)) * W + 2 * b + (k & 1)) * C + c, x[k]);
+    pool_quad<T>(p, nn, a, b, c, g);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long m = ((long)nn * H + 2 * a + (k >> 1)) * W + 2 * b + (k & 1);
+      pool_mask<T>(p, yv, m, c, x[k], s_k + c, s_sh + c, g[k]);
+      float o[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float xh = (x[k][j] - s_mean[c + j]) * s_istd[c + j];
+        o[j] = s_k[c + j] * (g[k][j] - s_a[c + j] - xh * s_b[c + j]);
+      }
+      storev<T>(dx + m * C + c, o);
+    }
+  }
+}
+
 // pass 1: per-channel sum(g), sum(g * xhat) with g = dout * (y > 0).  A block covers CGB channel groups
 // (16-byte lanes) x PL pixel lanes; two rows per iteration keep more loads in flight.
 template <typename T, int CGB, bool POOL = false>
@@ -729,6 +893,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const FsDual<FsBnBwdA
 // channel slabs of the element-wise passes: 32 16-byte groups each where a row has more (a power of two of them)
 int bn_slabs(int CG) { return (CG > 32 && (CG & (CG - 1)) == 0) ? CG / 32 : 1; }
 
+// POOL mode by quads: power-of-two lane counts up to 32 (the stems: 8 at bf16).  FSNET_AMD_BN_POOL_QUADS=0: per-pixel gather
+bool bn_pool_quads(int CG) {
+  static const bool on = [] { const char* e = getenv("FSNET_AMD_BN_POOL_QUADS"); return !(e && e[0] == '0'); }();
+  return on && CG >= 1 && CG <= 32 && (CG & (CG - 1)) == 0;
+}
+
 int grid_for(long items) {
   long b = (items + 255) / 256;
   // ~4 blocks per CU, each a grid-stride walk with the next vector in flight: the per-block coefficient preamble (8-64 KB
@@ -858,6 +1028,15 @@ extern "C" int fs_bn_bwd_reduce2(const FsBnBwdArgs* a, const FsBnBwdArgs* b, int
   long Mg = a->M / G;
   if (b) Mg = std::max<long>(Mg, b->M / G1);
   const FsDual<FsBnBwdArgs, FsNoGeom> d = bn_dual(a, b);
+  if (a->pool_dy && bn_pool_quads(CG)) {
+    long Qg = (a->M / G) / 4;
+    if (b) Qg = std::max<long>(Qg, (b->M / G1) / 4);
+    dim3 grid((unsigned)std::min<long>((Qg + 256 / CG - 1) / (256 / CG), 1024), 1, G + G1);
+    if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel<bf16>, grid, dim3(256), 0, st, d);
+    else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel<float>, grid, dim3(256), 0, st, d);
+    else return FS_EINVAL;
+    return fs_launch_status();
+  }
   // channel groups (16-byte lanes) per block: 32 for wide layers (8 pixel lanes), 8, or — for the 16 / 32-channel
   // decoder layers, whose 2 / 4 lanes would leave three quarters of an 8-lane block idle — 4 and 2
 #define LAUNCH_REDUCE(CGB, ROWS_PER_BLOCK, MAXB)                                                               \
@@ -905,6 +1084,16 @@ extern "C" int fs_bn_bwd_apply2(const FsBnBwdArgs* a, const FsBnBwdArgs* b, int 
   const unsigned lds = (a->pool_dy ? 6u : 5u) * (a->C / nslab) * sizeof(float);
   const FsDual<FsBnBwdArgs, FsNoGeom> d = bn_dual(a, b);
   static const int fast = [] { const char* e = getenv("FSNET_AMD_BN_FAST"); return e ? atoi(e) : 1; }();   // (0: A/B runs)
+  if (a->pool_dy && bn_pool_quads(a->C / vec)) {
+    const int CG = a->C / vec;
+    long Qg = (a->M / G) / 4;
+    if (b) Qg = std::max<long>(Qg, (b->M / G1) / 4);
+    dim3 qgrid((unsigned)std::min<long>((Qg + 256 / CG - 1) / (256 / CG), 2048), 1, G + G1);
+    if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(bn_bwd_apply_pool_kernel<bf16>, qgrid, dim3(256), lds, st, d);
+    else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(bn_bwd_apply_pool_kernel<float>, qgrid, dim3(256), lds, st, d);
+    else return FS_EINVAL;
+    return fs_launch_status();
+  }
   if (a->pool_dy) {
     if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, true>), grid, dim3(256), lds, st, d, 0);
     else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, true>), grid, dim3(256), lds, st, d, 0);
