@@ -37,6 +37,15 @@ for name, Ci, Co, st, H, W in SHAPES:
     tf = timeit(lambda: op.forward(x, out=y, stats=stats))
     tn = timeit(lambda: op.forward(x, out=y))
     td = timeit(lambda: op.dgrad(gy, H, W)) if st == 1 else float('nan')
+    tdf = float('nan')
+    if st == 1:     # the Bottleneck's conv1 data gradient: identity gradient added, previous block's ReLU mask and BatchNorm sums
+        from fsnet_amd.hip import ops
+        cprev, yprev, addend = torch.randn_like(x), torch.randn_like(x), torch.randn_like(x)
+        bst = ops.BnState(op.Ci_p, dev, 1)
+        bst.mean.normal_(0, 0.1); bst.invstd.uniform_(0.5, 1.5); bst.count = float(B * H * W)
+        sums = torch.zeros(8, 2, op.Ci_p, dtype=torch.float64, device=dev)
+        if op.can_fuse_bn_bwd(B, H, W, 1):
+            tdf = timeit(lambda: op.dgrad(gy, H, W, addend=addend, mask=yprev, bn_fuse=(cprev, bst, sums)))
     dw = torch.zeros(Co, Ci, 1, 1, device=dev)
     tw = timeit(lambda: op.wgrad(gy, x, dw))
-    print("%-16s %6.2f GF %6.1f MB | fwd %6.1f us %6.1f TF %5.2f TB/s | no stats %6.1f us | dgrad %6.1f us %6.1f TF | wgrad %6.1f us %6.1f TF" % (name, fl / 1e9, mb, tf * 1e6, fl / tf / 1e12, mb / tf / 1e6, tn * 1e6, td * 1e6, fl / td / 1e12, tw * 1e6, fl / tw / 1e12))
+    print("%-16s %6.2f GF %6.1f MB | fwd %6.1f us %6.1f TF %5.2f TB/s | no stats %6.1f us | dgrad %6.1f us %6.1f TF | dgrad+add+mask+bn %6.1f us | wgrad %6.1f us %6.1f TF" % (name, fl / 1e9, mb, tf * 1e6, fl / tf / 1e12, mb / tf / 1e6, tn * 1e6, td * 1e6, fl / td / 1e12, tdf * 1e6, tw * 1e6, fl / tw / 1e12))
