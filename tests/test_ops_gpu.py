@@ -112,6 +112,47 @@ def test_bn_forward_backward(dev, mode):
         assert torch.allclose(dg2.cpu(), g2.grad, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("N,C,H,W,dtype,res", [(4, 64, 160, 160, torch.bfloat16, True), (16, 1024, 20, 64, torch.float32, False),
+                                               (2, 2048, 10, 32, torch.bfloat16, True), (3, 512, 33, 47, torch.float32, True)])
+def test_bn_dense_fast_path_large_and_wide(dev, N, C, H, W, dtype, res):
+    """bn_apply / bn_bwd_apply on dense tensors large enough that a thread walks several rows (the fast path's ring of raw
+    operands two rows ahead) and wide enough for channel slabs (C > 32 16-byte groups: blockIdx.y), and bn_bwd_reduce on
+    the capped wide-row grid — against batch_norm + relu (+ residual) and its autograd (resnet.py:33-50, 70-89)."""
+    from fsnet_amd.hip import ops
+    g = torch.Generator().manual_seed(11 + C)
+    x = (torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3).to(dtype).float()
+    r = torch.randn(N, C, H, W, generator=g).to(dtype).float() if res else None
+    bn = bn_dict(C, g, dev)
+    xr = x.clone().requires_grad_(True)
+    gam = bn["weight"].cpu().clone().requires_grad_(True)
+    bet = bn["bias"].cpu().clone().requires_grad_(True)
+    out = F.batch_norm(xr, torch.zeros(C), torch.ones(C), gam, bet, training=True, momentum=0.1, eps=1e-5)
+    if res:
+        out = out + r
+    y_ref = F.relu(out)
+    gy = torch.randn(N, C, H, W, generator=g).to(dtype).float()
+    y_ref.backward(gy)
+    xd = nhwc(x).to(dev).to(dtype)
+    st = ops.BnState(C, dev)
+    y = torch.empty(N, H, W, C, device=dev, dtype=dtype)
+    kw = {"res": nhwc(r).to(dev).to(dtype)} if res else {}
+    ops.bn_apply(xd, stats_of(x).to(dev), bn, st, y, H, W, N * H * W, relu=True, **kw)
+    torch.cuda.synchronize()
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert (nchw(y) - y_ref.detach()).abs().max() <= tol * max(1.0, float(y_ref.detach().abs().max()))
+    dx = torch.empty(N, H, W, C, device=dev, dtype=dtype)
+    dgam, dbet = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    # (the mask comes from the reference's activation so that rounding of y at zero cannot flip a gradient)
+    yd = nhwc(y_ref.detach()).to(dev).to(dtype)
+    ops.bn_backward(nhwc(gy).to(dev).to(dtype), yd, xd, bn["weight"], st, dx, dgam, dbet, H, W, relu=True)
+    torch.cuda.synchronize()
+    sc = float(xr.grad.abs().max())
+    assert float((nchw(dx) - xr.grad).abs().max()) <= (2e-5 if dtype == torch.float32 else 2e-2) * sc + 1e-6
+    rt = 1e-4 if dtype == torch.float32 else 2e-2
+    assert torch.allclose(dgam.cpu(), gam.grad, rtol=rt, atol=rt * float(gam.grad.abs().max()))
+    assert torch.allclose(dbet.cpu(), bet.grad, rtol=rt, atol=rt * float(bet.grad.abs().max()))
+
+
 def test_bn_bf16_unit(dev):
     """bf16 storage of the BN input/output: errors stay at bf16 rounding level (no mask flips by construction:
     the oracle sees the same bf16-rounded conv output)."""
