@@ -14,6 +14,7 @@
 #include "lds_dma.h"
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 namespace {
 
@@ -224,15 +225,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const FsDual<FsWgradArg
   }
 }
 
+// Slab reductions take up to WG_MULTI problems per launch (blockIdx.z): the two problems of a shared launch — or, between
+// fs_wgrad_batch_begin() and fs_wgrad_batch_end(), the reductions of every weight gradient issued in between, grouped by
+// reduction kernel.  A ResNet-18 step has 57 of them at 5-9 us each (mostly ramp: 19 MB of slabs per 3x3 layer), a
+// ResNet-50 step 144; a hand-over batch of eight layers leaves two or three launches.
+constexpr int WG_MULTI = 8;
+struct WgMulti { FsWgradArgs a[WG_MULTI]; };
+
 // dw[co][ci][r][s] += sum_z workspace[z][co][col].  A block owns 64 consecutive columns of one row: 16 column quads x
 // 16 split lanes, every lane's 16-byte loads (slabs z, z + 16, ...) issued eight at a time — a 128-slab reduction is
 // ONE round of loads per thread (the 4-byte / four-in-flight version spent eight round trips: 10.9 us for 18.9 MB) —
 // then the 16 lanes combine through LDS.  (ncols and ws_cols are multiples of 4 by construction.)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const FsDual<FsWgradArgs, FsNoGeom> d, int eg) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgMulti d, int eg) {
   const FsWgradArgs& p = d.a[blockIdx.z];
   __shared__ float4 red[16][16];
   const int ncols = p.ncolgroups * eg;
   const int cblocks = (ncols + 63) / 64;
+  if ((int)blockIdx.x >= p.Co * cblocks) return;      // (a batch's grid is its largest item's)
   const int co = blockIdx.x / cblocks, cbase = (blockIdx.x % cblocks) * 64;
   const int q = threadIdx.x & 15, zl = threadIdx.x >> 4;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -281,11 +290,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const FsDual<FsWgradA
 // the same reduction for fewer than 32 slabs (the 16 split lanes of the kernel above would mostly idle: ResNet-50's 1x1
 // layers, 9-31 slabs, measured 13.1 us on this kernel against 15.2 on that one in the step): 64 consecutive columns x 4
 // split lanes per block, each lane strides the splits by 4 with independent (unrolled) loads, the 4 lanes combine through LDS.
-__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const FsDual<FsWgradArgs, FsNoGeom> d, int eg) {
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const WgMulti d, int eg) {
   const FsWgradArgs& p = d.a[blockIdx.z];
   __shared__ float red[4][64];
   const int ncols = p.ncolgroups * eg;
   const int cblocks = (ncols + 63) / 64;
+  if ((int)blockIdx.x >= p.Co * cblocks) return;
   const int co = blockIdx.x / cblocks, col = (blockIdx.x % cblocks) * 64 + (threadIdx.x & 63);
   const int zl = threadIdx.x >> 6;
   float acc = 0.f;
@@ -316,10 +326,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const FsDual<FsWgrad
 
 // few splits (deep stages: wide dW, 2-8 slabs): one thread per column, all slabs summed with independent loads —
 // the 4-lane kernel above would run 4x the blocks with most lanes idle
-__global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const FsDual<FsWgradArgs, FsNoGeom> d, int eg) {
+__global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const WgMulti d, int eg) {
   const FsWgradArgs& p = d.a[blockIdx.z];
   const int ncols = p.ncolgroups * eg;
   const int cblocks = (ncols + 255) / 256;
+  if ((int)blockIdx.x >= p.Co * cblocks) return;
   const int co = blockIdx.x / cblocks, col = (blockIdx.x % cblocks) * 256 + threadIdx.x;
   if (col >= ncols) return;
   const float* ws = p.workspace + (long)co * p.ws_cols + col;
@@ -341,10 +352,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const FsDual<FsW
 // 3x3 slabs in tap-major column order (col = tap*Cs + ci), few splits: a block owns one co x 32 ci x 9 taps.  It
 // reads nine 128-byte column segments per slab, transposes through LDS and adds into dW[co][ci][3][3] as ONE
 // contiguous 288-float run (the flat kernel's lanes hit dW with a 36-byte stride: 9x the lines per wave).
-__global__ __launch_bounds__(320) void wgrad_reduce3x3_kernel(const FsDual<FsWgradArgs, FsNoGeom> d, int Cs) {
+__global__ __launch_bounds__(320) void wgrad_reduce3x3_kernel(const WgMulti d, int eg) {
   const FsWgradArgs& p = d.a[blockIdx.z];
   __shared__ float tmp[288];
+  const int Cs = p.ncolgroups * eg / 9;
   const int co = blockIdx.y, ci0 = blockIdx.x * 32;
+  if (ci0 >= Cs || co >= p.Co) return;
   const int e = threadIdx.x;
   if (e < 288) {
     const int tap = e >> 5, j = e & 31;
@@ -372,26 +385,46 @@ __global__ __launch_bounds__(320) void wgrad_reduce3x3_kernel(const FsDual<FsWgr
   }
 }
 
+enum { RK_3X3 = 0, RK_FLAT = 1, RK_4 = 2, RK_16 = 3 };
+struct WgPending { FsWgradArgs a; int kind, eg, gx, gy; };
+thread_local bool g_batch = false;
+thread_local std::vector<WgPending>* g_pending = nullptr;
+
+void launch_reduce_group(const WgPending* it, int n, hipStream_t st) {
+  WgMulti d;
+  int gx = 1, gy = 1;
+  for (int i = 0; i < WG_MULTI; ++i) d.a[i] = it[i < n ? i : 0].a;
+  for (int i = 0; i < n; ++i) { gx = std::max(gx, it[i].gx); gy = std::max(gy, it[i].gy); }
+  const int eg = it[0].eg;
+  switch (it[0].kind) {
+    case RK_3X3: hipLaunchKernelGGL(wgrad_reduce3x3_kernel, dim3(gx, gy, n), dim3(320), 0, st, d, eg); break;
+    case RK_FLAT: hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3(gx, 1, n), dim3(256), 0, st, d, eg); break;
+    case RK_4: hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(gx, 1, n), dim3(256), 0, st, d, eg); break;
+    default: hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, 1, n), dim3(256), 0, st, d, eg); break;
+  }
+}
+
 // b: the launch's (filled-in) arguments; b2 != nullptr: the second problem's, same dW shape — one reduce launch for both
-// (blockIdx.z = problem).  A problem that was not split (nsplit == 1) accumulated into its dW directly.
-void launch_reduce(const FsWgradArgs& b, const FsWgradArgs* b2, int Co, int ncols, int eg, hipStream_t st) {
-  FsDual<FsWgradArgs, FsNoGeom> d;
-  d.g[0].unused = d.g[1].unused = 0; d.nb0 = 0;
+// (blockIdx.z = problem).  A problem that was not split (nsplit == 1) accumulated into its dW directly.  Inside a batch
+// (fs_wgrad_batch_begin) the reduction is queued instead: its slabs stay in the caller's workspace until the batch ends.
+void launch_reduce(const FsWgradArgs& b, const FsWgradArgs* b2, int Co, int ncols, int eg, hipStream_t st, bool always = false) {
+  WgPending it[2];
   int n = 0, ns = 0;
-  if (b.nsplit > 1) { d.a[n++] = b; ns = std::max(ns, b.nsplit); }
-  if (b2 && b2->nsplit > 1) { d.a[n++] = *b2; ns = std::max(ns, b2->nsplit); }
+  if (b.nsplit > 1 || always) { it[n++].a = b; ns = std::max(ns, b.nsplit); }
+  if (b2 && (b2->nsplit > 1 || always)) { it[n++].a = *b2; ns = std::max(ns, b2->nsplit); }
   if (n == 0) return;
-  if (n == 1) d.a[1] = d.a[0];
-  d.nprob = n;
   const bool tapmajor3x3 = b.R == 3 && b.S == 3 && ncols % 9 == 0 && (ncols / 9) % 32 == 0;
-  if (tapmajor3x3 && ns <= 16 && ncols >= 9 * 64)
-    hipLaunchKernelGGL(wgrad_reduce3x3_kernel, dim3((unsigned)(ncols / 9 / 32), (unsigned)Co, n), dim3(320), 0, st, d, ncols / 9);
-  else if (ns <= 8 && ncols >= 256)
-    hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)(Co * ((ncols + 255) / 256)), 1, n), dim3(256), 0, st, d, eg);
-  else if (ns < 32)
-    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)(Co * ((ncols + 63) / 64)), 1, n), dim3(256), 0, st, d, eg);
-  else
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(Co * ((ncols + 63) / 64)), 1, n), dim3(256), 0, st, d, eg);
+  int kind, gx, gy = 1;
+  if (tapmajor3x3 && ns <= 16 && ncols >= 9 * 64) { kind = RK_3X3; gx = ncols / 9 / 32; gy = Co; }
+  else if (ns <= 8 && ncols >= 256) { kind = RK_FLAT; gx = Co * ((ncols + 255) / 256); }
+  else if (ns < 32) { kind = RK_4; gx = Co * ((ncols + 63) / 64); }
+  else { kind = RK_16; gx = Co * ((ncols + 63) / 64); }
+  for (int i = 0; i < n; ++i) { it[i].kind = kind; it[i].eg = eg; it[i].gx = gx; it[i].gy = gy; }
+  if (g_batch && g_pending) {
+    for (int i = 0; i < n; ++i) g_pending->push_back(it[i]);
+    return;
+  }
+  launch_reduce_group(it, n, st);
 }
 
 // pixel splits of a launch shared by two problems: `total` slots divided in proportion to their work, at least one each
@@ -1141,15 +1174,7 @@ int launch_wgrad_stem(const FsWgradArgs& a, const FsWgradArgs* a2, hipStream_t s
   if (wg_plan(3, total, 256, slots)) return 0;
   hipLaunchKernelGGL(wgrad_stem_kernel, dim3(total), dim3(256), 0, st, d);
   // (the persistent blocks always leave slabs, also a single one)
-  {
-    FsDual<FsWgradArgs, FsNoGeom> r;
-    r.a[0] = b; r.a[1] = b2; r.g[0].unused = r.g[1].unused = 0; r.nb0 = 0; r.nprob = a2 ? 2 : 1;
-    const int ns = std::max(b.nsplit, a2 ? b2.nsplit : 0);
-    const int ncols = 49 * 8;
-    if (ns <= 8) hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)(a.Co * ((ncols + 255) / 256)), 1, r.nprob), dim3(256), 0, st, r, 8);
-    else if (ns < 32) hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)(a.Co * ((ncols + 63) / 64)), 1, r.nprob), dim3(256), 0, st, r, 8);
-    else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(a.Co * ((ncols + 63) / 64)), 1, r.nprob), dim3(256), 0, st, r, 8);
-  }
+  launch_reduce(b, a2 ? &b2 : nullptr, a.Co, 49 * 8, 8, st, true);
   return fs_launch_status();
 }
 
@@ -1493,4 +1518,37 @@ extern "C" int fs_conv_wgrad2_plan(const FsWgradArgs* args, const FsWgradArgs* a
   else if (dtype == FS_DTYPE_F32) r = launch_wgrad<float>(*args, a1, nullptr);
   g_plan = nullptr;
   return r;
+}
+
+// ---- batched slab reductions ----
+// Between begin and end (same host thread) every fs_conv_wgrad* call launches its main kernel and queues its reduction;
+// end launches the queued reductions on `stream`, grouped by reduction kernel, at most WG_MULTI problems per launch.  The
+// caller gives every call of the batch its own workspace (the slabs must survive until end) and issues the whole batch
+// on one stream.
+extern "C" int fs_wgrad_batch_begin(void) {
+  if (!g_pending) g_pending = new std::vector<WgPending>();
+  g_pending->clear();
+  g_batch = true;
+  return FS_OK;
+}
+
+extern "C" int fs_wgrad_batch_end(void* stream) {
+  if (!g_batch || !g_pending) return FS_EINVAL;
+  g_batch = false;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  std::vector<WgPending>& q = *g_pending;
+  std::vector<char> done(q.size(), 0);
+  for (size_t i = 0; i < q.size(); ++i) {
+    if (done[i]) continue;
+    WgPending grp[WG_MULTI];
+    int n = 0;
+    for (size_t j = i; j < q.size(); ++j) {
+      if (done[j] || q[j].kind != q[i].kind || q[j].eg != q[i].eg) continue;
+      grp[n++] = q[j]; done[j] = 1;
+      if (n == WG_MULTI) { launch_reduce_group(grp, n, st); n = 0; }
+    }
+    if (n) launch_reduce_group(grp, n, st);
+  }
+  q.clear();
+  return fs_launch_status();
 }

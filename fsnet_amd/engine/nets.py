@@ -15,7 +15,7 @@ import torch
 
 from ..hip import ops
 from ..hip.binding import raw_stream
-from ..hip.conv import ConvOp, run_specs
+from ..hip.conv import ConvOp, run_specs, wgrad_batch
 from .runtime import RT, grad_of
 
 STAT_SLOTS = ops.STAT_SLOTS
@@ -198,8 +198,10 @@ def flush_deferred(cur=None, spread=False):
             ws.wait_stream(chain)                   # one cross-stream edge per batch
             with torch.cuda.stream(ws):
                 sums = [] if CSUM_BATCH else None
-                for it in mine:
-                    _run_param_grads(*it, bias_later=sums)
+                with wgrad_batch() as wb:           # ... and the batch's slab reductions in two or three
+                    for it in mine:
+                        _run_param_grads(*it, bias_later=sums)
+                        wb.next_slot()
                 if sums:
                     ops.channel_sum_multi(sums)     # the batch's bias gradients in one launch
             _PENDING_JOIN.add((chain, ws))

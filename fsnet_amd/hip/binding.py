@@ -155,7 +155,7 @@ class FsSmoothArgs(C.Structure):
     ]
 
 
-ABI_VERSION = 8      # FS_ABI_VERSION of include/fsnet_hip.h (tests/test_abi.py holds the two together)
+ABI_VERSION = 9      # FS_ABI_VERSION of include/fsnet_hip.h (tests/test_abi.py holds the two together)
 _lib = None
 
 

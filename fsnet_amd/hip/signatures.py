@@ -22,6 +22,8 @@ SIGNATURES = {
     "fs_conv_stem2": (C.c_int, [P, P, I, P]),
     "fs_conv_wgrad2": (C.c_int, [P, P, I, P]),
     "fs_conv_wgrad2_plan": (C.c_int, [P, P, I, P]),
+    "fs_wgrad_batch_begin": (C.c_int, []),
+    "fs_wgrad_batch_end": (C.c_int, [P]),
     "fs_bn_apply2": (C.c_int, [P, P, I, P]),
     "fs_bn_bwd_reduce2": (C.c_int, [P, P, I, P]),
     "fs_bn_bwd_apply2": (C.c_int, [P, P, I, P]),

@@ -33,7 +33,7 @@ extern "C" {
 
 /* library/ABI version and the ISA the kernels were compiled for ("gfx950").  FS_ABI_VERSION changes whenever an
  * argument struct or a signature below does; a host binding refuses a library that reports another number. */
-#define FS_ABI_VERSION 8
+#define FS_ABI_VERSION 9
 int fs_abi_version(void);
 const char* fs_target_arch(void);
 /* debugging aid: writes the device's constant-rate clock (wall_clock64, 100 MHz) into *slot (u64) on `stream`;
@@ -234,6 +234,13 @@ int fs_conv_wgrad_plan(const FsWgradArgs* args, int dtype, int32_t* plan);
  * launch adds into both dW.  plan: blocks of the shared launch. */
 int fs_conv_wgrad2(const FsWgradArgs* a0, const FsWgradArgs* a1, int dtype, void* stream);
 int fs_conv_wgrad2_plan(const FsWgradArgs* a0, const FsWgradArgs* a1, int dtype, int32_t* plan);
+/* (ABI 9) Batched slab reductions.  The reference's optimizer step reads every parameter gradient only after the whole
+ * backward (scripts/train.py: loss.backward() ... optimizer.step()), so the split-K slabs of several weight gradients can be
+ * reduced together: between fs_wgrad_batch_begin() and fs_wgrad_batch_end(stream), on one host thread and one stream, every
+ * fs_conv_wgrad / fs_conv_wgrad2 call launches its main kernel and queues its reduction; _end launches the queued ones
+ * grouped by reduction kernel (up to eight problems per launch).  Every call of a batch needs a workspace of its own. */
+int fs_wgrad_batch_begin(void);
+int fs_wgrad_batch_end(void* stream);
 
 /* Weight packing.  OIHW fp32 master weights (the reference's state_dict layout,
  * e.g. depth_backbone.conv1.weight (64,3,7,7)) -> [rows_p][ktot_p] K-contiguous
