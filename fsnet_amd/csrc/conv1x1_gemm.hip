@@ -38,11 +38,14 @@ struct GemmCfg {
   static constexpr int LDS = WORK + 4 * CO * 2 * 4;    // + the waves' statistics sums [4][CO][2] fp32
 };
 
-// NST: K stages resident in LDS (NST - 1 in flight while one is multiplied)
-template <int CO, int PIX, int NST>
-__global__ __launch_bounds__(256, NST == 2 && PIX == 128 ? 4 : 2) void conv1x1_gemm_kernel(const FsConvArgs p, const FsDiv dW, const FsDiv dH,
+// NST: K stages resident in LDS (NST - 1 in flight while one is multiplied).  EPI: 0 the forward's epilogue (bias, addend, ReLU,
+// output statistics), 1 the data gradient's (addend, ReLU-backward mask, BatchNorm-backward sums: no bias, no ReLU — the
+// operands of the NEXT pixel row are requested before the current row is processed), 2 every option (the first version).
+template <int CO, int PIX, int NST, int EPI>
+__global__ __launch_bounds__(256, NST == 2 && PIX == 128 ? (EPI == 1 ? 3 : 4) : 2) void conv1x1_gemm_kernel(const FsConvArgs p, const FsDiv dW, const FsDiv dH,
                                                                const int nco, const int pt) {
   using G = GemmCfg<CO, PIX, NST>;
+  constexpr bool FWD = EPI == 0, DGR = EPI == 1;
   constexpr int WPIX = G::WPIX, TP = G::TP, TC = G::TC, STAGE = G::STAGE, OROW = G::OROW, OSTG = G::OSTG, HC = G::HC;
   constexpr int NLP = WPIX / 16, NLW = CO / 64;        // load instructions per wave and stage: pixels, weights
   constexpr int LPS = NLP + NLW;
@@ -165,14 +168,18 @@ __global__ __launch_bounds__(256, NST == 2 && PIX == 128 ? 4 : 2) void conv1x1_g
   for (int h = 0; h < NH; ++h) {
     const int co = co0 + h * HC + u * 8;
     const bool cok = co < p.Co;
-    float bias[8], mu[8], is[8], s1[8], s2[8];
+    float bias[DGR ? 1 : 8], mu[FWD ? 1 : 8], is[FWD ? 1 : 8], s1[8], s2[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { bias[j] = 0.f; mu[j] = 0.f; is[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; }
-    if (cok && p.bias) {
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < (DGR ? 1 : 8); ++j) bias[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < (FWD ? 1 : 8); ++j) { mu[j] = 0.f; is[j] = 0.f; }
+    if constexpr (!DGR) if (cok && p.bias) {
       const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co), b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
       bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w; bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
     }
-    if (cok && p.bnb_x) {
+    if constexpr (!FWD) if (cok && p.bnb_x) {
       const float4 m0 = *reinterpret_cast<const float4*>(p.bnb_mean + sgoff + co), m1 = *reinterpret_cast<const float4*>(p.bnb_mean + sgoff + co + 4);
       const float4 i0 = *reinterpret_cast<const float4*>(p.bnb_invstd + sgoff + co), i1 = *reinterpret_cast<const float4*>(p.bnb_invstd + sgoff + co + 4);
       mu[0] = m0.x; mu[1] = m0.y; mu[2] = m0.z; mu[3] = m0.w; mu[4] = m1.x; mu[5] = m1.y; mu[6] = m1.z; mu[7] = m1.w;
@@ -191,6 +198,68 @@ __global__ __launch_bounds__(256, NST == 2 && PIX == 128 ? 4 : 2) void conv1x1_g
         }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      if constexpr (DGR) {
+        // one row ahead: the (up to three) 16-byte operands of row i + 1 are in flight while row i is processed.  A row
+        // outside the problem reads element 0 and neither stores nor counts.
+        uint4 ea = make_uint4(0, 0, 0, 0), em = ea, ex = ea;
+        long doff = 0;
+        bool ok = false;
+        auto request = [&](int i, uint4& qa, uint4& qm, uint4& qx, long& qoff, bool& qok) {
+          const int m = pix0 + wave * WPIX + b * 32 + i * 8 + pr;
+          qok = m < p.M && cok;
+          const int mm = qok ? m : 0, cc = qok ? co : 0;
+          int qd = fs_div(mm, dW); int x = mm - qd * p.Wd; int n = fs_div(qd, dH); int y = qd - n * p.Hd; n += n0;
+          qoff = (long)n * p.dN + (long)y * p.dH + (long)x * p.dW + cc;
+          if (p.addend) qa = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p.addend) + (long)n * p.aN + (long)y * p.aH + (long)x * p.aW + cc);
+          if (p.mask) qm = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p.mask) + (long)n * p.mN + (long)y * p.mH + (long)x * p.mW + cc);
+          if (p.bnb_x) qx = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p.bnb_x) + qoff);
+        };
+        request(0, ea, em, ex, doff, ok);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          uint4 na = make_uint4(0, 0, 0, 0), nm = na, nx = na;
+          long noff = 0;
+          bool nok = false;
+          if (i + 1 < 4) request(i + 1, na, nm, nx, noff, nok);
+          const int prow = i * 8 + pr;
+          const float4 v0 = *reinterpret_cast<const float4*>(stg + prow * OROW + u * 32);
+          const float4 v1 = *reinterpret_cast<const float4*>(stg + prow * OROW + u * 32 + 16);
+          float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+          if (p.addend) {
+            float av[8];
+            Unit<bf16>::unpack(ea, av);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += av[j];
+          }
+          if (p.mask) {
+            float mv[8];
+            Unit<bf16>::unpack(em, mv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = mv[j] > 0.f ? v[j] : 0.f;
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = ok ? v[j] : 0.f;
+          if (p.bnb_x) {
+            float cv[8];
+            Unit<bf16>::unpack(ex, cv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] += v[j] * (cv[j] - mu[j]) * is[j]; }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+          }
+          if (ok) {
+            if (p.out_f32) {
+              float* dst = reinterpret_cast<float*>(p.dst) + doff;
+              *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+              *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+              *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.dst) + doff) = Unit<bf16>::pack(v);
+            }
+          }
+          ea = na; em = nm; ex = nx; doff = noff; ok = nok;
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int prow = i * 8 + pr;
@@ -213,17 +282,23 @@ __global__ __launch_bounds__(256, NST == 2 && PIX == 128 ? 4 : 2) void conv1x1_g
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
         }
-        if (p.mask) {
-          float mv[8];
-          loadv<bf16>(reinterpret_cast<const bf16*>(p.mask) + (long)n * p.mN + (long)y * p.mH + (long)x * p.mW + co, mv);
+        if constexpr (!FWD) {
+          if (p.mask) {
+            float mv[8];
+            loadv<bf16>(reinterpret_cast<const bf16*>(p.mask) + (long)n * p.mN + (long)y * p.mH + (long)x * p.mW + co, mv);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = mv[j] > 0.f ? v[j] : 0.f;
+            for (int j = 0; j < 8; ++j) v[j] = mv[j] > 0.f ? v[j] : 0.f;
+          }
         }
-        if (p.bnb_x) {
-          float cv[8];
-          loadv<bf16>(reinterpret_cast<const bf16*>(p.bnb_x) + doff, cv);
+        bool bnb = false;
+        if constexpr (!FWD) bnb = p.bnb_x != nullptr;
+        if (bnb) {
+          if constexpr (!FWD) {
+            float cv[8];
+            loadv<bf16>(reinterpret_cast<const bf16*>(p.bnb_x) + doff, cv);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] += v[j] * (cv[j] - mu[j]) * is[j]; }
+            for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] += v[j] * (cv[j] - mu[j]) * is[j]; }
+          }
         } else {
 #pragma unroll
           for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
@@ -235,6 +310,7 @@ __global__ __launch_bounds__(256, NST == 2 && PIX == 128 ? 4 : 2) void conv1x1_g
         } else {
           storev<bf16>(reinterpret_cast<bf16*>(p.dst) + doff, v);
         }
+      }
       }
     }
     if (p.stats) {
@@ -274,8 +350,8 @@ __global__ __launch_bounds__(256, NST == 2 && PIX == 128 ? 4 : 2) void conv1x1_g
   }
 }
 
-template <int CO, int PIX, int NST>
-int launch_gemm(const FsConvArgs& a, hipStream_t st) {
+template <int CO, int PIX, int NST, int EPI>
+int launch_gemm_epi(const FsConvArgs& a, hipStream_t st) {
   const int npix = (a.M + PIX - 1) / PIX, nco = (a.Co_p + CO - 1) / CO;
   const int z = a.grp_imgs > 0 ? a.N / a.grp_imgs : 1;
   // pixel tiles per block: only where statistics are summed, while >= 1024 blocks (one round of four per CU) remain,
@@ -288,9 +364,21 @@ int launch_gemm(const FsConvArgs& a, hipStream_t st) {
   }
   const int nsp = (npix + pt - 1) / pt;
   const int blocks = 8 * ((nsp + 7) / 8) * nco;
-  hipLaunchKernelGGL((conv1x1_gemm_kernel<CO, PIX, NST>), dim3(blocks, 1, z), dim3(256), 0, st, a, fs_make_div(a.Wd),
+  hipLaunchKernelGGL((conv1x1_gemm_kernel<CO, PIX, NST, EPI>), dim3(blocks, 1, z), dim3(256), 0, st, a, fs_make_div(a.Wd),
                      fs_make_div(a.Hd), nco, pt);
   return fs_launch_status();
+}
+
+// epilogue specialisation (128-pixel tiles; the 256-pixel probe configuration keeps the general epilogue)
+template <int CO, int PIX, int NST>
+int launch_gemm(const FsConvArgs& a, hipStream_t st) {
+  static const int f_epi = [] { const char* e = getenv("FSNET_AMD_1X1_EPI"); return e ? atoi(e) : -1; }();   // (2: A/B runs)
+  if constexpr (PIX == 128) {
+    const bool dgr = (a.mask || a.bnb_x) && !a.bias && !a.relu, fwd = !a.mask && !a.bnb_x;
+    if (f_epi != 2 && dgr) return launch_gemm_epi<CO, PIX, NST, 1>(a, st);
+    if (f_epi != 2 && fwd) return launch_gemm_epi<CO, PIX, NST, 0>(a, st);
+  }
+  return launch_gemm_epi<CO, PIX, NST, 2>(a, st);
 }
 
 // Measured per ResNet-50 shape at 320x1024 (tools/probes/conv1x1_shapes.py): 128-pixel tiles with two stages (35 KB of
