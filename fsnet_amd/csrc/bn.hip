@@ -651,7 +651,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const FsDual<FsB
 // pass 1: per-channel sum(g), sum(g * xhat) with g = dout * (y > 0).  A block covers CGB channel groups
 // (16-byte lanes) x PL pixel lanes; two rows per iteration keep more loads in flight.
 template <typename T, int CGB, bool POOL = false>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const FsDual<FsBnBwdArgs, FsNoGeom> d) {
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const FsDual<FsBnBwdArgs, FsNoGeom> d, const int fast) {
   const int prob = (int)blockIdx.z >= d.nb0 ? 1 : 0;
   const FsBnBwdArgs& p = d.a[prob];
   constexpr int V = VecN<T>::N;
@@ -708,6 +708,42 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const FsDual<FsBnBwd
   if (act) {
     const long stride = (long)gridDim.x * PL;
     long m = z * Mg + (long)blockIdx.x * PL + pl;
+    const long hw = (long)p.H * p.W;
+    if (fast && !p.fold && p.gW == C && p.gH == (long)p.W * C && p.gN == hw * C &&
+        (!p.relu || (p.yW == C && p.yH == (long)p.W * C && p.yN == hw * C))) {
+      // dense tensors: raw operands of two later rows in flight while the current row is summed (bn_bwd_apply_kernel)
+      const bool relu = p.relu != 0;
+      long left = m < m_end ? (m_end - m + stride - 1) / stride : 0;
+      long off = m * C + c;
+      const long step = stride * C;
+      uint4 d0, x0, y0, d1, x1, y1, d2, x2, y2;
+      d0 = x0 = y0 = d1 = x1 = y1 = d2 = x2 = y2 = make_uint4(0, 0, 0, 0);
+      auto req = [&](long o, uint4& dd, uint4& xx, uint4& yy) {
+        dd = *reinterpret_cast<const uint4*>(dout + o); xx = *reinterpret_cast<const uint4*>(xv + o);
+        if (relu) yy = *reinterpret_cast<const uint4*>(yv + o);
+      };
+      if constexpr (sizeof(T) == 2) {
+        if (left > 0) req(off, d0, x0, y0);
+        if (left > 1) req(off + step, d1, x1, y1);
+        if (left > 2) req(off + 2 * step, d2, x2, y2);
+        while (left > 0) {
+          float g[V], xr[V];
+          Unit<T>::unpack(d0, g); Unit<T>::unpack(x0, xr);
+          if (relu) {
+            float yy[V];
+            Unit<T>::unpack(y0, yy);
+#pragma unroll
+            for (int j = 0; j < V; ++j) g[j] = yy[j] > 0.f ? g[j] : 0.f;
+          }
+          d0 = d1; x0 = x1; y0 = y1; d1 = d2; x1 = x2; y1 = y2;
+          --left; off += step;
+          if (left > 2) req(off + 2 * step, d2, x2, y2);
+#pragma unroll
+          for (int j = 0; j < V; ++j) { s1[j] += g[j]; s2[j] += g[j] * (xr[j] - mean[j]) * istd[j]; }
+        }
+        m = m_end;       // (nothing left for the generic loops below)
+      }
+    }
     for (; m + stride < m_end; m += 2 * stride) {
       float g0[V], g1[V], x0[V], x1[V];
       masked_grad<T>(p, dout, yv, m, c, g0);
@@ -1043,14 +1079,15 @@ extern "C" int fs_bn_bwd_reduce2(const FsBnBwdArgs* a, const FsBnBwdArgs* b, int
   {                                                                                                             \
     dim3 grid((unsigned)std::min<long>((Mg + (ROWS_PER_BLOCK) - 1) / (ROWS_PER_BLOCK), MAXB), (CG + CGB - 1) / CGB, G + G1); \
     if (a->pool_dy) {                                                                                           \
-      if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, CGB, true>), grid, dim3(256), 0, st, d);  \
-      else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, CGB, true>), grid, dim3(256), 0, st, d); \
+      if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, CGB, true>), grid, dim3(256), 0, st, d, 0);  \
+      else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, CGB, true>), grid, dim3(256), 0, st, d, 0); \
       else return FS_EINVAL;                                                                                    \
     } else                                                                                                      \
-    if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, CGB>), grid, dim3(256), 0, st, d);  \
-    else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, CGB>), grid, dim3(256), 0, st, d); \
+    if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, CGB>), grid, dim3(256), 0, st, d, rfast);  \
+    else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, CGB>), grid, dim3(256), 0, st, d, rfast); \
     else return FS_EINVAL;                                                                                      \
   }
+  static const int rfast = [] { const char* e = getenv("FSNET_AMD_BN_FAST"); return e ? atoi(e) : 1; }();
   // (wide rows: every block ends in 2 x 256 f64 atomics and a block-wide fold — hold the grid near 1024 blocks)
   const long wide_cap = std::max<long>(32, std::min<long>(512, 1024 / ((long)((CG + 31) / 32) * (G + G1))));
   if (CG >= 32) LAUNCH_REDUCE(32, 16, wide_cap)
