@@ -5,18 +5,21 @@
 // and a third of that step.  The row-streaming kernel (conv1x1.hip) reads its pixel operand in MFMA-fragment shape
 // (16 rows x 64 bytes per load instruction: half-used cache lines, every pixel row re-read by each 64-channel tile) and
 // multiplies 64 x 32 wave tiles whose weight fragments alone saturate the LDS; it ran at 50-200 TFLOP/s.  Here:
-//   * block tile PIX x CO = 256 (128) pixels x 128 (64) channels, four waves splitting the pixels; a wave multiplies
-//     64 x 128 with v_mfma_f32_32x32x16_bf16 (six 16-byte fragment reads per eight MFMAs);
-//   * both operands go global -> LDS by `buffer_load_dwordx4 ... lds` (no staging registers, whole 64-byte row pieces
-//     per four lanes, out-of-range rows read as zero), two 32-channel K stages in flight, one barrier per stage; the
-//     LDS image is lane-linear, so the 16-byte units of a row are XOR-permuted on the SOURCE side and un-permuted by
-//     the fragment read ((row >> 2) & 3: the four 16-lane groups of a ds_read_b128 then hit 64 distinct banks);
-//   * the epilogue transposes the accumulators through LDS (fp32, per wave) so that every global access of the
-//     epilogue — addend, ReLU-backward mask, BatchNorm-backward operand, the store — is a 16-byte piece of a
-//     contiguous pixel row (the fragment layout gives 8-byte pieces of 32 different rows);
+//   * block tile PIX x CO = 128 pixels x 128 (64) channels (256-pixel tiles: a probe configuration, measured no better),
+//     four waves splitting the pixels; a wave multiplies its 32 pixels x all channels with v_mfma_f32_32x32x16_bf16;
+//   * both operands go global -> LDS by `buffer_load_dwordx4 ... lds` (lds_dma.h: no staging registers, whole 64-byte row
+//     pieces per four lanes, out-of-range rows read as zero), a ring of two (K = 2048: three) 32-channel K stages, one
+//     barrier per stage; the LDS image is lane-linear, so the 16-byte units of a row are XOR-permuted on the SOURCE side
+//     and un-permuted by the fragment read ((row >> 2) & 3: the four 16-lane groups of a ds_read_b128 then hit 64
+//     distinct banks); 35 KB of LDS and <= 128 registers: four blocks per CU, whose load / multiply / store phases overlap;
+//   * the epilogue transposes the accumulators through LDS (fp32, per wave, 64 channels per pass) so that every global
+//     access of the epilogue — addend, ReLU-backward mask, BatchNorm-backward operand, the store — is a 16-byte piece of
+//     a contiguous pixel row (the fragment layout gives 8-byte pieces of 32 different rows); it is compiled per mode
+//     (EPI: forward / data gradient / general), the data gradient's requesting the next row's operands a row ahead;
+//   * a block walks several pixel tiles where BatchNorm sums are carried and adds them with one round of f64 atomics;
 //   * channel tiles of one pixel tile run back to back on one XCD, so the pixel rows come from HBM once.
 // Epilogue semantics are conv1x1.hip's / conv_igemm.hip's (bias, addend, ReLU, mask, BatchNorm statistics or
-// backward sums with statistics groups, fp32 output).
+// backward sums with statistics groups, fp32 output).  Measurements: DESIGN section 18.
 #include <algorithm>
 #include <cstdlib>
 #include "common.h"
