@@ -937,12 +937,14 @@ bool bn_pool_quads(int CG) {
 
 int grid_for(long items) {
   long b = (items + 255) / 256;
-  // ~4 blocks per CU, each a grid-stride walk with the next vector in flight: the per-block coefficient preamble (8-64 KB
-  // of f64 sums re-read by EVERY block) is then paid 1 024 times per launch instead of once per 256 vectors — with one
-  // vector per thread it moved more bytes than the tensor on the deep layers.  Measured on the step (cap 4096 / 1536 /
-  // 1024 / 768 / 512): ResNet-18 B=12 5.75 / 5.71 / 5.65 / 5.66 / 5.67 ms, ResNet-50 @320x1024 27.7 / 26.1 / 25.8 / 25.8 /
-  // 25.8 (256: 26.9), fisheye 6.63 / - / 6.53.  FSNET_AMD_BN_GRID overrides (development).
-  static const long cap = getenv("FSNET_AMD_BN_GRID") ? atol(getenv("FSNET_AMD_BN_GRID")) : 1024;
+  // ~2 blocks per CU, each a walk over many rows: the per-block coefficient preamble (8-64 KB of f64 sums re-read by EVERY
+  // block) is then paid 512 times per launch instead of once per 256 vectors — with one vector per thread it moved more
+  // bytes than the tensor on the deep layers.  Measured on the step with the generic loop (cap 4096 / 1536 / 1024 / 768 /
+  // 512): ResNet-18 B=12 5.75 / 5.71 / 5.65 / 5.66 / 5.67 ms, ResNet-50 @320x1024 27.7 / 26.1 / 25.8 / 25.8 / 25.8; again with
+  // the dense fast path, whose threads keep two rows in flight (cap 2048 / 1024 / 768 / 512 / 384 / 256, same box each):
+  // ResNet-18 5.67 / 5.62 / - / 5.54 and 5.76 / 5.72 / 5.74 / 5.77, ResNet-50 20.65 / 20.09 / - / 19.89 and
+  // 20.44 / 20.41 / 20.43 / 20.58.  FSNET_AMD_BN_GRID overrides (development).
+  static const long cap = getenv("FSNET_AMD_BN_GRID") ? atol(getenv("FSNET_AMD_BN_GRID")) : 512;
   if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (int)b;
