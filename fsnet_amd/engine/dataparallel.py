@@ -116,6 +116,9 @@ class DataParallelContext:
         return ent[1]
 
     def _reduce_range(self, arena, lo, hi):
+        if arena.grad.is_cuda:
+            from .nets import flush_inline_bias
+            flush_inline_bias(torch.cuda.current_stream(arena.grad.device))   # bias sums collected along this chain
         if hi <= lo:
             return
         self.n_bucket += 1

@@ -131,6 +131,31 @@ def _run_param_grads(*item, bias_later=None):
                 ops.channel_sum(dc, gb, nb)
 
 
+_INLINE_BIAS = {}       # chain stream id -> (chain stream, [(dc, gb, nb)]): bias sums of inline weight gradients not yet issued
+
+
+def _inline_bias_list(dev):
+    """data parallel: the weight gradients run inline on their chain — their bias sums are still collected and issued as
+    one launch per gradient bucket (flush_inline_bias from DataParallelContext._reduce_range) instead of one per layer
+    (18 launches of ~10 us on the decoders' chains: tools/probes/dp_world1.py)"""
+    if not (CSUM_BATCH and RT.dp is not None and dev.type == "cuda"):
+        return None
+    cur = _current_stream(dev)
+    return _INLINE_BIAS.setdefault(cur.cuda_stream, (cur, []))[1]
+
+
+def flush_inline_bias(cur=None):
+    """issue the collected bias sums of chain stream `cur` (default: every chain) on their chain"""
+    for key in ([cur.cuda_stream] if cur is not None else list(_INLINE_BIAS.keys())):
+        ent = _INLINE_BIAS.get(key)
+        if ent is None or not ent[1]:
+            continue
+        chain, items = ent
+        with torch.cuda.stream(chain):
+            ops.channel_sum_multi(items)
+        items.clear()
+
+
 def accumulate_param_grads_multi(cls, ops_, dcs, xs, pros):
     """ConvLayer.accumulate_param_grads for the same layer of the lanes of an EncoderPass: the lanes whose weights are
     trained share one weight-gradient launch (deferred to the companion stream like a single layer's)"""
@@ -151,7 +176,7 @@ def accumulate_param_grads_multi(cls, ops_, dcs, xs, pros):
     if mode:
         _defer_param_grads(_current_stream(dc0.device), item)
         return
-    _run_param_grads(*item)
+    _run_param_grads(*item, bias_later=_inline_bias_list(dc0.device))
 
 
 def _defer_param_grads(cur, item):
@@ -211,6 +236,7 @@ def flush_deferred(cur=None, spread=False):
 
 def _end_of_backward():
     _CALLBACK_QUEUED[0] = None
+    flush_inline_bias()
     flush_deferred()
     _ACTIVE_CHAINS.clear()
     join_companions()
@@ -233,6 +259,7 @@ def join_companions():
 
 def join_companions_final():
     """the current stream waits for every companion with work in flight (before the optimizer reads gradients)"""
+    flush_inline_bias()
     flush_deferred()
     if not _PENDING_JOIN:
         return
@@ -408,7 +435,7 @@ class ConvLayer:
         if mode:
             _defer_param_grads(_current_stream(dc.device), item)
             return
-        _run_param_grads(*item)
+        _run_param_grads(*item, bias_later=_inline_bias_list(dc.device))
 
 
 def bn_tensors(bn):
