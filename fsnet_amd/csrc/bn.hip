@@ -983,19 +983,22 @@ int bn_apply_check(const FsBnApplyArgs* a) {
 }
 int bn_bwd_check(const FsBnBwdArgs* a, bool apply) {
   if (!a || (!a->dout && !a->pool_dy) || !a->x || !a->sums || !a->save_mean || !a->save_invstd) return FS_EINVAL;
+  // common to both paths: channel tiling, the LDS table's extent, statistics groups, what the second pass writes
+  if (apply && (!a->dx || !a->gamma)) return FS_EINVAL;
+  if (a->C % 8 != 0 || a->C > MAXC || a->M <= 0) return FS_EINVAL;
+  const int G = a->groups > 1 ? a->groups : 1;
+  if (a->M % G != 0) return FS_EINVAL;
   if (a->pool_dy) {
     if (!a->pool_idx || !a->gamma || a->fold || a->g_out || a->H <= 0 || a->W <= 0 || (a->H & 1) || (a->W & 1)) return FS_EINVAL;
     if (a->relu && !a->y && !a->beta) return FS_EINVAL;
-    if (a->M % (a->H * a->W) != 0 || (long)a->M >= 0x7fffffffL) return FS_EINVAL;
     const long hw = (long)a->H * a->W;
+    // (a statistics group is a whole number of images: the quad mode walks 2x2 windows of one image)
+    if (a->M % hw != 0 || (a->M / G) % hw != 0 || (long)a->M >= 0x7fffffffL) return FS_EINVAL;
     if (a->dout && !(a->gW == a->C && a->gH == (long)a->W * a->C && a->gN == hw * a->C)) return FS_EINVAL;
     if (a->y && !(a->yW == a->C && a->yH == (long)a->W * a->C && a->yN == hw * a->C)) return FS_EINVAL;
     return FS_OK;
   }
-  if (apply && (!a->dx || !a->gamma)) return FS_EINVAL;
-  if (a->C % 8 != 0 || a->C > MAXC || a->M <= 0 || (a->relu && !a->y)) return FS_EINVAL;
-  const int G = a->groups > 1 ? a->groups : 1;
-  if (a->M % G != 0) return FS_EINVAL;
+  if (a->relu && !a->y) return FS_EINVAL;
   return FS_OK;
 }
 template <typename A>

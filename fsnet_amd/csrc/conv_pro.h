@@ -81,6 +81,8 @@ __device__ inline void pro_block0(const FsConvArgs& p, int t, int nt) {
 
 // argument checks shared by the two kernels' entry points
 inline bool pro_args_ok(const FsConvArgs& a) {
+  // (retired slots of the round 3-4 backward prologue: header rule — they stay NULL whatever the mode)
+  if (a.pro_c || a.pro_m || a.pro_src2 || a.pro_stats_local || a.pro_dgamma || a.pro_dbeta || a.pro_dst) return false;
   if (a.pro_mode == 0) return true;
   if (a.pro_mode != 1) return false;
   // (the coefficient table is dynamic LDS on top of 38-78 KB of static LDS: 2 floats per source channel; the widest 3x3

@@ -38,6 +38,7 @@ class DataParallelContext:
         self._expected = {}        # id(module) -> module: ran a training forward in this step
         self._synced = False
         self.n_small = self.n_bucket = 0   # collectives issued in the current step (bench.py reports them at N > 1)
+        self.encoder_pass_ms = None        # the training hook's autotune result (two chains / two lanes), once it has run
         self._pg = group if group is not None else dist.distributed_c10d._get_default_group()
         self._sum = dist.AllreduceOptions()
         self._sum.reduceOp = dist.ReduceOp.SUM
@@ -47,6 +48,10 @@ class DataParallelContext:
         self._comm_stream = None
         self._graph_owners = []    # weak references to hooks whose captured step contains this communicator's nodes
         self.capturable = False
+        # weight gradients on the chains' companion streams as in the single-GPU step (a bucket's all-reduce then waits for
+        # the chain and for the companions holding its work), or inline on the chain
+        self.wgrad_companions = os.environ.get("FSNET_AMD_DP_WGRAD", "inline") == "companion"
+        self.pack_overlap = os.environ.get("FSNET_AMD_DP_PACK_OVERLAP", "1") != "0"
         if self._direct is not None:
             from .runtime import RT
             self._comm_stream = RT.new_stream(self._direct.device)
@@ -103,6 +108,9 @@ class DataParallelContext:
         self._done = {}
         self._expected = {}
         self.n_small = self.n_bucket = 0
+        # bias sums a backward that raised left behind would be flushed into this step's freshly zeroed gradients
+        from .nets import drop_inline_bias
+        drop_inline_bias()
 
     def note_forward(self, module):
         """a network ran a training forward: its gradients must be reduced before finish()"""
@@ -128,6 +136,11 @@ class DataParallelContext:
             # picks up from there, the chain goes on with the rest of the backward
             cur = torch.cuda.current_stream(g.device)
             self._comm_stream.wait_stream(cur)
+            if self.wgrad_companions:
+                from .nets import flush_deferred, pending_companions
+                flush_deferred(cur)                  # what the chain still holds goes to its companion now
+                for ws in pending_companions():
+                    self._comm_stream.wait_stream(ws)
             with torch.cuda.stream(self._comm_stream):
                 self._direct.all_reduce_sum(g)
             return
@@ -178,8 +191,18 @@ class DataParallelContext:
         watchdog to poll, valid for any backend."""
         if self._agreement is None:
             from .rccl_direct import StoreAgreement
-            self._agreement = self._direct.agreement if self._direct is not None else StoreAgreement(self.group)
+            own = self._direct.agreement if self._direct is not None else None
+            self._agreement = own if own is not None else StoreAgreement(self.group)
         return self._agreement.all_agree(ok)
+
+    def gather_floats(self, values):
+        """[[rank 0's values], [rank 1's], ...] on every rank, through the store (no collective: callable between steps
+        whatever the transport)"""
+        import struct
+        if self._agreement is None:
+            self.all_agree(True)          # (creates the agreement object; every rank takes this branch together)
+        blobs = self._agreement.gather(struct.pack("<%dd" % len(values), *[float(v) for v in values]))
+        return [list(struct.unpack("<%dd" % len(values), b)) for b in blobs]
 
     def reset_direct(self):
         """after a capture that failed on some rank: the direct communicator may hold half-captured launches of the rank
@@ -218,6 +241,9 @@ class DataParallelContext:
             c.close()
         self._direct = None
         self._agreement = None
+        from .runtime import RT
+        if RT.dp is self:
+            RT.override_lanes(None)          # the autotune's choice belonged to this context
         if self._comm_stream is not None:
             from .runtime import RT
             RT.release_stream(self._comm_stream.cuda_stream)

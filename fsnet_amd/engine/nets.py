@@ -59,20 +59,25 @@ class StatsPool:
     def __init__(self, device, capacity=1 << 21):
         self.buf = torch.zeros(capacity, dtype=torch.float64, device=device)
         self.off = 0
-        ops.register_prezero(self, StatsPool._prezero)
+        # everything below `high` may hold sums: captured steps of different arrangements (the training hook's autotune
+        # keeps two graphs for a while) each dirty their own extent whatever this object's bump pointer says
+        self.high = 0
+        self.dirty = False
+        ops.register_prezero(self, StatsPool._prezero, device)
 
     def _prezero(self):
         """(ops.prezero_all, at the step's head) the used prefix is about to be zeroed with the rest of the step's scratch:
         the reset() at the start of the network's forward / backward then finds nothing to do"""
-        if not self.off:
-            return []
-        t = self.buf[:self.off]
         self.off = 0
-        return [t]
+        if not self.dirty:
+            return []
+        self.dirty = False
+        return [self.buf[:self.high]]
 
     def reset(self):
-        if self.off:
-            self.buf[:self.off].zero_()     # everything beyond the bump pointer was never handed out: still zero
+        if self.dirty:
+            self.buf[:self.high].zero_()     # everything beyond the high-water mark was never handed out: still zero
+            self.dirty = False
         self.off = 0
 
     def span(self, a, b):
@@ -93,6 +98,8 @@ class StatsPool:
             return torch.zeros(shape, dtype=torch.float64, device=self.buf.device)
         v = self.buf[self.off:self.off + n].view(shape)
         self.off += n
+        self.high = max(self.high, self.off)
+        self.dirty = True
         return v
 
 
@@ -144,6 +151,13 @@ def _inline_bias_list(dev):
     return _INLINE_BIAS.setdefault(cur.cuda_stream, (cur, []))[1]
 
 
+def drop_inline_bias():
+    """a new step begins (DataParallelContext.begin_step): whatever a backward that raised left uncollected is not this
+    step's gradient"""
+    for ent in _INLINE_BIAS.values():
+        ent[1].clear()
+
+
 def flush_inline_bias(cur=None):
     """issue the collected bias sums of chain stream `cur` (default: every chain) on their chain"""
     for key in ([cur.cuda_stream] if cur is not None else list(_INLINE_BIAS.keys())):
@@ -172,7 +186,7 @@ def accumulate_param_grads_multi(cls, ops_, dcs, xs, pros):
         return
     item = lanes[0] if len(lanes) == 1 else ("lanes", lanes)
     dc0 = lanes[0][1]
-    mode = RT.wgrad_streams if (dc0.is_cuda and RT.overlap and RT.dp is None) else 0
+    mode = RT.wgrad_streams if (dc0.is_cuda and RT.overlap and (RT.dp is None or RT.dp.wgrad_companions)) else 0
     if mode:
         _defer_param_grads(_current_stream(dc0.device), item)
         return
@@ -257,6 +271,11 @@ def join_companions():
     _PENDING_KEEP.clear()
 
 
+def pending_companions():
+    """companion streams with weight-gradient work in flight in this step"""
+    return {ws for _, ws in _PENDING_JOIN}
+
+
 def join_companions_final():
     """the current stream waits for every companion with work in flight (before the optimizer reads gradients)"""
     flush_inline_bias()
@@ -291,7 +310,7 @@ def pack_everything_async(arena):
     the 70 us re-pack of every convolution's MFMA operands after the optimizer step ran in front of all of it.  Every
     stream that launches a convolution waits for the pack stream once (ConvLayer.ready -> join_pack)."""
     dev = arena.data.device if arena is not None else None
-    if not (RT.pack_overlap and RT.overlap and RT.dp is None and dev is not None and dev.type == "cuda"):
+    if not (RT.pack_overlap and RT.overlap and (RT.dp is None or RT.dp.pack_overlap) and dev is not None and dev.type == "cuda"):
         _PACK_PENDING.clear()
         pack_everything(arena)
         return
@@ -431,7 +450,7 @@ class ConvLayer:
         item = (op, dc, x, gw, gb, self.m.bias.numel() if gb is not None else 0, pro)
         # (data parallel: inline on the chain stream, so that one event after a stage's last weight gradient covers
         # the arena slice its gradient bucket reduces — also inside a captured step)
-        mode = RT.wgrad_streams if (dc.is_cuda and RT.overlap and RT.dp is None) else 0
+        mode = RT.wgrad_streams if (dc.is_cuda and RT.overlap and (RT.dp is None or RT.dp.wgrad_companions)) else 0
         if mode:
             _defer_param_grads(_current_stream(dc.device), item)
             return

@@ -105,6 +105,13 @@ class StoreAgreement(object):
                 pass
         return good
 
+    def gather(self, blob):
+        """every rank's bytes, in rank order, on every rank"""
+        self.seq += 1
+        pre = self._prefix()
+        self.store.set("%s/%d/g%d" % (pre, self.seq, self.me), bytes(blob))
+        return [bytes(self.store.get("%s/%d/g%d" % (pre, self.seq, r))) for r in self.ranks]
+
     def share(self, blob):
         """bytes from the group's first rank to everybody (blob is ignored elsewhere)"""
         self.seq += 1

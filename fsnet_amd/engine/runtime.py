@@ -32,13 +32,16 @@ class _Runtime:
         # the pose encoder's image pairs as one stacked pass with per-pair BatchNorm statistics
         self.batch_pose_pairs = os.environ.get("FSNET_AMD_BATCH_POSE", "1") != "0"
         # the depth encoder and the stacked pose encoder as the two lanes of ONE pass: every post-stem launch carries
-        # both networks' problems (EncoderPass in nets.py; fs_*2 entry points).  0: two passes on two streams (round 1-4)
-        # Default ("auto"): the two-lane pass under data parallelism (world size > 1: half the SyncBN exchanges, one chain of
-        # collectives instead of two that serialise on the communicator), two chains at world size 1 — measured there on
-        # the same box, 150 replayed steps each (profiles/r05_lanes_ab.txt): two chains 5.59-5.79 ms, two lanes 5.82-6.00 (295
-        # launches instead of 415, but the depth decoder no longer runs beside the pose encoder).
+        # both networks' problems (EncoderPass in nets.py; fs_*2 entry points).  0: two passes on two streams (round 1-4).
+        # Default ("auto"): two chains at world size 1 — measured there on the same box, 150 replayed steps each
+        # (profiles/r05_lanes_ab.txt): two chains 5.59-5.79 ms, two lanes 5.82-6.00 (295 launches instead of 415, but the
+        # depth decoder no longer runs beside the pose encoder).  Under data parallelism nobody knows in advance: two lanes
+        # issue half the SyncBN exchanges and one chain of collectives instead of two that serialise on the communicator,
+        # two chains overlap more — the training hook times both on the ranks it has and keeps the faster
+        # (BaseTrainingHook, "encoder-pass autotune"); where a step cannot be captured it stays with two lanes.
         self._lanes_env = os.environ.get("FSNET_AMD_LANES", "auto").lower()
         self._lanes = self._lanes_env not in ("0", "auto")
+        self._lanes_override = None     # set by the autotune while / after it runs (auto mode only)
         # (measured, same box: two lanes 6.38 -> 6.29 ms with the hand-over; two chains 6.03 -> 6.58 — there the other
         # chain's launches fill the stem's passes already and the extra cross-stream edge delays the chain)
         self._stem_flush_env = self.stem_flush
@@ -58,6 +61,7 @@ class _Runtime:
     @lanes.setter
     def lanes(self, v):
         """True / False: explicit; "auto": by world size (resolve_lanes)"""
+        self._lanes_override = None
         if isinstance(v, str) and v.lower() == "auto":
             self._lanes_env, self._lanes = "auto", False
         else:
@@ -65,12 +69,33 @@ class _Runtime:
         if self._stem_flush_env == "-1":
             self.stem_flush = self._lanes
 
+    @property
+    def lanes_auto(self):
+        return self._lanes_env == "auto"
+
+    @property
+    def encoder_pass_ms(self):
+        """{"chains": ms, "lanes": ms, "chosen": ...} once the autotune has run for the current data-parallel context"""
+        return getattr(self.dp, "encoder_pass_ms", None)
+
+    @encoder_pass_ms.setter
+    def encoder_pass_ms(self, v):
+        self.dp.encoder_pass_ms = v
+
+    def override_lanes(self, v):
+        """auto mode: the autotune's current / final choice (None: back to the world-size rule)"""
+        self._lanes_override = None if v is None else bool(v)
+        self.resolve_lanes()
+
     def resolve_lanes(self):
         """FSNET_AMD_LANES=auto: decided when the first training forward knows the world size"""
         if self._lanes_env == "auto":
-            import torch.distributed as dist
-            multi = self.dp is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
-            self._lanes = bool(multi)
+            if self._lanes_override is not None and self.dp is not None:      # (the autotune's: data parallel only)
+                self._lanes = self._lanes_override
+            else:
+                import torch.distributed as dist
+                multi = self.dp is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+                self._lanes = bool(multi)
             if self._stem_flush_env == "-1":
                 self.stem_flush = self._lanes
         return self._lanes

@@ -162,6 +162,7 @@ USE_1X1 = os.environ.get("FSNET_AMD_CONV1X1", "1") != "0"
 # the LDS-staged GEMM form of the 1x1 kernel (conv1x1_gemm.hip; fs_conv1x1 picks it per launch): every 1x1 / pad-0
 # forward and stride-1 data gradient then goes to fs_conv1x1, whatever its K extent or stride
 USE_1X1_GEMM = os.environ.get("FSNET_AMD_1X1_GEMM", "1") != "0"
+PRO_MAX_CI = 512      # conv_pro.h pro_args_ok: the operand prologue's coefficient table (2 floats per source channel in LDS)
 USE_HALO = os.environ.get("FSNET_AMD_HALO", "1") != "0"   # 3x3/s1 LDS-halo kernel (conv3x3_halo.hip)
 USE_STEM_LDS = os.environ.get("FSNET_AMD_STEM_LDS", "1") != "0"   # 7x7/s2 stem kernel (conv_stem.hip)
 USE_HALO_S2 = os.environ.get("FSNET_AMD_HALO_S2", "1") != "0"     # 3x3/s2 forward on the LDS-halo kernel (else implicit GEMM)
@@ -449,8 +450,8 @@ class ConvOp:
         and the data gradient derives the ReLU mask in its epilogue"""
         eb = 2 if self.dtype == torch.bfloat16 else 4
         return (USE_HALO and self.dtype == torch.bfloat16 and self.R == 3 and self.S == 3 and self.stride == 1
-                and self.Ci == self.Ci_p and (self.Ci_p * eb) % 64 == 0 and self.Co_p % 64 == 0 and self.Co % 4 == 0
-                and self.need_dgrad and N * H * W * max(self.Co_p, self.Ci_p) * eb < 0x7fffffff)
+                and self.Ci == self.Ci_p and (self.Ci_p * eb) % 64 == 0 and self.Ci_p <= PRO_MAX_CI
+                and self.Co_p % 64 == 0 and self.Co % 4 == 0 and self.need_dgrad and N * H * W * max(self.Co_p, self.Ci_p) * eb < 0x7fffffff)
 
     def can_fuse_bn_bwd(self, N, H, W, groups):
         """whether dgrad(..., bn_fuse=) may carry the BatchNorm-backward sums of a [N,H,W,Ci_p] gradient"""

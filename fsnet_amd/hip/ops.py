@@ -459,7 +459,7 @@ class PhotometricLoss:
         self.lut_table = self.mei = self.warp_mask = None
         self._lut_keep = None
         self._clean_acc = self._clean_dd = False
-        register_prezero(self, lambda o: o._prezero())
+        register_prezero(self, lambda o: o._prezero(), device)
 
     def stage_fisheye(self, tables, mei_rows):
         """tables: B device tensors [4,H,W] (fs_mei_lut); mei_rows: host float32 [B,8] = k1 k2 xi g1 g2 u0 v0 0.
@@ -695,9 +695,17 @@ def zero_multi(tensors):
 _PREZERO = []          # [(weakref to the owner, fn(owner) -> [tensors to zero]; fn marks them clean)]
 
 
-def register_prezero(owner, fn):
+def _indexed(device):
+    d = torch.device(device)
+    if d.type == "cuda" and d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device())
+    return d
+
+
+def register_prezero(owner, fn, device):
+    """fn(owner) -> tensors on `device` to zero; it marks them clean and is only called for that device's steps"""
     import weakref
-    _PREZERO.append((weakref.ref(owner), fn))
+    _PREZERO.append((weakref.ref(owner), fn, _indexed(device)))
 
 
 def _join_pack(device):
@@ -709,12 +717,15 @@ def prezero_all(device):
     """zero every registered scratch buffer that was used since its last zeroing, in one launch on the current stream; the
     owners' own zero_() calls are then skipped once (their `clean` flags)"""
     todo, alive = [], []
-    for ref, fn in _PREZERO:
+    device = _indexed(device)
+    for ref, fn, dev in _PREZERO:
         o = ref()
         if o is None:
             continue
-        alive.append((ref, fn))
-        todo.extend(t for t in fn(o) if t.device == device)
+        alive.append((ref, fn, dev))
+        if dev != device:        # (fn has side effects — clean flags, bump pointers: another device's owners are left alone)
+            continue
+        todo.extend(fn(o))
     _PREZERO[:] = alive
     if todo:
         zero_multi(todo)

@@ -77,7 +77,12 @@ class MonoDepthMeta(_HipMetaArch):
         """the depth encoder and the stacked pose encoder as the two lanes of ONE pass (engine/nets.py, EncoderPass):
         same architecture, BatchNorm modes and trained parameters, gradients wanted, and a pose head that takes the
         stacked feature"""
-        if not (RT.resolve_lanes() and RT.batch_pose_pairs and image_0.is_cuda and torch.is_grad_enabled()):
+        return bool(RT.resolve_lanes()) and self.lanes_possible(image_0)
+
+    def lanes_possible(self, image_0=None):
+        """could this model run the two-lane encoder pass at all (what the training hook's autotune asks — before the batch
+        is on the device, hence without an image — before it times both arrangements)"""
+        if not (RT.batch_pose_pairs and (image_0 is None or image_0.is_cuda) and torch.is_grad_enabled()):
             return False
         if len(self.train_cfg.frame_ids) < 3 or not hasattr(self.head, "forward_pose_pairs"):
             return False

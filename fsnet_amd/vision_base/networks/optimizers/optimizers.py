@@ -60,7 +60,6 @@ class FusedAdam(optim.Optimizer):
                 self._step_buf.fill_(step0)
         return self._arena_state[1], self._arena_state[2]
 
-    @torch.no_grad()
     def _prezero(self):
         """(ops.prezero_all) the gradient-norm accumulator is about to be zeroed with the step's scratch"""
         if self._sumsq is None:
@@ -68,6 +67,7 @@ class FusedAdam(optim.Optimizer):
         self._clean_sq = True
         return [self._sumsq_buf]
 
+    @torch.no_grad()
     def step(self, closure=None, max_norm=None, grad_scale=1.0):
         """max_norm: fused clip_grad_norm_ (joint L2 norm over all parameters) when given."""
         loss = None
@@ -96,7 +96,7 @@ class FusedAdam(optim.Optimizer):
                     self._sumsq_buf = torch.zeros(2, dtype=torch.float64, device=dev)
                     self._sumsq = self._sumsq_buf[:1]
                     self._clean_sq = False
-                    ops.register_prezero(self, lambda o: o._prezero())
+                    ops.register_prezero(self, lambda o: o._prezero(), dev)
                 if self._clean_sq:
                     from fsnet_amd.engine.nets import join_pack
                     join_pack(dev)

@@ -9,8 +9,15 @@ about what the GPU needs to run them.  After `graph_warmup` eager steps the hook
 stream and replays it; the per-step scalars (Adam step count, learning rate, tie-break noise seed) live in
 device memory, so a replay is a real step.  Inputs are copied into static device buffers; the returned
 tensors are the graph's static outputs, valid until the next call (loss_dict entries are cloned when a logger
-is attached).  Eager execution stays in use while a data-parallel context is active, for non-fused
-optimizers, and whenever the batch signature changes."""
+is attached).  Eager execution stays in use for non-fused optimizers, whenever the batch signature changes, and for
+data-parallel steps whose collectives cannot be captured (engine/dataparallel.py).
+
+Encoder-pass autotune (data parallel, FSNET_AMD_LANES=auto): the depth and the pose encoder run either as two chains on
+two streams or as the two lanes of one pass (engine/nets.py, EncoderPass).  Which is faster depends on what a SyncBN
+exchange costs on the ranks at hand — the lanes issue half as many, the chains overlap more — so the hook captures the
+step both ways, times `tune_steps` replays of each with device events (real training steps, every rank in lockstep), the
+ranks exchange their timings through the process group's store, and everybody keeps the arrangement whose slowest rank
+was faster (RT.encoder_pass_ms holds both figures)."""
 import os
 import weakref
 
@@ -39,6 +46,69 @@ class BaseTrainingHook(object):
         self._g_eager = 0         # eager steps seen with the current signature
         self._g_stream = None
         self.graph_replays = 0
+        # encoder-pass autotune: None = not looked at yet, dict = running, False = finished or not applicable
+        self._tune = None
+        self.tune_steps = int(os.environ.get("FSNET_AMD_TUNE_STEPS", "10"))
+
+    # ------------------------------------------------------------------ encoder-pass autotune (data parallel)
+    @property
+    def tune_done(self):
+        return self._tune is False
+
+    def _tune_init(self, inner, data):
+        """first call: is there a choice to make?  Only under data parallelism, with the arrangement left on "auto", for a
+        model that can run both, once per process"""
+        import torch.distributed as dist
+        multi = RT.dp is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        possible = getattr(inner, "lanes_possible", None)
+        if not (multi and RT.lanes_auto and RT.encoder_pass_ms is None and self.tune_steps > 0
+                and possible is not None and possible(None)):
+            self._tune = False
+            return
+        self._tune = dict(phase=0, modes=("chains", "lanes"), n=0, ms={}, graphs={}, ev0=None, t0=None)
+        RT.override_lanes(False)            # phase 0: two chains
+
+    def _tune_abort(self):
+        """a capture failed under the autotune's feet (the communicator is being re-made): back to the world-size rule"""
+        self._tune["graphs"].clear()
+        self._tune = False
+        RT.override_lanes(None)
+
+    def _tune_phase_end(self, t, ms):
+        """`ms`: this rank's time per step in the arrangement that just ran"""
+        mode = t["modes"][t["phase"]]
+        t["ms"][mode] = ms
+        t["graphs"][mode] = (self._g, self._g_sig)
+        if t["phase"] == 0:
+            # the next calls warm up (and capture) the other arrangement; the first one's graph stays alive beside it
+            t["phase"], t["n"] = 1, 0
+            self._g, self._g_sig, self._g_eager = None, None, 0
+            RT.override_lanes(True)
+            return
+        rows = RT.dp.gather_floats([t["ms"][m] for m in t["modes"]])       # every rank's pair, the same list everywhere
+        worst = [max(r[i] for r in rows) for i in range(len(t["modes"]))]
+        chosen = t["modes"][0] if worst[0] <= worst[1] else t["modes"][1]
+        RT.encoder_pass_ms = dict({m: round(w, 4) for m, w in zip(t["modes"], worst)}, chosen=chosen, steps=self.tune_steps,
+                                  ranks=len(rows), timed="hipgraph replays" if self._g is not None else "eager steps")
+        RT.override_lanes(chosen == "lanes")
+        self._g, self._g_sig = t["graphs"][chosen]
+        t["graphs"].clear()                                     # (the other graph goes: the device is idle)
+        self._tune = False
+
+    def _tune_eager_step(self, data, meta_arch, optimizer, arena, fused, meta, logger):
+        """data-parallel steps that are not captured (gloo, a failed communicator self-test): two warm-up steps, then
+        `tune_steps` eager steps per arrangement between two device synchronisations"""
+        import time
+        t = self._tune
+        if t["n"] == 2:
+            torch.cuda.synchronize()
+            t["t0"] = time.perf_counter()
+        output = self._eager_step(data, meta_arch, optimizer, arena, fused, meta, logger)
+        t["n"] += 1
+        if t["n"] >= 2 + self.tune_steps:
+            torch.cuda.synchronize()
+            self._tune_phase_end(t, (time.perf_counter() - t["t0"]) * 1e3 / self.tune_steps)
+        return output
 
     # ------------------------------------------------------------------ graph path
     def _signature(self, data, meta_arch, optimizer):
@@ -157,6 +227,8 @@ class BaseTrainingHook(object):
 
     def reset_graph(self):
         self._g, self._g_sig, self._g_eager = None, None, 0
+        if self._tune:
+            self._tune_abort()
 
     def _optim(self, meta_arch, optimizer, fused):
         grad_scale = RT.dp.finish() if RT.dp is not None else 1.0
@@ -184,12 +256,18 @@ class BaseTrainingHook(object):
         meta = dict(epoch_num=epoch_num, global_step=global_step, is_training=True)
         logger = training_loss_logger
 
+        if self._tune is None:
+            self._tune_init(inner, data)
         if not self._graph_ok(meta_arch, optimizer, arena, fused):
+            if self._tune and RT.dp is not None:        # (RT.dp is created by the first forward: only then is it known)
+                return self._tune_eager_step(data, meta_arch, optimizer, arena, fused, meta, logger)
             return self._eager_step(data, meta_arch, optimizer, arena, fused, meta, logger)
 
         sig = self._signature(data, meta_arch, optimizer)
         if sig != self._g_sig or (self._g is not None and not self._g["arena"] is arena):
             self._g, self._g_sig, self._g_eager = None, sig, 0
+            if self._tune:
+                self._tune["n"] = 0          # a timing window does not span a re-capture
         if self._g_stream is None:
             self._g_stream = RT.new_stream(next(meta_arch.parameters()).device)
             weakref.finalize(self, RT.release_stream, self._g_stream.cuda_stream)
@@ -233,12 +311,25 @@ class BaseTrainingHook(object):
                                   "continuing with eager launches" % failure)
                     self.use_graph = False
                     self._g = None
+                    if self._tune:
+                        self._tune_abort()
                     optimizer._step_count_fused = steps_before
                     torch.cuda.synchronize()
                     output = self._eager_step(data, meta_arch, optimizer, arena, fused, meta, logger)
                     logger = None
             else:
+                t = self._tune
+                if t and t["n"] == 0:
+                    t["ev0"] = torch.cuda.Event(enable_timing=True)
+                    t["ev0"].record()
                 output = self._replay(data, optimizer)
+                if t:
+                    t["n"] += 1
+                    if t["n"] >= self.tune_steps:
+                        ev1 = torch.cuda.Event(enable_timing=True)
+                        ev1.record()
+                        ev1.synchronize()
+                        self._tune_phase_end(t, t["ev0"].elapsed_time(ev1) / self.tune_steps)
             if logger is not None:
                 logger.update({k: v.clone() for k, v in output['loss_dict'].items()})
                 logger.update_hm(output.get('hm', dict()))

@@ -26,13 +26,15 @@ def _full_batch(it):
     return O.synthetic_batch(2 * B_RANK, H, W, seed=300 + it)
 
 
-def _build(dev):
+def _build(dev, lanes=None):
     from fsnet_amd.configs import meta_arch_cfg, training_cfg
     from fsnet_amd.engine.runtime import RT
     from fsnet_amd.vision_base.networks.optimizers.optimizers import build_optimizer
     from fsnet_amd.vision_base.utils.builder import build
     RT.set_compute_dtype(torch.float32)
     RT.tie_noise = False
+    if lanes is not None:
+        RT.lanes = lanes         # explicit: the encoders as two lanes of one pass / as two chains (no autotune in two steps)
     m = build(**meta_arch_cfg(H, W, with_pose=True))
     m.load_state_dict(O.init_state(seed=11, with_pose=True), strict=True)
     m = m.to(dev).train()
@@ -40,14 +42,14 @@ def _build(dev):
     return m, build_optimizer(m, **tc.optimizer), build(**tc.training_hook)
 
 
-def _rank_main(rank, world, port, out_path):
+def _rank_main(rank, world, port, out_path, lanes):
     import torch.distributed as dist
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     try:
-        m, opt, hook = _build(dev)
+        m, opt, hook = _build(dev, lanes)
         losses = []
         for it in range(STEPS):
             full = _full_batch(it)
@@ -56,7 +58,7 @@ def _rank_main(rank, world, port, out_path):
             losses.append(float(out["loss"].detach()))
         torch.cuda.synchronize()
         from fsnet_amd.engine.runtime import RT
-        assert RT.dp is not None and RT.dp.world == world and hook.graph_captures == 0
+        assert RT.dp is not None and RT.dp.world == world and hook.graph_captures == 0 and RT.lanes == lanes
         torch.save({"losses": losses,
                     "params": torch.cat([p.detach().flatten() for p in m.parameters()]).cpu(),
                     "running": torch.cat([b.detach().double().flatten() for n, b in m.named_buffers() if "running_" in n]).cpu()},
@@ -65,12 +67,15 @@ def _rank_main(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_process_on_the_full_batch(dev, tmp_path):
+@pytest.mark.parametrize("lanes", [True, False], ids=["two-lanes", "two-chains"])
+def test_two_ranks_equal_one_process_on_the_full_batch(dev, tmp_path, lanes):
+    """both arrangements of the encoders under data parallelism (the training hook's autotune picks between them on a
+    real node) against the single process, which runs two chains"""
     import torch.multiprocessing as mp
     port = _free_port()
     out_path = str(tmp_path / "rank%d.pt")
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, out_path)) for r in range(2)]
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, out_path, lanes)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -81,7 +86,7 @@ def test_two_ranks_equal_one_process_on_the_full_batch(dev, tmp_path):
     assert float((r0["params"] - r1["params"]).abs().max()) == 0.0
     assert float((r0["running"] - r1["running"]).abs().max()) == 0.0
 
-    m, opt, hook = _build(dev)
+    m, opt, hook = _build(dev, "auto")
     p_init = torch.cat([p.detach().flatten() for p in m.parameters()]).cpu()
     losses = []
     for it in range(STEPS):
@@ -110,7 +115,8 @@ def test_bench_script_runs_with_two_ranks(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FSNET_AMD_BENCH_SHARED_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, FSNET_AMD_BENCH_SHARED_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", FSNET_AMD_TUNE_STEPS="2")
+    env.pop("FSNET_AMD_LANES", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
            "--batch", "2", "--height", "64", "--width", "128"]
@@ -124,4 +130,8 @@ def test_bench_script_runs_with_two_ranks(tmp_path):
     assert d["config"]["dp_collectives"] == "torch.distributed"          # gloo rig: no direct RCCL communicator
     assert d["config"]["syncbn_exchanges_per_step"] > 40 and d["config"]["gradient_buckets_per_step"] >= 4
     assert d["value"] > 0 and abs(d["value"] - 4 * 3 / (d["ms_per_step"] * 3e-3)) < 0.02 * d["value"]
+    # the encoder-pass autotune ran before the warm-up steps (eager steps on this rig) and the line carries both timings
+    ep = d["config"]["encoder_pass_ms"]
+    assert ep["chains"] > 0 and ep["lanes"] > 0 and ep["chosen"] in ("chains", "lanes") and ep["ranks"] == 2
+    assert d["config"]["encoder_pass"].startswith("two " + ep["chosen"]) and d["config"]["autotune_steps"] >= 8
     assert "cpu_baseline" not in d                           # rank 0 at N = 1 only

@@ -153,3 +153,63 @@ def test_dp_step_replayed_from_a_hipgraph_on_rccl(dev):
         assert losses[:2] == pytest.approx(l_ref, rel=2e-4)   # (later steps: tests/test_graph_gpu.py on the run-to-run spread)
         assert all(l == l and l < 10 for l in losses)
         assert losses == pytest.approx(all_losses[0], rel=1e-3)
+
+
+def test_encoder_pass_autotune_on_rccl(dev):
+    """data parallel with the encoder arrangement left on "auto": the hook captures the step as two chains and as two lanes,
+    times `tune_steps` replays of each, the ranks agree on the faster through the store, its graph stays — and the training
+    trajectory is the plain one throughout (world size 1 over RCCL: every exchange and bucket is issued)"""
+    from fsnet_amd.configs import meta_arch_cfg, training_cfg
+    from fsnet_amd.engine.dataparallel import DataParallelContext
+    from fsnet_amd.engine.runtime import RT
+    from fsnet_amd.vision_base.networks.optimizers.optimizers import build_optimizer
+    from fsnet_amd.vision_base.utils.builder import build
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    STEPS, K = 16, 3
+
+    def run(use_dp):
+        RT.set_compute_dtype(torch.float32)
+        RT.tie_noise = False
+        RT.lanes = "auto"
+        m = build(**meta_arch_cfg(64, 128, with_pose=True))
+        m.load_state_dict(O.init_state(seed=6, with_pose=True), strict=True)
+        m = m.to(dev).train()
+        tc = training_cfg()
+        opt = build_optimizer(m, **tc.optimizer)
+        hook = build(graph_warmup=2, **tc.training_hook)
+        hook.tune_steps = K
+        if use_dp:
+            m.ensure_arena()
+            RT.dp = DataParallelContext(m)
+            assert RT.dp.direct and RT.dp.capturable
+        losses, modes = [], []
+        for it in range(STEPS):
+            out = hook(dict(O.synthetic_batch(2, 64, 128, seed=50 + it % 4)), m, opt)
+            losses.append(float(out["loss"].detach()))
+            modes.append(RT.lanes)
+        torch.cuda.synchronize()
+        return losses, modes, hook
+
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
+    try:
+        l_dp, modes, hook = run(True)
+        ep = RT.encoder_pass_ms
+        # chains: 2 eager + capture + K replays; lanes: the same again; then the chosen graph only
+        # (the arrangement switches inside the call that ends a phase: recorded with that step)
+        assert modes[:2 + K] == [False] * (2 + K) and modes[2 + K:5 + 2 * K] == [True] * (3 + K)
+        assert hook.tune_done and hook.graph_captures == 2 and hook.use_graph
+        assert ep["chains"] > 0 and ep["lanes"] > 0 and ep["ranks"] == 1 and ep["steps"] == K and ep["timed"] == "hipgraph replays"
+        assert ep["chosen"] == ("chains" if ep["chains"] <= ep["lanes"] else "lanes")
+        assert all(mode == (ep["chosen"] == "lanes") for mode in modes[5 + 2 * K:])
+        assert hook.graph_replays == 2 * K + (STEPS - 6 - 2 * K)
+        RT.dp.close()
+        assert RT.resolve_lanes() is True          # (the override went with the context: "auto" under a process group again)
+        RT.dp = None
+    finally:
+        RT.dp = None
+        dist.destroy_process_group()
+    l_ref, _, _ = run(False)
+    assert all(l == l and l < 10 for l in l_dp)
+    # the same training run whatever arrangement each step used (run-to-run spread of the fp32 atomics grows with the steps)
+    assert l_dp[:4] == pytest.approx(l_ref[:4], rel=2e-4)
+    assert l_dp == pytest.approx(l_ref, rel=2e-2)
