@@ -149,7 +149,7 @@ def main():
     # present and keeps the faster (BaseTrainingHook, encoder-pass autotune) — set-up, before the contract's warm-up steps
     pre = 0
     if world > 1:
-        while not hook.tune_done and pre < 100:
+        while not hook.tune_done and pre < 200:
             run_steps(1, pre)
             pre += 1
     run_steps(args.warmup, pre)
@@ -273,8 +273,9 @@ def main():
                                     "full step (fwd+loss+bwd+clip35+Adam, weight decay 1e-5); inputs HBM-resident"
                                     % (args.depth, H, W, args.dtype, B)),
                        "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(loss, 6),
-                       "encoder_pass": ("two lanes (depth + stacked pose encoder share every launch)" if RT.lanes
-                                        else "two chains (depth and pose encoder on two streams)") if not fisheye else "one network",
+                       "encoder_pass": ((("two lanes (depth + stacked pose encoder share every launch)" if RT.lanes
+                                          else "two chains (depth and pose encoder on two streams)")
+                                         + ("" if RT.dp is None else "; weight gradients " + RT.dp.wgrad_mode)) if not fisheye else "one network"),
                        "encoder_pass_ms": RT.encoder_pass_ms, "autotune_steps": pre,
                        "hipgraph_replays": hook.graph_replays, "frames_per_s": round(3 * B * world * args.steps / elapsed, 1),
                        "dp_collectives": (None if RT.dp is None else ("rccl-direct" + ("+hipgraph" if RT.dp.capturable else "")

@@ -48,9 +48,16 @@ class DataParallelContext:
         self._comm_stream = None
         self._graph_owners = []    # weak references to hooks whose captured step contains this communicator's nodes
         self.capturable = False
-        # weight gradients on the chains' companion streams as in the single-GPU step (a bucket's all-reduce then waits for
-        # the chain and for the companions holding its work), or inline on the chain
-        self.wgrad_companions = os.environ.get("FSNET_AMD_DP_WGRAD", "inline") == "companion"
+        # Where the weight gradients run under data parallelism (they feed nothing downstream but their gradient bucket):
+        #   inline     on their chain, so one event after a stage's last weight gradient covers its bucket;
+        #   companion  on the chains' companion streams as in the single-GPU step — a bucket's all-reduce then waits for the
+        #              chain and for every companion holding work;
+        #   tail       inline, except the depth decoder's, which run at the tail of the pose chain's stream when the backward
+        #              has been issued (the depth chain — decoder, then encoder — is the longer one: nets.flush_tail).
+        # FSNET_AMD_DP_WGRAD names one; "auto" (default) lets the training hook's autotune time them on the ranks present.
+        self.wgrad_env = os.environ.get("FSNET_AMD_DP_WGRAD", "auto").lower()
+        assert self.wgrad_env in ("auto", "inline", "companion", "tail"), self.wgrad_env
+        self.wgrad_mode = "inline" if self.wgrad_env == "auto" else self.wgrad_env
         self.pack_overlap = os.environ.get("FSNET_AMD_DP_PACK_OVERLAP", "1") != "0"
         if self._direct is not None:
             from .runtime import RT
@@ -60,6 +67,14 @@ class DataParallelContext:
     @property
     def direct(self):
         return self._direct is not None
+
+    @property
+    def wgrad_companions(self):
+        return self.wgrad_mode == "companion"
+
+    @property
+    def decoder_tail(self):
+        return self.wgrad_mode == "tail"
 
     # ---- small latency-bound exchanges (BN) ------------------------------------------------
     def allreduce_small(self, t, out=None):

@@ -203,13 +203,10 @@ def _defer_param_grads(cur, item):
         ent = _DEFERRED[cur.cuda_stream] = (cur, [])
     ent[1].append(item)
     _ACTIVE_CHAINS.add(cur.cuda_stream)
-    task = torch._C._current_graph_task_id()
-    if _CALLBACK_QUEUED[0] != task:
-        # runs once, when the autograd engine has executed every node of this backward pass and before it
-        # synchronises the streams it used with the caller's stream.  (Keyed by the pass: a backward that died in an
-        # exception never ran its callback, and must not keep the next one from queueing its own.)
-        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
-        _CALLBACK_QUEUED[0] = task
+    # runs once, when the autograd engine has executed every node of this backward pass and before it synchronises the
+    # streams it used with the caller's stream.  (Keyed by the pass: a backward that died in an exception never ran its
+    # callback, and must not keep the next one from queueing its own.)
+    _queue_end_of_backward()
     if len(ent[1]) >= (RT.wgrad_flush_side if RT.is_side(cur) else RT.wgrad_flush):
         flush_deferred(cur)
 
@@ -250,6 +247,7 @@ def flush_deferred(cur=None, spread=False):
 
 def _end_of_backward():
     _CALLBACK_QUEUED[0] = None
+    flush_tail()
     flush_inline_bias()
     flush_deferred()
     _ACTIVE_CHAINS.clear()
@@ -269,6 +267,50 @@ def join_companions():
         cur.wait_stream(ws)
     _PENDING_JOIN.clear()
     _PENDING_KEEP.clear()
+
+
+_TAIL_SINK = [None]     # while a network's backward collects its weight gradients for the tail: the list they go to
+_TAIL = []              # [(event on the network's chain, device, items, runner)] waiting for the end of the backward pass
+
+
+def _queue_end_of_backward():
+    task = torch._C._current_graph_task_id()
+    if _CALLBACK_QUEUED[0] != task:
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+        _CALLBACK_QUEUED[0] = task
+
+
+def defer_to_tail(items, runner, device):
+    """data parallel, weight gradients "tail" (DataParallelContext.wgrad_mode): the depth decoder's weight gradients — its
+    chain goes on with the depth encoder's backward and ends the step, the pose chain's stream finishes earlier — are
+    issued on the pose chain's stream once every node of the backward pass has been issued (flush_tail), behind that
+    chain's own work; the decoder's gradient bucket follows them there."""
+    if _TAIL and _CALLBACK_QUEUED[0] != torch._C._current_graph_task_id():
+        _TAIL.clear()                        # leftovers of a backward pass that raised
+    chain = _current_stream(device)
+    ev = torch.cuda.Event()
+    ev.record(chain)
+    runner.tail_pending = True
+    _TAIL.append((ev, chain, items, runner))
+    _queue_end_of_backward()
+
+
+def flush_tail():
+    for ev, chain, items, runner in _TAIL:
+        side = RT.side_stream(chain.device)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            sums = [] if CSUM_BATCH else None
+            for it in items:
+                _run_param_grads(*it, bias_later=sums)
+            if sums:
+                ops.channel_sum_multi(sums)
+            runner.tail_pending = False
+            if RT.dp is not None and runner.m._pending == 0:
+                RT.dp.grads_ready(runner.m)          # the bucket's all-reduce picks up from this stream
+        _PENDING_JOIN.add((chain, side))             # (joined, and the operands released, like a companion's batch)
+        _PENDING_KEEP.extend(items)
+    _TAIL.clear()
 
 
 def pending_companions():
@@ -448,6 +490,9 @@ class ConvLayer:
                 ops.channel_sum(dc, gb, self.m.bias.numel())
             return
         item = (op, dc, x, gw, gb, self.m.bias.numel() if gb is not None else 0, pro)
+        if _TAIL_SINK[0] is not None:
+            _TAIL_SINK[0].append(item)       # (data parallel, "tail": issued when the backward pass has been issued)
+            return
         # (data parallel: inline on the chain stream, so that one event after a stage's last weight gradient covers
         # the arena slice its gradient bucket reduces — also inside a captured step)
         mode = RT.wgrad_streams if (dc.is_cuda and RT.overlap and (RT.dp is None or RT.dp.wgrad_companions)) else 0
@@ -1074,6 +1119,7 @@ class DepthDecoderRunner:
         self.unc = {s: ConvLayer(module.convs[("uncertain_logz", s)], valid_over_padded=True)
                     for s in module.scales if ("uncertain_logz", s) in module.convs}
         self.pool = None
+        self.tail_pending = False      # its weight gradients (and gradient bucket) are waiting for the end of the backward
 
     def forward(self, feats, train, P2=None):
         """feats: 5 NHWC dense tensors.  Returns ({scale: (logits, depth, disp[, uncertain_z])}, ctx).
@@ -1163,6 +1209,20 @@ class DepthDecoderRunner:
         gfeats = [None] * 5
         bwd_pool_reset(dev)
         RT.mark("ddec.bwd.start")
+        tail = RT.dp is not None and RT.dp.decoder_tail and RT.overlap and dev.type == "cuda" and \
+            torch._C._current_graph_task_id() >= 0
+        if tail:
+            _TAIL_SINK[0] = []
+        try:
+            return self._backward(ctx, g_depth, g_disp, g_unc, gfeats, dev, dt, K)
+        finally:
+            items, _TAIL_SINK[0] = _TAIL_SINK[0], None
+            if items:
+                defer_to_tail(items, self, dev)
+
+    def _backward(self, ctx, g_depth, g_disp, g_unc, gfeats, dev, dt, K):
+        m = self.m
+        feats = ctx["feats"]
 
         # logit gradients of every scale that received one, in one launch at the head of the backward
         sc = [i for i in range(5) if i in m.scales and (g_depth.get(i) is not None or g_disp.get(i) is not None)]

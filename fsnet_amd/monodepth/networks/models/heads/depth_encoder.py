@@ -45,8 +45,8 @@ class _DepthDecoderFn(torch.autograd.Function):
         gfeats = mod._runner.backward(ctx.c, g_depth, g_disp, g_unc)
         ctx.c = None
         mod._pending -= 1
-        if mod._pending == 0 and RT.dp is not None:
-            RT.dp.grads_ready(mod)
+        if mod._pending == 0 and RT.dp is not None and not mod._runner.tail_pending:
+            RT.dp.grads_ready(mod)      # (tail_pending: nets.flush_tail reduces the bucket behind the weight gradients)
         gf = tuple(None if t is None else t.permute(0, 3, 1, 2) for t in gfeats[: ctx.nfeat])
         return (None, None, None) + gf + (None,) * ctx.nparam
 

@@ -17,7 +17,9 @@ two streams or as the two lanes of one pass (engine/nets.py, EncoderPass).  Whic
 exchange costs on the ranks at hand — the lanes issue half as many, the chains overlap more — so the hook captures the
 step both ways, times `tune_steps` replays of each with device events (real training steps, every rank in lockstep), the
 ranks exchange their timings through the process group's store, and everybody keeps the arrangement whose slowest rank
-was faster (RT.encoder_pass_ms holds both figures)."""
+was fastest (RT.encoder_pass_ms holds every figure).  Where the weight gradients run under data parallelism — inline on
+their chain, on companion streams, the depth decoder's at the tail of the pose chain (engine/dataparallel.py) — is timed
+the same way: the candidates are the combinations of what was left on "auto"."""
 import os
 import weakref
 
@@ -55,44 +57,65 @@ class BaseTrainingHook(object):
     def tune_done(self):
         return self._tune is False
 
+    @staticmethod
+    def _tune_name(cand):
+        return ("lanes" if cand[0] else "chains") + {"inline": "", "tail": "+tail", "companion": "+companions"}[cand[1]]
+
     def _tune_init(self, inner, data):
-        """first call: is there a choice to make?  Only under data parallelism, with the arrangement left on "auto", for a
-        model that can run both, once per process"""
+        """first call: is there a choice to make?  Only under data parallelism, for what was left on "auto" — the encoder
+        arrangement (FSNET_AMD_LANES) and where the weight gradients run (FSNET_AMD_DP_WGRAD, engine/dataparallel.py) —
+        once per data-parallel context"""
         import torch.distributed as dist
         multi = RT.dp is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
-        possible = getattr(inner, "lanes_possible", None)
-        if not (multi and RT.lanes_auto and RT.encoder_pass_ms is None and self.tune_steps > 0
-                and possible is not None and possible(None)):
+        if not (multi and RT.encoder_pass_ms is None and self.tune_steps > 0):
             self._tune = False
             return
-        self._tune = dict(phase=0, modes=("chains", "lanes"), n=0, ms={}, graphs={}, ev0=None, t0=None)
-        RT.override_lanes(False)            # phase 0: two chains
+        possible = getattr(inner, "lanes_possible", None)
+        lanes = [False, True] if (RT.lanes_auto and possible is not None and possible(None)) else [None]
+        wenv = os.environ.get("FSNET_AMD_DP_WGRAD", "auto").lower()
+        wgrad = ["inline", "tail", "companion"] if wenv == "auto" else [wenv]
+        cands = [(l, w) for l in lanes for w in wgrad]
+        if len(cands) < 2:
+            self._tune = False
+            return
+        self._tune = dict(phase=0, cands=cands, n=0, ms={}, graphs={}, ev0=None, t0=None)
+        self._tune_apply(cands[0])
+
+    def _tune_apply(self, cand):
+        lanes, wgrad = cand
+        if lanes is not None:
+            RT.override_lanes(lanes)
+        if RT.dp is not None:                # (created by the first training forward)
+            RT.dp.wgrad_mode = wgrad
 
     def _tune_abort(self):
-        """a capture failed under the autotune's feet (the communicator is being re-made): back to the world-size rule"""
+        """a capture failed under the autotune's feet (the communicator is being re-made): back to the defaults"""
         self._tune["graphs"].clear()
         self._tune = False
         RT.override_lanes(None)
+        if RT.dp is not None:
+            RT.dp.wgrad_mode = "inline" if RT.dp.wgrad_env == "auto" else RT.dp.wgrad_env
 
     def _tune_phase_end(self, t, ms):
         """`ms`: this rank's time per step in the arrangement that just ran"""
-        mode = t["modes"][t["phase"]]
-        t["ms"][mode] = ms
-        t["graphs"][mode] = (self._g, self._g_sig)
-        if t["phase"] == 0:
-            # the next calls warm up (and capture) the other arrangement; the first one's graph stays alive beside it
-            t["phase"], t["n"] = 1, 0
+        cands = t["cands"]
+        t["ms"][t["phase"]] = ms
+        t["graphs"][t["phase"]] = (self._g, self._g_sig)
+        if t["phase"] + 1 < len(cands):
+            # the next calls warm up (and capture) the next arrangement; the graphs so far stay alive beside it
+            t["phase"], t["n"] = t["phase"] + 1, 0
             self._g, self._g_sig, self._g_eager = None, None, 0
-            RT.override_lanes(True)
+            self._tune_apply(cands[t["phase"]])
             return
-        rows = RT.dp.gather_floats([t["ms"][m] for m in t["modes"]])       # every rank's pair, the same list everywhere
-        worst = [max(r[i] for r in rows) for i in range(len(t["modes"]))]
-        chosen = t["modes"][0] if worst[0] <= worst[1] else t["modes"][1]
-        RT.encoder_pass_ms = dict({m: round(w, 4) for m, w in zip(t["modes"], worst)}, chosen=chosen, steps=self.tune_steps,
-                                  ranks=len(rows), timed="hipgraph replays" if self._g is not None else "eager steps")
-        RT.override_lanes(chosen == "lanes")
-        self._g, self._g_sig = t["graphs"][chosen]
-        t["graphs"].clear()                                     # (the other graph goes: the device is idle)
+        rows = RT.dp.gather_floats([t["ms"][i] for i in range(len(cands))])    # every rank's figures, the same list everywhere
+        worst = [max(r[i] for r in rows) for i in range(len(cands))]
+        best = min(range(len(cands)), key=lambda i: (worst[i], i))
+        RT.encoder_pass_ms = dict({self._tune_name(c): round(w, 4) for c, w in zip(cands, worst)},
+                                  chosen=self._tune_name(cands[best]), steps=self.tune_steps, ranks=len(rows),
+                                  timed="hipgraph replays" if self._g is not None else "eager steps")
+        self._tune_apply(cands[best])
+        self._g, self._g_sig = t["graphs"][best]
+        t["graphs"].clear()                                     # (the other graphs go: the device is idle)
         self._tune = False
 
     def _tune_eager_step(self, data, meta_arch, optimizer, arena, fused, meta, logger):
@@ -258,6 +281,8 @@ class BaseTrainingHook(object):
 
         if self._tune is None:
             self._tune_init(inner, data)
+        elif self._tune:
+            self._tune_apply(self._tune["cands"][self._tune["phase"]])
         if not self._graph_ok(meta_arch, optimizer, arena, fused):
             if self._tune and RT.dp is not None:        # (RT.dp is created by the first forward: only then is it known)
                 return self._tune_eager_step(data, meta_arch, optimizer, arena, fused, meta, logger)

@@ -42,9 +42,10 @@ def _build(dev, lanes=None):
     return m, build_optimizer(m, **tc.optimizer), build(**tc.training_hook)
 
 
-def _rank_main(rank, world, port, out_path, lanes):
+def _rank_main(rank, world, port, out_path, lanes, wgrad):
     import torch.distributed as dist
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["FSNET_AMD_DP_WGRAD"] = wgrad
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
@@ -59,6 +60,7 @@ def _rank_main(rank, world, port, out_path, lanes):
         torch.cuda.synchronize()
         from fsnet_amd.engine.runtime import RT
         assert RT.dp is not None and RT.dp.world == world and hook.graph_captures == 0 and RT.lanes == lanes
+        assert RT.dp.wgrad_mode == wgrad and hook.tune_done
         torch.save({"losses": losses,
                     "params": torch.cat([p.detach().flatten() for p in m.parameters()]).cpu(),
                     "running": torch.cat([b.detach().double().flatten() for n, b in m.named_buffers() if "running_" in n]).cpu()},
@@ -67,15 +69,17 @@ def _rank_main(rank, world, port, out_path, lanes):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("lanes", [True, False], ids=["two-lanes", "two-chains"])
-def test_two_ranks_equal_one_process_on_the_full_batch(dev, tmp_path, lanes):
-    """both arrangements of the encoders under data parallelism (the training hook's autotune picks between them on a
-    real node) against the single process, which runs two chains"""
+@pytest.mark.parametrize("lanes,wgrad", [(True, "inline"), (False, "inline"), (False, "tail"), (True, "tail"),
+                                         (True, "companion"), (False, "companion")])
+def test_two_ranks_equal_one_process_on_the_full_batch(dev, tmp_path, lanes, wgrad):
+    """every arrangement the training hook's autotune chooses between on a real node — the encoders as two lanes or two
+    chains, the weight gradients inline, on companion streams, or the decoder's at the pose chain's tail — against the
+    single process, which runs two chains with companions"""
     import torch.multiprocessing as mp
     port = _free_port()
     out_path = str(tmp_path / "rank%d.pt")
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, out_path, lanes)) for r in range(2)]
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, out_path, lanes, wgrad)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -132,6 +136,7 @@ def test_bench_script_runs_with_two_ranks(tmp_path):
     assert d["value"] > 0 and abs(d["value"] - 4 * 3 / (d["ms_per_step"] * 3e-3)) < 0.02 * d["value"]
     # the encoder-pass autotune ran before the warm-up steps (eager steps on this rig) and the line carries both timings
     ep = d["config"]["encoder_pass_ms"]
-    assert ep["chains"] > 0 and ep["lanes"] > 0 and ep["chosen"] in ("chains", "lanes") and ep["ranks"] == 2
-    assert d["config"]["encoder_pass"].startswith("two " + ep["chosen"]) and d["config"]["autotune_steps"] >= 8
+    assert ep["chains"] > 0 and ep["lanes"] > 0 and ep["chosen"] in ep and ep["ranks"] == 2
+    assert ep["chains+tail"] > 0 and ep["lanes+companions"] > 0
+    assert d["config"]["encoder_pass"].startswith("two " + ep["chosen"].split("+")[0]) and d["config"]["autotune_steps"] >= 24
     assert "cpu_baseline" not in d                           # rank 0 at N = 1 only

@@ -81,6 +81,7 @@ def _rank_main(rank, world, port, out_path):
 
     import torch.distributed as dist
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["FSNET_AMD_DP_WGRAD"] = "inline"          # (with RT.lanes set: nothing left for the hook's autotune)
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)

@@ -165,6 +165,7 @@ def test_encoder_pass_autotune_on_rccl(dev):
     from fsnet_amd.vision_base.networks.optimizers.optimizers import build_optimizer
     from fsnet_amd.vision_base.utils.builder import build
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["FSNET_AMD_DP_WGRAD"] = "inline"          # (this test: the encoder arrangement only)
     STEPS, K = 16, 3
 
     def run(use_dp):
@@ -207,9 +208,67 @@ def test_encoder_pass_autotune_on_rccl(dev):
         RT.dp = None
     finally:
         RT.dp = None
+        del os.environ["FSNET_AMD_DP_WGRAD"]
         dist.destroy_process_group()
     l_ref, _, _ = run(False)
     assert all(l == l and l < 10 for l in l_dp)
     # the same training run whatever arrangement each step used (run-to-run spread of the fp32 atomics grows with the steps)
+    assert l_dp[:4] == pytest.approx(l_ref[:4], rel=2e-4)
+    assert l_dp == pytest.approx(l_ref, rel=2e-2)
+
+
+def test_weight_gradient_placement_autotune_on_rccl(dev):
+    """where the weight gradients run under data parallelism (inline / the decoder's at the pose chain's tail / companion
+    streams), timed by the hook for a fixed encoder arrangement: three captured graphs, one kept, the plain trajectory"""
+    from fsnet_amd.configs import meta_arch_cfg, training_cfg
+    from fsnet_amd.engine.dataparallel import DataParallelContext
+    from fsnet_amd.engine.runtime import RT
+    from fsnet_amd.vision_base.networks.optimizers.optimizers import build_optimizer
+    from fsnet_amd.vision_base.utils.builder import build
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    STEPS, K = 18, 2
+
+    def run(use_dp):
+        RT.set_compute_dtype(torch.float32)
+        RT.tie_noise = False
+        RT.lanes = False
+        m = build(**meta_arch_cfg(64, 128, with_pose=True))
+        m.load_state_dict(O.init_state(seed=6, with_pose=True), strict=True)
+        m = m.to(dev).train()
+        tc = training_cfg()
+        opt = build_optimizer(m, **tc.optimizer)
+        hook = build(graph_warmup=2, **tc.training_hook)
+        hook.tune_steps = K
+        if use_dp:
+            m.ensure_arena()
+            RT.dp = DataParallelContext(m)
+        losses, modes = [], []
+        for it in range(STEPS):
+            out = hook(dict(O.synthetic_batch(2, 64, 128, seed=50 + it % 4)), m, opt)
+            losses.append(float(out["loss"].detach()))
+            modes.append(RT.dp.wgrad_mode if use_dp else None)
+        torch.cuda.synchronize()
+        return losses, modes, hook
+
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
+    try:
+        l_dp, modes, hook = run(True)
+        ep = RT.encoder_pass_ms
+        assert hook.tune_done and hook.graph_captures == 3 and hook.use_graph and not RT.lanes
+        assert set(ep) >= {"chains", "chains+tail", "chains+companions", "chosen"} and "lanes" not in ep
+        P = 3 + K                      # two eager steps, the capture, K timed replays per candidate
+        assert modes[:P - 1] == ["inline"] * (P - 1) and modes[P - 1:2 * P - 1] == ["tail"] * P
+        assert modes[2 * P - 1:3 * P - 1] == ["companion"] * P
+        want = {"chains": "inline", "chains+tail": "tail", "chains+companions": "companion"}[ep["chosen"]]
+        assert all(mode == want for mode in modes[3 * P - 1:]) and len(modes[3 * P - 1:]) >= 3
+        RT.dp.close()
+        RT.dp = None
+    finally:
+        RT.dp = None
+        RT.lanes = "auto"
+        dist.destroy_process_group()
+    l_ref, _, _ = run(False)
+    RT.lanes = "auto"
+    assert all(l == l and l < 10 for l in l_dp)
     assert l_dp[:4] == pytest.approx(l_ref[:4], rel=2e-4)
     assert l_dp == pytest.approx(l_ref, rel=2e-2)

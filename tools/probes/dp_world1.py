@@ -41,7 +41,7 @@ if use_dp:
     RT.dp.allreduce_small = counted
 batches = bench.synthetic_device_batches(12, 192, 640, dev, 0)
 pre = 0
-while use_dp and graph and not hook.tune_done and pre < 100:       # encoder-pass autotune (FSNET_AMD_LANES=auto)
+while use_dp and graph and not hook.tune_done and pre < 200:       # encoder-pass autotune (FSNET_AMD_LANES=auto)
     hook(dict(batches[pre % len(batches)]), model, opt, global_step=pre)
     pre += 1
 for i in range(8):
@@ -57,5 +57,6 @@ torch.cuda.synchronize()
 el = time.perf_counter() - t0
 print("dp=%s graph=%s: %.3f ms/step, %.1f samples/s, small collectives/step: %s" % (
     use_dp, graph, el / K * 1e3, 12 * K / el, (n[0] / K) if use_dp else "-"))
-print("encoder pass: %s, autotune: %s after %d steps" % ("lanes" if RT.lanes else "chains", RT.encoder_pass_ms, pre))
+print("encoder pass: %s, weight gradients %s, autotune: %s after %d steps" % (
+    "lanes" if RT.lanes else "chains", RT.dp.wgrad_mode if RT.dp is not None else "-", RT.encoder_pass_ms, pre))
 dist.destroy_process_group()

@@ -1,4 +1,5 @@
-"""Unprofiled timeline of a replayed step: device-clock marks (FSNET_AMD_MARKS=1) stamped on each chain's stream."""
+"""Unprofiled timeline of a replayed step: device-clock marks (FSNET_AMD_MARKS=1) stamped on each chain's stream.
+    python tools/probes/step_marks.py [dp]      dp: the data-parallel step at world size 1 over RCCL (set FSNET_AMD_LANES)"""
 import os, sys, time
 os.environ["FSNET_AMD_MARKS"] = "1"
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
@@ -15,6 +16,14 @@ model = build(**meta_arch_cfg(192, 640, with_pose=True, depth=18)).to(dev).train
 tc = training_cfg(clip_gradients=35.0, lr=1e-4)
 opt = build_optimizer(model, **tc.optimizer)
 hook = build(**tc.training_hook)
+if "dp" in sys.argv:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    from fsnet_amd.engine.dataparallel import DataParallelContext
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    hook.tune_steps = 0
+    RT.dp = DataParallelContext(model)
 batches = bench.synthetic_device_batches(12, 192, 640, dev, 0)
 for i in range(12):
     hook(dict(batches[i % 4]), model, opt, global_step=i)
