@@ -52,6 +52,19 @@ def pmc_traffic(kind):
         return None
 
 
+def pmc_valu_insts(kind):
+    """wave-level vector-ALU instructions per launch (SQ_INSTS_VALU pass of tools/pmc_traffic.sh); None if absent"""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        return json.load(open(path)).get(kind, {}).get("valu_insts_per_launch")
+    except Exception:
+        return None
+
+
+N_SIMD = 256 * 4            # MI355X: 256 CUs x 4 SIMDs; a wave64 vector instruction occupies its SIMD's issue port for 4 cycles
+CLOCK_HZ = 2.4e9            # peak engine clock, /opt/skills/guides/MI355X_MICROARCH.md
+
+
 def cpu_baseline(max_seconds=25.0):
     """Oracle (CPU restatement of the reference path, parity-pinned to the reference) on this box's host
     cores: BASELINE config[0] (B=2, 192x640, depth+pose, fp32), full step incl. clip + Adam."""
@@ -191,14 +204,42 @@ def main():
         for i in range(nprof):
             eager_hook(dict(batches[i % len(batches)]), model, optimizer, global_step=args_start + args.steps + i)
         rec = LaunchProfile.end()
+        tagged = list(LaunchProfile.tagged)
         agg = {}
         for kind, work, dt in rec:
             a = agg.setdefault(kind, [0, 0.0, 0.0])
             a[0] += 1; a[1] += work; a[2] += dt
+        # ... and the same steps once more with everything on ONE stream (no pose chain beside the depth chain, no companion
+        # streams), so that every launch also has samples taken while nothing else was running.  "Alone" figures = every
+        # launch priced at the MINIMUM duration seen for its grid (kind + shape tag) over all 2 x nprof samples — what
+        # tools/rocprof_bygrid_csv.py + tools/sum_alone.py compute from a rocprofv3 trace (profiles/r06*_sum_alone_by_family.txt)
+        ov, ws = RT.overlap, RT.wgrad_streams
+        RT.overlap, RT.wgrad_streams = False, 0
+        try:
+            LaunchProfile.begin()
+            for i in range(nprof):
+                eager_hook(dict(batches[i % len(batches)]), model, optimizer, global_step=args_start + args.steps + nprof + i)
+            LaunchProfile.end()
+            serial = list(LaunchProfile.tagged)
+        finally:
+            RT.overlap, RT.wgrad_streams = ov, ws
+        best = {}
+        for kind, work, dt, tag in tagged + serial:
+            key = (kind, tag if tag is not None else work)
+            best[key] = min(best.get(key, dt), dt)
+        alone = {}
+        for kind, work, dt, tag in tagged:                       # the in-situ passes' launch list, re-priced
+            a = alone.setdefault(kind, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += work; a[2] += best[(kind, tag if tag is not None else work)]
         # sum of the per-launch durations of one step (HIP events around every launch of the eager steps; their streams still
         # overlap, so this is the in-situ sum — the alone-time sum comes from the rocprof per-grid table, profiles/r05*_by_grid)
         extra["sum_launch_ms"] = round(sum(a[2] for a in agg.values()) / nprof * 1e3, 3)
         extra["launches_per_step"] = sum(a[0] for a in agg.values()) // nprof
+        # the same launches at their grids' minimum durations: what the replayed step's duration tracks
+        extra["sum_alone_ms"] = round(sum(a[2] for a in alone.values()) / nprof * 1e3, 3)
+        extra["timed_launches_note"] = ("HIP-event pairs around the convolution, BatchNorm, pooling / upsample, bias-sum and "
+                                        "photometric launches (the loss's small kernels, heads, clip + Adam, re-pack and "
+                                        "zeroing launches are not bracketed: see profiles/ for the rocprofv3 totals)")
         def tf(a):
             return a[1] / a[2] / 1e12
         # (the committed PMC passes were taken on the default workload: no figure for any other)
@@ -216,6 +257,12 @@ def main():
                     "algorithmic_flop_per_launch": round(ch[1] / ch[0]),
                     "kernel_split": {k + "_kernel": {"launches_per_step": a[0] // nprof, "avg_launch_us": round(a[2] / a[0] * 1e6, 2),
                                                      "achieved_tflops": round(tf(a), 2)} for k, a in parts.items()}}
+        pa_ = [a for k, a in alone.items() if k in parts]
+        if pa_:
+            ca = [sum(a[i] for a in pa_) for i in range(3)]
+            roofline["frac_alone"] = round(tf(ca) / PEAK_TFLOPS[args.dtype], 4)
+            roofline["achieved_alone"] = round(tf(ca), 2)
+            roofline["avg_launch_alone_us"] = round(ca[2] / ca[0] * 1e6, 2)
         allc = [ch]
         # (a family may be absent: with the 1x1 GEMM kernel the fisheye configuration has no implicit-GEMM launch left)
         for key, name in (("conv_igemm", "conv_igemm_generic"), ("conv_wgrad", "conv_wgrad")):
@@ -252,6 +299,16 @@ def main():
             a = agg[k]
             extra[k] = {"algorithmic_GBps": round(a[1] / a[2] / 1e9, 1), "frac_hbm_peak": round(a[1] / a[2] / 1e9 / PEAK_HBM_GBS, 4),
                         "avg_launch_us": round(a[2] / a[0] * 1e6, 2)}
+            if k in alone:
+                extra[k]["avg_launch_alone_us"] = round(alone[k][2] / alone[k][0] * 1e6, 2)
+            # the roof these kernels are against is vector-instruction issue, not HBM (their real traffic is 0.4x the
+            # algorithmic bytes): wave instructions x 4 cycles / (SIMDs x cycles of the launch), instruction count from the
+            # committed SQ_INSTS_VALU pass
+            vi = pmc_valu_insts(k) if default_workload else None
+            if vi:
+                dt_alone = (alone[k][2] / alone[k][0]) if k in alone else (a[2] / a[0])
+                extra[k]["valu_insts_per_launch"] = int(vi)
+                extra[k]["frac_valu_issue"] = round(vi * 4.0 / (N_SIMD * dt_alone * CLOCK_HZ), 4)
         conv_time = sum(a[2] for a in allc) / nprof
         extra["conv_time_ms_per_step"] = round(conv_time * 1e3, 3)
 

@@ -34,6 +34,15 @@ def main(root="gpurun_out/pmc_traffic", out="profiles/pmc_traffic.json"):
             fk, wk = f[fam][1] / f[fam][0], w[fam][1] / w[fam][0]
             res[fam] = {"launches_sampled": f[fam][0], "fetch_kb_raw_per_launch": round(fk, 1),
                         "write_kb_per_launch": round(wk, 1), "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
+    import os
+    vpath = root + "/valu/pmc_counter_collection.csv"
+    if os.path.exists(vpath):
+        v, wv = load(vpath, "SQ_INSTS_VALU"), load(vpath, "SQ_WAVES")
+        for fam in FAMILIES:
+            if fam in res and fam in v and v[fam][0]:
+                res[fam]["valu_insts_per_launch"] = round(v[fam][1] / v[fam][0], 1)
+                if fam in wv and wv[fam][0]:
+                    res[fam]["waves_per_launch"] = round(wv[fam][1] / wv[fam][0], 1)
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
