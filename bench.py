@@ -293,7 +293,7 @@ def main():
             allc.append(cs)
         extra["conv_all"] = {"achieved_tflops": round(sum(a[1] for a in allc) / sum(a[2] for a in allc) / 1e12, 2),
                              "frac_mfma_peak": round(sum(a[1] for a in allc) / sum(a[2] for a in allc) / 1e12 / PEAK_TFLOPS[args.dtype], 4)}
-        for k in ("photo_warp", "photo_loss_fwd", "photo_loss_bwd", "photo_fused_fwd", "photo_fused_bwd"):
+        for k in ("photo_fused_fwd", "photo_fused_bwd"):
             if k not in agg:
                 continue
             a = agg[k]

@@ -929,11 +929,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const FsDual<FsBnBwdA
 // channel slabs of the element-wise passes: 32 16-byte groups each where a row has more (a power of two of them)
 int bn_slabs(int CG) { return (CG > 32 && (CG & (CG - 1)) == 0) ? CG / 32 : 1; }
 
-// POOL mode by quads: power-of-two lane counts up to 32 (the stems: 8 at bf16).  FSNET_AMD_BN_POOL_QUADS=0: per-pixel gather
-bool bn_pool_quads(int CG) {
-  static const bool on = [] { const char* e = getenv("FSNET_AMD_BN_POOL_QUADS"); return !(e && e[0] == '0'); }();
-  return on && CG >= 1 && CG <= 32 && (CG & (CG - 1)) == 0;
-}
+// POOL mode by quads: power-of-two lane counts up to 32 (the stems: 8 at bf16); other widths gather per pixel
+bool bn_pool_quads(int CG) { return CG >= 1 && CG <= 32 && (CG & (CG - 1)) == 0; }
 
 int grid_for(long items) {
   long b = (items + 255) / 256;
@@ -943,8 +940,8 @@ int grid_for(long items) {
   // 512): ResNet-18 B=12 5.75 / 5.71 / 5.65 / 5.66 / 5.67 ms, ResNet-50 @320x1024 27.7 / 26.1 / 25.8 / 25.8 / 25.8; again with
   // the dense fast path, whose threads keep two rows in flight (cap 2048 / 1024 / 768 / 512 / 384 / 256, same box each):
   // ResNet-18 5.67 / 5.62 / - / 5.54 and 5.76 / 5.72 / 5.74 / 5.77, ResNet-50 20.65 / 20.09 / - / 19.89 and
-  // 20.44 / 20.41 / 20.43 / 20.58.  FSNET_AMD_BN_GRID overrides (development).
-  static const long cap = getenv("FSNET_AMD_BN_GRID") ? atol(getenv("FSNET_AMD_BN_GRID")) : 512;
+  // 20.44 / 20.41 / 20.43 / 20.58.
+  const long cap = 512;
   if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (int)b;
@@ -1043,7 +1040,7 @@ extern "C" int fs_bn_apply2(const FsBnApplyArgs* a, const FsBnApplyArgs* b, int 
   const int nslab = bn_slabs(a->C / vec);
   dim3 grid(std::min(grid_for(items / nslab), std::max(32, grid_for(1L << 40) / nslab)), nslab, G + G1);   // (the cap holds per launch)
   const unsigned lds = ((a->gamma2 || (b && b->gamma2)) ? 4u : 2u) * (a->C / nslab) * sizeof(float);
-  static const int fast = [] { const char* e = getenv("FSNET_AMD_BN_FAST"); return e ? atoi(e) : 1; }();   // (0: A/B runs)
+  const int fast = 1;       // dense tensors take the kernels' fast path (the generic loop serves strided / padded ones)
   if (dtype == FS_DTYPE_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16>, grid, dim3(256), lds, st, d, fast);
   else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), lds, st, d, fast);
   else return FS_EINVAL;
@@ -1092,7 +1089,7 @@ extern "C" int fs_bn_bwd_reduce2(const FsBnBwdArgs* a, const FsBnBwdArgs* b, int
     else if (dtype == FS_DTYPE_F32) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, CGB>), grid, dim3(256), 0, st, d, rfast); \
     else return FS_EINVAL;                                                                                      \
   }
-  static const int rfast = [] { const char* e = getenv("FSNET_AMD_BN_FAST"); return e ? atoi(e) : 1; }();
+  const int rfast = 1;
   // (wide rows: every block ends in 2 x 256 f64 atomics and a block-wide fold — hold the grid near 1024 blocks)
   const long wide_cap = std::max<long>(32, std::min<long>(512, 1024 / ((long)((CG + 31) / 32) * (G + G1))));
   if (CG >= 32) LAUNCH_REDUCE(32, 16, wide_cap)
@@ -1125,7 +1122,7 @@ extern "C" int fs_bn_bwd_apply2(const FsBnBwdArgs* a, const FsBnBwdArgs* b, int 
   dim3 grid(std::min(grid_for(items / nslab), std::max(32, grid_for(1L << 40) / nslab)), nslab, G + G1);
   const unsigned lds = (a->pool_dy ? 6u : 5u) * (a->C / nslab) * sizeof(float);
   const FsDual<FsBnBwdArgs, FsNoGeom> d = bn_dual(a, b);
-  static const int fast = [] { const char* e = getenv("FSNET_AMD_BN_FAST"); return e ? atoi(e) : 1; }();   // (0: A/B runs)
+  const int fast = 1;       // dense tensors take the kernels' fast path (the generic loop serves strided / padded ones)
   if (a->pool_dy && bn_pool_quads(a->C / vec)) {
     const int CG = a->C / vec;
     long Qg = (a->M / G) / 4;

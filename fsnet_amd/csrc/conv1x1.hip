@@ -275,8 +275,8 @@ extern "C" int fs_conv1x1(const FsConvArgs* args, int dtype, void* stream) {
     return FS_EINVAL;
   if (args->stats && args->stat_group_rows > 0 && args->stat_group_rows % 128 != 0) return FS_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  static const bool use_gemm = [] { const char* e = getenv("FSNET_AMD_1X1_GEMM"); return !(e && e[0] == '0'); }();
-  if (use_gemm) {
+  {
+    // LDS-DMA GEMM kernel first; what it declines (< 128 rows, channel counts that are not multiples of 8) streams rows
     const int r = fs_conv1x1_gemm(*args, st);
     if (r != FS_EINVAL) return r;
   }

@@ -361,8 +361,7 @@ int launch_gemm_epi(const FsConvArgs& a, hipStream_t st) {
   // whole statistics groups
   int pt = 1;
   if (a.stats) {
-    static const int f_pt = [] { const char* e = getenv("FSNET_AMD_1X1_PT"); return e ? atoi(e) : 0; }();
-    pt = f_pt > 0 ? f_pt : (int)std::min<long>(8, std::max<long>(1, (long)npix * nco * z / 1024));
+    pt = (int)std::min<long>(8, std::max<long>(1, (long)npix * nco * z / 1024));
     while (pt > 1 && a.stat_group_rows > 0 && a.stat_group_rows % (pt * PIX) != 0) --pt;
   }
   const int nsp = (npix + pt - 1) / pt;
@@ -372,29 +371,21 @@ int launch_gemm_epi(const FsConvArgs& a, hipStream_t st) {
   return fs_launch_status();
 }
 
-// epilogue specialisation (128-pixel tiles; the 256-pixel probe configuration keeps the general epilogue)
+// epilogue specialisation: forward (0), data gradient (1), anything else (2)
 template <int CO, int PIX, int NST>
 int launch_gemm(const FsConvArgs& a, hipStream_t st) {
-  static const int f_epi = [] { const char* e = getenv("FSNET_AMD_1X1_EPI"); return e ? atoi(e) : -1; }();   // (2: A/B runs)
-  if constexpr (PIX == 128) {
-    const bool dgr = (a.mask || a.bnb_x) && !a.bias && !a.relu, fwd = !a.mask && !a.bnb_x;
-    if (f_epi != 2 && dgr) return launch_gemm_epi<CO, PIX, NST, 1>(a, st);
-    if (f_epi != 2 && fwd) return launch_gemm_epi<CO, PIX, NST, 0>(a, st);
-  }
+  const bool dgr = (a.mask || a.bnb_x) && !a.bias && !a.relu, fwd = !a.mask && !a.bnb_x;
+  if (dgr) return launch_gemm_epi<CO, PIX, NST, 1>(a, st);
+  if (fwd) return launch_gemm_epi<CO, PIX, NST, 0>(a, st);
   return launch_gemm_epi<CO, PIX, NST, 2>(a, st);
 }
 
 // Measured per ResNet-50 shape at 320x1024 (tools/probes/conv1x1_shapes.py): 128-pixel tiles with two stages (35 KB of
 // LDS, four blocks per CU whose load / multiply / store phases interleave) beat 256-pixel tiles and deeper rings on every
-// shape but K = 2048, which wants three stages.  FSNET_AMD_1X1_PIX / FSNET_AMD_1X1_NST force a configuration (probes).
+// shape but K = 2048, which wants three stages (the 256-pixel and four-stage instantiations were removed with their probes).
 template <int CO>
 int launch_co(const FsConvArgs& a, hipStream_t st) {
-  static const int f_pix = [] { const char* e = getenv("FSNET_AMD_1X1_PIX"); return e ? atoi(e) : 0; }();
-  static const int f_nst = [] { const char* e = getenv("FSNET_AMD_1X1_NST"); return e ? atoi(e) : 0; }();
-  const bool big = f_pix == 256 && !(a.stats && a.stat_group_rows % 256 != 0);
-  const int nst = f_nst ? f_nst : (a.Cs >= 2048 ? 3 : 2);
-  if (big) return nst == 2 ? launch_gemm<CO, 256, 2>(a, st) : nst == 3 ? launch_gemm<CO, 256, 3>(a, st) : launch_gemm<CO, 256, 3>(a, st);
-  return nst == 2 ? launch_gemm<CO, 128, 2>(a, st) : nst == 3 ? launch_gemm<CO, 128, 3>(a, st) : launch_gemm<CO, 128, 4>(a, st);
+  return a.Cs >= 2048 ? launch_gemm<CO, 128, 3>(a, st) : launch_gemm<CO, 128, 2>(a, st);
 }
 
 }  // namespace

@@ -475,9 +475,7 @@ template <typename T>
 int dispatch_s2(const FsConvArgs& a, const FsConvArgs* b, hipStream_t st) {
   HaloGeom g = pick_geom_s2(a.Hd, a.Wd, 128, halo_hmax(128, 2));
   if (g.TH == 0 || a.Co_p % 16 != 0) return FS_EINVAL;
-  const char* fe = getenv("FSNET_AMD_S2_CO");          // development knob: channels per block tile
-  const int co = fe ? atoi(fe) : (a.Co_p % 32 == 0 ? 32 : 16);
-  if (co == 32 && a.Co_p % 32 == 0) return launch_halo_pro<T, 128, 32, 4, 0, 2>(a, b, st);
+  if (a.Co_p % 32 == 0) return launch_halo_pro<T, 128, 32, 4, 0, 2>(a, b, st);
   return launch_halo_pro<T, 128, 16, 4, 0, 2>(a, b, st);
 }
 
@@ -579,17 +577,20 @@ int conv3x3_entry(const FsConvArgs* args, const FsConvArgs* b, int dtype, hipStr
     if (dtype == FS_DTYPE_F32) return dispatch_s2<float>(*args, b, st);
     return FS_EINVAL;
   }
-  if (!b) {
+  // FsConvArgs.force_impl (tests): 0 = the choice below; 1 = the 16x16-tile kernel; 2-4 = the 32x32-tile kernel in tile
+  // configuration 1-3 (FS_EINVAL where it cannot take the launch); 5 = the persistent one-chunk kernel whatever the number
+  // of tiles (shapes it does not cover go on to the usual choice).
+  const int force = args->force_impl;
+  if (force < 0 || force > 5 || (b && b->force_impl != force)) return FS_EINVAL;
+  if (!b && (force == 0 || force == 5)) {
     // one-chunk layers with <= 32 output channels and many pixel tiles (the decoder's 192x640 / 96x320 layers): the
     // persistent kernel with resident weights
     r = fs_conv3x3_p1(*args, dtype, st);
     if (r != FS_EINVAL) return r;
   }
-  const char* te = getenv("FSNET_AMD_T32");
-  const bool use_t32 = !(te && te[0] == '0');
-  if (use_t32) {
+  if (force != 1) {
     r = fs_conv3x3_t32(*args, b, dtype, st);
-    if (r != FS_EINVAL) return r;
+    if (r != FS_EINVAL || (force >= 2 && force <= 4)) return r;
   }
   if (dtype == FS_DTYPE_BF16) return dispatch<bf16>(*args, b, st);
   if (dtype == FS_DTYPE_F32) return dispatch<float>(*args, b, st);

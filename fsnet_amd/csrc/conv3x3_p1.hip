@@ -317,9 +317,8 @@ int p1_launch(const FsConvArgs& a, hipStream_t st) {
   }
   const long ntiles = (long)a.N * g.tiles_x * g.tiles_y;
   // worth it from two tiles per resident block on (below that the one-tile-per-block kernel has as little to repeat)
-  // (FSNET_AMD_P1_MIN: development / test switch, read per launch so that a test can force small launches onto this kernel)
-  const char* min_env = getenv("FSNET_AMD_P1_MIN");
-  const long min_rounds_x10 = min_env ? atol(min_env) : 20;
+  // (FsConvArgs.force_impl = 5: a test forces small launches onto this kernel)
+  const long min_rounds_x10 = a.force_impl == 5 ? 0 : 20;
   static const int slots = p1_resident(conv3x3_p1_kernel<T, CO, UQ>);
   if (ntiles * 10 < (long)slots * min_rounds_x10 || ntiles > 0x7fffffffL) return FS_EINVAL;
   g.ntiles = (int)ntiles;
@@ -336,8 +335,6 @@ int p1_launch(const FsConvArgs& a, hipStream_t st) {
 
 // internal entry: FS_EINVAL = "not mine" (fs_conv3x3_halo goes on to its other kernels)
 int fs_conv3x3_p1(const FsConvArgs& a, int dtype, hipStream_t st) {
-  static const bool on = !(getenv("FSNET_AMD_P1") && getenv("FSNET_AMD_P1")[0] == '0');
-  if (!on) return FS_EINVAL;
   const int es = dtype == FS_DTYPE_BF16 ? 2 : 4;
   if (a.pro_mode != 0 || a.hb_mul != 1 || a.Cs * es > 64 || (a.Co_p != 16 && a.Co_p != 32) || a.Co % 4 != 0) return FS_EINVAL;
   if (a.src_bytes >= 0x7ffff000LL) return FS_EINVAL;

@@ -404,15 +404,15 @@ double t32_waste(const FsConvArgs& a, int PIX) {
 
 // -1: leave the launch to the 16x16-tile kernel
 int t32_pick_cfg(const FsConvArgs& a, int nimg) {
-  const char* fe = getenv("FSNET_AMD_T32_CFG");        // development knob (tools/probes/t32_ab.py)
-  if (fe) { const int c = atoi(fe); return (a.Co_p % 64 != 0 && c == 1) ? 2 : c; }
+  if (a.force_impl >= 2 && a.force_impl <= 4) {        // (tests: FsConvArgs.force_impl, see fs_conv3x3_halo)
+    const int c = a.force_impl - 1;
+    return (a.Co_p % 64 != 0 && c == 1) ? 2 : c;
+  }
   // 256-pixel tiles where they do not waste lanes and the launch still fills the chip's three block slots per CU a
   // few times over; everything else is faster on the 16x16-tile kernel (same prologues and epilogues there)
   const bool big = t32_waste(a, 256) <= 1.15 * t32_waste(a, 128);
   if (big && t32_blocks(a, nimg, 256, 32) >= 512) return 3;
-  // (development knob: 128 x 32 tiles for launches with at least this many of them, instead of the 16x16-tile kernel)
-  static const int mid = getenv("FSNET_AMD_T32_MID") ? atoi(getenv("FSNET_AMD_T32_MID")) : 0;
-  if (mid > 0 && t32_blocks(a, nimg, 128, 32) >= mid) return 2;
+  // (measured and left out: 128 x 32 tiles for the launches in between — slower than the 16x16-tile kernel there)
   return -1;
 }
 

@@ -225,11 +225,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const FsDual<FsWgradArg
   }
 }
 
-// Slab reductions take up to WG_MULTI problems per launch (blockIdx.z): the two problems of a shared launch — or, between
-// fs_wgrad_batch_begin() and fs_wgrad_batch_end(), the reductions of every weight gradient issued in between, grouped by
-// reduction kernel.  A ResNet-18 step has 57 of them at 5-9 us each (mostly ramp: 19 MB of slabs per 3x3 layer), a
-// ResNet-50 step 144; a hand-over batch of eight layers leaves two or three launches.
-constexpr int WG_MULTI = 8;
+// Slab reductions take the two problems of a shared launch in one launch (blockIdx.z).  (Round 5 also had a batched form —
+// the reductions of a whole hand-over batch of layers in two or three launches — which measured 0.8 % slower on the step:
+// a reduction launched right behind its main kernel reads slabs that are still in L2 / Infinity Cache.  Removed in round 6.)
+constexpr int WG_MULTI = 2;
 struct WgMulti { FsWgradArgs a[WG_MULTI]; };
 
 // dw[co][ci][r][s] += sum_z workspace[z][co][col].  A block owns 64 consecutive columns of one row: 16 column quads x
@@ -241,7 +240,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgMulti d, int 
   __shared__ float4 red[16][16];
   const int ncols = p.ncolgroups * eg;
   const int cblocks = (ncols + 63) / 64;
-  if ((int)blockIdx.x >= p.Co * cblocks) return;      // (a batch's grid is its largest item's)
+  if ((int)blockIdx.x >= p.Co * cblocks) return;      // (the grid is the larger problem's)
   const int co = blockIdx.x / cblocks, cbase = (blockIdx.x % cblocks) * 64;
   const int q = threadIdx.x & 15, zl = threadIdx.x >> 4;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -387,8 +386,6 @@ __global__ __launch_bounds__(320) void wgrad_reduce3x3_kernel(const WgMulti d, i
 
 enum { RK_3X3 = 0, RK_FLAT = 1, RK_4 = 2, RK_16 = 3 };
 struct WgPending { FsWgradArgs a; int kind, eg, gx, gy; };
-thread_local bool g_batch = false;
-thread_local std::vector<WgPending>* g_pending = nullptr;
 
 void launch_reduce_group(const WgPending* it, int n, hipStream_t st) {
   WgMulti d;
@@ -405,8 +402,7 @@ void launch_reduce_group(const WgPending* it, int n, hipStream_t st) {
 }
 
 // b: the launch's (filled-in) arguments; b2 != nullptr: the second problem's, same dW shape — one reduce launch for both
-// (blockIdx.z = problem).  A problem that was not split (nsplit == 1) accumulated into its dW directly.  Inside a batch
-// (fs_wgrad_batch_begin) the reduction is queued instead: its slabs stay in the caller's workspace until the batch ends.
+// (blockIdx.z = problem).  A problem that was not split (nsplit == 1) accumulated into its dW directly.
 void launch_reduce(const FsWgradArgs& b, const FsWgradArgs* b2, int Co, int ncols, int eg, hipStream_t st, bool always = false) {
   WgPending it[2];
   int n = 0, ns = 0;
@@ -420,10 +416,6 @@ void launch_reduce(const FsWgradArgs& b, const FsWgradArgs* b2, int Co, int ncol
   else if (ns < 32) { kind = RK_4; gx = Co * ((ncols + 63) / 64); }
   else { kind = RK_16; gx = Co * ((ncols + 63) / 64); }
   for (int i = 0; i < n; ++i) { it[i].kind = kind; it[i].eg = eg; it[i].gx = gx; it[i].gy = gy; }
-  if (g_batch && g_pending) {
-    for (int i = 0; i < n; ++i) g_pending->push_back(it[i]);
-    return;
-  }
   launch_reduce_group(it, n, st);
 }
 
@@ -1387,11 +1379,10 @@ int launch_w1(const FsWgradArgs& a, const FsWgradArgs* a2, hipStream_t st) {
   return fs_launch_status();
 }
 
-// 1x1 / pad 0 layers with whole 64-channel tiles on both sides and enough pixels to pipeline (FSNET_AMD_WGRAD_1X1=0: off)
+// 1x1 / pad 0 layers with whole 64-channel tiles on both sides and enough pixels to pipeline
 inline bool w1_takes(const FsWgradArgs& a) {
-  static const bool on = [] { const char* e = getenv("FSNET_AMD_WGRAD_1X1"); return !(e && e[0] == '0'); }();
   const int Cs = a.ncolgroups * 8;
-  return on && a.R == 1 && a.S == 1 && a.pad == 0 && !a.pro_a && a.stride >= 1 && a.Cd % 64 == 0 && Cs % 64 == 0 && a.M >= 2048 &&
+  return a.R == 1 && a.S == 1 && a.pad == 0 && !a.pro_a && a.stride >= 1 && a.Cd % 64 == 0 && Cs % 64 == 0 && a.M >= 2048 &&
          a.x_bytes > 0 && a.x_bytes <= 0x7fffffffLL && (long)a.M * a.Cd * 2 <= 0x7fffffffLL &&
          a.sN % 8 == 0 && a.sH % 8 == 0 && a.sW % 8 == 0 && ((uintptr_t)a.dy | (uintptr_t)a.x) % 16 == 0;
 }
@@ -1518,37 +1509,4 @@ extern "C" int fs_conv_wgrad2_plan(const FsWgradArgs* args, const FsWgradArgs* a
   else if (dtype == FS_DTYPE_F32) r = launch_wgrad<float>(*args, a1, nullptr);
   g_plan = nullptr;
   return r;
-}
-
-// ---- batched slab reductions ----
-// Between begin and end (same host thread) every fs_conv_wgrad* call launches its main kernel and queues its reduction;
-// end launches the queued reductions on `stream`, grouped by reduction kernel, at most WG_MULTI problems per launch.  The
-// caller gives every call of the batch its own workspace (the slabs must survive until end) and issues the whole batch
-// on one stream.
-extern "C" int fs_wgrad_batch_begin(void) {
-  if (!g_pending) g_pending = new std::vector<WgPending>();
-  g_pending->clear();
-  g_batch = true;
-  return FS_OK;
-}
-
-extern "C" int fs_wgrad_batch_end(void* stream) {
-  if (!g_batch || !g_pending) return FS_EINVAL;
-  g_batch = false;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  std::vector<WgPending>& q = *g_pending;
-  std::vector<char> done(q.size(), 0);
-  for (size_t i = 0; i < q.size(); ++i) {
-    if (done[i]) continue;
-    WgPending grp[WG_MULTI];
-    int n = 0;
-    for (size_t j = i; j < q.size(); ++j) {
-      if (done[j] || q[j].kind != q[i].kind || q[j].eg != q[i].eg) continue;
-      grp[n++] = q[j]; done[j] = 1;
-      if (n == WG_MULTI) { launch_reduce_group(grp, n, st); n = 0; }
-    }
-    if (n) launch_reduce_group(grp, n, st);
-  }
-  q.clear();
-  return fs_launch_status();
 }

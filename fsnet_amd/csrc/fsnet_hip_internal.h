@@ -22,6 +22,6 @@ struct FsNoGeom { int unused; };
 // kernels' tile mappings derive the XCD from the problem-local block index
 inline int fs_xcd_round(long blocks) { return (int)((blocks + 7) / 8 * 8); }
 
-// the LDS-staged GEMM form of fs_conv1x1 (conv1x1_gemm.hip); FS_EINVAL = not a case for it.  FSNET_AMD_1X1_GEMM=0 keeps
-// every 1x1 launch on the row-streaming kernel (A/B runs).
+// the LDS-staged GEMM form of fs_conv1x1 (conv1x1_gemm.hip); FS_EINVAL = not a case for it (the row-streaming kernel of
+// conv1x1.hip then takes the launch).
 int fs_conv1x1_gemm(const FsConvArgs& a, hipStream_t st);

@@ -47,6 +47,7 @@ class DataParallelContext:
         self._agreement = None
         self._comm_stream = None
         self._graph_owners = []    # weak references to hooks whose captured step contains this communicator's nodes
+        self._parked = []          # captured steps (they hold state of this communicator) — destroyed in close(), before it
         self.capturable = False
         # Where the weight gradients run under data parallelism (they feed nothing downstream but their gradient bucket):
         #   inline     on their chain, so one event after a stage's last weight gradient covers its bucket;
@@ -58,7 +59,6 @@ class DataParallelContext:
         self.wgrad_env = os.environ.get("FSNET_AMD_DP_WGRAD", "auto").lower()
         assert self.wgrad_env in ("auto", "inline", "companion", "tail"), self.wgrad_env
         self.wgrad_mode = "inline" if self.wgrad_env == "auto" else self.wgrad_env
-        self.pack_overlap = os.environ.get("FSNET_AMD_DP_PACK_OVERLAP", "1") != "0"
         if self._direct is not None:
             from .runtime import RT
             self._comm_stream = RT.new_stream(self._direct.device)
@@ -232,11 +232,25 @@ class DataParallelContext:
             if owner is not None:
                 owner.reset_graph()
         self._graph_owners = []
+        self._destroy_parked()
         self._direct.close()
         from .rccl_direct import DirectComm
         self._agreement = None
         self._direct = DirectComm.create(self.group)
         self.capturable = False                      # this context steps eagerly from here on
+
+    def park_graph(self, graph):
+        """a captured step with this communicator's RCCL nodes: kept alive (BaseTrainingHook: graph execs are not destroyed
+        while the process goes on capturing) until close() destroys it, before the communicator"""
+        self._parked.append(graph)
+
+    def _destroy_parked(self):
+        for g in self._parked:
+            try:
+                g.reset()
+            except Exception:       # noqa: BLE001 — a half-captured graph of a failed capture
+                pass
+        self._parked = []
 
     def note_graph_owner(self, owner):
         """`owner.reset_graph()` drops a hipGraph captured with this context's collectives"""
@@ -252,6 +266,7 @@ class DataParallelContext:
             if owner is not None:
                 owner.reset_graph()
         self._graph_owners = []
+        self._destroy_parked()
         for c in ([self._direct] if self._direct is not None else []):
             c.close()
         self._direct = None

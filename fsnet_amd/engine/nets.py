@@ -15,40 +15,21 @@ import torch
 
 from ..hip import ops
 from ..hip.binding import raw_stream
-from ..hip.conv import ConvOp, run_specs, wgrad_batch
+from ..hip.conv import ConvOp, run_specs
 from .runtime import RT, grad_of
 
 STAT_SLOTS = ops.STAT_SLOTS
-# BatchNorm-backward reduction pass fused into the epilogue of the data-gradient convolution that feeds it
-FUSE_BN_BWD = os.environ.get("FSNET_AMD_FUSE_BN_BWD", "1") != "0"
 # BatchNorm + ReLU between two convolutions of a residual block applied by the SECOND convolution while it stages its
-# operand (and by its weight gradient), instead of a pass of its own: the normalised activation never reaches HBM
-# (0: never; 1: wherever the kernels can; 2: only launches the 32x32-tile kernel takes)
-def _env_level(name, default):
-    """0 / 1 / 2 switches: anything that is not an integer means "on" (as before these were levels)"""
-    v = os.environ.get(name)
-    if v is None:
-        return default
-    try:
-        return int(v)
-    except ValueError:
-        return 0 if v.strip().lower() in ("", "off", "false", "no") else 1
-
-
-FOLD_BN = _env_level("FSNET_AMD_BN_FOLD", 1)
+# operand (and by its weight gradient), instead of a pass of its own: the normalised activation never reaches HBM.
+# FSNET_AMD_BN_FOLD=0 keeps the pass (tests/test_bn_fold_gpu.py compares the two).
+FOLD_BN = os.environ.get("FSNET_AMD_BN_FOLD", "1").strip().lower() not in ("0", "off", "false", "no")
 # (The backward counterpart — the second pass of a BatchNorm's backward applied by the data gradient in front of it while it
 # stages dY, FsConvArgs.pro_mode = 2 of rounds 3-4 — was built, pinned to the oracle and measured slower: two staged tensors,
 # 172-198 registers, half the blocks per CU, +19-25 us for a 15 us pass.  Removed in round 5 with its kernel paths.)
-# the 1x1 / stride-2 downsample projection's data gradient inside the block's 3x3 / stride-2 data gradient launch
-FOLD_DS_DGRAD = os.environ.get("FSNET_AMD_FOLD_DS_DGRAD", "1") != "0"
-# The pose decoder's four weight gradients: handed to the companion stream at the end of its backward (1), or left with the
-# pose encoder's first batch (0).  Default: only with the two-lane pass.  With two chains the pose chain is the step's tail
-# (its encoder backward ends 0.5 ms after the depth encoder's) and the companion shares a hardware queue with it: the
-# hand-over put 0.15 ms of weight gradients in front of that chain — 5.59 / 5.62 -> 5.52 ms without it (same box).
-PDEC_FLUSH = int(os.environ.get("FSNET_AMD_PDEC_FLUSH", "-1"))
-CSUM_BATCH = os.environ.get("FSNET_AMD_CSUM_BATCH", "1") != "0"      # a hand-off batch's bias gradients in one launch
-# the stem's BatchNorm + ReLU + max-pool as one pass, its backward's pooling gradient gathered inside the BatchNorm passes
-FUSE_STEM_POOL = os.environ.get("FSNET_AMD_FUSE_STEM_POOL", "1") != "0"
+# Always on since round 6 (their switches are gone; docs/LAB_r02_r05.md has the measurements): the BatchNorm-backward
+# reduction fused into the epilogue of the data gradient that feeds it; the 1x1 / stride-2 downsample projection's data
+# gradient inside the block's 3x3 / stride-2 data-gradient launch; a hand-off batch's bias gradients in one launch; the stem's
+# BatchNorm + ReLU + max-pool as one pass with its backward's pooling gradient gathered inside the BatchNorm passes.
 
 
 class StatsPool:
@@ -145,7 +126,7 @@ def _inline_bias_list(dev):
     """data parallel: the weight gradients run inline on their chain — their bias sums are still collected and issued as
     one launch per gradient bucket (flush_inline_bias from DataParallelContext._reduce_range) instead of one per layer
     (18 launches of ~10 us on the decoders' chains: tools/probes/dp_world1.py)"""
-    if not (CSUM_BATCH and RT.dp is not None and dev.type == "cuda"):
+    if not (RT.dp is not None and dev.type == "cuda"):
         return None
     cur = _current_stream(dev)
     return _INLINE_BIAS.setdefault(cur.cuda_stream, (cur, []))[1]
@@ -233,11 +214,9 @@ def flush_deferred(cur=None, spread=False):
                 continue
             ws.wait_stream(chain)                   # one cross-stream edge per batch
             with torch.cuda.stream(ws):
-                sums = [] if CSUM_BATCH else None
-                with wgrad_batch() as wb:           # ... and the batch's slab reductions in two or three
-                    for it in mine:
-                        _run_param_grads(*it, bias_later=sums)
-                        wb.next_slot()
+                sums = []
+                for it in mine:
+                    _run_param_grads(*it, bias_later=sums)
                 if sums:
                     ops.channel_sum_multi(sums)     # the batch's bias gradients in one launch
             _PENDING_JOIN.add((chain, ws))
@@ -300,7 +279,7 @@ def flush_tail():
         side = RT.side_stream(chain.device)
         side.wait_event(ev)
         with torch.cuda.stream(side):
-            sums = [] if CSUM_BATCH else None
+            sums = []
             for it in items:
                 _run_param_grads(*it, bias_later=sums)
             if sums:
@@ -352,7 +331,7 @@ def pack_everything_async(arena):
     the 70 us re-pack of every convolution's MFMA operands after the optimizer step ran in front of all of it.  Every
     stream that launches a convolution waits for the pack stream once (ConvLayer.ready -> join_pack)."""
     dev = arena.data.device if arena is not None else None
-    if not (RT.pack_overlap and RT.overlap and (RT.dp is None or RT.dp.pack_overlap) and dev is not None and dev.type == "cuda"):
+    if not (RT.pack_overlap and RT.overlap and dev is not None and dev.type == "cuda"):
         _PACK_PENDING.clear()
         pack_everything(arena)
         return
@@ -715,13 +694,11 @@ class EncoderPass:
 
     def _can_fold(self, bns, nxt_cls, c_shapes, xs, train):
         """unit -> next unit of a block: may the BatchNorm + ReLU in between be folded into the next convolution?"""
-        if not (FOLD_BN and FUSE_BN_BWD and train and bns[0].training):
+        if not (FOLD_BN and train and bns[0].training):
             return False
         for bn, ncl, (N, H, W), x, G in zip(bns, nxt_cls, c_shapes, xs, self.groups):
             nop = ncl.ready(x.dtype, x.device)
             if not (nop.can_fold_input(N, H, W) and nop.can_fuse_bn_bwd(N, H, W, G) and N * H * W >= 1):
-                return False
-            if int(FOLD_BN) == 2 and nop.plan_3x3(N, H, W, forward=True, pro_mode=1)["kernel"] != "t32":
                 return False
         return True
 
@@ -767,7 +744,7 @@ class EncoderPass:
         """stem BatchNorm + ReLU + max-pool as one pass (fs_bn_apply with FsBnApplyArgs.pool_y) and, backwards, the pooling
         gradient gathered inside both BatchNorm-backward passes (FsBnBwdArgs.pool_dy): training-mode BatchNorm and an
         even convolution output"""
-        if not (FUSE_STEM_POOL and train and all(bn.training for bn in bns)):
+        if not (train and all(bn.training for bn in bns)):
             return False
         for cl, x in zip(cls, xs):
             Ho, Wo = cl.ready(x.dtype, x.device).out_hw(x.shape[1], x.shape[2])
@@ -986,7 +963,7 @@ class EncoderPass:
                 dc_ds = self._bn_bwd(g, None, c_ds, [d[1] for d in ds], st2, relu=False)
             self._param_grads(dcl, dop, dc_ds, x)
             op_first = self._ready([u[0][0] for u in units], x)
-            if FOLD_DS_DGRAD and k > 1 and all(o.can_fold_ds_dgrad(dp, t, t) for o, dp, t in zip(op_first, dop, dc_ds)):
+            if k > 1 and all(o.can_fold_ds_dgrad(dp, t, t) for o, dp, t in zip(op_first, dop, dc_ds)):
                 # the projection's data gradient rides in conv1's (fs_conv3x3_s2d, FsConvArgs.ds_src): its result is one
                 # more K segment of the (even, even) class there, never a tensor; the feature gradient stays the addend
                 ds_fold = [(dop[l], dc_ds[l]) for l in range(nl)]
@@ -1009,7 +986,7 @@ class EncoderPass:
                 # evaluated (with the BatchNorm-backward sums) in the data gradient's epilogue from c
                 sums = self._sums(c, st)
                 dy_prev = self._dgrad(op, src, hw_in, [dict(bn_fuse=(c[l], st[l], sums[l]), mask_bn=True, **kw[l]) for l in range(nl)])
-            elif FUSE_BN_BWD and all(o.can_fuse_bn_bwd(t.shape[0], t.shape[1], t.shape[2], s.groups) for o, t, s in zip(op, xin, st)):
+            elif all(o.can_fuse_bn_bwd(t.shape[0], t.shape[1], t.shape[2], s.groups) for o, t, s in zip(op, xin, st)):
                 sums = self._sums(c, st)
                 dy_prev = self._dgrad(op, src, hw_in, [dict(mask=y[l], bn_fuse=(c[l], st[l], sums[l]), **kw[l]) for l in range(nl)])
             else:
@@ -1026,7 +1003,7 @@ class EncoderPass:
         if ds_fold is not None:
             for l in range(nl):
                 kw[l]["ds"] = ds_fold[l]
-        if prev is not None and FUSE_BN_BWD and all(o.can_fuse_bn_bwd(t.shape[0], t.shape[1], t.shape[2], p.groups)
+        if prev is not None and all(o.can_fuse_bn_bwd(t.shape[0], t.shape[1], t.shape[2], p.groups)
                                                     for o, t, p in zip(op, x, prev[2])):
             py, pc, pst = prev
             sums = self._sums(pc, pst)
@@ -1075,7 +1052,7 @@ class EncoderPass:
                 for r in self.R:
                     if r.m._pending == 1:
                         # (only the module's LAST pending backward of the step: an encoder that ran several training forwards —
-                        # the pose encoder with FSNET_AMD_BATCH_POSE=0 — accumulates every call's gradients first; a slice
+                        # the pose encoder with RT.batch_pose_pairs = False — accumulates every call's gradients first; a slice
                         # reduced after the first backward would be reduced again with the second one's local sums on top)
                         # gradient bucket of this stage (reverse parameter order, like DDP): layer4 and layer3 carry 94 % of
                         # the encoder's parameters and finish first
@@ -1340,6 +1317,9 @@ class PoseDecoderRunner:
             self.cl[j].accumulate_param_grads(op, d, xin)
             # gradient w.r.t. the input activation, masked by the producing ReLU (none for the encoder feature)
             d = op.dgrad(d, xin.shape[1], xin.shape[2], mask=(xin if j > 0 else None))
-        if PDEC_FLUSH == 1 or (PDEC_FLUSH < 0 and RT.lanes):
+        if RT.lanes:
+            # the four weight gradients go to the companion now — only with the two-lane pass: with two chains the pose chain
+            # is the step's tail (its encoder backward ends 0.5 ms after the depth encoder's) and the companion shares a
+            # hardware queue with it: the hand-over put 0.15 ms of weight gradients in front of that chain (5.59 -> 5.52 ms)
             flush_deferred(_current_stream())
         return d

@@ -127,6 +127,7 @@ class DirectComm(object):
         self.capture_ok = False
         self.capture_test = "not run"      # what the start-up capture self-test exercised (bench.py reports it)
         self.agreement = None
+        self._selftest_graph = None        # kept until close(): see BaseTrainingHook on destroying graph execs
 
     @classmethod
     def create(cls, group=None, device=None):
@@ -170,6 +171,9 @@ class DirectComm(object):
     def close(self):
         if self.comm is not None and self.comm.value:
             torch.cuda.synchronize(self.device)
+            if self._selftest_graph is not None:
+                self._selftest_graph.reset()           # RCCL nodes of this communicator: gone before it is
+                self._selftest_graph = None
             self.lib.ncclCommDestroy(self.comm)
             self.comm = None
 
@@ -242,6 +246,7 @@ class DirectComm(object):
             warnings.warn("fsnet_amd: RCCL collectives could not be captured into a hipGraph (%s: %s); data-parallel "
                           "steps run eagerly" % (type(e).__name__, e))
             captured = False
+        self._selftest_graph = graph
         if not agree(captured):          # nobody replays unless everybody captured
             return False
         graph.replay()

@@ -16,7 +16,7 @@ class _Runtime:
         self.tie_noise = os.environ.get("FSNET_AMD_TIE_NOISE", "1") != "0"
         # run the pose chain on a second HIP stream next to the depth chain (they are independent until the
         # loss): measured, ~40 % of the GPU idles in kernel boundaries / tails of the many small launches
-        self.overlap = os.environ.get("FSNET_AMD_OVERLAP", "1") != "0"
+        self.overlap = True          # (False: everything on one stream — bench.py's single-stream timing pass, tests)
         # Weight gradients feed nothing downstream in the backward pass: every chain hands them to a companion stream in
         # batches of `wgrad_flush` layers (cross-stream edges are not free — host time eagerly, barrier packets in a
         # hipGraph — hence batches rather than one fork per layer), and the pose chain's last batch, which ends the
@@ -24,13 +24,13 @@ class _Runtime:
         # inline 6.13 ms, main chain only 6.1, onto the pose stream's tail 6.15, this placement 5.93; batches of 6 / 16
         # are 3-4 % slower than 8.  wgrad_streams = 0 (inline) is what data parallelism uses and what tests may set.
         self.wgrad_streams = 2
-        self.wgrad_flush = int(os.environ.get("FSNET_AMD_WGRAD_FLUSH", "8"))
-        self.wgrad_flush_side = int(os.environ.get("FSNET_AMD_WGRAD_FLUSH_SIDE", str(self.wgrad_flush)))
-        # hand over what is pending when an encoder's backward reaches its stem (see EncoderPass.backward)
-        self.stem_flush = os.environ.get("FSNET_AMD_STEM_FLUSH", "-1")      # -1: with the two-lane pass only (resolved below)
+        self.wgrad_flush = self.wgrad_flush_side = 8
+        # hand over what is pending when an encoder's backward reaches its stem (see EncoderPass.backward): with the two-lane
+        # pass only (follows `lanes`)
+        self.stem_flush = False
         self.wgrad_spread = 1
         # the pose encoder's image pairs as one stacked pass with per-pair BatchNorm statistics
-        self.batch_pose_pairs = os.environ.get("FSNET_AMD_BATCH_POSE", "1") != "0"
+        self.batch_pose_pairs = True     # (False: one call per pair, the reference's pattern — tests/test_pose_pairs_gpu.py)
         # the depth encoder and the stacked pose encoder as the two lanes of ONE pass: every post-stem launch carries
         # both networks' problems (EncoderPass in nets.py; fs_*2 entry points).  0: two passes on two streams (round 1-4).
         # Default ("auto"): two chains at world size 1 — measured there on the same box, 150 replayed steps each
@@ -44,10 +44,9 @@ class _Runtime:
         self._lanes_override = None     # set by the autotune while / after it runs (auto mode only)
         # (measured, same box: two lanes 6.38 -> 6.29 ms with the hand-over; two chains 6.03 -> 6.58 — there the other
         # chain's launches fill the stem's passes already and the extra cross-stream edge delays the chain)
-        self._stem_flush_env = self.stem_flush
-        self.stem_flush = self._lanes if self.stem_flush == "-1" else self.stem_flush != "0"
+        self.stem_flush = self._lanes
         # the per-step weight re-pack beside the step's weight-free head (nets.pack_everything_async)
-        self.pack_overlap = os.environ.get("FSNET_AMD_PACK_OVERLAP", "1") != "0"
+        self.pack_overlap = True
         self._side = {}
         self._held = {}           # raw stream handle -> Stream: every stream the engine created (see new_stream)
         # FSNET_AMD_MARKS=1: device-clock marks along the step (mark() below), read back with marks_report()
@@ -66,8 +65,7 @@ class _Runtime:
             self._lanes_env, self._lanes = "auto", False
         else:
             self._lanes_env, self._lanes = ("1" if v else "0"), bool(v)
-        if self._stem_flush_env == "-1":
-            self.stem_flush = self._lanes
+        self.stem_flush = self._lanes
 
     @property
     def lanes_auto(self):
@@ -96,8 +94,7 @@ class _Runtime:
                 import torch.distributed as dist
                 multi = self.dp is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
                 self._lanes = bool(multi)
-            if self._stem_flush_env == "-1":
-                self.stem_flush = self._lanes
+            self.stem_flush = self._lanes
         return self._lanes
 
     def mark(self, name):

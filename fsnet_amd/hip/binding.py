@@ -32,7 +32,7 @@ class FsConvArgs(C.Structure):
         ("bnb_x", C.c_void_p), ("bnb_mean", C.c_void_p), ("bnb_invstd", C.c_void_p),
         ("stat_group_rows", C.c_int32),
         ("pro_a", C.c_void_p), ("pro_b", C.c_void_p), ("pro_c", C.c_void_p), ("pro_m", C.c_void_p), ("pro_src2", C.c_void_p),
-        ("pro_mode", C.c_int32), ("pro_relu", C.c_int32), ("pro_group_imgs", C.c_int32), ("reserved1", C.c_int32),
+        ("pro_mode", C.c_int32), ("pro_relu", C.c_int32), ("pro_group_imgs", C.c_int32), ("force_impl", C.c_int32),
         ("bnb_scale", C.c_void_p), ("bnb_shift", C.c_void_p),
         ("pro_stats", C.c_void_p), ("pro_stats_local", C.c_void_p),
         ("pro_gamma", C.c_void_p), ("pro_beta", C.c_void_p),
@@ -155,7 +155,7 @@ class FsSmoothArgs(C.Structure):
     ]
 
 
-ABI_VERSION = 9      # FS_ABI_VERSION of include/fsnet_hip.h (tests/test_abi.py holds the two together)
+ABI_VERSION = 10     # FS_ABI_VERSION of include/fsnet_hip.h (tests/test_abi.py holds the two together)
 _lib = None
 
 

@@ -158,61 +158,20 @@ import os
 BN_EPS = 1e-5            # nn.BatchNorm2d defaults (resnet.py:17-19, blocks.py:46)
 BN_MOMENTUM = 0.1
 
-USE_1X1 = os.environ.get("FSNET_AMD_CONV1X1", "1") != "0"
-# the LDS-staged GEMM form of the 1x1 kernel (conv1x1_gemm.hip; fs_conv1x1 picks it per launch): every 1x1 / pad-0
-# forward and stride-1 data gradient then goes to fs_conv1x1, whatever its K extent or stride
-USE_1X1_GEMM = os.environ.get("FSNET_AMD_1X1_GEMM", "1") != "0"
 PRO_MAX_CI = 512      # conv_pro.h pro_args_ok: the operand prologue's coefficient table (2 floats per source channel in LDS)
-USE_HALO = os.environ.get("FSNET_AMD_HALO", "1") != "0"   # 3x3/s1 LDS-halo kernel (conv3x3_halo.hip)
-USE_STEM_LDS = os.environ.get("FSNET_AMD_STEM_LDS", "1") != "0"   # 7x7/s2 stem kernel (conv_stem.hip)
-USE_HALO_S2 = os.environ.get("FSNET_AMD_HALO_S2", "1") != "0"     # 3x3/s2 forward on the LDS-halo kernel (else implicit GEMM)
-USE_S2D = os.environ.get("FSNET_AMD_S2D", "1") != "0"   # 3x3/s2 data gradient: four parity classes from one dY halo (conv3x3_s2d.hip)
+# Tests only: FsConvArgs.force_impl of every 3x3 / stride-1 launch (include/fsnet_hip.h: 1 = 16x16-tile kernel, 2-4 = 32x32-tile
+# kernel in tile configuration 1-3, 5 = persistent one-chunk kernel).  0 in the product: the entry point chooses.
+FORCE_3X3 = 0
 _WGRAD_WS = {}
 
 
-_WGRAD_SLOT = [0]         # workspace slot of the next weight-gradient launch (a batch of deferred reductions: one each)
-
-
 def wgrad_workspace(device, elems=1 << 23):
-    """per-device fp32 scratch for split-K partial slabs (32 MB; stream-ordered reuse).  Inside a batch of deferred slab
-    reductions (wgrad_batch) every launch takes the next slot: its slabs live until the batch's reductions have run."""
-    key = (device, raw_stream(device.index), _WGRAD_SLOT[0])   # one scratch per stream: no cross-stream reuse
+    """per-device fp32 scratch for split-K partial slabs (32 MB; stream-ordered reuse)"""
+    key = (device, raw_stream(device.index))   # one scratch per stream: no cross-stream reuse
     ws = _WGRAD_WS.get(key)
     if ws is None or ws.numel() < elems:
         ws = _WGRAD_WS[key] = torch.empty(elems, dtype=torch.float32, device=device)
     return ws
-
-
-# Off by default: measured (same box, both workloads) the batch is 0.7-0.9 % SLOWER than one reduction behind each layer —
-# a reduction launched right behind its main kernel reads slabs that are still in L2 / Infinity Cache, eight layers later
-# 150 MB of them are not; the launches it saves (57 -> 18 per ResNet-18 step) ran on the companion streams anyway.
-WGRAD_BATCH = os.environ.get("FSNET_AMD_WGRAD_BATCH", "0") == "1"
-
-
-class wgrad_batch:
-    """`with wgrad_batch(): ...` — the weight gradients issued inside (one host thread, one stream) launch their main
-    kernels at once and their slab reductions together at the end (fs_wgrad_batch_begin / _end: one launch per reduction
-    kernel and eight problems instead of one per layer).  Call next_slot() between layers."""
-
-    def __init__(self, force=False):
-        self.force = force
-
-    def __enter__(self):
-        self.on = (WGRAD_BATCH or self.force) and not LaunchProfile.active
-        if self.on:
-            check(lib.fs_wgrad_batch_begin(), "wgrad_batch_begin")
-            _WGRAD_SLOT[0] = 0
-        return self
-
-    def next_slot(self):
-        if self.on:
-            _WGRAD_SLOT[0] += 1
-
-    def __exit__(self, *exc):
-        if self.on:
-            _WGRAD_SLOT[0] = 0
-            check(lib.fs_wgrad_batch_end(stream_ptr()), "wgrad_batch_end")
-        return False
 
 
 class ConvOp:
@@ -256,21 +215,20 @@ class ConvOp:
         # zero (+ addend) elsewhere — class (0,0) with its one tap, three classes with none.  The parity-test formulation
         # multiplies four times the rows (ResNet-50 @320x1024: 170-270 us per launch at 80-130 TFLOP/s of mostly zeros).
         self.s2_classes_1x1 = bool(need_dgrad and stride == 2 and R == 1 and S == 1 and pad == 0
-                                   and (self.Co_p * eb) % (self.kg_d * 16) == 0
-                                   and os.environ.get("FSNET_AMD_S2_1X1_CLASSES", "1") != "0")
+                                   and (self.Co_p * eb) % (self.kg_d * 16) == 0)
         # ... all four classes from one staged dY halo (conv3x3_s2d.hip) when dY has whole 64-byte channel chunks
-        self.s2d = bool(self.s2_classes and USE_S2D and (self.Co_p * eb) % 64 == 0 and self.rows_d % 32 == 0
+        self.s2d = bool(self.s2_classes and (self.Co_p * eb) % 64 == 0 and self.rows_d % 32 == 0
                         and self.Ci_p % 8 == 0)
         halo_ok = (R == 3 and S == 3 and stride == 1)
         def chunks_ok(c):      # whole 64-byte chunks, or exactly half of one (16 bf16 channels)
             return (c * eb) % 64 == 0 or c * eb == 32
         # 7x7/s2 stem over 16-byte pixels: LDS-resident weights + im2col from an LDS patch (conv_stem.hip)
         self.stem_lds = (R == 7 and S == 7 and stride == 2 and pad == 3 and dtype == torch.bfloat16 and self.Ci_p == 8
-                         and Co == 64 and USE_STEM_LDS)
+                         and Co == 64)
         self.halo_f = halo_ok and chunks_ok(self.Ci_p) and self.Co_p % 16 == 0
         # stride-2 3x3 forward (ResNet stage entries) on the LDS-halo kernel too: whole 64-byte channel chunks, pad 1
         self.halo_f_s2 = (R == 3 and S == 3 and stride == 2 and pad == 1 and (self.Ci_p * eb) % 64 == 0
-                          and self.Co_p % 16 == 0 and USE_HALO_S2)
+                          and self.Co_p % 16 == 0)
         self.halo_d = halo_ok and need_dgrad and chunks_ok(self.Co_p) and roundup(self.Ci_p, 16) % 16 == 0
         # wgrad columns (r, s, ci): same grouping as the forward K walk without chunk padding
         self.ncolgroups = R * S * self.Ci_p // eg
@@ -327,7 +285,7 @@ class ConvOp:
         if out is None:
             out = torch.empty(N, Ho, Wo, self.Co_p, dtype=torch.float32 if out_f32 else self.dtype,
                               device=x.device)
-        halo = (self.halo_f or self.halo_f_s2) and USE_HALO
+        halo = self.halo_f or self.halo_f_s2
         stem = (self.stem_lds and bias is None and addend is None and not relu and not out_f32
                 and out.shape[3] == 64 and out.dtype == self.dtype)
         group_rows, grp_imgs = 0, 0
@@ -385,6 +343,7 @@ class ConvOp:
         if stem:
             return Spec(["conv_stem"], a, self.code, "conv_stem", flops, tag, out, "conv_stem")
         if halo:
+            a.force_impl = FORCE_3X3
             return Spec(["conv3x3_halo"], a, self.code, lambda other: self._kind3x3(a, other), flops, tag, out, "conv_fwd")
         return Spec(["conv_igemm"], a, self.code, "conv_igemm", flops, tag, out, "conv_fwd")
 
@@ -421,6 +380,7 @@ class ConvOp:
         a.N, a.Cs = N, Cs
         if pro_mode:
             a.pro_mode, a.pro_a, a.pro_b = pro_mode, 16, 16
+        a.force_impl = FORCE_3X3
         plan = (C.c_int32 * 4)()
         check(lib.fs_conv3x3_halo_plan(C.byref(a), self.code, plan), "conv3x3_plan")
         return {"kernel": {0: "halo", 1: "t32", 2: "p1"}[int(plan[0])], "blocks": int(plan[1]), "pix": int(plan[2]), "co": int(plan[3])}
@@ -428,20 +388,13 @@ class ConvOp:
     def _wants_1x1(self, a):
         """1x1 convolutions (forward, stride-1 data gradient) on the row-streaming GEMM kernel (conv1x1.hip); the launch
         chain is then fs_conv1x1 -> fs_conv_igemm (the kernel may still say FS_EINVAL = "not mine")"""
-        if not (USE_1X1 and self.R == 1 and self.S == 1 and self.pad == 0 and self.dtype == torch.bfloat16):
+        if not (self.R == 1 and self.S == 1 and self.pad == 0 and self.dtype == torch.bfloat16):
             return False
         if a.stat_group_rows and a.stat_group_rows % 128 != 0:
             return False
-        # measured per shape at ResNet-50 / 320x1024 / B=8 (tools/probes/conv1x1_shapes.py): the streaming kernel wins
-        # while the K walk is one or two chunks (forward 64->256 49.5 -> 40.8 us, data gradient 256<-64 43.7 -> 33.9),
-        # the implicit GEMM with its deeper K pipeline from there on (forward 256->128 44 vs 52 us, K = 1024: 25.5 vs 29.5)
         if a.dshift != 0 or a.ncls > 1:
             return False              # (a stride-2 data gradient: the kernel would decline it — straight to the implicit GEMM)
-        if USE_1X1_GEMM:
-            return True               # LDS-staged GEMM: any K extent, strided projections too
-        if a.Cs > (128 if a.sgn > 0 else 256) or a.hb_mul != 1:
-            return False
-        return True
+        return True                   # LDS-staged GEMM (or, for what it declines, the row-streaming kernel): any K extent
 
     def can_fold_input(self, N, H, W):
         """whether this convolution can take its input as (raw convolution output, BatchNorm statistics, ReLU) — forward
@@ -449,7 +402,7 @@ class ConvOp:
         LDS-halo weight-gradient kernel: bf16, 3x3 / stride 1, whole 64-byte channel chunks, >= 64 output channels),
         and the data gradient derives the ReLU mask in its epilogue"""
         eb = 2 if self.dtype == torch.bfloat16 else 4
-        return (USE_HALO and self.dtype == torch.bfloat16 and self.R == 3 and self.S == 3 and self.stride == 1
+        return (self.dtype == torch.bfloat16 and self.R == 3 and self.S == 3 and self.stride == 1
                 and self.Ci == self.Ci_p and (self.Ci_p * eb) % 64 == 0 and self.Ci_p <= PRO_MAX_CI
                 and self.Co_p % 64 == 0 and self.Co % 4 == 0 and self.need_dgrad and N * H * W * max(self.Co_p, self.Ci_p) * eb < 0x7fffffff)
 
@@ -460,7 +413,7 @@ class ConvOp:
         rows = (N // groups) * H * W
         if (self.s2_classes or self.s2_classes_1x1) and H % 2 == 0 and W % 2 == 0:
             rows //= 4                                  # one launch per output-parity class
-        if groups > 1 and not (self.halo_d and USE_HALO) and not self.s2d and rows % 256 != 0:
+        if groups > 1 and not self.halo_d and not self.s2d and rows % 256 != 0:
             return False      # an implicit-GEMM tile could straddle two statistics groups
         return True
 
@@ -620,16 +573,17 @@ class ConvOp:
             if mask_bn:
                 # the ReLU mask of a folded BatchNorm: sign of scale * c + shift, evaluated in the epilogue from the
                 # tensor it reads anyway (the normalised activation was never stored)
-                assert mask is None and st.scale is not None and self.halo_d and USE_HALO
+                assert mask is None and st.scale is not None and self.halo_d
                 a.bnb_scale, a.bnb_shift = st.scale.data_ptr(), st.shift.data_ptr()
         else:
             assert not mask_bn
         flops = 2.0 * N * Ho * Wo * self.Co * self.R * self.S * self.Ci
-        halo = self.halo_d and USE_HALO
+        halo = self.halo_d
         tag = lambda: "dgrd %s dy[%d,%d,%d,%d]" % (self.describe(), N, Ho, Wo, Cd)
         if self._wants_1x1(a):
             return Spec(["conv1x1", "conv_igemm"], a, self.code, "conv1x1", flops, tag, out, "conv_dgrad")
         if halo:
+            a.force_impl = FORCE_3X3
             return Spec(["conv3x3_halo"], a, self.code, lambda other: self._kind3x3(a, other), flops, tag, out, "conv_dgrad")
         return Spec(["conv_igemm"], a, self.code, "conv_igemm", flops, tag, out, "conv_dgrad")
 
@@ -656,7 +610,7 @@ class ConvOp:
         a.stride, a.pad, a.ncolgroups, a.pix_per_split = self.stride, self.pad, self.ncolgroups, 0
         ws = wgrad_workspace(dy.device)
         a.workspace, a.workspace_elems = ws.data_ptr(), ws.numel()
-        a.x_bytes, a.use_halo = _span_bytes(x), int(USE_HALO)
+        a.x_bytes, a.use_halo = _span_bytes(x), 1
         if pro is not None:
             pst, prelu = pro
             a.pro_a, a.pro_b, a.pro_relu = pst.scale.data_ptr(), pst.shift.data_ptr(), int(prelu)

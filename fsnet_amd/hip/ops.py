@@ -394,11 +394,6 @@ def pose_tail_bwd(x, dT, nframes, invert, dtype, scale=0.01, out=None):
     return dx
 
 
-import os as _os
-
-PHOTO_FUSED = _os.environ.get("FSNET_AMD_PHOTO_FUSED", "1") != "0"   # one-launch warp + loss forward (photo_fused.hip)
-
-
 class PhotometricLoss:
     """Fused loss chain for one batch geometry (B, H, W, scales).  forward() returns the loss
     vector (f64 [2S+1]: loss/s, smooth_loss/s, total); backward() returns d depth_s and dT_f.
@@ -416,9 +411,8 @@ class PhotometricLoss:
         f32, f64, u8 = torch.float32, torch.float64, torch.uint8
         self.geo = torch.zeros(B, 48, dtype=f32, device=device)
         self.want_pred = bool(want_pred)
-        self.fused = PHOTO_FUSED
         self.pred = self.ov = None
-        if self.want_pred or not self.fused:
+        if self.want_pred:
             self.pred = torch.empty(S, 2, B, 3, H, W, dtype=f32, device=device)
             self.ov = torch.empty(S, 2, B, H, W, dtype=u8, device=device)
         self.ident = torch.empty(B, 2, H, W, dtype=f32, device=device)
@@ -435,7 +429,7 @@ class PhotometricLoss:
         self.out = torch.zeros(2 * S + 1, dtype=f64, device=device)
         self.hw = [(H >> s, W >> s) for s in self.scales]
         self.color = [None] * S
-        self.bwd_tiles = int(lib.fs_photo_fused_bwd_tiles(H, W) if PHOTO_FUSED else lib.fs_photo_bwd_tiles(H, W))
+        self.bwd_tiles = int(lib.fs_photo_fused_bwd_tiles(H, W))
         self.dP = torch.zeros(self.S * B * self.bwd_tiles, 2, 12, dtype=f32, device=device)   # per-tile partials
         # one flat buffer behind the per-scale depth gradients: a single memset per backward instead of one per scale
         sizes = [B * h * w for (h, w) in self.hw]
@@ -549,8 +543,6 @@ class PhotometricLoss:
         st = stream_ptr()
         if motion_mask is not None:
             assert motion_mask.dtype == torch.float32 and motion_mask.is_contiguous() and motion_mask.shape == (self.B, self.H, self.W)
-            if not self.fused:
-                raise NotImplementedError("motion_mask needs the fused photometric kernels (FSNET_AMD_PHOTO_FUSED=1)")
         self.motion_mask = motion_mask
         assert img0.is_contiguous() and all(s.is_contiguous() for s in srcs)
         if patched_mask is not None:
@@ -584,11 +576,7 @@ class PhotometricLoss:
         N_px = float(self.B * self.H * self.W)
         # algorithmic bytes: per scale, target 12N + 2 sources 24N + depth 4N/4^s + result 4N
         fwd_bytes = sum(40.0 * N_px + 4.0 * N_px / (4 ** s) for s in self.scales)
-        if self.fused:
-            _timed("photo_fused_fwd", fwd_bytes, lambda: check(lib.fs_photo_fused_fwd(pa, st), "photo_fused_fwd"))
-        else:
-            _timed("photo_warp", fwd_bytes * 0.5, lambda: check(lib.fs_photo_warp(pa, st), "photo_warp"))
-            _timed("photo_loss_fwd", fwd_bytes * 0.5, lambda: check(lib.fs_photo_loss_fwd(pa, st), "photo_loss_fwd"))
+        _timed("photo_fused_fwd", fwd_bytes, lambda: check(lib.fs_photo_fused_fwd(pa, st), "photo_fused_fwd"))
         if fork is not None:
             fork[0].wait_stream(fork[1])         # smoothness sums (side stream) before the finalize kernel
         # fresh result tensors per call (the previous step's stay valid for whoever kept them) — the kernel writes
@@ -626,10 +614,7 @@ class PhotometricLoss:
                 check(lib.fs_smooth_bwd(sa, stream_ptr()), "smooth_bwd")
         N_px = float(self.B * self.H * self.W)
         bwd_bytes = sum(40.0 * N_px + 8.0 * N_px / (4 ** s) for s in self.scales)
-        if self.fused:
-            _timed("photo_fused_bwd", bwd_bytes, lambda: check(lib.fs_photo_fused_bwd(pa, st), "photo_fused_bwd"))
-        else:
-            _timed("photo_loss_bwd", bwd_bytes, lambda: check(lib.fs_photo_loss_bwd(pa, st), "photo_loss_bwd"))
+        _timed("photo_fused_bwd", bwd_bytes, lambda: check(lib.fs_photo_fused_bwd(pa, st), "photo_fused_bwd"))
         check(lib.fs_photo_pose_grad(self.geo.data_ptr(), self.dP.data_ptr(), self.dT[0].data_ptr(),
                                      self.dT[1].data_ptr(), self.B, self.S, self.bwd_tiles, st), "photo_pose_grad")
         if fork is not None:

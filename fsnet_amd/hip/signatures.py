@@ -22,8 +22,6 @@ SIGNATURES = {
     "fs_conv_stem2": (C.c_int, [P, P, I, P]),
     "fs_conv_wgrad2": (C.c_int, [P, P, I, P]),
     "fs_conv_wgrad2_plan": (C.c_int, [P, P, I, P]),
-    "fs_wgrad_batch_begin": (C.c_int, []),
-    "fs_wgrad_batch_end": (C.c_int, [P]),
     "fs_bn_apply2": (C.c_int, [P, P, I, P]),
     "fs_bn_bwd_reduce2": (C.c_int, [P, P, I, P]),
     "fs_bn_bwd_apply2": (C.c_int, [P, P, I, P]),
@@ -68,14 +66,10 @@ SIGNATURES = {
     "fs_mei_stage_mask": (C.c_int, [P, P, P, I, I, I, P]),
     "fs_mei_points": (C.c_int, [P, P, P, I, I, I, P]),
     "fs_photo_identity": (C.c_int, [P, P]),
-    "fs_photo_warp": (C.c_int, [P, P]),
-    "fs_photo_loss_fwd": (C.c_int, [P, P]),
-    "fs_photo_loss_bwd": (C.c_int, [P, P]),
     "fs_photo_fused_fwd": (C.c_int, [P, P]),
     "fs_photo_fused_bwd": (C.c_int, [P, P]),
     "fs_photo_fused_bwd_tiles": (C.c_int64, [I, I]),
     "fs_photo_pose_grad": (C.c_int, [P, P, P, P, I, I, I, P]),
-    "fs_photo_bwd_tiles": (C.c_int64, [I, I]),
     "fs_augment_frames": (C.c_int, [P, P]),
     "fs_resize_frames": (C.c_int, [P, P]),
     "fs_color_pyramid": (C.c_int, [P, P, I, I, I, I, I, P]),

@@ -29,6 +29,26 @@ from fsnet_amd.engine.runtime import RT
 from fsnet_amd.vision_base.utils.timer import profile
 
 
+# ROCm 7.0 / 7.2: destroying a hipGraphExec can leave graphs instantiated LATER in the process with too few internal streams —
+# hip::Graph::UpdateStreams reads past the exec's parallel-stream vector on their first hipGraphLaunch and the process
+# segfaults (native backtrace: tools/probes/segv_bt.sh; reproduced with three test files in sequence, gone as soon as no exec
+# is destroyed).  Captured steps are therefore PARKED, not destroyed, when a hook lets go of them — a changed batch signature,
+# the autotune's losing arrangements, the hook itself going away: this list owns every captured graph until the process ends
+# (one graph's private pool is the step's activations: 2.3 GB at the benchmark size; a training run retires a handful).
+# Graphs captured under data parallelism hold state of the context's RCCL communicator (a graph outliving its communicator
+# aborts the process when it is finally freed): those are owned by the data-parallel context and destroyed with it, before
+# the communicator goes (engine/dataparallel.py: park_graph / close) — one context per process lifetime in a training run;
+# the RCCL tests run each context in a process of its own (tests/test_dp_gpu.py).
+_PARKED = []
+
+
+def _own_graph(graph):
+    if RT.dp is not None:
+        RT.dp.park_graph(graph)
+    else:
+        _PARKED.append(graph)
+
+
 class BaseTrainingHook(object):
     def __init__(self, tensor_keys=None, clip_gradients=None, use_graph=None, graph_warmup=3, **kwargs):
         self.tensor_keys = tensor_keys
@@ -225,6 +245,7 @@ class BaseTrainingHook(object):
         assert optimizer._step_count_fused == steps_before + 1
         self._g = dict(graph=graph, sig=sig, static=static, output=output, arena=arena,
                        stage_meta=stage)
+        _own_graph(graph)
         if RT.dp is not None:
             RT.dp.note_graph_owner(self)     # the graph holds RCCL nodes: it must go before the communicator does
             return output                    # data parallel: the ranks agree first (__call__), then _first_replay()
@@ -290,6 +311,9 @@ class BaseTrainingHook(object):
 
         sig = self._signature(data, meta_arch, optimizer)
         if sig != self._g_sig or (self._g is not None and not self._g["arena"] is arena):
+            # (the old signature's graph stays parked, see _PARKED: it is not replayed again — objects the model caches per
+            # batch geometry, the loss chain's buffers among them, are rebuilt for the new one and the old graph's pointers
+            # into them die)
             self._g, self._g_sig, self._g_eager = None, sig, 0
             if self._tune:
                 self._tune["n"] = 0          # a timing window does not span a re-capture

@@ -33,7 +33,7 @@ extern "C" {
 
 /* library/ABI version and the ISA the kernels were compiled for ("gfx950").  FS_ABI_VERSION changes whenever an
  * argument struct or a signature below does; a host binding refuses a library that reports another number. */
-#define FS_ABI_VERSION 9
+#define FS_ABI_VERSION 10
 int fs_abi_version(void);
 const char* fs_target_arch(void);
 /* debugging aid: writes the device's constant-rate clock (wall_clock64, 100 MHz) into *slot (u64) on `stream`;
@@ -123,7 +123,10 @@ typedef struct FsConvArgs {
   const float* pro_a; const float* pro_b; const float* pro_c; const float* pro_m;
   const void* pro_src2;
   int32_t pro_mode, pro_relu, pro_group_imgs;
-  int32_t reserved1;
+  /* fs_conv3x3_halo only, for tests: 0 = the entry point chooses its kernel (always, in the product); 1 = 16x16-tile
+   * kernel; 2-4 = 32x32-tile kernel, tile configuration 1-3 (FS_EINVAL where it cannot take the launch); 5 = persistent
+   * one-chunk kernel whatever the tile count (shapes it does not cover: the usual choice).  (ABI 10; was reserved1.) */
+  int32_t force_impl;
   /* ReLU-backward mask derived instead of read: with bnb_x set and bnb_scale != NULL the mask is
    * bnb_scale[c]*bnb_x + bnb_shift[c] > 0 (the folded forward's own expression; [groups][Co]) and `mask` must be NULL */
   const float* bnb_scale; const float* bnb_shift;
@@ -234,13 +237,7 @@ int fs_conv_wgrad_plan(const FsWgradArgs* args, int dtype, int32_t* plan);
  * launch adds into both dW.  plan: blocks of the shared launch. */
 int fs_conv_wgrad2(const FsWgradArgs* a0, const FsWgradArgs* a1, int dtype, void* stream);
 int fs_conv_wgrad2_plan(const FsWgradArgs* a0, const FsWgradArgs* a1, int dtype, int32_t* plan);
-/* (ABI 9) Batched slab reductions.  The reference's optimizer step reads every parameter gradient only after the whole
- * backward (scripts/train.py: loss.backward() ... optimizer.step()), so the split-K slabs of several weight gradients can be
- * reduced together: between fs_wgrad_batch_begin() and fs_wgrad_batch_end(stream), on one host thread and one stream, every
- * fs_conv_wgrad / fs_conv_wgrad2 call launches its main kernel and queues its reduction; _end launches the queued ones
- * grouped by reduction kernel (up to eight problems per launch).  Every call of a batch needs a workspace of its own. */
-int fs_wgrad_batch_begin(void);
-int fs_wgrad_batch_end(void* stream);
+/* (ABI 9 had fs_wgrad_batch_begin / _end — batched slab reductions, measured slower on the step; removed in ABI 10.) */
 
 /* Weight packing.  OIHW fp32 master weights (the reference's state_dict layout,
  * e.g. depth_backbone.conv1.weight (64,3,7,7)) -> [rows_p][ktot_p] K-contiguous
@@ -515,10 +512,11 @@ int fs_pose_tail_bwd(const float* x, const float* dT, void* dx, int B, int hw, i
  * Images are planar NCHW fp32; all S scales are processed per launch.
  *   fs_photo_setup     K, K^-1 (f64), P_f = (K T_f)[:3] per batch element -> geo [B][48]
  *   fs_photo_identity  identity reprojection losses ident[B][2][H][W]; mask_sum[b] += sum(patched_mask[b])
- *   fs_photo_warp      pred[S][2][B][3][H][W], ov[S][2][B][H][W] (bilinear/border + nearest/zeros)
- *   fs_photo_loss_fwd  sel[S][B][H][W] (argmin: 0,1 identity; 2,3 reprojection), loss_sums[s][b] += masked sum
- *   fs_photo_loss_bwd  d_depth[s] += dL/d depth_s (low-res); dP[S][B][tiles][2][12] = per-tile partial sums of
- *                      dL/dP (overwritten; tiles = fs_photo_bwd_tiles(H, W))
+ *   fs_photo_fused_fwd warp (bilinear/border + nearest/zeros overlap sample) and loss of all scales and both frames:
+ *                      sel[S][B][H][W] (argmin: 0,1 identity; 2,3 reprojection), loss_sums[s][b] += masked sum;
+ *                      optionally pred[S][2][B][3][H][W], ov[S][2][B][H][W]
+ *   fs_photo_fused_bwd d_depth[s] += dL/d depth_s (low-res); dP[S][B][tiles][2][12] = per-strip partial sums of
+ *                      dL/dP (overwritten; tiles = fs_photo_fused_bwd_tiles(H, W))
  *   fs_photo_pose_grad dT_f[B][4][4] = K^T sum_{s,tile} dP  (fixed summation order: run-to-run reproducible)
  * noise_seed < 0 disables the tie-break noise (reference: randn*1e-5, :258-259).
  */
@@ -549,7 +547,7 @@ typedef struct FsPhotoArgs {
   const float* mei;               /* device [B][8]: k1, k2, xi, gamma1, gamma2, u0, v0, 0 */
   const float* warp_mask;         /* [B][H][W] fp32 = patched_mask x ray-table mask (fs_mei_stage_mask): the plane the
                                      nearest-neighbour overlap sample reads (:409-411) */
-  /* precomputed motion mask (monodepth2_decoder.py:243-246; fused kernels only): [B][H][W] fp32 or NULL.  With it the
+  /* precomputed motion mask (monodepth2_decoder.py:243-246): [B][H][W] fp32 or NULL.  With it the
    * per-pixel minimum runs over the two reprojection terms alone (no identity auto-mask) and the gradient of a pixel
    * is scaled by (1 - motion_mask): to_optimise.detach() * m + to_optimise * (1 - m). */
   const float* motion_mask;
@@ -563,19 +561,16 @@ int fs_photo_setup(const float* P2, const float* T0, const float* T1, float* geo
                    int fisheye, void* stream);   /* seed_counter (or NULL): device int bumped by one — the noise seed of
                                                     this step */
 int fs_photo_identity(const FsPhotoArgs* args, void* stream);
-int fs_photo_warp(const FsPhotoArgs* args, void* stream);
-int fs_photo_loss_fwd(const FsPhotoArgs* args, void* stream);
-int fs_photo_loss_bwd(const FsPhotoArgs* args, void* stream);
-/* fs_photo_fused_fwd = fs_photo_warp + fs_photo_loss_fwd in ONE launch for all scales and both frames: the warped
- * images stay in registers (pred / ov may be NULL; when given they are written as fs_photo_warp writes them, for
- * logging and for outputs[("original_image", f, s)] of _generate_images_pred :98-116).  Needs ident, sel, loss_sums. */
+/* (ABI <= 9 also had the staged form fs_photo_warp / fs_photo_loss_fwd / fs_photo_loss_bwd / fs_photo_bwd_tiles.)
+ * fs_photo_fused_fwd: ONE launch for all scales and both frames, the warped images stay in registers (pred / ov may be
+ * NULL; when given they are written for logging and for outputs[("original_image", f, s)] of _generate_images_pred
+ * :98-116).  Needs ident (or motion_mask), sel, loss_sums. */
 int fs_photo_fused_fwd(const FsPhotoArgs* args, void* stream);
-/* fs_photo_fused_bwd = fs_photo_loss_bwd without `pred`: the warp is recomputed (gathers through L2) instead of
- * reading eight warped images back.  Same outputs: d_depth[s] (accumulated: zero it first) and the per-strip partials
+/* fs_photo_fused_bwd: the warp is recomputed (gathers through L2) instead of reading eight warped images back.
+ * Outputs: d_depth[s] (accumulated: zero it first) and the per-strip partials
  * dP[S][B][tiles][2][12] with tiles = fs_photo_fused_bwd_tiles(H, W), reduced by fs_photo_pose_grad. */
 int fs_photo_fused_bwd(const FsPhotoArgs* args, void* stream);
 int64_t fs_photo_fused_bwd_tiles(int H, int W);
-int64_t fs_photo_bwd_tiles(int H, int W);
 int fs_photo_pose_grad(const float* geo, const float* dP, float* dT0, float* dT1, int B, int S, int tiles,
                        void* stream);
 

@@ -108,7 +108,7 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert lib.fs_conv_stem(None, 1, None) == 1 and lib.fs_conv3x3_halo(None, 1, None) == 1
     assert lib.fs_augment_frames(None, None) == 1 and lib.fs_resize_frames(None, None) == 1
     assert lib.fs_sumsq(None, 0, None, None, None) == 1
-    assert lib.fs_photo_bwd_tiles(192, 640) == 20 * 24 and lib.fs_photo_bwd_tiles(1, 1) == -1
+    assert lib.fs_photo_fused_bwd_tiles(192, 640) == 11 * 6 and lib.fs_photo_fused_bwd_tiles(1, 1) == -1
     assert lib.fs_pack_tile_blocks(64, 64, 3, 3) == 4 and lib.fs_pack_tile_blocks(1, 1, 20, 20) == -1
 
 

@@ -9,7 +9,7 @@ vision_base/networks/models/backbone/resnet.py:33-50, conv1 -> bn1 -> relu -> co
     BatchNorm-backward sums;
 at sizes where the benchmark step runs them (the launches the 32x32-tile kernel takes by its own choice), and the
 32x32-tile kernel's three tile configurations x {fp32, bf16} x the epilogue combinations the networks use, forced through
-FSNET_AMD_T32_CFG (read per launch)."""
+FsConvArgs.force_impl (hip.conv.FORCE_3X3)."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -175,7 +175,8 @@ def _nhwc(x, dev, dtype):
 def test_t32_tile_configurations_against_conv2d(dev, monkeypatch, shape, cfg, dtype):
     from fsnet_amd.hip import ops
     from fsnet_amd.hip.conv import ConvOp
-    monkeypatch.setenv("FSNET_AMD_T32_CFG", str(cfg))
+    from fsnet_amd.hip import conv as _conv
+    monkeypatch.setattr(_conv, "FORCE_3X3", 1 + cfg)        # FsConvArgs.force_impl 2-4: the 32x32-tile kernel, configuration cfg
     Ci, Co, N, H, W = shape
     lo = dtype == torch.bfloat16
     g = torch.Generator().manual_seed(17 * cfg + Ci + Co + H)
@@ -276,11 +277,13 @@ def test_t32_tile_configurations_against_conv2d(dev, monkeypatch, shape, cfg, dt
 
 
 def test_fold_survives_the_t32_switch(dev, monkeypatch):
-    """FSNET_AMD_T32=0 with the default BatchNorm fold: launches that carry a prologue or a derived
-    mask still run (they returned FS_EINVAL and the step raised)"""
+    """every launch forced onto the 16x16-tile kernel (FsConvArgs.force_impl = 1; until round 5 the FSNET_AMD_T32=0 switch) with
+    the default BatchNorm fold: launches that carry a prologue or a derived mask still run (they returned
+    FS_EINVAL and the step raised)"""
     from fsnet_amd.hip import ops
     from fsnet_amd.hip.conv import ConvOp
-    monkeypatch.setenv("FSNET_AMD_T32", "0")
+    from fsnet_amd.hip import conv as _conv
+    monkeypatch.setattr(_conv, "FORCE_3X3", 1)              # FsConvArgs.force_impl 1: the 16x16-tile kernel
     Ci = Co = 64
     N, H, W = 12, 48, 160
     g = torch.Generator().manual_seed(5)
@@ -424,7 +427,7 @@ def test_stride2_forward_on_the_halo_kernel(dev, case, dtype):
 def test_persistent_one_chunk_kernel_against_conv2d(dev, monkeypatch, case, dtype):
     """conv3x3_p1.hip (the depth decoder's 16 / 32-channel layers, depth_encoder.py:45-63: weights resident, a block walks
     pixel tiles): forward with bias + statistics + fp32 output, bias + ReLU, and the data gradient with addend / ReLU mask /
-    BatchNorm-backward sums, against conv2d and autograd on the CPU — forced on for small launches through FSNET_AMD_P1_MIN,
+    BatchNorm-backward sums, against conv2d and autograd on the CPU — forced on for small launches through FsConvArgs.force_impl,
     ragged tiles included, and by its own choice at 192x640"""
     from fsnet_amd.hip import ops
     from fsnet_amd.hip.conv import ConvOp
@@ -433,7 +436,8 @@ def test_persistent_one_chunk_kernel_against_conv2d(dev, monkeypatch, case, dtyp
     if not lo and Ci > 16:
         pytest.skip("fp32: one 64-byte chunk is 16 channels")
     if H < 192:
-        monkeypatch.setenv("FSNET_AMD_P1_MIN", "0")
+        from fsnet_amd.hip import conv as _conv
+        monkeypatch.setattr(_conv, "FORCE_3X3", 5)          # FsConvArgs.force_impl 5: this kernel whatever the tile count
     g = torch.Generator().manual_seed(700 + Ci + Co + H)
     rnd = _bf if lo else (lambda t: t)
     x = rnd(torch.randn(N, Ci, H, W, generator=g))
@@ -489,7 +493,8 @@ def test_persistent_one_chunk_kernel_statistic_groups(dev, monkeypatch):
     call): forward statistics and the data gradient's BatchNorm-backward sums land in the group of the tile's image"""
     from fsnet_amd.hip import ops
     from fsnet_amd.hip.conv import ConvOp
-    monkeypatch.setenv("FSNET_AMD_P1_MIN", "0")
+    from fsnet_amd.hip import conv as _conv
+    monkeypatch.setattr(_conv, "FORCE_3X3", 5)
     dtype, Ci, Co, N, H, W, G = torch.bfloat16, 16, 16, 4, 40, 72, 2
     g = torch.Generator().manual_seed(911)
     x, gy = _bf(torch.randn(N, Ci, H, W, generator=g)), _bf(torch.randn(N, Co, H, W, generator=g))

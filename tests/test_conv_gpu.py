@@ -263,7 +263,7 @@ def test_stride2_data_gradient_on_the_class_fused_kernel(dev, case, dtype):
     """fs_conv3x3_s2d (conv3x3_s2d.hip: the four output-parity classes of a 3x3 / stride-2 data gradient from one staged
     dY halo) takes the ResNet stage entries' launches and equals autograd's convolution_backward(input) of
     resnet.py:33-50 with stride 2, with every epilogue the encoders use (residual addend, ReLU mask, BatchNorm-backward
-    sums per statistics group) — and the implicit GEMM's class launch it replaces (FSNET_AMD_S2D=0 path)."""
+    sums per statistics group) — and the implicit GEMM's class launch it replaces (the path of rounds 1-4)."""
     import ctypes as C
     from fsnet_amd.hip import ops
     from fsnet_amd.hip.binding import lib, stream_ptr
@@ -412,36 +412,3 @@ def test_conv1x1_gemm_epilogues(dev, case):
     torch.cuda.synchronize()
     ref2 = F.relu(ref + add.float())
     assert float((y2.float().cpu() - ref2).abs().max()) <= 1e-2 * float(ref2.abs().max())
-
-
-def test_batched_slab_reductions_equal_per_layer_ones(dev):
-    """fs_wgrad_batch_begin / _end: the weight gradients of several layers (3x3 LDS-halo, narrow, 1x1 LDS-DMA, generic, stem —
-    every slab-reduction kernel) issued inside a batch, their reductions launched together at the end, give bit for bit the
-    dW of the same calls issued one by one (each call of the batch on a workspace of its own)."""
-    from fsnet_amd.hip.conv import ConvOp, wgrad_batch
-    dt = torch.bfloat16
-    g = torch.Generator().manual_seed(3)
-    layers = [(64, 64, 3, 1, 1, 4, 48, 80), (128, 128, 3, 1, 1, 4, 24, 40), (16, 16, 3, 1, 1, 2, 96, 160), (256, 256, 3, 1, 1, 4, 12, 20),
-              (256, 64, 1, 1, 0, 4, 40, 64), (64, 128, 3, 2, 1, 4, 48, 80), (6, 64, 7, 2, 3, 4, 96, 160), (512, 512, 3, 1, 1, 4, 6, 10),
-              (128, 256, 1, 2, 0, 4, 24, 40), (96, 32, 3, 1, 1, 2, 48, 80)]
-    work = []
-    for Ci, Co, k, s, p, N, H, W in layers:
-        op = ConvOp(Ci, Co, k, k, s, p, dt, dev, need_dgrad=False)
-        Ho, Wo = op.out_hw(H, W)
-        x = torch.randn(N, H, W, op.Ci_p, generator=g).to(dev).to(dt)
-        dy = torch.randn(N, Ho, Wo, op.Co_p, generator=g).to(dev).to(dt)
-        work.append((op, dy, x, Co, Ci, k))
-    ref = []
-    for op, dy, x, Co, Ci, k in work:
-        dw = torch.zeros(Co, Ci, k, k, device=dev)
-        op.wgrad(dy, x, dw)
-        ref.append(dw)
-    got = [torch.zeros_like(r) for r in ref]
-    with wgrad_batch(force=True) as wb:
-        assert wb.on
-        for (op, dy, x, Co, Ci, k), dw in zip(work, got):
-            op.wgrad(dy, x, dw)
-            wb.next_slot()
-    torch.cuda.synchronize()
-    for r, d, l in zip(ref, got, layers):
-        assert float(r.abs().max()) > 0 and torch.equal(r, d), l

@@ -1,4 +1,4 @@
-"""1x1 convolutions of ResNet-50 at 320x1024, B=8: forward / data gradient per shape (run with FSNET_AMD_CONV1X1=0|1)."""
+"""1x1 convolutions of ResNet-50 at 320x1024, B=8: forward / data gradient per shape."""
 import sys; sys.path.insert(0, '.')
 import torch
 from fsnet_amd.hip.conv import ConvOp, USE_1X1
