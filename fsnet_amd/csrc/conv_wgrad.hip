@@ -548,17 +548,26 @@ __global__ __launch_bounds__(256 * NG) void wgrad3x3_halo_kernel(const FsDual<Fs
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
 
+  // Which pixel a thread stages.  A 16-byte ds_write is served 16 lanes at a time; with the padded row strides (44 / 28
+  // dwords) the two (four) consecutive pixels a 16-lane group would write overlap on 12 of the 64 banks.  Within each run
+  // of 16 pixel slots the group takes pixels whose rows tile the banks exactly instead: p and p + 8 for 8 units per pixel
+  // (11 k = 8 mod 16 at k = 8), p, p + 4, p + 8, p + 12 for 4 (7 k = 12, 8, 4 mod 16 at k = 4, 8, 12).  The global loads
+  // keep a pixel's units in consecutive lanes.
+  auto stage_pix = [](int q, int U) {
+    const int q16 = q & 15, base = q - q16;
+    return U == 8 ? base + (q16 >> 1) + 8 * (q16 & 1) : (U == 4 ? base + (q16 >> 2) + 4 * (q16 & 3) : q);
+  };
   // per-thread load units: tile-relative coordinates are fixed, only (n, y0, x0) changes per tile
   int aty[LA], atx[LA], bhy[LB], bhx[LB];
 #pragma unroll
   for (int i = 0; i < LA; ++i) {
-    int pix = (t + i * NT) / UA;
+    int pix = stage_pix((t + i * NT) / UA, UA);
     const int aq = fs_fastdiv(min(pix, 4095), g.mTW);
     aty[i] = pix < ntile ? aq : -1; atx[i] = pix < ntile ? pix - aq * g.TW : 0;
   }
 #pragma unroll
   for (int i = 0; i < LB; ++i) {
-    int hp = (t + i * NT) / UB;
+    int hp = stage_pix((t + i * NT) / UB, UB);
     const int bq = fs_fastdiv(min(hp, 4095), g.mHW);
     bhy[i] = hp < nhalo ? bq : -1; bhx[i] = hp < nhalo ? hp - bq * HW : 0;
   }
@@ -620,12 +629,12 @@ __global__ __launch_bounds__(256 * NG) void wgrad3x3_halo_kernel(const FsDual<Fs
   auto store_lds = [&]() {
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-      int idx = t + i * NT; int pix = idx / UA, u = idx % UA;
+      int idx = t + i * NT; int pix = stage_pix(idx / UA, UA), u = idx % UA;
       if (pix < PIXT) *reinterpret_cast<uint4*>(&lds_a[pix * SA + u * 8]) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
-      int idx = t + i * NT; int hp = idx / UB, u = idx % UB;
+      int idx = t + i * NT; int hp = stage_pix(idx / UB, UB), u = idx % UB;
       uint4 v = rb[i];
       if (has_pro) v = ((bok >> i) & 1u) ? pro_unit(v) : make_uint4(0u, 0u, 0u, 0u);
       if (hp < HMAX) *reinterpret_cast<uint4*>(&lds_b[hp * SB + u * 8]) = v;

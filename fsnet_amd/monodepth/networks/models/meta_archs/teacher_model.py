@@ -15,17 +15,12 @@ class MonoDepthInference(nn.Module):
         self.is_produce_detached = is_produce_detached
 
     def forward(self, x):
-        features = self.depth_backbone(x)
-        return self.depth_decoder(features)
+        return self.depth_decoder(self.depth_backbone(x))
 
     def compute_teacher_depth(self, x):
-        if self.is_produce_detached:
-            with torch.no_grad():
-                output_dict = self(x)
-        else:
-            output_dict = self(x)
-        teacher_output = {}
-        for key in output_dict:
-            if key[0] == 'depth':
-                teacher_output[("teacher_depth", key[1], key[2])] = output_dict[key]
-        return teacher_output
+        """{("teacher_depth", s, s): depth of scale s} — what DistillWPoseMeta feeds compute_distill_loss
+        (monodepth2_model.py:177-180).  The frozen teacher runs without an autograd graph unless the config asks otherwise."""
+        grad_mode = torch.enable_grad() if not self.is_produce_detached else torch.no_grad()
+        with grad_mode:
+            predicted = self.forward(x)
+        return {("teacher_depth",) + tuple(k[1:3]): v for k, v in predicted.items() if k[0] == "depth"}
