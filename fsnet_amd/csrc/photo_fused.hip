@@ -31,9 +31,42 @@ __device__ __forceinline__ float hsum3(float v) {
   return (dpp_mov<0x138>(v) + v) + dpp_mov<0x130>(v);
 }
 
+// Two source frames per lane as one 2-vector: everything a frame owns — projection, sampler weights, the SSIM terms —
+// is the same arithmetic on two independent values, and gfx950 issues v_pk_fma / v_pk_mul / v_pk_add_f32 on a register
+// pair at the rate of the scalar forms (round 6; what has no packed form — v_rcp, min / max, floor, the DPP row sums —
+// runs per component).  The compiler's own SLP packing of the scalar code had been measured slower (register shuffles
+// to build the pairs: hence -fno-slp-vectorize above); here the pairs are the data layout.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
+__device__ __forceinline__ f2 hsum3(f2 v) { return f2{hsum3(v.x), hsum3(v.y)}; }
+
+// The three colour channels of one quantity as a packed pair + a scalar (backward kernel: a wave owns ONE frame there, the
+// channels are what is independent): two instructions where three scalar ones stood, no register overhead.
+struct C3 { f2 p; float s; };
+__device__ __forceinline__ C3 c3(float a, float b, float c) { return C3{f2{a, b}, c}; }
+__device__ __forceinline__ C3 c3(float a) { return C3{f2{a, a}, a}; }
+__device__ __forceinline__ C3 operator+(C3 a, C3 b) { return C3{a.p + b.p, a.s + b.s}; }
+__device__ __forceinline__ C3 operator-(C3 a, C3 b) { return C3{a.p - b.p, a.s - b.s}; }
+__device__ __forceinline__ C3 operator*(C3 a, C3 b) { return C3{a.p * b.p, a.s * b.s}; }
+__device__ __forceinline__ C3 operator+(C3 a, float b) { return C3{a.p + b, a.s + b}; }
+__device__ __forceinline__ C3 operator-(C3 a, float b) { return C3{a.p - b, a.s - b}; }
+__device__ __forceinline__ C3 operator*(C3 a, float b) { return C3{a.p * b, a.s * b}; }
+__device__ __forceinline__ C3 operator*(float b, C3 a) { return C3{a.p * b, a.s * b}; }
+__device__ __forceinline__ C3 operator-(float b, C3 a) { return C3{b - a.p, b - a.s}; }
+__device__ __forceinline__ C3 operator-(C3 a) { return C3{-a.p, -a.s}; }
+__device__ __forceinline__ C3 hsum3(C3 v) { return C3{f2{hsum3(v.p.x), hsum3(v.p.y)}, hsum3(v.s)}; }
+__device__ __forceinline__ C3 rcp3(C3 v) {
+  return C3{f2{__builtin_amdgcn_rcpf(v.p.x), __builtin_amdgcn_rcpf(v.p.y)}, __builtin_amdgcn_rcpf(v.s)};
+}
+__device__ __forceinline__ void put(C3& v, int c, float x) { if (c == 0) v.p.x = x; else if (c == 1) v.p.y = x; else v.s = x; }
+__device__ __forceinline__ float get(const C3& v, int c) { return c == 0 ? v.p.x : (c == 1 ? v.p.y : v.s); }
+__device__ __forceinline__ float dot3(C3 a, C3 b) { const f2 q = a.p * b.p; return (q.x + q.y) + a.s * b.s; }
+
 struct Row {       // one image row of a strip: horizontal 3-tap sums + the raw values (needed when it is the centre)
-  float t[3], tt[3], x[2][3], xx[2][3], xt[2][3];
-  float rt[3], rx[2][3];
+  float t[3], tt[3];
+  f2 x[3], xx[3], xt[3];        // component = source frame
+  float rt[3];
+  f2 rx[3];
   bool ov[2];
 };
 
@@ -94,15 +127,13 @@ __global__ __launch_bounds__(256) void photo_fused_fwd_kernel(const FsPhotoArgs 
   const float dlx = w > 1 ? fxu - (float)dx0 : 0.f;
   const float pxf = (float)xr;
   float ra[3] = {0.f, 0.f, 0.f};
-  float Pm[2][12];
+  f2 Pm[12];                    // (frame 0, frame 1) entries of the two projection matrices
   if (!FISH) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) ra[i] = ge[3 * i] * pxf;
   }
 #pragma unroll
-  for (int f = 0; f < 2; ++f)
-#pragma unroll
-    for (int k = 0; k < 12; ++k) Pm[f][k] = ge[18 + f * 12 + k];
+  for (int k = 0; k < 12; ++k) Pm[k] = f2{ge[18 + k], ge[30 + k]};
   double acc = 0.0;
 
   // one row: fill `r0` (row y = ys - 1 + it) and, from the third row on, finish the window centred on row y - 1 = `r1`
@@ -133,43 +164,48 @@ __global__ __launch_bounds__(256) void photo_fused_fwd_kernel(const FsPhotoArgs 
       for (int i = 0; i < 3; ++i) g.r[i] = (ra[i] + ge[3 * i + 1] * pyf) + ge[3 * i + 2];
     }
     unsigned og[2][2];
-    float wgt[2][4];
+    f2 w01[2], w23[2];           // per frame: the sampler weights of the upper / lower tap pair
     unsigned om[2];
     bool inb[2];
+    f2 ixu2, iyu2;
+    if (FISH) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        project_ray(p, b, H, W, ge, f, g);
+        ixu2[f] = g.ixu; iyu2[f] = g.iyu;
+      }
+    } else {
+      const float cx_ = g.D * g.r[0], cy_ = g.D * g.r[1], cz_ = g.D * g.r[2];
+      const f2 X = Pm[0] * cx_ + Pm[1] * cy_ + Pm[2] * cz_ + Pm[3];
+      const f2 Y = Pm[4] * cx_ + Pm[5] * cy_ + Pm[6] * cz_ + Pm[7];
+      const f2 Zp = (Pm[8] * cx_ + Pm[9] * cy_ + Pm[10] * cz_ + Pm[11]) + 1e-7f;
+      const f2 iz = f2{__builtin_amdgcn_rcpf(Zp.x), __builtin_amdgcn_rcpf(Zp.y)};
+      const f2 u = X * iz, v = Y * iz;
+      // Project3D normalisation followed by grid_sample's align_corners=True un-normalisation
+      const f2 un = (u * iwm1 - 0.5f) * 2.f, vn = (v * ihm1 - 0.5f) * 2.f;
+      ixu2 = (un + 1.f) * 0.5f * wm1;
+      iyu2 = (vn + 1.f) * 0.5f * hm1;
+    }
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
-      if (FISH) {
-        project_ray(p, b, H, W, ge, f, g);
-      } else {
-        const float* P = Pm[f];
-        const float cx_ = g.D * g.r[0], cy_ = g.D * g.r[1], cz_ = g.D * g.r[2];
-        const float X = P[0] * cx_ + P[1] * cy_ + P[2] * cz_ + P[3];
-        const float Y = P[4] * cx_ + P[5] * cy_ + P[6] * cz_ + P[7];
-        const float Zp = (P[8] * cx_ + P[9] * cy_ + P[10] * cz_ + P[11]) + 1e-7f;
-        const float iz = __builtin_amdgcn_rcpf(Zp);
-        const float u = X * iz, v = Y * iz;
-        // Project3D normalisation followed by grid_sample's align_corners=True un-normalisation
-        const float un = (u * iwm1 - 0.5f) * 2.f, vn = (v * ihm1 - 0.5f) * 2.f;
-        g.ixu = (un + 1.f) * 0.5f * wm1;
-        g.iyu = (vn + 1.f) * 0.5f * hm1;
-      }
       // bilinear taps with border clamping; the tap pair always starts at x0 <= W - 2 / y0 <= H - 2 (at the right /
       // bottom border the weight moves to the second tap: same value) so that (x0, x0 + 1) is one 8-byte load
-      const float ix = fminf(fmaxf(g.ixu, 0.f), wm1), iy = fminf(fmaxf(g.iyu, 0.f), hm1);
+      const float ixu = ixu2[f], iyu = iyu2[f];
+      const float ix = fminf(fmaxf(ixu, 0.f), wm1), iy = fminf(fmaxf(iyu, 0.f), hm1);
       const float fx0 = fminf(floorf(ix), wm1 - 1.f), fy0 = fminf(floorf(iy), hm1 - 1.f);
       const float wx = ix - fx0, wy = iy - fy0;
       const int tx0 = (int)fx0, ty0 = (int)fy0;
       og[f][0] = (unsigned)(ty0 * W + tx0) * 4u;
       og[f][1] = og[f][0] + (unsigned)W * 4u;
-      wgt[f][0] = (1.f - wy) * (1.f - wx); wgt[f][1] = (1.f - wy) * wx;
-      wgt[f][2] = wy * (1.f - wx); wgt[f][3] = wy * wx;
+      const f2 wxs = f2{1.f - wx, wx};
+      w01[f] = wxs * (1.f - wy); w23[f] = wxs * wy;
       // nearest sample of patched_mask (fisheye: x ray-table mask) with zeros padding, round half to even
-      const float xn = nearbyintf(g.ixu), yn = nearbyintf(g.iyu);
+      const float xn = nearbyintf(ixu), yn = nearbyintf(iyu);
       inb[f] = xn >= 0.f && xn <= wm1 && yn >= 0.f && yn <= hm1;
       om[f] = inb[f] ? (unsigned)((int)yn * W + (int)xn) : 0u;
     }
-    // all gathers of the row in flight together
-    float tap[2][3][4];
+    // all gathers of the row in flight together: (x0, x0 + 1) of a tap row arrive as one register pair
+    f2 tap[2][3][2];
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -177,7 +213,7 @@ __global__ __launch_bounds__(256) void photo_fused_fwd_kernel(const FsPhotoArgs 
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           const F2u v2 = ldg2(srcs[f] + c * HW, og[f][k]);
-          tap[f][c][2 * k] = v2.a; tap[f][c][2 * k + 1] = v2.b;
+          tap[f][c][k] = f2{v2.a, v2.b};
         }
     float mv[2] = {1.f, 1.f};
     if (have_mask) {
@@ -191,47 +227,50 @@ __global__ __launch_bounds__(256) void photo_fused_fwd_kernel(const FsPhotoArgs 
       r0.tt[c] = hsum3(r0.rt[c] * r0.rt[c]);
     }
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
+    for (int c = 0; c < 3; ++c) {
+      f2 v;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float v = (wgt[f][0] * tap[f][c][0] + wgt[f][1] * tap[f][c][1]) + (wgt[f][2] * tap[f][c][2] + wgt[f][3] * tap[f][c][3]);
-        r0.rx[f][c] = v;
-        r0.x[f][c] = hsum3(v);
-        r0.xx[f][c] = hsum3(v * v);
-        r0.xt[f][c] = hsum3(v * r0.rt[c]);
+      for (int f = 0; f < 2; ++f) {
+        const f2 q = w01[f] * tap[f][c][0] + w23[f] * tap[f][c][1];      // (x0 column, x0 + 1 column) partial sums
+        v[f] = q.x + q.y;
       }
-      r0.ov[f] = no_ovm || (inb[f] && mv[f] == 1.f);   // overlapped_mask=False: every sample counts (border-clamped)
+      r0.rx[c] = v;
+      r0.x[c] = hsum3(v);
+      r0.xx[c] = hsum3(v * v);
+      r0.xt[c] = hsum3(v * r0.rt[c]);
     }
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+      r0.ov[f] = no_ovm || (inb[f] && mv[f] == 1.f);   // overlapped_mask=False: every sample counts (border-clamped)
     if (WRITE_PRED) {
       if (col_out && y >= ys && y < ys + FRH && y < H) {
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
           float* pr = p.pred + (((long)s * 2 + f) * p.B + b) * 3 * HW + (unsigned)(y * W + x);
-          pr[0] = r0.rx[f][0]; pr[HW] = r0.rx[f][1]; pr[2 * HW] = r0.rx[f][2];
+          pr[0] = r0.rx[0][f]; pr[HW] = r0.rx[1][f]; pr[2 * HW] = r0.rx[2][f];
           p.ov[(((long)s * 2 + f) * p.B + b) * HW + (unsigned)(y * W + x)] = r0.ov[f] ? 1 : 0;
         }
       }
     }
     if (it < 2) return;
     const int yc = y - 1;          // window centre row; rows y-2 (r2), y-1 (r1), y (r0)
-    float ssim_sum[2] = {0.f, 0.f}, l1[2] = {0.f, 0.f};
+    f2 ssim_sum = splat(0.f), l1 = splat(0.f);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float sy_ = (r2.t[c] + r1.t[c]) + r0.t[c], syy = (r2.tt[c] + r1.tt[c]) + r0.tt[c];
       const float muy = sy_ * k9;
       const float sgy = syy * k9 - muy * muy;
-#pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        const float sxs = (r2.x[f][c] + r1.x[f][c]) + r0.x[f][c], sxx = (r2.xx[f][c] + r1.xx[f][c]) + r0.xx[f][c],
-                    sxy = (r2.xt[f][c] + r1.xt[f][c]) + r0.xt[f][c];
-        const float mux = sxs * k9;
-        const float sgx = sxx * k9 - mux * mux, sgxy = sxy * k9 - mux * muy;
-        const float n = (2.f * mux * muy + C1) * (2.f * sgxy + C2);
-        const float d = (mux * mux + muy * muy + C1) * (sgx + sgy + C2);
-        const float q = FISH ? n / d : n * __builtin_amdgcn_rcpf(d);
-        ssim_sum[f] += fminf(fmaxf((1.f - q) * 0.5f, 0.f), 1.f);
-        l1[f] += fabsf(r1.rt[c] - r1.rx[f][c]);
-      }
+      const f2 sxs = (r2.x[c] + r1.x[c]) + r0.x[c], sxx = (r2.xx[c] + r1.xx[c]) + r0.xx[c],
+               sxy = (r2.xt[c] + r1.xt[c]) + r0.xt[c];
+      const f2 mux = sxs * k9;
+      const f2 sgx = sxx * k9 - mux * mux, sgxy = sxy * k9 - mux * muy;
+      const f2 n = (2.f * mux * muy + C1) * (2.f * sgxy + C2);
+      const f2 d = (mux * mux + muy * muy + C1) * (sgx + sgy + C2);
+      const f2 q = FISH ? n / d : n * f2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+      const f2 sv = (1.f - q) * 0.5f;
+      ssim_sum += f2{fminf(fmaxf(sv.x, 0.f), 1.f), fminf(fmaxf(sv.y, 0.f), 1.f)};
+      const f2 df = r1.rt[c] - r1.rx[c];
+      l1 += f2{fabsf(df.x), fabsf(df.y)};
     }
     if (col_out && yc < H) {       // (yc >= ys always: it >= 2)
       const unsigned i = (unsigned)(yc * W + x);
@@ -291,14 +330,14 @@ constexpr int LDS_C = 40;  // low-res accumulation tile of a wave (scales >= 1):
 constexpr int LDS_R = 24;
 
 struct BRow {
-  float t[3], tt[3], x[3], xx[3], xt[3];   // horizontal 3-tap sums
-  float rt[3], rx[3];                       // raw values
-  float Jx[3], Jy[3];                       // d pred_c / d (ix, iy) with the border-clamp multipliers applied
+  C3 t, tt, x, xx, xt;                      // horizontal 3-tap sums (per colour channel)
+  C3 rt, rx;                                // raw values
+  C3 Jx, Jy;                                // d pred_c / d (ix, iy) with the border-clamp multipliers applied
   float X, Y, Z, D;                         // transformed point (pinhole: Z + eps) and the upsampled depth
   float pm;                                 // patched_mask at the pixel (0 for virtual positions)
   int sel;                                  // selection byte at the pixel (-1 for virtual positions)
 };
-struct CRow { float a[3], b[3], c[3]; };    // horizontally box-summed coefficients of one centre row
+struct CRow { C3 a, b, c; };                // horizontally box-summed coefficients of one centre row
 
 template <bool FISH>
 __global__ __launch_bounds__(256) void photo_fused_bwd_kernel(const FsPhotoArgs p, int SX, int SY, int nwaves) {
@@ -383,8 +422,7 @@ __global__ __launch_bounds__(256) void photo_fused_bwd_kernel(const FsPhotoArgs 
     const int yr = min(max(refl(y, H), 0), H - 1);
     const bool y_real = y >= 0 && y < H;
     const unsigned ob = (unsigned)(yr * W + xr) * 4u;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) r0.rt[c] = ldg(timg + c * HW, ob);
+    r0.rt = c3(ldg(timg, ob), ldg(timg + HW, ob), ldg(timg + 2 * HW, ob));
     r0.sel = (x_real && y_real) ? (int)selb[(unsigned)(yr * W + xr)] : -1;
     r0.pm = (x_real && y_real) ? (p.patched_mask ? (float)p.patched_mask[(long)b * HW + (unsigned)(yr * W + xr)] : 1.f) : 0.f;
     if (p.motion_mask && x_real && y_real) r0.pm *= 1.f - p.motion_mask[(long)b * HW + (unsigned)(yr * W + xr)];
@@ -429,71 +467,73 @@ __global__ __launch_bounds__(256) void photo_fused_bwd_kernel(const FsPhotoArgs 
       const float fx0 = fminf(floorf(ix), wm1 - 1.f), fy0 = fminf(floorf(iy), hm1 - 1.f);
       const float wx = ix - fx0, wy = iy - fy0;
       const unsigned o0 = (unsigned)((int)fy0 * W + (int)fx0) * 4u, o1 = o0 + (unsigned)W * 4u;
+      float rxv[3], jxv[3], jyv[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const F2u a = ldg2(src + c * HW, o0), bb = ldg2(src + c * HW, o1);
         const float top = a.a + wx * (a.b - a.a), bot = bb.a + wx * (bb.b - bb.a);
-        r0.rx[c] = top + wy * (bot - top);
-        r0.Jx[c] = mx * ((a.b - a.a) * (1.f - wy) + (bb.b - bb.a) * wy);
-        r0.Jy[c] = my * (bot - top);
+        rxv[c] = top + wy * (bot - top);
+        jxv[c] = mx * ((a.b - a.a) * (1.f - wy) + (bb.b - bb.a) * wy);
+        jyv[c] = my * (bot - top);
       }
+      r0.rx = c3(rxv[0], rxv[1], rxv[2]); r0.Jx = c3(jxv[0], jxv[1], jxv[2]); r0.Jy = c3(jyv[0], jyv[1], jyv[2]);
     }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      r0.t[c] = hsum3(r0.rt[c]);
-      r0.tt[c] = hsum3(r0.rt[c] * r0.rt[c]);
-      r0.x[c] = hsum3(r0.rx[c]);
-      r0.xx[c] = hsum3(r0.rx[c] * r0.rx[c]);
-      r0.xt[c] = hsum3(r0.rx[c] * r0.rt[c]);
-    }
+    r0.t = hsum3(r0.rt);
+    r0.tt = hsum3(r0.rt * r0.rt);
+    r0.x = hsum3(r0.rx);
+    r0.xx = hsum3(r0.rx * r0.rx);
+    r0.xt = hsum3(r0.rx * r0.rt);
     // ------------------------------------------------------------------ stage B: window centre = row y - 1 (r1)
     {
       const float wgt = (it >= 2 && r1.sel == 2 + f) ? r1.pm * wss : 0.f;
+      const C3 sxs = (r2.x + r1.x) + r0.x, sys_ = (r2.t + r1.t) + r0.t;
+      const C3 sxx = (r2.xx + r1.xx) + r0.xx, syy = (r2.tt + r1.tt) + r0.tt;
+      const C3 sxy = (r2.xt + r1.xt) + r0.xt;
+      const C3 mux = sxs * k9, muy = sys_ * k9;
+      const C3 sgx = sxx * k9 - mux * mux, sgy = syy * k9 - muy * muy, sgxy = sxy * k9 - mux * muy;
+      const C3 n1 = 2.f * mux * muy + C1, n2 = 2.f * sgxy + C2;
+      const C3 d1 = mux * mux + muy * muy + C1, d2 = sgx + sgy + C2;
+      const C3 n = n1 * n2, d = d1 * d2;
+      const C3 id = rcp3(d);
+      const C3 sv = (1.f - n * id) * 0.5f;
+      // d n / d x(q) = a1 + a2 (t(q) - muy),  d d / d x(q) = b1 + b2 (x(q) - mux)   (each tap weight 1/9)
+      const C3 a1 = 2.f * muy * n2 * k9, a2 = 2.f * n1 * k9;
+      const C3 b1 = 2.f * mux * d2 * k9, b2 = 2.f * d1 * k9;
+      const C3 hh = -0.5f * id * id;
+      C3 A = hh * ((a1 - a2 * muy) * d - n * (b1 - b2 * mux));
+      C3 Bc = -(hh * n * b2);
+      C3 Cc = hh * a2 * d;
+      const bool on = wgt != 0.f;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float sxs = (r2.x[c] + r1.x[c]) + r0.x[c], sys_ = (r2.t[c] + r1.t[c]) + r0.t[c];
-        const float sxx = (r2.xx[c] + r1.xx[c]) + r0.xx[c], syy = (r2.tt[c] + r1.tt[c]) + r0.tt[c];
-        const float sxy = (r2.xt[c] + r1.xt[c]) + r0.xt[c];
-        const float mux = sxs * k9, muy = sys_ * k9;
-        const float sgx = sxx * k9 - mux * mux, sgy = syy * k9 - muy * muy, sgxy = sxy * k9 - mux * muy;
-        const float n1 = 2.f * mux * muy + C1, n2 = 2.f * sgxy + C2;
-        const float d1 = mux * mux + muy * muy + C1, d2 = sgx + sgy + C2;
-        const float n = n1 * n2, d = d1 * d2;
-        const float id = __builtin_amdgcn_rcpf(d);
-        const float sv = (1.f - n * id) * 0.5f;
-        float A = 0.f, Bc = 0.f, Cc = 0.f;
-        if (sv >= 0.f && sv <= 1.f) {
-          // d n / d x(q) = a1 + a2 (t(q) - muy),  d d / d x(q) = b1 + b2 (x(q) - mux)   (each tap weight 1/9)
-          const float a1 = 2.f * muy * n2 * k9, a2 = 2.f * n1 * k9;
-          const float b1 = 2.f * mux * d2 * k9, b2 = 2.f * d1 * k9;
-          const float hh = -0.5f * id * id;
-          A = hh * ((a1 - a2 * muy) * d - n * (b1 - b2 * mux));
-          Bc = -hh * n * b2;
-          Cc = hh * a2 * d;
-        }
-        const bool on = wgt != 0.f;
-        c0.a[c] = hsum3(on ? wgt * A : 0.f);
-        c0.b[c] = hsum3(on ? wgt * Bc : 0.f);
-        c0.c[c] = hsum3(on ? wgt * Cc : 0.f);
+        const float svc = get(sv, c);
+        const bool ok = on && svc >= 0.f && svc <= 1.f;     // (outside the clamp of the SSIM term: no gradient)
+        put(A, c, ok ? wgt * get(A, c) : 0.f);
+        put(Bc, c, ok ? wgt * get(Bc, c) : 0.f);
+        put(Cc, c, ok ? wgt * get(Cc, c) : 0.f);
       }
+      c0.a = hsum3(A);
+      c0.b = hsum3(Bc);
+      c0.c = hsum3(Cc);
     }
     // ------------------------------------------------------------------ stage C: output row q = y - 2 (r2, centres c2 c1 c0)
     const int qy = y - 2;
     if (it >= 3 && qy >= q_lo && qy <= q_hi) {
-      float dpred[3];
       const bool l1_on = r2.sel == 2 + f;
+      const C3 ga = (c2.a + c1.a) + c0.a, gb = (c2.b + c1.b) + c0.b, gc = (c2.c + c1.c) + c0.c;
+      C3 dpred = ga + gb * r2.rx + gc * r2.rt;
+      if (l1_on) {
+        const C3 df = r2.rx - r2.rt;
+        const float w1 = r2.pm * wl1;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float ga = (c2.a[c] + c1.a[c]) + c0.a[c], gb = (c2.b[c] + c1.b[c]) + c0.b[c], gc = (c2.c[c] + c1.c[c]) + c0.c[c];
-        float v = ga + gb * r2.rx[c] + gc * r2.rt[c];
-        if (l1_on) {
-          const float df = r2.rx[c] - r2.rt[c];
-          v += r2.pm * wl1 * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
+        for (int c = 0; c < 3; ++c) {
+          const float dfc = get(df, c);
+          put(dpred, c, get(dpred, c) + w1 * (dfc > 0.f ? 1.f : (dfc < 0.f ? -1.f : 0.f)));
         }
-        dpred[c] = col_own ? v : 0.f;
       }
-      const float du = dpred[0] * r2.Jx[0] + dpred[1] * r2.Jx[1] + dpred[2] * r2.Jx[2];
-      const float dv = dpred[0] * r2.Jy[0] + dpred[1] * r2.Jy[1] + dpred[2] * r2.Jy[2];
+      if (!col_own) dpred = c3(0.f);
+      const float du = dot3(dpred, r2.Jx);
+      const float dv = dot3(dpred, r2.Jy);
       if (du != 0.f || dv != 0.f) {
         float dX, dY, dZ;
         if (FISH) {
