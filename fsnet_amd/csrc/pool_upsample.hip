@@ -182,6 +182,77 @@ __global__ __launch_bounds__(256) void upcat_pad_bwd_kernel(const T* __restrict_
   }
 }
 
+template <typename T> __device__ __forceinline__ float round_to(float v);
+template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_to<bf16>(float v) { return bf16_bits_to_f(f_to_bf16_bits(v)); }
+
+// upcat_pad_bwd with the first pass of the BatchNorm backward it feeds (depth_encoder.py:126-133 backwards: the up-sampled
+// half of the concatenation is y = relu(bn(c)) of the level's first ConvBnReLU): da is stored ReLU-masked (mask = y > 0) and
+// the sums (sum g, sum g * xhat) of the masked, storage-rounded gradient go to the f64 slots bn_bwd_apply reads — what
+// fs_bn_bwd_reduce computes from da in a launch of its own.  blockIdx.y = 0: the da part, a thread keeps one channel group
+// (256 % CGa == 0 and the grid stride is a multiple of CGa); blockIdx.y = 1: the skip half, a plain copy.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void upcat_pad_bwd_bn_kernel(const T* __restrict__ dpad, T* __restrict__ da,
+                                                               T* __restrict__ db, int N, int h, int w, int Ca, int Cb,
+                                                               const T* __restrict__ yact, const T* __restrict__ xraw,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, double* __restrict__ sums) {
+  const int H = 2 * h, W = 2 * w, C = Ca + Cb;
+  const int CGa = Ca / V, CGb = Cb / V;
+  if (blockIdx.y == 1) {
+    const long tb = (long)N * H * W * CGb;
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < tb; k += (long)gridDim.x * 256) {
+      int cg = (int)(k % CGb); long m = k / CGb;
+      int x = (int)(m % W); long q = m / W; int y = (int)(q % H); long n = q / H;
+      float g[V];
+      fold_load<T, V>(dpad, n, y, x, H, W, C, Ca + cg * V, g);
+      stc<T, V>(db + m * Cb + cg * V, g);
+    }
+    return;
+  }
+  __shared__ float red[2][V][256];
+  const int cg = threadIdx.x % CGa, c = cg * V;
+  float mu[V], is[V], s1[V], s2[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) { mu[j] = mean[c + j]; is[j] = invstd[c + j]; s1[j] = 0.f; s2[j] = 0.f; }
+  const long ta = (long)N * h * w * CGa;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < ta; i += (long)gridDim.x * 256) {
+    long m = i / CGa;
+    int x = (int)(m % w); long q = m / w; int y = (int)(q % h); long n = q / h;
+    float acc[V], yy[V], xr[V];
+    ldc<T, V>(yact + m * Ca + c, yy);
+    ldc<T, V>(xraw + m * Ca + c, xr);
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    for (int dy = 0; dy < 2; ++dy)
+      for (int dx = 0; dx < 2; ++dx) {
+        float g[V];
+        fold_load<T, V>(dpad, n, 2 * y + dy, 2 * x + dx, H, W, C, c, g);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] += g[j];
+      }
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float g = yy[j] > 0.f ? round_to<T>(acc[j]) : 0.f;      // what the apply pass will read back from da
+      acc[j] = g;
+      s1[j] += g; s2[j] += g * (xr[j] - mu[j]) * is[j];
+    }
+    stc<T, V>(da + m * Ca + c, acc);
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) { red[0][j][threadIdx.x] = s1[j]; red[1][j][threadIdx.x] = s2[j]; }
+  __syncthreads();
+  // thread t < CGa * 2 * V finishes (channel group, kind, j) = one channel's one sum: PL = 256 / CGa partials
+  const int PL = 256 / CGa;
+  for (int t = threadIdx.x; t < CGa * 2 * V; t += 256) {
+    const int g2 = t % CGa, kj = t / CGa, kind = kj / V, j = kj % V;
+    float a = 0.f;
+    for (int k = 0; k < PL; ++k) a += red[kind][j][k * CGa + g2];
+    double* sl = sums + (long)(blockIdx.x % FS_STAT_SLOTS) * 2 * Ca;
+    atomicAdd(sl + kind * Ca + g2 * V + j, (double)a);
+  }
+}
+
 // out[c] += sum_m x[m][c]   (x dense [M][C], fp32 accumulate, one atomic per channel per block).
 // 16-byte lanes when C allows (VL = 8 bf16 / 4 f32 channels per lane, else 4), four rows in flight per thread.
 template <typename T, int VL>
@@ -338,6 +409,31 @@ extern "C" int fs_upcat_pad_bwd(const void* dpad, void* da, void* db, int N, int
     hipLaunchKernelGGL((upcat_pad_bwd_kernel<bf16, 4>), grid, dim3(256), 0, st, (const bf16*)dpad, (bf16*)da, (bf16*)db, N, h, w, Ca, Cb);
   else if (dtype == FS_DTYPE_F32)
     hipLaunchKernelGGL((upcat_pad_bwd_kernel<float, 4>), grid, dim3(256), 0, st, (const float*)dpad, (float*)da, (float*)db, N, h, w, Ca, Cb);
+  else return FS_EINVAL;
+  return fs_launch_status();
+}
+
+extern "C" int fs_upcat_pad_bwd_bn(const void* dpad, void* da, void* db, int N, int h, int w, int Ca, int Cb, const void* y,
+                                   const void* x, const float* mean, const float* invstd, double* sums, int dtype,
+                                   void* stream) {
+  if (!dpad || !da || (Cb > 0 && !db) || !y || !x || !mean || !invstd || !sums || Ca % 4 != 0 || Cb % 4 != 0 || Ca <= 0)
+    return FS_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bool wide = dtype == FS_DTYPE_BF16 && Ca % 8 == 0 && Cb % 8 == 0;
+  const int V = wide ? 8 : 4;
+  const int CGa = Ca / V;
+  if (CGa > 256 || 256 % CGa != 0) return FS_EINVAL;        // a thread keeps its channel group: powers of two up to 256
+  const long ta = (long)N * h * w * CGa, tb = (long)N * 4 * h * w * (Cb / V);
+  dim3 grid(grid_for(std::max(ta, tb)), Cb > 0 ? 2 : 1);
+  if (wide)
+    hipLaunchKernelGGL((upcat_pad_bwd_bn_kernel<bf16, 8>), grid, dim3(256), 0, st, (const bf16*)dpad, (bf16*)da, (bf16*)db, N, h, w, Ca, Cb,
+                       (const bf16*)y, (const bf16*)x, mean, invstd, sums);
+  else if (dtype == FS_DTYPE_BF16)
+    hipLaunchKernelGGL((upcat_pad_bwd_bn_kernel<bf16, 4>), grid, dim3(256), 0, st, (const bf16*)dpad, (bf16*)da, (bf16*)db, N, h, w, Ca, Cb,
+                       (const bf16*)y, (const bf16*)x, mean, invstd, sums);
+  else if (dtype == FS_DTYPE_F32)
+    hipLaunchKernelGGL((upcat_pad_bwd_bn_kernel<float, 4>), grid, dim3(256), 0, st, (const float*)dpad, (float*)da, (float*)db, N, h, w, Ca, Cb,
+                       (const float*)y, (const float*)x, mean, invstd, sums);
   else return FS_EINVAL;
   return fs_launch_status();
 }

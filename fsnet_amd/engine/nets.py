@@ -334,6 +334,8 @@ def pack_everything_async(arena):
     if not (RT.pack_overlap and RT.overlap and dev is not None and dev.type == "cuda"):
         _PACK_PENDING.clear()
         pack_everything(arena)
+        if arena is not None:
+            arena.flush_zero()            # (a gradient memset the training hook left to the scratch-zeroing launch)
         return
     cur = _current_stream(dev)
     ps = RT.pack_stream(dev)
@@ -341,6 +343,7 @@ def pack_everything_async(arena):
     with torch.cuda.stream(ps):
         pack_everything(arena)
         ops.prezero_all(dev)          # ... and the step's scratch, one launch instead of a fill here and there along the chains
+    arena.flush_zero()                # (nothing to do: prezero_all took the gradient arena's memset)
     _PACK_PENDING[dev.index] = (ps, {ps.cuda_stream})
 
 
@@ -1251,10 +1254,12 @@ class DepthDecoderRunner:
             dxcat = op1.dgrad(dc1, H2 + 2, W2 + 2)
             cl0, bn0 = self.up0[i]
             op0 = cl0.ready(dt, dev)
-            d_y0, d_skip = ops.upcat_pad_bwd(dxcat, h, w, op0.Co_p, lv["Cs"])
+            # (the first pass of bn0's backward rides in the launch that produces its gradient: no fs_bn_bwd_reduce)
+            sums0 = _bwd_sums(lv["c0"], lv["s0"])
+            d_y0, d_skip = ops.upcat_pad_bwd(dxcat, h, w, op0.Co_p, lv["Cs"], bn=(lv["y0"], lv["c0"], lv["s0"], sums0))
             if i > 0 and lv["Cs"]:
                 gfeats[i - 1] = d_skip
-            dc0 = _bn_bwd(d_y0, lv["y0"], lv["c0"], bn0, lv["s0"], h, w, relu=True)
+            dc0 = _bn_bwd(d_y0, None, lv["c0"], bn0, lv["s0"], h, w, sums=sums0)
             cl0.accumulate_param_grads(op0, dc0, lv["x"])
             if i < 4:
                 Gp = disp_grad(i + 1)

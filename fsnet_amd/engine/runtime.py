@@ -212,6 +212,10 @@ class ParamArena:
                 self.views.append(g)
                 p.grad = g
         self._by_id = {id(p): i for i, p in enumerate(self.params)}
+        self._zero_pending = False
+        if self.grad.is_cuda:
+            from ..hip import ops
+            ops.register_prezero(self, ParamArena._prezero, self.grad.device)
         RT.bump_weights()
 
     def owns(self, p):
@@ -229,11 +233,30 @@ class ParamArena:
     def attach_grads(self, zero=True):
         if zero:
             self.grad.zero_()
+            self._zero_pending = False
         for p, g in zip(self.params, self.views):
             p.grad = g
 
-    def zero_grads(self):
-        self.attach_grads(zero=True)
+    def zero_grads(self, lazy=False):
+        """lazy (the training hook): the memset joins the step's one scratch-zeroing launch on the re-pack stream
+        (nets.pack_everything_async -> ops.prezero_all) instead of a 107 MB fill at the head of the main stream; whoever
+        starts the step calls flush_zero() where that launch did not happen"""
+        if lazy and self.grad.is_cuda:
+            self._zero_pending = True
+            self.attach_grads(zero=False)
+        else:
+            self.attach_grads(zero=True)
+
+    def _prezero(self):
+        if not self._zero_pending:
+            return []
+        self._zero_pending = False
+        return [self.grad]
+
+    def flush_zero(self):
+        if self._zero_pending:
+            self.grad.zero_()
+            self._zero_pending = False
 
     def slice_of(self, params):
         """[lo, hi) element range of the arena covering the given parameters (must be contiguous)."""

@@ -268,11 +268,24 @@ def upcat_pad_fwd(a, b):
     return out
 
 
-def upcat_pad_bwd(dpad, h, w, Ca, Cb):
+def upcat_pad_bwd(dpad, h, w, Ca, Cb, bn=None):
+    """bn = (y, x, BnState, sums): also the first pass of the BatchNorm backward the `da` half feeds (fs_upcat_pad_bwd_bn):
+    da comes back masked by y > 0 and `sums` (zeroed f64 [SLOTS][2][Ca]) holds (sum g, sum g * xhat)"""
     N = dpad.shape[0]
     da = torch.empty(N, h, w, Ca, dtype=dpad.dtype, device=dpad.device)
     db = torch.empty(N, 2 * h, 2 * w, Cb, dtype=dpad.dtype, device=dpad.device) if Cb else None
-    _timed("upcat_pad_bwd", (da.numel() + (db.numel() if db is not None else 0) + dpad.numel()) * da.element_size(),
+    nbytes = (da.numel() + (db.numel() if db is not None else 0) + dpad.numel()) * da.element_size()
+    if bn is not None:
+        y, x, st, sums = bn
+        assert y.is_contiguous() and x.is_contiguous() and y.shape == da.shape == x.shape and st.groups == 1
+        assert sums.dtype == torch.float64 and sums.numel() == STAT_SLOTS * 2 * Ca
+        _timed("upcat_pad_bwd", nbytes + 2 * da.numel() * da.element_size(),
+               lambda: check(lib.fs_upcat_pad_bwd_bn(dpad.data_ptr(), da.data_ptr(), _p(db), N, h, w, Ca, Cb, y.data_ptr(),
+                                                     x.data_ptr(), st.mean.data_ptr(), st.invstd.data_ptr(), sums.data_ptr(),
+                                                     dtype_code(dpad.dtype), stream_ptr()), "upcat_pad_bwd_bn"),
+               tag=str(tuple(dpad.shape)) + " bn")
+        return da, db
+    _timed("upcat_pad_bwd", nbytes,
            lambda: check(lib.fs_upcat_pad_bwd(dpad.data_ptr(), da.data_ptr(), _p(db), N, h, w, Ca, Cb,
                                               dtype_code(dpad.dtype), stream_ptr()), "upcat_pad_bwd"),
            tag=str(tuple(dpad.shape)))

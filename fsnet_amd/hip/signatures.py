@@ -53,6 +53,7 @@ SIGNATURES = {
     "fs_maxpool_bwd": (C.c_int, [P, P, P, P, I, I, I, I, I, P]),
     "fs_upcat_pad_fwd": (C.c_int, [P, P, P, I, I, I, I, I, I, P]),
     "fs_upcat_pad_bwd": (C.c_int, [P, P, P, I, I, I, I, I, I, P]),
+    "fs_upcat_pad_bwd_bn": (C.c_int, [P, P, P, I, I, I, I, I, P, P, P, P, P, I, P]),
     "fs_channel_sum": (C.c_int, [P, P, L, I, I, I, P]),
     "fs_channel_sum_multi": (C.c_int, [P, P, P, P, P, I, I, P]),
     "fs_depth_head_fwd": (C.c_int, [P, P, P, P, L, I, I, F, F, P]),

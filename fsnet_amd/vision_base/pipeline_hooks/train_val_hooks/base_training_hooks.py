@@ -184,7 +184,7 @@ class BaseTrainingHook(object):
 
     def _eager_step(self, data, meta_arch, optimizer, arena, fused, meta, logger):
         if arena is not None:
-            arena.zero_grads()
+            arena.zero_grads(lazy=True)       # (zeroed with the step's scratch at the head of the forward: _begin_train)
         else:
             optimizer.zero_grad()
         stage = getattr(getattr(meta_arch, "module", meta_arch), "stage_step_inputs", None)
@@ -229,7 +229,7 @@ class BaseTrainingHook(object):
         mode = "thread_local" if RT.dp is not None else "global"
         with torch.cuda.graph(graph, stream=self._g_stream, capture_error_mode=mode):
             RT.mark("step.start")
-            arena.zero_grads()
+            arena.zero_grads(lazy=True)
             output = meta_arch(sdata, meta)
             loss = output['loss']
             RT.mark("loss.fwd.end")

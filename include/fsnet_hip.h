@@ -455,6 +455,12 @@ int fs_upcat_pad_fwd(const void* a, const void* b, void* out, int N, int h, int 
                      void* stream);
 int fs_upcat_pad_bwd(const void* dpad, void* da, void* db, int N, int h, int w, int Ca, int Cb, int dtype,
                      void* stream);
+/* fs_upcat_pad_bwd + the first pass of the BatchNorm backward its `da` half feeds (the level's upconv(i,0) ConvBnReLU,
+ * depth_encoder.py:126-133 backwards; ABI 10): da is stored masked by y > 0 (y, x: dense [N,h,w,Ca] activation and raw
+ * convolution output of that BatchNorm; mean / invstd [Ca]) and sums [FS_STAT_SLOTS][2][Ca] += (sum g, sum g * xhat) of the
+ * stored values — fs_bn_bwd_apply then runs as after a fused data gradient (dout already masked, sums accumulated). */
+int fs_upcat_pad_bwd_bn(const void* dpad, void* da, void* db, int N, int h, int w, int Ca, int Cb, const void* y,
+                        const void* x, const float* mean, const float* invstd, double* sums, int dtype, void* stream);
 int fs_channel_sum(const void* x, float* out, int64_t M, int C, int Creal, int dtype, void* stream);
 /* n (<= 16) column sums in one launch: the bias gradients of a hand-off batch of weight gradients (each convolution bias
  * gradient = sum over N,H,W of its dY: autograd of nn.Conv2d(bias=True), blocks.py:41-46, depth_encoder.py:45-63). */

@@ -219,6 +219,34 @@ def test_upcat_pad(dev):
     assert (nchw(out2) - F.pad(F.interpolate(a, scale_factor=2, mode="nearest"), (1, 1, 1, 1), mode="replicate")).abs().max() == 0
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 5, 7, 8, 12), (3, 6, 20, 32, 64), (2, 12, 40, 256, 256), (2, 9, 11, 16, 0)])
+def test_upcat_pad_bwd_with_batchnorm_sums(dev, shape, dtype):
+    """fs_upcat_pad_bwd_bn == fs_upcat_pad_bwd followed by the first BatchNorm-backward pass (fs_bn_bwd_reduce with the ReLU
+    mask): the same masked gradient (bit for bit) and the same (sum g, sum g * xhat)"""
+    from fsnet_amd.hip import ops
+    N, h, w, Ca, Cb = shape
+    g = torch.Generator().manual_seed(11 + Ca)
+    gp = torch.randn(N, 2 * h + 2, 2 * w + 2, Ca + Cb, generator=g).to(dev).to(dtype)
+    y = torch.randn(N, h, w, Ca, generator=g).clamp_min(0).to(dev).to(dtype)
+    c = torch.randn(N, h, w, Ca, generator=g).to(dev).to(dtype)
+    st = ops.BnState(Ca, dev, 1)
+    st.mean.copy_(torch.randn(Ca, generator=g) * 0.2)
+    st.invstd.copy_(torch.rand(Ca, generator=g) + 0.5)
+    st.count = float(N * h * w)
+    da0, db0 = ops.upcat_pad_bwd(gp, h, w, Ca, Cb)
+    sums = torch.zeros(ops.STAT_SLOTS, 2, Ca, dtype=torch.float64, device=dev)
+    da1, db1 = ops.upcat_pad_bwd(gp, h, w, Ca, Cb, bn=(y, c, st, sums))
+    torch.cuda.synchronize()
+    masked = da0.float() * (y.float() > 0)
+    assert torch.equal(da1.float(), masked)
+    assert (db0 is None and db1 is None) or torch.equal(db0, db1)
+    xhat = (c.float().double() - st.mean.double()) * st.invstd.double()
+    want = torch.stack([masked.double().sum((0, 1, 2)), (masked.double() * xhat).sum((0, 1, 2))])
+    got = sums.sum(0)
+    assert float((got - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
+
+
 def test_channel_sum(dev):
     from fsnet_amd.hip import ops
     g = torch.Generator().manual_seed(4)
