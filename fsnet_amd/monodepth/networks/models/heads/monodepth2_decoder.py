@@ -167,6 +167,8 @@ class MonoDepth2Decoder(nn.Module):
         pm = self._mask64(input_dict)
         depths = [output_dict[("depth", s, s)] for s in self.scales]
         disps = [output_dict[("disp", s)] for s in self.scales]
+        # (what the loss differentiates: the training hook's per-chain capture cuts the backward here)
+        self._loss_inputs = ([output_dict[("cam_T_cam", fa)], output_dict[("cam_T_cam", fb)]], depths + disps)
         total, vec = _PhotoLossFn.apply(self._pl, S, img0, input_dict[("original_image", fa)],
                                         input_dict[("original_image", fb)], input_dict["P2"], pm,
                                         input_dict.get("motion_mask", None),
