@@ -189,19 +189,22 @@ template <> __device__ __forceinline__ float round_to<bf16>(float v) { return bf
 // upcat_pad_bwd with the first pass of the BatchNorm backward it feeds (depth_encoder.py:126-133 backwards: the up-sampled
 // half of the concatenation is y = relu(bn(c)) of the level's first ConvBnReLU): da is stored ReLU-masked (mask = y > 0) and
 // the sums (sum g, sum g * xhat) of the masked, storage-rounded gradient go to the f64 slots bn_bwd_apply reads — what
-// fs_bn_bwd_reduce computes from da in a launch of its own.  blockIdx.y = 0: the da part, a thread keeps one channel group
-// (256 % CGa == 0 and the grid stride is a multiple of CGa); blockIdx.y = 1: the skip half, a plain copy.
+// fs_bn_bwd_reduce computes from da in a launch of its own.  The first nA blocks: the da part, a thread keeps one channel
+// group (256 % CGa == 0 and the stride nA * 256 is a multiple of CGa) — at most 512 of them: every block ends in 2 * Ca
+// same-slot f64 atomics; the other blocks: the skip half, a plain copy.
 template <typename T, int V>
 __global__ __launch_bounds__(256) void upcat_pad_bwd_bn_kernel(const T* __restrict__ dpad, T* __restrict__ da,
                                                                T* __restrict__ db, int N, int h, int w, int Ca, int Cb,
                                                                const T* __restrict__ yact, const T* __restrict__ xraw,
                                                                const float* __restrict__ mean,
-                                                               const float* __restrict__ invstd, double* __restrict__ sums) {
+                                                               const float* __restrict__ invstd, double* __restrict__ sums,
+                                                               const int nA) {
   const int H = 2 * h, W = 2 * w, C = Ca + Cb;
   const int CGa = Ca / V, CGb = Cb / V;
-  if (blockIdx.y == 1) {
+  if ((int)blockIdx.x >= nA) {
     const long tb = (long)N * H * W * CGb;
-    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < tb; k += (long)gridDim.x * 256) {
+    const int bx = (int)blockIdx.x - nA, nB = (int)gridDim.x - nA;
+    for (long k = (long)bx * 256 + threadIdx.x; k < tb; k += (long)nB * 256) {
       int cg = (int)(k % CGb); long m = k / CGb;
       int x = (int)(m % W); long q = m / W; int y = (int)(q % H); long n = q / H;
       float g[V];
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(256) void upcat_pad_bwd_bn_kernel(const T* __restri
 #pragma unroll
   for (int j = 0; j < V; ++j) { mu[j] = mean[c + j]; is[j] = invstd[c + j]; s1[j] = 0.f; s2[j] = 0.f; }
   const long ta = (long)N * h * w * CGa;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < ta; i += (long)gridDim.x * 256) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < ta; i += (long)nA * 256) {
     long m = i / CGa;
     int x = (int)(m % w); long q = m / w; int y = (int)(q % h); long n = q / h;
     float acc[V], yy[V], xr[V];
@@ -424,16 +427,18 @@ extern "C" int fs_upcat_pad_bwd_bn(const void* dpad, void* da, void* db, int N, 
   const int CGa = Ca / V;
   if (CGa > 256 || 256 % CGa != 0) return FS_EINVAL;        // a thread keeps its channel group: powers of two up to 256
   const long ta = (long)N * h * w * CGa, tb = (long)N * 4 * h * w * (Cb / V);
-  dim3 grid(grid_for(std::max(ta, tb)), Cb > 0 ? 2 : 1);
+  const int nA = (int)std::max<long>(1, std::min<long>((ta + 511) / 512, 512));
+  const int nB = Cb > 0 ? grid_for(tb) : 0;
+  dim3 grid(nA + nB);
   if (wide)
     hipLaunchKernelGGL((upcat_pad_bwd_bn_kernel<bf16, 8>), grid, dim3(256), 0, st, (const bf16*)dpad, (bf16*)da, (bf16*)db, N, h, w, Ca, Cb,
-                       (const bf16*)y, (const bf16*)x, mean, invstd, sums);
+                       (const bf16*)y, (const bf16*)x, mean, invstd, sums, nA);
   else if (dtype == FS_DTYPE_BF16)
     hipLaunchKernelGGL((upcat_pad_bwd_bn_kernel<bf16, 4>), grid, dim3(256), 0, st, (const bf16*)dpad, (bf16*)da, (bf16*)db, N, h, w, Ca, Cb,
-                       (const bf16*)y, (const bf16*)x, mean, invstd, sums);
+                       (const bf16*)y, (const bf16*)x, mean, invstd, sums, nA);
   else if (dtype == FS_DTYPE_F32)
     hipLaunchKernelGGL((upcat_pad_bwd_bn_kernel<float, 4>), grid, dim3(256), 0, st, (const float*)dpad, (float*)da, (float*)db, N, h, w, Ca, Cb,
-                       (const float*)y, (const float*)x, mean, invstd, sums);
+                       (const float*)y, (const float*)x, mean, invstd, sums, nA);
   else return FS_EINVAL;
   return fs_launch_status();
 }
