@@ -153,7 +153,7 @@ class DataParallelContext:
             self._comm_stream.wait_stream(cur)
             if self.wgrad_companions:
                 from .nets import flush_deferred, pending_companions
-                flush_deferred(cur)                  # what the chain still holds goes to its companion now
+                flush_deferred(cur, now=True)        # what the chain still holds goes to its companion now
                 for ws in pending_companions():
                     self._comm_stream.wait_stream(ws)
             with torch.cuda.stream(self._comm_stream):
@@ -162,7 +162,7 @@ class DataParallelContext:
         from .nets import flush_deferred, join_companions
         if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
             raise RuntimeError("torch.distributed gradient buckets cannot be captured into a hipGraph")
-        flush_deferred()          # weight-gradient kernels handed to companion streams must have landed in the
+        flush_deferred(now=True)  # weight-gradient kernels handed to companion streams must have landed in the
         join_companions()         # arena slice before it is reduced
         self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 

@@ -178,6 +178,7 @@ def _defer_param_grads(cur, item):
     if _CALLBACK_QUEUED[0] is not None and _CALLBACK_QUEUED[0] != torch._C._current_graph_task_id():
         for stale in _DEFERRED.values():       # leftovers of a backward pass that raised: not this pass's gradients
             stale[1].clear()
+        _LATE.clear()
         _ACTIVE_CHAINS.clear()
     ent = _DEFERRED.get(cur.cuda_stream)
     if ent is None:
@@ -192,14 +193,55 @@ def _defer_param_grads(cur, item):
         flush_deferred(cur)
 
 
-def flush_deferred(cur=None, spread=False):
+_LATE = []              # inside a hipGraph capture: [(event on the chain, chain, companion, items)] batches not yet issued
+_CHAINS_BEGUN = [None, []]    # backward pass (graph task id), chain streams whose backward has begun in it
+
+
+def _issue_batch(chain, ws, mine, ev=None):
+    if ev is None:
+        ws.wait_stream(chain)                   # one cross-stream edge per batch
+    else:
+        ws.wait_event(ev)
+    with torch.cuda.stream(ws):
+        sums = []
+        for it in mine:
+            _run_param_grads(*it, bias_later=sums)
+        if sums:
+            ops.channel_sum_multi(sums)         # the batch's bias gradients in one launch
+    _PENDING_JOIN.add((chain, ws))
+
+
+def issue_late(chain=None):
+    """issue the batches of `chain` (default: every chain) whose launch was put off (flush_deferred, inside a capture)"""
+    if not _LATE:
+        return
+    rest = []
+    for ent in _LATE:
+        if chain is None or ent[1].cuda_stream == chain.cuda_stream:
+            _issue_batch(ent[1], ent[2], ent[3], ev=ent[0])
+        else:
+            rest.append(ent)
+    _LATE[:] = rest
+
+
+def flush_deferred(cur=None, spread=False, now=False):
     """hand the collected weight-gradient work of chain stream `cur` (default: all chains) to its companion;
-    `spread`: the batch that ends a network's backward may also use the other chains' companions"""
+    `spread`: the batch that ends a network's backward may also use the other chains' companions.
+
+    Inside a hipGraph capture the batch's kernels are issued one hand-over LATER (or at the end of the backward pass; `now`:
+    at once), behind the event recorded here.  Dependencies are the same; what changes is the ORDER of the edges that leave
+    the chain's last node: the chain's next kernel becomes its first successor, the batch its second.  The HIP graph executor
+    (ROCm 7.2) hands out its 4 streams by a depth-first walk in which a node's first successor stays on the node's stream and
+    every further one moves to the next stream: with the batch first, the weight gradients inherited the chain's stream and
+    the chain hopped to a stream where it queued behind whatever the other chain had there (docs/LAB_r06.md, "the
+    executor's stream assignment": DEBUG_HIP_GRAPH_DOT_PRINT dump)."""
+    late = RT.wgrad_late and not now and torch.cuda.is_current_stream_capturing()
     for key in ([cur.cuda_stream] if cur is not None else list(_DEFERRED.keys())):
         ent = _DEFERRED.get(key)
         if ent is None or not ent[1]:
             continue
         chain, items = ent
+        issue_late(chain)                       # (earlier batches first: the companion runs them in this order)
         targets = [RT.companion_stream(chain.device, chain)[1]]
         if spread and RT.wgrad_spread and RT.is_side(chain):
             # the pose chain's last batch (its largest layers) otherwise runs serially after everything else has
@@ -208,27 +250,58 @@ def flush_deferred(cur=None, spread=False):
                 if key2 != key:
                     chain2 = _DEFERRED[key2][0]
                     targets.append(RT.companion_stream(chain2.device, chain2)[1])
+        ev = None
+        if late:
+            ev = torch.cuda.Event()
+            ev.record(chain)
         for k, ws in enumerate(targets):
             mine = items[k::len(targets)]
             if not mine:
                 continue
-            ws.wait_stream(chain)                   # one cross-stream edge per batch
-            with torch.cuda.stream(ws):
-                sums = []
-                for it in mine:
-                    _run_param_grads(*it, bias_later=sums)
-                if sums:
-                    ops.channel_sum_multi(sums)     # the batch's bias gradients in one launch
-            _PENDING_JOIN.add((chain, ws))
+            if late:
+                _LATE.append((ev, chain, ws, mine))
+            else:
+                _issue_batch(chain, ws, mine)
         _PENDING_KEEP.extend(items)
         ent[1].clear()
+    if not late:
+        issue_late(cur)
+
+
+def chain_begins(device):
+    """called where a network's backward begins on its chain (the decoders' autograd nodes).  Inside a hipGraph capture,
+    when the SECOND chain of the pass begins, one empty launch is put on the first chain's companion, behind the second
+    chain's pending dependencies — a third successor of the loss backward's last node, between the two chains' first
+    kernels.  By the executor's rule (flush_deferred) the first chain then keeps that node's stream s, its weight gradients
+    get s+1, the second chain s+2 and its weight gradients s+3: four streams, one each.  Without it the second chain
+    shares s+1 with the first chain's weight gradients, behind them in launch order."""
+    if not (RT.wgrad_late and device.type == "cuda" and RT.overlap and RT.wgrad_streams
+            and torch.cuda.is_current_stream_capturing()):
+        return
+    task = torch._C._current_graph_task_id()
+    if task < 0:
+        return
+    if _CHAINS_BEGUN[0] != task:
+        _CHAINS_BEGUN[0], _CHAINS_BEGUN[1] = task, []
+    cur = _current_stream(device)
+    begun = _CHAINS_BEGUN[1]
+    if any(c.cuda_stream == cur.cuda_stream for c in begun):
+        return
+    begun.append(cur)
+    if len(begun) == 2:
+        first = begun[0]
+        ws = RT.companion_stream(device, first)[1]
+        ws.wait_stream(cur)
+        with torch.cuda.stream(ws):
+            RT.nop(device)
+        _PENDING_JOIN.add((first, ws))
 
 
 def _end_of_backward():
     _CALLBACK_QUEUED[0] = None
     flush_tail()
     flush_inline_bias()
-    flush_deferred()
+    flush_deferred(now=True)
     _ACTIVE_CHAINS.clear()
     join_companions()
 
@@ -300,7 +373,8 @@ def pending_companions():
 def join_companions_final():
     """the current stream waits for every companion with work in flight (before the optimizer reads gradients)"""
     flush_inline_bias()
-    flush_deferred()
+    flush_deferred(now=True)
+    issue_late()
     if not _PENDING_JOIN:
         return
     cur = torch.cuda.current_stream()
@@ -1078,7 +1152,7 @@ class EncoderPass:
         stems = [r.stem for r in self.R]
         self._param_grads(stems, self._ready(stems, xs), dc0, xs)
         RT.mark(tag + ".bwd.end")
-        flush_deferred(_current_stream(), spread=True)
+        flush_deferred(_current_stream(), spread=True, now=True)
 
 
 # ==============================================================================================
@@ -1188,6 +1262,7 @@ class DepthDecoderRunner:
         K = int(m.num_output_channels)
         gfeats = [None] * 5
         bwd_pool_reset(dev)
+        chain_begins(dev)
         RT.mark("ddec.bwd.start")
         tail = RT.dp is not None and RT.dp.decoder_tail and RT.overlap and dev.type == "cuda" and \
             torch._C._current_graph_task_id() >= 0
@@ -1307,6 +1382,7 @@ class PoseDecoderRunner:
     def backward(self, ctx, dT):
         acts, x3 = ctx["acts"], ctx["x3"]
         dt, dev = acts[0].dtype, acts[0].device
+        chain_begins(dev)
         RT.mark("pdec.bwd.start")
         if isinstance(ctx["invert"], tuple):
             G = len(ctx["invert"])

@@ -25,6 +25,11 @@ class _Runtime:
         # are 3-4 % slower than 8.  wgrad_streams = 0 (inline) is what data parallelism uses and what tests may set.
         self.wgrad_streams = 2
         self.wgrad_flush = self.wgrad_flush_side = 8
+        # inside a capture: issue a batch one hand-over late, so that the chain's next kernel is its last node's FIRST
+        # successor in the graph, and separate the two chains' first kernels by an empty launch (nets.flush_deferred,
+        # nets.chain_begins: the executor's stream assignment follows the order of the edges)
+        self.wgrad_late = os.environ.get("FSNET_AMD_WGRAD_LATE", "1") != "0"
+        self._nop = {}
         # hand over what is pending when an encoder's backward reaches its stem (see EncoderPass.backward): with the two-lane
         # pass only (follows `lanes`)
         self.stem_flush = False
@@ -118,6 +123,13 @@ class _Runtime:
         rows = [(n, t[i]) for n, i in self._marks.items() if t[i] > 0]
         t0 = min(v for _, v in rows)
         return sorted(((n, (v - t0) / 1e5) for n, v in rows), key=lambda r: r[1])
+
+    def nop(self, device):
+        """one empty-handed launch on the current stream (a node for the graph executor's stream assignment)"""
+        t = self._nop.get(device)
+        if t is None:
+            t = self._nop[device] = torch.zeros(1, device=device)
+        t.zero_()
 
     def new_stream(self, device):
         """a HIP stream no other part of the engine holds.  torch.cuda.Stream() hands out a pool of 32 streams per
