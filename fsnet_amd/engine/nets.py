@@ -179,6 +179,7 @@ def _defer_param_grads(cur, item):
         for stale in _DEFERRED.values():       # leftovers of a backward pass that raised: not this pass's gradients
             stale[1].clear()
         _LATE.clear()
+        _AT_END.clear()
         _ACTIVE_CHAINS.clear()
     ent = _DEFERRED.get(cur.cuda_stream)
     if ent is None:
@@ -189,26 +190,38 @@ def _defer_param_grads(cur, item):
     # streams it used with the caller's stream.  (Keyed by the pass: a backward that died in an exception never ran its
     # callback, and must not keep the next one from queueing its own.)
     _queue_end_of_backward()
-    if len(ent[1]) >= (RT.wgrad_flush_side if RT.is_side(cur) else RT.wgrad_flush):
+    if len(ent[1]) >= (RT.wgrad_flush_even if RT.even_chains else RT.wgrad_flush):
         flush_deferred(cur)
 
 
+_BATCH_NO = [0]
+_IN_ENCODER = [False]   # an encoder's backward is being issued (EncoderPass.backward)
+_AT_END = []            # [(event, chain, [(stream, items)])]: parts of a batch issued once every node of the pass has been
 _LATE = []              # inside a hipGraph capture: [(event on the chain, chain, companion, items)] batches not yet issued
 _CHAINS_BEGUN = [None, []]    # backward pass (graph task id), chain streams whose backward has begun in it
 
 
 def _issue_batch(chain, ws, mine, ev=None):
-    if ev is None:
+    if ws is chain:
+        pass
+    elif ev is None:
         ws.wait_stream(chain)                   # one cross-stream edge per batch
     else:
         ws.wait_event(ev)
     with torch.cuda.stream(ws):
+        if RT._marks is not None:
+            _BATCH_NO[0] += 1
+            tag = "wg.%s%s.%d" % ("pose" if RT.is_side(chain) else "depth", "" if ws is not chain else ".inline", _BATCH_NO[0])
+            RT.mark(tag + ".start")
         sums = []
         for it in mine:
             _run_param_grads(*it, bias_later=sums)
         if sums:
             ops.channel_sum_multi(sums)         # the batch's bias gradients in one launch
-    _PENDING_JOIN.add((chain, ws))
+        if RT._marks is not None:
+            RT.mark(tag + ".end(%d)" % len(mine))
+    if ws is not chain:
+        _PENDING_JOIN.add((chain, ws))
 
 
 def issue_late(chain=None):
@@ -224,17 +237,17 @@ def issue_late(chain=None):
     _LATE[:] = rest
 
 
-def flush_deferred(cur=None, spread=False, now=False):
-    """hand the collected weight-gradient work of chain stream `cur` (default: all chains) to its companion;
-    `spread`: the batch that ends a network's backward may also use the other chains' companions.
+def flush_deferred(cur=None, now=False):
+    """hand the collected weight-gradient work of chain stream `cur` (default: all chains) to its companion.
 
     Inside a hipGraph capture the batch's kernels are issued one hand-over LATER (or at the end of the backward pass; `now`:
     at once), behind the event recorded here.  Dependencies are the same; what changes is the ORDER of the edges that leave
     the chain's last node: the chain's next kernel becomes its first successor, the batch its second.  The HIP graph executor
     (ROCm 7.2) hands out its 4 streams by a depth-first walk in which a node's first successor stays on the node's stream and
-    every further one moves to the next stream: with the batch first, the weight gradients inherited the chain's stream and
-    the chain hopped to a stream where it queued behind whatever the other chain had there (docs/LAB_r06.md, "the
-    executor's stream assignment": DEBUG_HIP_GRAPH_DOT_PRINT dump)."""
+    the k-th further one goes k streams on (mod 4); each stream runs its nodes in the order they were captured.  With the
+    batch first, the weight gradients inherited the chain's stream and the chain hopped to one where it queued behind
+    whatever the other chain had there (docs/LAB_r06.md, "the executor's stream assignment": DEBUG_HIP_GRAPH_DOT_PRINT
+    dumps read with tools/probes/graph_streams.py)."""
     late = RT.wgrad_late and not now and torch.cuda.is_current_stream_capturing()
     for key in ([cur.cuda_stream] if cur is not None else list(_DEFERRED.keys())):
         ent = _DEFERRED.get(key)
@@ -242,26 +255,28 @@ def flush_deferred(cur=None, spread=False, now=False):
             continue
         chain, items = ent
         issue_late(chain)                       # (earlier batches first: the companion runs them in this order)
-        targets = [RT.companion_stream(chain.device, chain)[1]]
-        if spread and RT.wgrad_spread and RT.is_side(chain):
-            # the pose chain's last batch (its largest layers) otherwise runs serially after everything else has
-            # finished: the other chains' companions are idle by then and take every other layer
-            for key2 in _ACTIVE_CHAINS:         # chains of THIS backward pass only
-                if key2 != key:
-                    chain2 = _DEFERRED[key2][0]
-                    targets.append(RT.companion_stream(chain2.device, chain2)[1])
+        ws = RT.companion_stream(chain.device, chain)[1]
         ev = None
-        if late:
+        capturing = late or torch.cuda.is_current_stream_capturing()
+        if capturing:
             ev = torch.cuda.Event()
             ev.record(chain)
-        for k, ws in enumerate(targets):
-            mine = items[k::len(targets)]
-            if not mine:
-                continue
-            if late:
-                _LATE.append((ev, chain, ws, mine))
-            else:
-                _issue_batch(chain, ws, mine)
+        mine = list(items)
+        if (RT.wgrad_balance and RT.even_chains and capturing and _IN_ENCODER[0] and RT.dp is None and not RT.is_side(chain)
+                and len(items) >= 2 and torch._C._current_graph_task_id() >= 0):
+            # the main chain's encoder: its weight gradients end the step on their companion, when the pose chain and its
+            # companion have finished.  A share of each batch goes to those streams (wgrad_balance of them), issued when
+            # every node of the pass has been — behind their own work in launch order too; as the third (fourth) successor
+            # of the hand-over point the shares land on the executor's streams of the pose chain (and its companion).
+            side = RT.side_stream(chain.device)
+            others = [side, RT.companion_stream(chain.device, side)[1]][:RT.wgrad_balance]
+            n = 1 + len(others)
+            _AT_END.append((ev, chain, [(o, items[1 + k::n]) for k, o in enumerate(others)]))
+            mine = items[0::n]
+        if late:
+            _LATE.append((ev, chain, ws, mine))
+        else:
+            _issue_batch(chain, ws, mine, ev=ev)
         _PENDING_KEEP.extend(items)
         ent[1].clear()
     if not late:
@@ -302,7 +317,14 @@ def _end_of_backward():
     flush_tail()
     flush_inline_bias()
     flush_deferred(now=True)
+    for ev, chain, parts in _AT_END:
+        for ws, mine in parts:
+            if mine:
+                _issue_batch(chain, ws, mine, ev=ev)
+    _AT_END.clear()
+    _IN_ENCODER[0] = False
     _ACTIVE_CHAINS.clear()
+    _BATCH_NO[0] = 0
     join_companions()
 
 
@@ -1100,6 +1122,7 @@ class EncoderPass:
         bwd_pool_reset(xs[0].device)
         tag = "enc%d" % sum(x.shape[0] for x in xs)
         RT.mark(tag + ".bwd.start")
+        _IN_ENCODER[0] = True
         last = ctx["blocks"][-1]["u"][-1][2]
         dout = [gfeats[l][nst] if gfeats[l][nst] is not None else torch.zeros_like(last[l]) for l in range(nl)]
         bi = len(ctx["blocks"])
@@ -1152,7 +1175,8 @@ class EncoderPass:
         stems = [r.stem for r in self.R]
         self._param_grads(stems, self._ready(stems, xs), dc0, xs)
         RT.mark(tag + ".bwd.end")
-        flush_deferred(_current_stream(), spread=True, now=True)
+        flush_deferred(_current_stream(), now=True)
+        _IN_ENCODER[0] = False
 
 
 # ==============================================================================================

@@ -19,12 +19,20 @@ class _Runtime:
         self.overlap = True          # (False: everything on one stream — bench.py's single-stream timing pass, tests)
         # Weight gradients feed nothing downstream in the backward pass: every chain hands them to a companion stream in
         # batches of `wgrad_flush` layers (cross-stream edges are not free — host time eagerly, barrier packets in a
-        # hipGraph — hence batches rather than one fork per layer), and the pose chain's last batch, which ends the
-        # backward, also uses the depth chain's by then idle companion.  Measured on the replayed step:
-        # inline 6.13 ms, main chain only 6.1, onto the pose stream's tail 6.15, this placement 5.93; batches of 6 / 16
-        # are 3-4 % slower than 8.  wgrad_streams = 0 (inline) is what data parallelism uses and what tests may set.
+        # hipGraph — hence batches rather than one fork per layer).  wgrad_streams = 0 (inline) is what data parallelism
+        # uses by default and what tests may set.
         self.wgrad_streams = 2
-        self.wgrad_flush = self.wgrad_flush_side = 8
+        self.wgrad_flush = 8
+        # the step runs the same encoder architecture on each of two streams (set per step by MonoDepthMeta.forward_train):
+        # the chains are then about equally long, and the main chain's companion — which has the depth decoder's weight
+        # gradients on top of the encoder's — ends the backward ~0.3 ms after everything else.  Batches of 4 instead of 8,
+        # and the main chain's encoder leaves half of each batch to the pose chain's stream (nets.flush_deferred).
+        # Same box, 150 replayed steps: ResNet-18 + ResNet-18 bf16 5.19 -> 5.12 ms (fp32 15.95 -> 16.09); applied to the
+        # ResNet-50 + ResNet-18 configuration it costs 3 % (the pose chain ends early there and the shares run beside the
+        # depth chain instead of behind it) and with one chain 8 %: hence the condition.
+        self.even_chains = False
+        self.wgrad_flush_even = 4
+        self.wgrad_balance = 1
         # inside a capture: issue a batch one hand-over late, so that the chain's next kernel is its last node's FIRST
         # successor in the graph, and separate the two chains' first kernels by an empty launch (nets.flush_deferred,
         # nets.chain_begins: the executor's stream assignment follows the order of the edges)
@@ -33,7 +41,6 @@ class _Runtime:
         # hand over what is pending when an encoder's backward reaches its stem (see EncoderPass.backward): with the two-lane
         # pass only (follows `lanes`)
         self.stem_flush = False
-        self.wgrad_spread = 1
         # the pose encoder's image pairs as one stacked pass with per-pair BatchNorm statistics
         self.batch_pose_pairs = True     # (False: one call per pair, the reference's pattern — tests/test_pose_pairs_gpu.py)
         # the depth encoder and the stacked pose encoder as the two lanes of ONE pass: every post-stem launch carries
@@ -126,10 +133,11 @@ class _Runtime:
 
     def nop(self, device):
         """one empty-handed launch on the current stream (a node for the graph executor's stream assignment)"""
+        from ..hip.binding import check, lib, stream_ptr
         t = self._nop.get(device)
         if t is None:
-            t = self._nop[device] = torch.zeros(1, device=device)
-        t.zero_()
+            t = self._nop[device] = torch.zeros(1, dtype=torch.int64, device=device)
+        check(lib.fs_debug_timestamp(t.data_ptr(), stream_ptr()), "fs_debug_timestamp")
 
     def new_stream(self, device):
         """a HIP stream no other part of the engine holds.  torch.cuda.Stream() hands out a pool of 32 streams per

@@ -34,6 +34,7 @@ class _HipMetaArch(BaseMetaArch):
 
     def _begin_train(self):
         self.ensure_arena()
+        RT.even_chains = False      # (MonoDepthMeta.forward_train: the same encoder architecture on each of two streams)
         if RT.dp is None and torch.distributed.is_available() and torch.distributed.is_initialized() \
                 and torch.distributed.get_world_size() > 1:
             from fsnet_amd.engine.dataparallel import DataParallelContext
@@ -94,6 +95,15 @@ class MonoDepthMeta(_HipMetaArch):
                 any(p.requires_grad for p in self.depth_backbone.parameters()) and \
                 any(p.requires_grad for p in self.pose_backbone.parameters())
             c = self.__dict__["_lanes_cache"] = (key, ok)
+        return c[1]
+
+    def _same_encoders(self):
+        """both encoders the same trained architecture (RT.even_chains)?"""
+        from fsnet_amd.vision_base.networks.models.backbone.resnet import lanes_compatible
+        key = (self.depth_backbone.training, self.pose_backbone.training)
+        c = self.__dict__.get("_same_enc_cache")
+        if c is None or c[0] != key:
+            c = self.__dict__["_same_enc_cache"] = (key, bool(lanes_compatible(self.depth_backbone, self.pose_backbone)))
         return c[1]
 
     def _pose_chain(self, data, image_0, outputs, stacked=None):
@@ -176,6 +186,7 @@ class MonoDepthMeta(_HipMetaArch):
             main = torch.cuda.current_stream(image_0.device)
             side = RT.side_stream(image_0.device)
             side.wait_stream(main)
+            RT.even_chains = self._same_encoders()
             with torch.cuda.stream(side):
                 RT.mark("side.fork")
                 RT.mark("pose.fwd.start")

@@ -1,8 +1,17 @@
-set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/late
+python tools/probes/fisheye_late.py 2>&1 | tail -5
+python -m pytest tests/test_fisheye_gpu.py tests/test_graph_gpu.py -x -q 2>&1 | tail -3
+run() { n="$1"; shift; env $ENVV python tools/probes/ab_rt.py $SETS -- "$@" --no-cpu-baseline --no-kernel-profile 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$n', '$ENVV', '$SETS', d['ms_per_step'])"; }
 for rep in 1 2; do
-for v in 0 1; do
-  FSNET_AMD_WGRAD_LATE=$v python bench.py --steps 150 --warmup 20 --no-cpu-baseline --no-kernel-profile 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('late=$v', d['ms_per_step'], d['value'])"
-done; done | tee gpurun_out/late/ab.txt
-mkdir -p /tmp/dot1 && cd /tmp/dot1 && DEBUG_HIP_GRAPH_DOT_PRINT=1 python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 5 --no-cpu-baseline --no-kernel-profile > out.txt 2> err.txt; ls; cp graph_*dot_print* $GRAFT_REPO_ROOT/gpurun_out/late/ ; cd $GRAFT_REPO_ROOT; python tools/probes/graph_streams.py gpurun_out/late/graph_*dot_print* | tee gpurun_out/late/streams.txt
+ENVV="A=1" SETS="" run base --steps 150 --warmup 20
+ENVV="A=1" SETS="wgrad_balance=0" run base --steps 150 --warmup 20
+ENVV="A=1" SETS="wgrad_balance=0 wgrad_flush_even=8" run base --steps 150 --warmup 20
+ENVV="FSNET_AMD_LANES=1" SETS="" run lanes --steps 150 --warmup 20
+ENVV="A=1" SETS="" run r50 --depth 50 --height 320 --width 1024 --batch 8 --steps 40 --warmup 10
+ENVV="A=1" SETS="wgrad_flush=4" run r50 --depth 50 --height 320 --width 1024 --batch 8 --steps 40 --warmup 10
+ENVV="A=1" SETS="wgrad_late=false" run r50 --depth 50 --height 320 --width 1024 --batch 8 --steps 40 --warmup 10
+ENVV="A=1" SETS="" run fisheye --workload fisheye --steps 80 --warmup 10
+ENVV="A=1" SETS="" run fp32 --dtype fp32 --steps 80 --warmup 10
+ENVV="A=1" SETS="wgrad_balance=0" run fp32 --dtype fp32 --steps 80 --warmup 10
+done | tee gpurun_out/late/sweep7.txt
