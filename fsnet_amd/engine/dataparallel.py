@@ -149,15 +149,27 @@ class DataParallelContext:
         if self._direct is not None:
             # the bucket's weight gradients were issued on the current (chain) stream: the communication stream
             # picks up from there, the chain goes on with the rest of the backward
+            from .nets import flush_deferred, late_call, pending_companions
             cur = torch.cuda.current_stream(g.device)
-            self._comm_stream.wait_stream(cur)
-            if self.wgrad_companions:
-                from .nets import flush_deferred, pending_companions
-                flush_deferred(cur, now=True)        # what the chain still holds goes to its companion now
-                for ws in pending_companions():
-                    self._comm_stream.wait_stream(ws)
-            with torch.cuda.stream(self._comm_stream):
-                self._direct.all_reduce_sum(g)
+            comm, companions = self._comm_stream, self.wgrad_companions
+
+            def reduce_bucket(ev=None):
+                if ev is None:
+                    comm.wait_stream(cur)
+                else:
+                    comm.wait_event(ev)
+                if companions:
+                    for ws in pending_companions():
+                        comm.wait_stream(ws)
+                with torch.cuda.stream(comm):
+                    self._direct.all_reduce_sum(g)
+            if companions:
+                flush_deferred(cur)                  # what the chain still holds goes to its companion (inside a capture:
+            #                                          at the end of the pass, the bucket behind it — nets.flush_deferred)
+            if not late_call(cur, reduce_bucket):
+                if companions:
+                    flush_deferred(cur, now=True)
+                reduce_bucket()
             return
         from .nets import flush_deferred, join_companions
         if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():

@@ -174,13 +174,18 @@ def accumulate_param_grads_multi(cls, ops_, dcs, xs, pros):
     _run_param_grads(*item, bias_later=_inline_bias_list(dc0.device))
 
 
-def _defer_param_grads(cur, item):
+def _drop_stale():
+    """leftovers of a backward pass that raised (its end-of-backward callback never ran): not this pass's gradients"""
     if _CALLBACK_QUEUED[0] is not None and _CALLBACK_QUEUED[0] != torch._C._current_graph_task_id():
-        for stale in _DEFERRED.values():       # leftovers of a backward pass that raised: not this pass's gradients
+        for stale in _DEFERRED.values():
             stale[1].clear()
+        _ACTIVE_CHAINS.clear()
         _LATE.clear()
         _AT_END.clear()
-        _ACTIVE_CHAINS.clear()
+
+
+def _defer_param_grads(cur, item):
+    _drop_stale()
     ent = _DEFERRED.get(cur.cuda_stream)
     if ent is None:
         ent = _DEFERRED[cur.cuda_stream] = (cur, [])
@@ -195,6 +200,7 @@ def _defer_param_grads(cur, item):
 
 
 _BATCH_NO = [0]
+HANDOVERS = {"late": 0, "shared": 0}    # batches issued late / shared with the other chain's streams (tests read it)
 _IN_ENCODER = [False]   # an encoder's backward is being issued (EncoderPass.backward)
 _AT_END = []            # [(event, chain, [(stream, items)])]: parts of a batch issued once every node of the pass has been
 _LATE = []              # inside a hipGraph capture: [(event on the chain, chain, companion, items)] batches not yet issued
@@ -225,36 +231,54 @@ def _issue_batch(chain, ws, mine, ev=None):
 
 
 def issue_late(chain=None):
-    """issue the batches of `chain` (default: every chain) whose launch was put off (flush_deferred, inside a capture)"""
+    """issue what was put off on `chain` (default: every chain) inside a capture, in the order it was put off: weight-
+    gradient batches (flush_deferred) and gradient-bucket reductions (late_call, from DataParallelContext._reduce_range)"""
     if not _LATE:
         return
-    rest = []
-    for ent in _LATE:
-        if chain is None or ent[1].cuda_stream == chain.cuda_stream:
-            _issue_batch(ent[1], ent[2], ent[3], ev=ent[0])
+    todo = [e for e in _LATE if chain is None or e[1].cuda_stream == chain.cuda_stream]
+    _LATE[:] = [e for e in _LATE if not (chain is None or e[1].cuda_stream == chain.cuda_stream)]
+    for ent in todo:
+        if ent[2] is None:
+            ent[3](ent[0])                      # fn(event recorded on the chain where the call was put off)
         else:
-            rest.append(ent)
-    _LATE[:] = rest
+            _issue_batch(ent[1], ent[2], ent[3], ev=ent[0])
+
+
+def late_call(chain, fn):
+    """inside a capture: call fn(event) when every node of the backward pass has been issued (see flush_deferred) —
+    `event` is recorded on `chain` now, and what fn issues on another stream behind it becomes a LATER successor of the
+    chain's last node than the chain's next kernel.  Returns False, and does nothing, outside a capture or an autograd
+    pass."""
+    if not (RT.wgrad_late and torch.cuda.is_current_stream_capturing() and torch._C._current_graph_task_id() >= 0):
+        return False
+    _drop_stale()
+    ev = torch.cuda.Event()
+    ev.record(chain)
+    _LATE.append((ev, chain, None, fn))
+    _queue_end_of_backward()
+    return True
 
 
 def flush_deferred(cur=None, now=False):
     """hand the collected weight-gradient work of chain stream `cur` (default: all chains) to its companion.
 
-    Inside a hipGraph capture the batch's kernels are issued one hand-over LATER (or at the end of the backward pass; `now`:
-    at once), behind the event recorded here.  Dependencies are the same; what changes is the ORDER of the edges that leave
+    Inside a hipGraph capture the batch's kernels are ISSUED when every node of the backward pass has been (`now`: at
+    once), behind the event recorded here.  Dependencies are the same; what changes is the ORDER of the edges that leave
     the chain's last node: the chain's next kernel becomes its first successor, the batch its second.  The HIP graph executor
     (ROCm 7.2) hands out its 4 streams by a depth-first walk in which a node's first successor stays on the node's stream and
     the k-th further one goes k streams on (mod 4); each stream runs its nodes in the order they were captured.  With the
     batch first, the weight gradients inherited the chain's stream and the chain hopped to one where it queued behind
     whatever the other chain had there (docs/LAB_r06.md, "the executor's stream assignment": DEBUG_HIP_GRAPH_DOT_PRINT
     dumps read with tools/probes/graph_streams.py)."""
-    late = RT.wgrad_late and not now and torch.cuda.is_current_stream_capturing()
+    late = (RT.wgrad_late and not now and torch.cuda.is_current_stream_capturing()
+            and torch._C._current_graph_task_id() >= 0)
     for key in ([cur.cuda_stream] if cur is not None else list(_DEFERRED.keys())):
         ent = _DEFERRED.get(key)
         if ent is None or not ent[1]:
             continue
         chain, items = ent
-        issue_late(chain)                       # (earlier batches first: the companion runs them in this order)
+        if not late:
+            issue_late(chain)                   # (what was put off goes first: the companion runs batches in this order)
         ws = RT.companion_stream(chain.device, chain)[1]
         ev = None
         capturing = late or torch.cuda.is_current_stream_capturing()
@@ -272,9 +296,11 @@ def flush_deferred(cur=None, now=False):
             others = [side, RT.companion_stream(chain.device, side)[1]][:RT.wgrad_balance]
             n = 1 + len(others)
             _AT_END.append((ev, chain, [(o, items[1 + k::n]) for k, o in enumerate(others)]))
+            HANDOVERS["shared"] += 1
             mine = items[0::n]
         if late:
             _LATE.append((ev, chain, ws, mine))
+            HANDOVERS["late"] += 1
         else:
             _issue_batch(chain, ws, mine, ev=ev)
         _PENDING_KEEP.extend(items)
@@ -1175,7 +1201,7 @@ class EncoderPass:
         stems = [r.stem for r in self.R]
         self._param_grads(stems, self._ready(stems, xs), dc0, xs)
         RT.mark(tag + ".bwd.end")
-        flush_deferred(_current_stream(), now=True)
+        flush_deferred(_current_stream())
         _IN_ENCODER[0] = False
 
 

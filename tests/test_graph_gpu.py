@@ -79,3 +79,55 @@ def test_graph_falls_back_on_new_batch_shape(dev):
     torch.cuda.synchronize()
     assert hook.graph_replays == 2 and hook.graph_captures == 2 and hook.use_graph
     assert torch.isfinite(out["loss"]) and opt._step_count_fused == 9
+
+
+@pytest.mark.parametrize("arch", ["two equal chains", "resnet34 + resnet18", "one chain"])
+def test_replayed_step_leaves_every_parameter_gradient(dev, arch):
+    """Inside a capture the weight-gradient batches are issued late, and with two equal chains partly on the pose chain's
+    streams (nets.flush_deferred): every parameter's gradient after the first replayed step is the eager step's (a batch
+    dropped or issued against the wrong event leaves zeros or garbage in ITS layers only — relative error 1 or more — and
+    the loss and parameter comparisons above have tolerances a few layers can hide in.  Two EAGER runs of this step differ
+    by up to 4e-2 in single encoder layers, tools/probes/grad_late.py: per-pixel minima that flip with the summation order
+    of the step before)."""
+    from fsnet_amd.configs import meta_arch_cfg, training_cfg
+    from fsnet_amd.engine import nets
+    from tests.helpers_scene import corridor_batch
+    from fsnet_amd.engine.runtime import RT
+    from fsnet_amd.vision_base.networks.optimizers.optimizers import build_optimizer
+    from fsnet_amd.vision_base.utils.builder import build
+    RT.set_compute_dtype(torch.float32)
+    B, H, W = 2, 64, 128
+    with_pose = arch != "one chain"
+    depth = 34 if arch.startswith("resnet34") else 18
+    cfg = meta_arch_cfg(H, W, with_pose=with_pose, depth=depth)
+    if depth == 34:
+        cfg["pose_backbone_cfg"]["depth"] = 18
+    sd0 = {k: v.clone() for k, v in build(**cfg).state_dict().items()}
+    grads = {}
+    try:
+        for use_graph in (False, True):
+            m = build(**cfg)
+            m.load_state_dict(sd0, strict=True)
+            m = m.to(dev).train()
+            tc = training_cfg()
+            opt = build_optimizer(m, **tc.optimizer)
+            hook = build(use_graph=use_graph, graph_warmup=2, **tc.training_hook)
+            before = dict(nets.HANDOVERS)
+            for it in range(3):                        # two eager steps, then the captured step's first replay
+                hook(dict(corridor_batch(B, H, W, seed=90 + it, device=dev)[0]), m, opt)
+            torch.cuda.synchronize()
+            assert hook.graph_captures == (1 if use_graph else 0)
+            grads[use_graph] = {k: p.grad.detach().double().cpu() for k, p in m.named_parameters() if p.grad is not None}
+            if use_graph:
+                assert nets.HANDOVERS["late"] > before["late"]
+                assert (nets.HANDOVERS["shared"] > before["shared"]) == (arch == "two equal chains")
+                assert not nets._LATE and not nets._AT_END
+    finally:
+        RT.set_compute_dtype(torch.bfloat16)
+    gmax = max(float(g.norm()) for g in grads[False].values())
+    assert set(grads[True]) == set(grads[False])
+    for k, ge in grads[False].items():
+        if float(ge.norm()) < 1e-6 * gmax:            # (a convolution bias in front of a BatchNorm: zero up to rounding)
+            continue
+        rel = float((grads[True][k] - ge).norm() / ge.norm())
+        assert rel < 0.15, (arch, k, rel)

@@ -39,6 +39,15 @@ if use_dp:
         n[0] += 1
         orig(t, out)
     RT.dp.allreduce_small = counted
+    if "fakecomm" in sys.argv:
+        # RCCL runs a single-rank collective as nothing (in place) or a copy: stand-in kernels, so that the captured step has
+        # the nodes a multi-rank step has (graph structure / executor stream assignment; not their duration)
+        def fake(t, out=None):
+            if out is None:
+                t.mul_(1.0)
+            else:
+                torch.mul(t, 1.0, out=out)
+        RT.dp._direct.all_reduce_sum = fake
 batches = bench.synthetic_device_batches(12, 192, 640, dev, 0)
 pre = 0
 while use_dp and graph and not hook.tune_done and pre < 200:       # encoder-pass autotune (FSNET_AMD_LANES=auto)
