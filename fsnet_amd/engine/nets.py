@@ -201,7 +201,7 @@ def _defer_param_grads(cur, item):
 
 _BATCH_NO = [0]
 HANDOVERS = {"late": 0, "shared": 0}    # batches issued late / shared with the other chain's streams (tests read it)
-_IN_ENCODER = [False]   # an encoder's backward is being issued (EncoderPass.backward)
+_ENCODER_END = [False]  # the last two stages and the stem of an encoder's backward are being issued (EncoderPass.backward)
 _AT_END = []            # [(event, chain, [(stream, items)])]: parts of a batch issued once every node of the pass has been
 _LATE = []              # inside a hipGraph capture: [(event on the chain, chain, companion, items)] batches not yet issued
 _CHAINS_BEGUN = [None, []]    # backward pass (graph task id), chain streams whose backward has begun in it
@@ -286,12 +286,14 @@ def flush_deferred(cur=None, now=False):
             ev = torch.cuda.Event()
             ev.record(chain)
         mine = list(items)
-        if (RT.wgrad_balance and RT.even_chains and capturing and _IN_ENCODER[0] and RT.dp is None and not RT.is_side(chain)
+        if (RT.wgrad_balance and RT.even_chains and capturing and _ENCODER_END[0] and RT.dp is None and not RT.is_side(chain)
                 and len(items) >= 2 and torch._C._current_graph_task_id() >= 0):
-            # the main chain's encoder: its weight gradients end the step on their companion, when the pose chain and its
-            # companion have finished.  A share of each batch goes to those streams (wgrad_balance of them), issued when
-            # every node of the pass has been — behind their own work in launch order too; as the third (fourth) successor
-            # of the hand-over point the shares land on the executor's streams of the pose chain (and its companion).
+            # the end of the main chain's encoder: the chain's companion still has the depth decoder's weight gradients to
+            # run when the encoder's arrive, and ends the step with them after the pose chain and its companion have
+            # finished.  Half of each batch from layer2 on goes to the pose chain's stream, issued at the end of the pass
+            # like everything else — behind the pose chain's own work; as the third successor of the hand-over point the
+            # share lands on the executor's stream of the pose chain.  (Shares of the encoder's earlier batches run
+            # beside the depth chain rather than after it: measured, they slow it more than they relieve the companion.)
             side = RT.side_stream(chain.device)
             others = [side, RT.companion_stream(chain.device, side)[1]][:RT.wgrad_balance]
             n = 1 + len(others)
@@ -348,7 +350,7 @@ def _end_of_backward():
             if mine:
                 _issue_batch(chain, ws, mine, ev=ev)
     _AT_END.clear()
-    _IN_ENCODER[0] = False
+    _ENCODER_END[0] = False
     _ACTIVE_CHAINS.clear()
     _BATCH_NO[0] = 0
     join_companions()
@@ -1148,13 +1150,13 @@ class EncoderPass:
         bwd_pool_reset(xs[0].device)
         tag = "enc%d" % sum(x.shape[0] for x in xs)
         RT.mark(tag + ".bwd.start")
-        _IN_ENCODER[0] = True
         last = ctx["blocks"][-1]["u"][-1][2]
         dout = [gfeats[l][nst] if gfeats[l][nst] is not None else torch.zeros_like(last[l]) for l in range(nl)]
         bi = len(ctx["blocks"])
         dsums = None
         for si in range(nst - 1, -1, -1):
             nblk = len(R0.stages[si])
+            _ENCODER_END[0] = si <= 1           # (layer2, layer1 and the stem: what flush_deferred may share, see there)
             for b in range(nblk - 1, -1, -1):
                 bi -= 1
                 units = [r.stages[si][b][0] for r in self.R]
@@ -1202,7 +1204,7 @@ class EncoderPass:
         self._param_grads(stems, self._ready(stems, xs), dc0, xs)
         RT.mark(tag + ".bwd.end")
         flush_deferred(_current_stream())
-        _IN_ENCODER[0] = False
+        _ENCODER_END[0] = False
 
 
 # ==============================================================================================

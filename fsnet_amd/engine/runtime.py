@@ -26,17 +26,17 @@ class _Runtime:
         # the step runs the same encoder architecture on each of two streams (set per step by MonoDepthMeta.forward_train):
         # the chains are then about equally long, and the main chain's companion — which has the depth decoder's weight
         # gradients on top of the encoder's — ends the backward ~0.3 ms after everything else.  Batches of 4 instead of 8,
-        # and the main chain's encoder leaves half of each batch to the pose chain's stream (nets.flush_deferred).
-        # Same box, 150 replayed steps: ResNet-18 + ResNet-18 bf16 5.19 -> 5.12 ms (fp32 15.95 -> 16.09); applied to the
-        # ResNet-50 + ResNet-18 configuration it costs 3 % (the pose chain ends early there and the shares run beside the
-        # depth chain instead of behind it) and with one chain 8 %: hence the condition.
+        # and from layer2 on the main chain's encoder leaves half of each batch to the pose chain's stream
+        # (nets.flush_deferred).  Same box, replayed steps: ResNet-18 + ResNet-18 bf16 5.26 -> 5.20 ms, ResNet-50 +
+        # ResNet-50 unchanged (18.2); sharing the whole encoder's batches costs that configuration 2 %, sharing with one
+        # chain only (fisheye) 8 %: the shares then run beside the depth chain instead of after it.
         self.even_chains = False
         self.wgrad_flush_even = 4
         self.wgrad_balance = 1
-        # inside a capture: issue a batch one hand-over late, so that the chain's next kernel is its last node's FIRST
-        # successor in the graph, and separate the two chains' first kernels by an empty launch (nets.flush_deferred,
-        # nets.chain_begins: the executor's stream assignment follows the order of the edges)
-        self.wgrad_late = os.environ.get("FSNET_AMD_WGRAD_LATE", "1") != "0"
+        # inside a capture: issue what is handed over when the whole backward pass has been issued, so that the chain's
+        # next kernel is its last node's FIRST successor in the graph, and separate the two chains' first kernels by an
+        # empty launch (nets.flush_deferred, nets.chain_begins: the executor's stream assignment follows the edge order)
+        self.wgrad_late = True
         self._nop = {}
         # hand over what is pending when an encoder's backward reaches its stem (see EncoderPass.backward): with the two-lane
         # pass only (follows `lanes`)
