@@ -311,6 +311,16 @@ def flush_deferred(cur=None, now=False):
         issue_late(cur)
 
 
+def chain_ends(device):
+    """a chain has issued its last kernel (the end of an encoder's backward).  Inside a capture, with hand-overs put off: one
+    empty launch on the chain, so that the last hand-over point has a first successor that stays on the chain's stream like
+    every other one — otherwise the last batch inherits the chain's executor stream and the share that follows it the
+    companion's, behind the companion's backlog."""
+    if (RT.wgrad_late and (_LATE or _AT_END) and device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+            and torch._C._current_graph_task_id() >= 0):
+        RT.nop(device)
+
+
 def chain_begins(device):
     """called where a network's backward begins on its chain (the decoders' autograd nodes).  Inside a hipGraph capture,
     when the SECOND chain of the pass begins, one empty launch is put on the first chain's companion, behind the second
@@ -1205,6 +1215,7 @@ class EncoderPass:
         RT.mark(tag + ".bwd.end")
         flush_deferred(_current_stream())
         _ENCODER_END[0] = False
+        chain_ends(xs[0].device)
 
 
 # ==============================================================================================
