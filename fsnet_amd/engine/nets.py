@@ -230,18 +230,44 @@ def _issue_batch(chain, ws, mine, ev=None):
         _PENDING_JOIN.add((chain, ws))
 
 
-def issue_late(chain=None):
+def _position(chain):
+    """token of `chain`'s position in the running capture (fs_capture_position: changes whenever the stream captures a node)"""
+    import ctypes as C
+    from ..hip.binding import check, lib
+    tok = C.c_ulonglong(0)
+    check(lib.fs_capture_position(C.c_void_p(chain.cuda_stream), C.byref(tok)), "fs_capture_position")
+    return tok.value
+
+
+def issue_late(chain=None, advanced=False):
     """issue what was put off on `chain` (default: every chain) inside a capture, in the order it was put off: weight-
-    gradient batches (flush_deferred) and gradient-bucket reductions (late_call, from DataParallelContext._reduce_range)"""
+    gradient batches (flush_deferred) and gradient-bucket reductions (late_call, from DataParallelContext._reduce_range).
+    advanced: only what was put off at an EARLIER position of the chain than its current one — the chain has captured its
+    next kernel since, which is all the putting-off is for (flush_deferred); what was put off where the chain still stands
+    stays."""
     if not _LATE:
         return
-    todo = [e for e in _LATE if chain is None or e[1].cuda_stream == chain.cuda_stream]
-    _LATE[:] = [e for e in _LATE if not (chain is None or e[1].cuda_stream == chain.cuda_stream)]
-    for ent in todo:
+    mine = [e for e in _LATE if chain is None or e[1].cuda_stream == chain.cuda_stream]
+    if advanced and mine:
+        here = _position(chain)
+        mine = [e for e in mine if e[4] != here]
+    if not mine:
+        return
+    ids = {id(e) for e in mine}
+    _LATE[:] = [e for e in _LATE if id(e) not in ids]
+    for ent in mine:
         if ent[2] is None:
             ent[3](ent[0])                      # fn(event recorded on the chain where the call was put off)
         else:
             _issue_batch(ent[1], ent[2], ent[3], ev=ent[0])
+
+
+def issue_advanced(device):
+    """a cheap place to let go of what the current chain put off (block and level boundaries of the backward passes): under
+    data parallelism a bucket's all-reduce takes its place in the communicator's launch order when it is ISSUED, and one
+    issued at the end of the pass would run after every SyncBN exchange of the backward instead of beside it"""
+    if _LATE:
+        issue_late(_current_stream(device), advanced=True)
 
 
 def late_call(chain, fn):
@@ -252,9 +278,10 @@ def late_call(chain, fn):
     if not (RT.wgrad_late and torch.cuda.is_current_stream_capturing() and torch._C._current_graph_task_id() >= 0):
         return False
     _drop_stale()
+    issue_late(chain, advanced=True)
     ev = torch.cuda.Event()
     ev.record(chain)
-    _LATE.append((ev, chain, None, fn))
+    _LATE.append((ev, chain, None, fn, _position(chain)))
     _queue_end_of_backward()
     return True
 
@@ -262,8 +289,9 @@ def late_call(chain, fn):
 def flush_deferred(cur=None, now=False):
     """hand the collected weight-gradient work of chain stream `cur` (default: all chains) to its companion.
 
-    Inside a hipGraph capture the batch's kernels are ISSUED when every node of the backward pass has been (`now`: at
-    once), behind the event recorded here.  Dependencies are the same; what changes is the ORDER of the edges that leave
+    Inside a hipGraph capture the batch's kernels are ISSUED later (`now`: at once) — at the chain's next hand-over or block
+    boundary that finds it further on (issue_late(advanced=True)), at the latest when the whole backward pass has been
+    issued — behind the event recorded here.  Dependencies are the same; what changes is the ORDER of the edges that leave
     the chain's last node: the chain's next kernel becomes its first successor, the batch its second.  The HIP graph executor
     (ROCm 7.2) hands out its 4 streams by a depth-first walk in which a node's first successor stays on the node's stream and
     the k-th further one goes k streams on (mod 4); each stream runs its nodes in the order they were captured.  With the
@@ -277,8 +305,7 @@ def flush_deferred(cur=None, now=False):
         if ent is None or not ent[1]:
             continue
         chain, items = ent
-        if not late:
-            issue_late(chain)                   # (what was put off goes first: the companion runs batches in this order)
+        issue_late(chain, advanced=late)        # (what was put off goes first: the companion runs batches in this order)
         ws = RT.companion_stream(chain.device, chain)[1]
         ev = None
         capturing = late or torch.cuda.is_current_stream_capturing()
@@ -301,7 +328,7 @@ def flush_deferred(cur=None, now=False):
             HANDOVERS["shared"] += 1
             mine = items[0::n]
         if late:
-            _LATE.append((ev, chain, ws, mine))
+            _LATE.append((ev, chain, ws, mine, _position(chain)))
             HANDOVERS["late"] += 1
         else:
             _issue_batch(chain, ws, mine, ev=ev)
@@ -319,6 +346,7 @@ def chain_ends(device):
     if (RT.wgrad_late and (_LATE or _AT_END) and device.type == "cuda" and torch.cuda.is_current_stream_capturing()
             and torch._C._current_graph_task_id() >= 0):
         RT.nop(device)
+        issue_late(_current_stream(device))
 
 
 def chain_begins(device):
@@ -1185,6 +1213,7 @@ class EncoderPass:
                     # the consumer of the returned gradient is the previous block's output BatchNorm, unless a
                     # feature gradient still has to be added to it first (stage boundary without downsample)
                     prev = (pu[2], pu[1], pu[3])
+                issue_advanced(xs[0].device)
                 dout, dsums = self._block_bwd(units, ds, ctx["blocks"][bi], dout, extra, dout_sums=dsums, prev=prev)
             if RT.dp is not None and si >= 2:
                 for r in self.R:
@@ -1381,6 +1410,7 @@ class DepthDecoderRunner:
 
         Gp = disp_grad(0)
         for i in range(0, 5):
+            issue_advanced(dev)
             lv = ctx["lv"][i]
             h, w = lv["h"], lv["w"]
             H2, W2 = 2 * h, 2 * w

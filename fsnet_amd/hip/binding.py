@@ -155,7 +155,7 @@ class FsSmoothArgs(C.Structure):
     ]
 
 
-ABI_VERSION = 10     # FS_ABI_VERSION of include/fsnet_hip.h (tests/test_abi.py holds the two together)
+ABI_VERSION = 11     # FS_ABI_VERSION of include/fsnet_hip.h (tests/test_abi.py holds the two together)
 _lib = None
 
 

@@ -12,6 +12,7 @@ SIGNATURES = {
     "fs_abi_version": (C.c_int, []),
     "fs_target_arch": (C.c_char_p, []),
     "fs_debug_timestamp": (C.c_int, [P, P]),
+    "fs_capture_position": (C.c_int, [P, P]),
     "fs_conv_igemm": (C.c_int, [P, I, P]),
     # two problems per launch (ABI 7): (args0, args1 | NULL, dtype, stream)
     "fs_conv_igemm2": (C.c_int, [P, P, I, P]),

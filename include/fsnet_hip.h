@@ -33,12 +33,17 @@ extern "C" {
 
 /* library/ABI version and the ISA the kernels were compiled for ("gfx950").  FS_ABI_VERSION changes whenever an
  * argument struct or a signature below does; a host binding refuses a library that reports another number. */
-#define FS_ABI_VERSION 10
+#define FS_ABI_VERSION 11
 int fs_abi_version(void);
 const char* fs_target_arch(void);
 /* debugging aid: writes the device's constant-rate clock (wall_clock64, 100 MHz) into *slot (u64) on `stream`;
  * capturable.  No reference counterpart (the engine's FSNET_AMD_MARKS=1 step timeline). */
 int fs_debug_timestamp(void* slot, void* stream);
+/* host-side query, no launch: *token identifies the position of `stream` in the hipGraph capture it takes part in (a hash of
+ * the nodes its next node would depend on; equal tokens <=> nothing captured on the stream in between), 0 outside a capture.
+ * No reference counterpart (the engine orders its hand-overs to other streams by it: the graph executor assigns streams by
+ * edge order). */
+int fs_capture_position(void* stream, unsigned long long* token);
 
 /* ------------------------------------------------------------------------------------------
  * Convolution forward / data-gradient (implicit GEMM on MFMA).

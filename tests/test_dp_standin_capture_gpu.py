@@ -64,13 +64,17 @@ def _build(dev, lanes):
 
 
 def _steps(hook, m, opt):
-    losses = []
+    losses, grads = [], None
     for it in range(STEPS):
         out = hook(dict(O.synthetic_batch(B, H, W, seed=800 + it)), m, opt)
         losses.append(float(out["loss"].detach()))
+        if it == 2:
+            # the captured step's first replay, on weights that two eager steps made (the same in every run up to summation
+            # order; later steps' gradients differ by what Adam makes of that: 0.24 seen on the pose encoder's stem at step 5).
+            # The gradients stay in the arena until the next step zeroes them: SUMs over the ranks under data parallelism.
+            torch.cuda.synchronize()
+            grads = {k: p.grad.detach().double().cpu() for k, p in m.named_parameters() if p.grad is not None}
     torch.cuda.synchronize()
-    # (the last step's gradients stay in the arena until the next step zeroes them: SUMs over the ranks under data parallelism)
-    grads = {k: p.grad.detach().double().cpu() for k, p in m.named_parameters() if p.grad is not None}
     return losses, torch.cat([p.detach().flatten() for p in m.parameters()]).cpu(), grads
 
 
