@@ -33,9 +33,9 @@ class _Runtime:
         self.even_chains = False
         self.wgrad_flush_even = 4
         self.wgrad_balance = 1
-        # inside a capture: issue what is handed over when the whole backward pass has been issued, so that the chain's
-        # next kernel is its last node's FIRST successor in the graph, and separate the two chains' first kernels by an
-        # empty launch (nets.flush_deferred, nets.chain_begins: the executor's stream assignment follows the edge order)
+        # inside a capture: issue what is handed over only once the chain has captured its next kernel, so that this kernel
+        # is its last node's FIRST successor in the graph, and separate the two chains' first kernels by an empty launch
+        # (nets.flush_deferred, nets.chain_begins: the executor's stream assignment follows the edge order)
         self.wgrad_late = True
         self._nop = {}
         # hand over what is pending when an encoder's backward reaches its stem (see EncoderPass.backward): with the two-lane
