@@ -267,6 +267,7 @@ def issue_advanced(device):
     data parallelism a bucket's all-reduce takes its place in the communicator's launch order when it is ISSUED, and one
     issued at the end of the pass would run after every SyncBN exchange of the backward instead of beside it"""
     if _LATE:
+        _drop_stale()
         issue_late(_current_stream(device), advanced=True)
 
 
@@ -362,6 +363,7 @@ def chain_begins(device):
     task = torch._C._current_graph_task_id()
     if task < 0:
         return
+    _drop_stale()
     if _CHAINS_BEGUN[0] != task:
         _CHAINS_BEGUN[0], _CHAINS_BEGUN[1] = task, []
     cur = _current_stream(device)

@@ -264,3 +264,41 @@ def test_rank_agreement_through_the_store():
         out, blob = res[r]
         assert out == [True, False, False, True, True, False, True]
         assert blob == b"unique-id-from-rank-0"
+
+
+def test_hand_overs_left_by_a_backward_that_raised_are_dropped_by_the_next_pass():
+    """nets._LATE / _AT_END / _DEFERRED hold work that was put off inside a backward pass (flush_deferred, late_call); their
+    end-of-backward callback empties them.  A pass that raised never ran it: the next pass must not issue that work (events of a
+    dead capture, gradients of another step) — the first entry point it reaches drops it (nets._drop_stale)."""
+    from fsnet_amd.engine import nets
+
+    class Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            nets._drop_stale()
+            Probe.seen = (len(nets._LATE), len(nets._AT_END), sum(len(v[1]) for v in nets._DEFERRED.values()))
+            return g * 2
+
+    saved = (list(nets._LATE), list(nets._AT_END), nets._CALLBACK_QUEUED[0])
+    try:
+        nets._LATE.append(("event", None, None, None, 0))
+        nets._AT_END.append(("event", None, []))
+        nets._DEFERRED[-1] = (None, ["item"])
+        nets._CALLBACK_QUEUED[0] = -12345                      # a pass whose callback never ran
+        x = torch.ones(3, requires_grad=True)
+        Probe.apply(x).sum().backward()
+        assert Probe.seen == (0, 0, 0)
+        # ... while the running pass's own entries stay
+        nets._LATE.append(("event", None, None, None, 0))
+        nets._CALLBACK_QUEUED[0] = None
+        Probe.apply(x).sum().backward()
+        assert Probe.seen[0] == 1
+    finally:
+        nets._DEFERRED.pop(-1, None)
+        nets._LATE[:] = saved[0]
+        nets._AT_END[:] = saved[1]
+        nets._CALLBACK_QUEUED[0] = saved[2]
