@@ -199,25 +199,25 @@ def _defer_param_grads(cur, item):
         flush_deferred(cur)
 
 
-_BATCH_NO = [0]
+_BATCH_NO = [0]         # (numbering of the FSNET_AMD_MARKS=1 marks around each batch)
 HANDOVERS = {"late": 0, "shared": 0}    # batches issued late / shared with the other chain's streams (tests read it)
 _ENCODER_END = [False]  # the last two stages and the stem of an encoder's backward are being issued (EncoderPass.backward)
 _AT_END = []            # [(event, chain, [(stream, items)])]: parts of a batch issued once every node of the pass has been
-_LATE = []              # inside a hipGraph capture: [(event on the chain, chain, companion, items)] batches not yet issued
+_LATE = []              # inside a hipGraph capture, put off: [(event on the chain, chain, companion, items, position)] batches,
+                        # [(event, chain, None, fn, position)] calls (late_call)
 _CHAINS_BEGUN = [None, []]    # backward pass (graph task id), chain streams whose backward has begun in it
 
 
 def _issue_batch(chain, ws, mine, ev=None):
-    if ws is chain:
-        pass
-    elif ev is None:
+    """weight-gradient items of `chain` on stream `ws`, behind the chain (ev: behind an event recorded on it earlier)"""
+    if ev is None:
         ws.wait_stream(chain)                   # one cross-stream edge per batch
     else:
         ws.wait_event(ev)
     with torch.cuda.stream(ws):
         if RT._marks is not None:
             _BATCH_NO[0] += 1
-            tag = "wg.%s%s.%d" % ("pose" if RT.is_side(chain) else "depth", "" if ws is not chain else ".inline", _BATCH_NO[0])
+            tag = "wg.%s.%d" % ("pose" if RT.is_side(chain) else "depth", _BATCH_NO[0])
             RT.mark(tag + ".start")
         sums = []
         for it in mine:
@@ -226,8 +226,7 @@ def _issue_batch(chain, ws, mine, ev=None):
             ops.channel_sum_multi(sums)         # the batch's bias gradients in one launch
         if RT._marks is not None:
             RT.mark(tag + ".end(%d)" % len(mine))
-    if ws is not chain:
-        _PENDING_JOIN.add((chain, ws))
+    _PENDING_JOIN.add((chain, ws))
 
 
 def _position(chain):
