@@ -44,12 +44,14 @@ class StatsPool:
         # keeps two graphs for a while) each dirty their own extent whatever this object's bump pointer says
         self.high = 0
         self.dirty = False
+        self.epoch = -1           # ops.PREZERO_EPOCH of the step-head zeroing that last covered this pool
         ops.register_prezero(self, StatsPool._prezero, device)
 
     def _prezero(self):
         """(ops.prezero_all, at the step's head) the used prefix is about to be zeroed with the rest of the step's scratch:
         the reset() at the start of the network's forward / backward then finds nothing to do"""
         self.off = 0
+        self.epoch = ops.PREZERO_EPOCH[0]
         if not self.dirty:
             return []
         self.dirty = False
@@ -671,12 +673,16 @@ _BWD_POOLS = {}
 
 
 def bwd_pool_reset(device):
-    """one memset per network backward for all its BatchNorm backward sums"""
+    """the current stream's pool of BatchNorm-backward sums, zeroed (one memset per network backward outside a training step;
+    inside one: by the step's one zeroing launch)"""
     key = (device, raw_stream(device.index))
     p = _BWD_POOLS.get(key)
     if p is None:
         p = _BWD_POOLS[key] = StatsPool(device)
-    p.reset()
+    if p.epoch != ops.PREZERO_EPOCH[0]:
+        p.reset()
+    # (else: zeroed at the head of the running step with the rest of its scratch, and a network earlier on this chain has
+    # taken from it since — the depth decoder before the depth encoder: the next network's sums follow on, no fill launch)
     return p
 
 
@@ -1266,6 +1272,7 @@ class DepthDecoderRunner:
         self.unc = {s: ConvLayer(module.convs[("uncertain_logz", s)], valid_over_padded=True)
                     for s in module.scales if ("uncertain_logz", s) in module.convs}
         self.pool = None
+        self._border0 = None
         self.tail_pending = False      # its weight gradients (and gradient bucket) are waiting for the end of the backward
 
     def forward(self, feats, train, P2=None):
@@ -1407,9 +1414,16 @@ class DepthDecoderRunner:
                 dlu = ops.sigmoid_head_bwd(lv["unc"], g_unc[i], opu.Co_p, dt)
                 clu.accumulate_param_grads(opu, dlu, y1p)
                 G = opu.dgrad(dlu, y1p.shape[1], y1p.shape[2], addend=G)
-            return G if G is not None else torch.zeros_like(y1p)
+            if G is not None:
+                return G, False
+            # no head on this level (the lowest one): nothing to add the next gradient to, but the replicate-pad border must
+            # read as zero (fs_bn_bwd_*, fold) — a buffer that is zeroed once and whose interior every step overwrites
+            key = (tuple(y1p.shape), y1p.dtype, y1p.device)
+            if self._border0 is None or self._border0[0] != key:
+                self._border0 = (key, torch.zeros_like(y1p))
+            return self._border0[1], True
 
-        Gp = disp_grad(0)
+        Gp, _ = disp_grad(0)
         for i in range(0, 5):
             issue_advanced(dev)
             lv = ctx["lv"][i]
@@ -1431,9 +1445,9 @@ class DepthDecoderRunner:
             dc0 = _bn_bwd(d_y0, None, lv["c0"], bn0, lv["s0"], h, w, sums=sums0)
             cl0.accumulate_param_grads(op0, dc0, lv["x"])
             if i < 4:
-                Gp = disp_grad(i + 1)
+                Gp, fresh = disp_grad(i + 1)
                 interior = Gp[:, 1:-1, 1:-1]
-                op0.dgrad(dc0, h, w, out=interior, addend=interior)
+                op0.dgrad(dc0, h, w, out=interior, addend=None if fresh else interior)
             else:
                 gfeats[4] = op0.dgrad(dc0, h, w)
         RT.mark("ddec.bwd.end")

@@ -131,13 +131,20 @@ class _Runtime:
         t0 = min(v for _, v in rows)
         return sorted(((n, (v - t0) / 1e5) for n, v in rows), key=lambda r: r[1])
 
+    def nop_buffer(self, device):
+        """the word nop() writes to.  The training hook asks for it BEFORE it opens a capture: nop() only ever runs inside
+        captures, and an allocation there would belong to that graph's pool (and a zero-filled one would add a fill node)."""
+        from ..hip.ops import _indexed
+        device = _indexed(device)
+        t = self._nop.get(device)
+        if t is None:
+            t = self._nop[device] = torch.empty(1, dtype=torch.int64, device=device)
+        return t
+
     def nop(self, device):
         """one empty-handed launch on the current stream (a node for the graph executor's stream assignment)"""
         from ..hip.binding import check, lib, stream_ptr
-        t = self._nop.get(device)
-        if t is None:
-            t = self._nop[device] = torch.zeros(1, dtype=torch.int64, device=device)
-        check(lib.fs_debug_timestamp(t.data_ptr(), stream_ptr()), "fs_debug_timestamp")
+        check(lib.fs_debug_timestamp(self.nop_buffer(device).data_ptr(), stream_ptr()), "fs_debug_timestamp")
 
     def new_stream(self, device):
         """a HIP stream no other part of the engine holds.  torch.cuda.Stream() hands out a pool of 32 streams per

@@ -691,6 +691,7 @@ def zero_multi(tensors):
 
 # ---- per-step scratch zeroed together at the step's head (engine/nets.py pack_everything_async -> prezero_all) ----
 _PREZERO = []          # [(weakref to the owner, fn(owner) -> [tensors to zero]; fn marks them clean)]
+PREZERO_EPOCH = [0]    # bumped by every prezero_all: owners can tell "zeroed at the head of the running step" from "some time ago"
 
 
 def _indexed(device):
@@ -716,6 +717,7 @@ def prezero_all(device):
     owners' own zero_() calls are then skipped once (their `clean` flags)"""
     todo, alive = [], []
     device = _indexed(device)
+    PREZERO_EPOCH[0] += 1
     for ref, fn, dev in _PREZERO:
         o = ref()
         if o is None:

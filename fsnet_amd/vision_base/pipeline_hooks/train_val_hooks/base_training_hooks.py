@@ -67,6 +67,7 @@ class BaseTrainingHook(object):
         self._g_sig = None
         self._g_eager = 0         # eager steps seen with the current signature
         self._g_stream = None
+        self._seed = None
         self.graph_replays = 0
         # encoder-pass autotune: None = not looked at yet, dict = running, False = finished or not applicable
         self._tune = None
@@ -182,6 +183,15 @@ class BaseTrainingHook(object):
         from fsnet_amd.hip import ops
         ops.copy_multi([(static[k], v) for k, v in data.items() if isinstance(v, torch.Tensor) and k in static])
 
+    def _backward(self, loss):
+        """loss.backward() with the seed gradient handed in (autograd otherwise launches a fill for its ones_like — a node of
+        its own between the loss and its backward, the one stretch of the step nothing runs beside)"""
+        loss = loss if loss.dim() == 0 else loss.mean()
+        seed = self._seed
+        if seed is None or seed.device != loss.device or seed.dtype != loss.dtype:
+            seed = self._seed = torch.ones((), dtype=loss.dtype, device=loss.device)
+        loss.backward(gradient=seed)
+
     def _eager_step(self, data, meta_arch, optimizer, arena, fused, meta, logger):
         if arena is not None:
             arena.zero_grads(lazy=True)       # (zeroed with the step's scratch at the head of the forward: _begin_train)
@@ -199,7 +209,7 @@ class BaseTrainingHook(object):
             logger.update(output['loss_dict'])
             logger.update_hm(output.get('hm', dict()))
         loss = output['loss']
-        (loss if loss.dim() == 0 else loss.mean()).backward()
+        self._backward(loss)
         self._optim(meta_arch, optimizer, fused)
         return output
 
@@ -216,6 +226,7 @@ class BaseTrainingHook(object):
         if stage is not None:
             stage(data)
         optimizer.sync_lr()
+        RT.nop_buffer(dev)
         torch.cuda.synchronize(dev)
         if RT.dp is not None:
             from fsnet_amd.engine.rccl_direct import quiesce_watchdog
@@ -233,7 +244,7 @@ class BaseTrainingHook(object):
             output = meta_arch(sdata, meta)
             loss = output['loss']
             RT.mark("loss.fwd.end")
-            (loss if loss.dim() == 0 else loss.mean()).backward()
+            self._backward(loss)
             RT.mark("bwd.joined")
             grad_scale = RT.dp.finish() if RT.dp is not None else 1.0
             optimizer.step(max_norm=self.clip_gradients, grad_scale=grad_scale)
