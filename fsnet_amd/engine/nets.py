@@ -1294,12 +1294,35 @@ class DepthDecoderRunner:
         outs = {}
         x = feats[-1]
         K = int(m.num_output_channels)
+        # the heads of the lower levels feed nothing but the loss: each runs on the chain's companion stream beside the next
+        # level (issued after that level's first kernel, so that the chain keeps its executor stream: flush_deferred).
+        # Same box, with / without: headline 5.167 / 5.179 ms, ResNet-50 18.24 / 18.32, fisheye 6.48 / 6.53.
+        aside = bool(RT.overlap and dev.type == "cuda" and RT.wgrad_streams)
+        cur = _current_stream(dev) if aside else None
+        ws = RT.companion_stream(dev, cur)[1] if aside else None
+        put_off, used_ws = None, False
+
+        def head(i, lv, y1p):
+            cld = self.disp[i]
+            opd = cld.ready(dt, dev)
+            lv["logits"] = opd.forward(y1p, bias=cld.bias, out_f32=True)
+            if i in self.unc:
+                clu = self.unc[i]
+                opu = clu.ready(dt, dev)
+                lv["unc"] = ops.sigmoid_head_fwd(opu.forward(y1p, bias=clu.bias, out_f32=True))
+
         for i in range(4, -1, -1):
             cl0, bn0 = self.up0[i]
             op0 = cl0.ready(dt, dev)
             N, h, w, _ = x.shape
             st_a = self.pool.take(op0.Co_p) if train else None
             c0 = op0.forward(x, bias=cl0.bias, stats=st_a)
+            if put_off is not None:
+                ev, j, lvj, yj = put_off
+                ws.wait_event(ev)
+                with torch.cuda.stream(ws):
+                    head(j, lvj, yj)
+                put_off, used_ws = None, True
             world = _dp_stats(st_a) if train else 1
             y0 = torch.empty(N, h, w, op0.Co_p, dtype=dt, device=dev)
             s0 = ops.BnState(op0.Co_p, dev)
@@ -1319,16 +1342,16 @@ class DepthDecoderRunner:
             lv = dict(x=x, c0=c0, y0=y0, s0=s0, xcat=xcat, c1=c1, y1p=y1p, s1=s1, h=h, w=w,
                       Cs=(skip.shape[3] if skip is not None else 0))
             if i in m.scales:
-                cld = self.disp[i]
-                opd = cld.ready(dt, dev)
-                logits = opd.forward(y1p, bias=cld.bias, out_f32=True)
-                lv["logits"] = logits
-                if i in self.unc:
-                    clu = self.unc[i]
-                    opu = clu.ready(dt, dev)
-                    lv["unc"] = ops.sigmoid_head_fwd(opu.forward(y1p, bias=clu.bias, out_f32=True))
+                if aside and i > 0:
+                    ev = torch.cuda.Event()
+                    ev.record(cur)
+                    put_off = (ev, i, lv, y1p)
+                else:
+                    head(i, lv, y1p)
             ctx["lv"][i] = lv
             x = y1p[:, 1:-1, 1:-1]
+        if used_ws:
+            cur.wait_stream(ws)
         sc = [i for i in range(4, -1, -1) if "logits" in ctx["lv"][i]]
         if getattr(m, "sigmoid_head", False):
             # base-class DepthDecoder (depth_encoder.py:90-111): disp = sigmoid(dispconv), depth = scale / (min_disp +
