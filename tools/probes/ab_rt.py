@@ -1,5 +1,5 @@
 """bench.py with RT attributes overridden: A/B of the engine's placement constants on one box.
-    python tools/probes/ab_rt.py wgrad_flush=4 wgrad_flush_side=4 -- --steps 150 --warmup 20 --no-cpu-baseline --no-kernel-profile"""
+    python tools/probes/ab_rt.py wgrad_flush_even=8 wgrad_balance=0 -- --steps 150 --warmup 20 --no-cpu-baseline --no-kernel-profile"""
 import json, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 cut = sys.argv.index("--") if "--" in sys.argv else len(sys.argv)
